@@ -1,0 +1,147 @@
+"""Synthetic inputs for parity tests and benchmarks.
+
+Nothing here is on the accelerated path: it only manufactures the *inputs* of
+``cna.tl.association`` -- an AnnData-like object whose ``obsp['connectivities']``
+looks like what ``scanpy.pp.neighbors`` emits (UMAP fuzzy-union kNN graph,
+CSR float32/int32, empty diagonal, symmetric; /root/reference/demo/demo.ipynb:590)
+and whose ``obs[sid]`` assigns every cell to a sample.
+
+scanpy / umap-learn are not installed in this image, so the graph builder below is
+our own stand-in: exact kNN with ``scipy.spatial.cKDTree`` plus UMAP's published
+smooth-kNN weighting.  It is an input generator, not a parity target.
+"""
+import numpy as np
+import pandas as pd
+import scipy.sparse as sp
+from scipy.spatial import cKDTree
+
+
+class CellData:
+    """Minimal AnnData duck type: ``.obs`` (DataFrame), ``.obsp``, ``.uns``.
+
+    The reference only touches ``data.obs[...]``, ``data.obsp['connectivities']``
+    (or ``data.uns['neighbors']['connectivities']``) -- /root/reference/src/cna/tools/_nam.py:12-19.
+    """
+
+    def __init__(self, obs, connectivities):
+        self.obs = obs
+        self.obsp = {'connectivities': connectivities}
+        self.uns = {'neighbors': {'connectivities': connectivities}}
+
+    @property
+    def n_obs(self):
+        return len(self.obs)
+
+    def __len__(self):
+        return len(self.obs)
+
+
+def mixture_points(n, dim=8, n_clusters=20, seed=0, spread=4.0, cluster_sorted=True):
+    """n points in R^dim from a mixture of Gaussians; returns (X float32, cluster int32)."""
+    rs = np.random.RandomState(seed)
+    centers = rs.randn(n_clusters, dim) * spread
+    weights = rs.dirichlet(np.full(n_clusters, 5.0))
+    cl = rs.choice(n_clusters, size=n, p=weights).astype(np.int32)
+    if cluster_sorted:
+        cl.sort()
+    X = centers[cl] + rs.randn(n, dim)
+    return X.astype(np.float32), cl
+
+
+def fuzzy_knn_graph(X, k=30, dtype=np.float32, workers=-1, n_iter=40):
+    """UMAP-style connectivities for points X with ``k`` neighbours (self included,
+    as scanpy counts them), symmetrised by fuzzy union A + A^T - A*A^T."""
+    n = X.shape[0]
+    kk = min(k, n)
+    tree = cKDTree(X)
+    dist, idx = tree.query(X, k=kk, workers=workers)
+    dist = dist[:, 1:].astype(np.float64)      # drop self
+    idx = idx[:, 1:]
+    m = dist.shape[1]
+    rho = dist[:, 0].copy()
+    target = np.log2(kk)
+    lo = np.zeros(n)
+    hi = np.full(n, np.inf)
+    sigma = np.ones(n)
+    d0 = np.maximum(dist - rho[:, None], 0.0)
+    for _ in range(n_iter):
+        val = np.exp(-d0 / sigma[:, None]).sum(axis=1)
+        too_big = val > target
+        hi = np.where(too_big, sigma, hi)
+        lo = np.where(too_big, lo, sigma)
+        sigma = np.where(np.isinf(hi), sigma * 2.0, 0.5 * (lo + hi))
+    w = np.exp(-d0 / sigma[:, None])
+    rows = np.repeat(np.arange(n, dtype=np.int64), m)
+    A = sp.csr_matrix((w.ravel(), (rows, idx.ravel().astype(np.int64))), shape=(n, n))
+    A = A + A.T - A.multiply(A.T)
+    A = sp.csr_matrix(A)
+    A.setdiag(0)
+    A.eliminate_zeros()
+    A.sort_indices()
+    A = A.astype(dtype)
+    A.indices = A.indices.astype(np.int32)
+    A.indptr = A.indptr.astype(np.int32)
+    return A
+
+
+def assign_samples(cluster, n_samples, seed=0, skew=1.0):
+    """Sample id per cell with a per-sample preference over clusters so the NAM
+    carries signal.  Returns (sid int64[n], sample_cluster_props float64[N, K])."""
+    rs = np.random.RandomState(seed + 1)
+    n = len(cluster)
+    K = int(cluster.max()) + 1
+    logits = rs.randn(n_samples, K) * skew
+    p = np.exp(logits)
+    p /= p.sum(axis=0, keepdims=True)          # P(sample | cluster)
+    cdf = np.cumsum(p, axis=0)                 # N x K
+    u = rs.rand(n)
+    sid = (u[None, :] > cdf[:, cluster]).sum(axis=0).astype(np.int64)
+    sid = np.minimum(sid, n_samples - 1)
+    props = np.zeros((n_samples, K))
+    np.add.at(props, (sid, cluster), 1.0)
+    props /= np.maximum(props.sum(axis=1, keepdims=True), 1)
+    return sid, props
+
+
+def make_dataset(n_cells, n_samples, k=30, seed=0, dim=8, n_clusters=20,
+                 graph_dtype=np.float32, cluster_sorted=True, sid_name='id',
+                 sid_kind='int', signal=True, n_covs=0, n_batches=0):
+    """Build a CellData plus sample-level phenotype/covariates.
+
+    Returns (data, meta) where meta has y (Series), covs (DataFrame|None),
+    batches (Series|None), props, cluster.
+    """
+    X, cl = mixture_points(n_cells, dim=dim, n_clusters=n_clusters, seed=seed,
+                           cluster_sorted=cluster_sorted)
+    A = fuzzy_knn_graph(X, k=k, dtype=graph_dtype)
+    sid, props = assign_samples(cl, n_samples, seed=seed)
+    labels = np.arange(n_samples)
+    if sid_kind == 'str':
+        names = np.array(['s%03d' % i for i in range(n_samples)])
+        sid_col = names[sid]
+        index = pd.Index(names)
+    elif sid_kind == 'cat':
+        names = np.array(['s%03d' % i for i in range(n_samples)])
+        sid_col = pd.Categorical(names[sid], categories=list(names))
+        index = pd.Index(names)
+    else:
+        sid_col = sid
+        index = pd.Index(labels)
+    obs = pd.DataFrame({sid_name: sid_col},
+                       index=pd.Index(['cell_%d' % i for i in range(n_cells)], name='cell'))
+    data = CellData(obs, A)
+    rs = np.random.RandomState(seed + 2)
+    if signal:
+        yv = props[:, 0] * 10 + 0.3 * rs.randn(n_samples)
+    else:
+        yv = rs.randn(n_samples)
+    meta = {
+        'y': pd.Series(yv, index=index),
+        'covs': (pd.DataFrame(rs.randn(n_samples, n_covs), index=index,
+                              columns=['cov%d' % j for j in range(n_covs)])
+                 if n_covs else None),
+        'batches': (pd.Series(np.arange(n_samples) % n_batches, index=index)
+                    if n_batches else None),
+        'props': props, 'cluster': cl, 'sid': sid,
+    }
+    return data, meta

@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE (imported from /root/reference,
+this container only) on small synthetic inputs.  Output: tests/golden/*.npz.
+
+    python tests/golden/make_golden.py
+
+Each fixture holds the inputs (CSR arrays, per-cell sample labels, sample-level
+y / covs / batches / donorids, call kwargs as JSON) and every output the reference
+produced (SURVEY.md §8a a20 result fields, per-step diffusion states, data.obs columns,
+progress text).  Fixtures are data only; the reference source is not copied.
+Versions used: see the 'versions' entry of each fixture.
+"""
+import io
+import json
+import os
+import sys
+import contextlib
+import warnings
+
+import numpy as np
+import pandas as pd
+import scipy
+import scipy.sparse as sp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+from refshim import load_reference  # noqa: E402
+import importlib.util  # noqa: E402
+
+_spec = importlib.util.spec_from_file_location('synth', os.path.join(ROOT, 'cna_amd', 'synth.py'))
+synth = importlib.util.module_from_spec(_spec)
+_spec.loader.exec_module(synth)
+
+cna = load_reference()
+from cna.tools._nam import _nam as ref__nam  # noqa: E402
+
+
+def _labels_array(x):
+    x = np.asarray(x)
+    if x.dtype == object:
+        x = x.astype(str)
+    return x
+
+
+def add_isolated_blob(data, meta, n_iso=20, label=None):
+    """Append a far-away blob of cells that all belong to one extra sample."""
+    A = data.obsp['connectivities'].tocsr()
+    n = A.shape[0]
+    rs = np.random.RandomState(7)
+    B = sp.random(n_iso, n_iso, density=0.6, random_state=rs, format='csr', dtype=np.float64)
+    B = B + B.T
+    B.setdiag(0)
+    B.eliminate_zeros()
+    B.data = np.clip(B.data, 0.05, 1.0)
+    A2 = sp.block_diag([A, B.astype(A.dtype)], format='csr')
+    A2.sort_indices()
+    A2.indices = A2.indices.astype(np.int32)
+    A2.indptr = A2.indptr.astype(np.int32)
+    sidcol = data.obs.columns[0]
+    old = data.obs[sidcol]
+    lab = label if label is not None else (int(np.max(old)) + 1)
+    new_obs = pd.DataFrame({sidcol: np.concatenate([np.asarray(old), np.repeat(lab, n_iso)])},
+                           index=pd.Index(['cell_%d' % i for i in range(n + n_iso)], name='cell'))
+    d2 = synth.CellData(new_obs, A2)
+    return d2, lab
+
+
+def result_fields(res):
+    out = {}
+    out['p'] = np.float64(res.p)
+    out['k'] = np.int64(res.k)
+    out['ks'] = np.asarray(res.ks, dtype=np.int64)
+    out['r'] = np.int64(res.r)
+    out['nullminps'] = np.asarray(res.nullminps)
+    out['ncorrs'] = res.ncorrs.values
+    out['kept'] = np.asarray(res.kept, dtype=bool)
+    out['M'] = res.M.values
+    out['nam'] = res.nam.values
+    out['nam_index'] = _labels_array(res.nam.index)
+    out['namresid'] = res.namresid.values
+    out['U'] = res.namresid_sampleXpc.values
+    out['V'] = res.namresid_nbhdXpc.values
+    out['svs'] = res.namresid_svs.values
+    out['varexp'] = res.namresid_varexp.values
+    out['yresid_hat'] = np.asarray(res.yresid_hat)
+    out['yresid'] = np.asarray(res.yresid)
+    out['beta'] = np.asarray(res.beta)
+    out['r2'] = np.float64(res.r2)
+    out['r2_perpc'] = np.asarray(res.r2_perpc)
+    out['nullr2_mean'] = np.float64(res.nullr2_mean)
+    out['nullr2_std'] = np.float64(res.nullr2_std)
+    if res.fdrs is not None:
+        out['fdr_threshold'] = res.fdrs.threshold.values
+        out['fdr_fdr'] = res.fdrs.fdr.values
+        out['fdr_num_detected'] = res.fdrs.num_detected.values.astype(np.int64)
+        out['fdr_5p_t'] = np.float64(np.nan if res.fdr_5p_t is None else res.fdr_5p_t)
+        out['fdr_10p_t'] = np.float64(np.nan if res.fdr_10p_t is None else res.fdr_10p_t)
+    return out
+
+
+def build_cases():
+    cases = []
+
+    def base(name, n=1000, N=20, k=15, seed=0, gen=None, call=None, mutate=None, extras=()):
+        cases.append(dict(name=name, gen=dict(n_cells=n, n_samples=N, k=k, seed=seed, **(gen or {})),
+                          call=dict(call or {}), mutate=mutate, extras=tuple(extras)))
+
+    base('c01_plain_f32', call=dict(nsteps=3, Nnull=200, seed=0), extras=('steps', 'diffuse', 'svd', 'nam', 'progress'))
+    base('c02_covs_autostop', seed=1, gen=dict(n_covs=2), call=dict(Nnull=150, seed=1), extras=('steps', 'progress'))
+    base('c03_covs_batches', seed=2, N=24, gen=dict(n_covs=1, n_batches=4), call=dict(nsteps=3, Nnull=120, seed=2),
+         extras=('progress', 'nam'))
+    base('c04_donorids', seed=3, N=30, call=dict(nsteps=2, Nnull=100, seed=3), mutate='donorids')
+    base('c05_ks_f64', seed=4, gen=dict(graph_dtype='float64'), call=dict(nsteps=3, Nnull=100, seed=4, ks=[2, 5]),
+         extras=('steps',))
+    base('c06_nnull_cap', n=600, seed=5, call=dict(nsteps=3, Nnull=1300, seed=5))
+    base('c07_no_local', seed=6, call=dict(nsteps=3, Nnull=100, seed=6, local_test=False))
+    base('c08_force_permute_all', seed=7, N=24, gen=dict(n_batches=3),
+         call=dict(nsteps=3, Nnull=100, seed=7, force_permute_all=True))
+    base('c09_y_nan_extra_reordered', seed=8, N=26, gen=dict(n_covs=1), call=dict(nsteps=3, Nnull=100, seed=8),
+         mutate='y_messy')
+    base('c10_categorical_ids', seed=9, gen=dict(sid_kind='cat'), call=dict(nsteps=3, Nnull=100, seed=9))
+    base('c11_string_ids_null_y', seed=10, gen=dict(sid_kind='str', signal=False), call=dict(nsteps=3, Nnull=100, seed=10))
+    base('c12_batchy_qc', seed=11, N=40, n=1200, gen=dict(n_batches=10), call=dict(nsteps=3, Nnull=100, seed=11),
+         mutate='batchy', extras=('nam', 'progress'))
+    base('c13_zero_variance', seed=12, N=22, call=dict(nsteps=3, Nnull=100, seed=12), mutate='isolated')
+    base('c14_selfweight_autostop_unsorted', seed=13, gen=dict(cluster_sorted=False), call=dict(Nnull=100, seed=13),
+         extras=('steps', 'nam_sw2'))
+    base('c15_ridges_custom', seed=14, N=30, gen=dict(n_batches=10, n_covs=1),
+         call=dict(nsteps=3, Nnull=100, seed=14, ridges=[10.0, 1.0, 0.0]), mutate='batchy', extras=('progress',))
+    base('c16_ridge_loop', seed=15, N=30, gen=dict(n_batches=10), call=dict(nsteps=3, Nnull=100, seed=15),
+         mutate='batchy_all', extras=('progress',))
+    return cases
+
+
+def run_case(case):
+    gen = dict(case['gen'])
+    if 'graph_dtype' in gen:
+        gen['graph_dtype'] = np.dtype(gen['graph_dtype']).type
+    data, meta = synth.make_dataset(**gen)
+    y, covs, batches = meta['y'], meta['covs'], meta['batches']
+    donorids = None
+    sid_name = 'id'
+    mut = case['mutate']
+    if mut == 'donorids':
+        N = len(y)
+        donor = np.arange(N) // 2
+        donorids = pd.Series(donor, index=y.index)
+        yv = np.random.RandomState(99).randn(N // 2 + 1)[donor]
+        y = pd.Series(yv + 2.0 * meta['props'][:, 0][donor * 2], index=y.index)
+        # y must be identical within donor
+        y = pd.Series(y.groupby(donorids).transform('first').values, index=y.index)
+    elif mut == 'y_messy':
+        yv = y.copy()
+        yv.iloc[3] = np.nan
+        covs = covs.copy()
+        covs.iloc[7, 0] = np.nan
+        extra = pd.Series([0.5, -0.25], index=pd.Index([1000, 1001]))
+        y = pd.concat([yv, extra])
+        covs = pd.concat([covs, pd.DataFrame({'cov0': [0.1, 0.2]}, index=extra.index)])
+        perm = np.random.RandomState(5).permutation(len(y))
+        y = y.iloc[perm]
+        covs = covs.iloc[perm]   # same order as y: the reference mis-aligns its sample filter otherwise
+    elif mut == 'batchy':
+        # make one cluster's cells come only from batch-0 samples so that batch
+        # kurtosis of those neighbourhoods is extreme (_nam.py:85-99)
+        cl = meta['cluster']
+        b = batches.values
+        sid = np.asarray(data.obs[sid_name]).copy()
+        b0 = np.flatnonzero(b == 0)
+        target = np.flatnonzero(cl == np.bincount(cl).argmax())
+        rs = np.random.RandomState(3)
+        sid[target] = rs.choice(b0, size=len(target))
+        data.obs[sid_name] = sid
+    elif mut == 'batchy_all':
+        # every cluster is populated by the samples of a single batch, so that the
+        # ridge schedule of _nam.py:142-156 has to iterate
+        cl = meta['cluster']
+        b = batches.values
+        sid = np.asarray(data.obs[sid_name]).copy()
+        rs = np.random.RandomState(4)
+        for c in np.unique(cl):
+            members = np.flatnonzero(cl == c)
+            pool = np.flatnonzero(b == (c % (b.max() + 1)))
+            sid[members] = rs.choice(pool, size=len(members))
+        data.obs[sid_name] = sid
+    elif mut == 'isolated':
+        data, lab = add_isolated_blob(data, meta)
+        y = pd.concat([y, pd.Series([np.nan], index=pd.Index([lab]))])
+
+    call = dict(case['call'])
+    out = {}
+    A = data.obsp['connectivities']
+    out['in_indptr'] = A.indptr.astype(np.int64)
+    out['in_indices'] = A.indices.astype(np.int32)
+    out['in_data'] = A.data
+    col = data.obs[sid_name]
+    if isinstance(col.dtype, pd.CategoricalDtype):
+        out['in_sid_codes'] = np.asarray(col.cat.codes)
+        out['in_sid_categories'] = _labels_array(col.cat.categories)
+    else:
+        out['in_sid'] = _labels_array(col.values)
+    out['in_y_index'] = _labels_array(y.index)
+    out['in_y'] = y.values.astype(np.float64)
+    if covs is not None:
+        out['in_covs_index'] = _labels_array(covs.index)
+        out['in_covs'] = covs.values.astype(np.float64)
+        out['in_covs_columns'] = _labels_array(covs.columns)
+    if batches is not None:
+        out['in_batches_index'] = _labels_array(batches.index)
+        out['in_batches'] = batches.values
+    if donorids is not None:
+        out['in_donorids_index'] = _labels_array(donorids.index)
+        out['in_donorids'] = donorids.values
+
+    extras = case['extras']
+    # ---- the headline call
+    buf = io.StringIO()
+    raised = None
+    res = None
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter('always')
+        with contextlib.redirect_stdout(buf):
+            try:
+                res = cna.tl.association(data, y, sid_name, batches=batches, covs=covs, donorids=donorids,
+                                         return_full=True, show_progress=('progress' in extras), **call)
+            except Exception as e:  # reference quirk: local_test=False dies at _association.py:235
+                raised = e
+    out['stdout'] = np.array(buf.getvalue())
+    out['warnings'] = np.array(json.dumps([str(w.message) for w in wlist
+                                           if issubclass(w.category, UserWarning)]))
+    out['raised'] = np.array('' if raised is None else type(raised).__name__ + ': ' + str(raised))
+    if 'coef' in data.obs:
+        out['obs_coef'] = data.obs['coef'].values.astype(np.float64)
+    if res is not None:
+        out.update(result_fields(res))
+        if res.fdrs is not None:
+            out['obs_coef_fdr'] = data.obs['coef_fdr'].values.astype(np.float64)
+
+    # ---- extras
+    if 'steps' in extras:
+        # per-step diffusion state of the sample indicators, as _nam.py:51,58 drives it
+        S = pd.get_dummies(data.obs[sid_name])
+        nst = call.get('nsteps') or 4
+        steps = []
+        for i, s in enumerate(cna.tl.diffuse_stepwise(data, S, maxnsteps=nst)):
+            steps.append(np.asarray(s, dtype=np.float64))
+        out['steps'] = np.stack(steps)
+        import scipy.stats as st
+        C = S.sum(axis=0).values
+        out['steps_medkurt'] = np.array([np.median(st.kurtosis(s / C, axis=1)) for s in steps])
+    if 'diffuse' in extras:
+        rs = np.random.RandomState(11)
+        s0 = rs.rand(A.shape[0], 3)
+        out['diffuse_in'] = s0
+        out['diffuse_out_2'] = np.asarray(cna.tl.diffuse(data, s0, 2))
+        out['diffuse_out_2_sw05'] = np.asarray(cna.tl.diffuse(data, s0, 2, self_weight=0.5))
+    if 'svd' in extras and res is not None:
+        U, svs, V = cna.tl.svd_nam(res.nam)
+        out['svd_U'] = U.values
+        out['svd_svs'] = svs.values
+        out['svd_V'] = V.values
+    if 'nam' in extras:
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            NAM, keep = cna.tl.nam(data, sid_name, batches=batches, nsteps=call.get('nsteps'),
+                                   show_progress=True)
+        out['tlnam'] = NAM.values
+        out['tlnam_index'] = _labels_array(NAM.index)
+        out['tlnam_keep'] = np.asarray(keep, dtype=bool)
+        out['tlnam_stdout'] = np.array(buf.getvalue())
+    if 'nam_sw2' in extras:
+        NAM, keep = cna.tl.nam(data, sid_name, nsteps=2, self_weight=2)
+        out['tlnam_sw2'] = NAM.values
+
+    out['call'] = np.array(json.dumps(call))
+    out['sid_name'] = np.array(sid_name)
+    out['versions'] = np.array(json.dumps(dict(numpy=np.__version__, scipy=scipy.__version__,
+                                               pandas=pd.__version__, python=sys.version.split()[0],
+                                               cna='0.2.3 (/root/reference)')))
+    return out
+
+
+def main():
+    only = set(sys.argv[1:])
+    for case in build_cases():
+        if only and case['name'] not in only:
+            continue
+        out = run_case(case)
+        path = os.path.join(HERE, case['name'] + '.npz')
+        np.savez_compressed(path, **out)
+        if 'p' in out:
+            print('%-36s p=%.6g k=%d kept=%d/%d steps=%s  %.0f KB' % (
+                case['name'], out['p'], out['k'], out['kept'].sum(), len(out['kept']),
+                out['stdout'].item().count('taking step') or '-', os.path.getsize(path) / 1024))
+        else:
+            print('%-36s raised %s' % (case['name'], out['raised']))
+
+
+if __name__ == '__main__':
+    main()
