@@ -1,0 +1,99 @@
+"""ctypes binding of libcna_hip.so (ABI: include/cna_hip.h).
+
+There is deliberately no fallback: if the shared library has not been built, or no GPU is
+visible, every call raises.  Build with ``python -c "import __graft_entry__ as g; g.build()"``
+(or ``make -C cna_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libcna_hip.so')
+
+c_ctx = C.c_void_p
+c_i64p = C.POINTER(C.c_int64)
+c_i32p = C.POINTER(C.c_int32)
+c_f64p = C.POINTER(C.c_double)
+c_u8p = C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes); one entry per function declared in include/cna_hip.h
+SIGNATURES = {
+    'cna_last_error': (C.c_char_p, []),
+    'cna_abi_version': (C.c_int, []),
+    'cna_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'cna_ctx_create': (C.c_int, [C.c_int, C.POINTER(c_ctx)]),
+    'cna_ctx_destroy': (C.c_int, [c_ctx]),
+    'cna_ctx_sync': (C.c_int, [c_ctx]),
+    'cna_ctx_device_bytes': (C.c_int, [c_ctx, c_i64p]),
+    'cna_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'cna_comm_init': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p]),
+    'cna_graph_upload': (C.c_int, [c_ctx, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int]),
+    'cna_colsums': (C.c_int, [c_ctx, C.c_double]),
+    'cna_fetch_colsums': (C.c_int, [c_ctx, C.c_void_p]),
+    'cna_set_samples': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p]),
+    'cna_nam_step': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int]),
+    'cna_fetch_cell_stat': (C.c_int, [c_ctx, C.c_void_p, C.c_int64]),
+    'cna_dense_load': (C.c_int, [c_ctx, C.c_void_p, C.c_int]),
+    'cna_dense_step': (C.c_int, [c_ctx]),
+    'cna_dense_fetch': (C.c_int, [c_ctx, C.c_void_p]),
+    'cna_batch_kurtosis': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int]),
+    'cna_zero_variance': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, c_i64p]),
+    'cna_select': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
+    'cna_upload_x': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_int]),
+    'cna_resid_apply': (C.c_int, [c_ctx, C.c_void_p, C.c_int]),
+    'cna_standardize': (C.c_int, [c_ctx, C.c_int]),
+    'cna_gram': (C.c_int, [c_ctx, C.c_void_p]),
+    'cna_project': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p]),
+    'cna_ncorrs': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, c_f64p]),
+    'cna_null_local': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'cna_obs_counts': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'cna_percell_fdr': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'cna_matrix_shape': (C.c_int, [c_ctx, C.c_int, c_i64p, C.POINTER(C.c_int)]),
+    'cna_fetch_matrix': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int]),
+    'cna_allgather_host': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+    'cna_prof_enable': (C.c_int, [c_ctx, C.c_int]),
+    'cna_prof_reset': (C.c_int, [c_ctx]),
+    'cna_prof_get': (C.c_int, [c_ctx, C.c_int, c_f64p, c_i64p]),
+    'cna_kernel_name': (C.c_char_p, [C.c_int]),
+}
+
+MAT_NAM, MAT_X = 0, 1
+KERNELS = ['colsum', 'nam_first', 'nam_step', 'batch_kurtosis', 'zero_variance', 'select', 'resid_xb',
+           'standardize', 'gram', 'gram_reduce', 'ncorrs', 'null_local', 'obs_counts', 'percell_fdr',
+           'project_xb', 'transpose', 'rccl']
+
+_lib = None
+
+
+class CnaHipError(RuntimeError):
+    """A libcna_hip.so entry point returned a non-zero status."""
+
+
+def load():
+    """dlopen the library and attach prototypes.  Raises if it is missing -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CnaHipError(
+            'libcna_hip.so is not built (%s).  cna_amd has no CPU path; build the HIP library with '
+            '`python -c "import __graft_entry__ as g; g.build()"` or `make -C cna_amd/csrc`.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().cna_last_error()
+        raise CnaHipError('%s failed (status %d): %s' % (what, status, msg.decode() if msg else '?'))
+
+
+def ptr(a):
+    """Raw data pointer of a C-contiguous numpy array (or None)."""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

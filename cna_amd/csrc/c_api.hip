@@ -1,0 +1,795 @@
+// extern "C" entry points of libcna_hip.so (see include/cna_hip.h for the contract).
+#include "common.h"
+#include <cmath>
+#include <cstring>
+
+int comm_destroy(cna_ctx* c);
+
+static thread_local std::string g_err;
+void cna_set_error(const std::string& msg) { g_err = msg; }
+
+// ------------------------------------------------------------------ memory / profiling
+int dev_alloc(cna_ctx* c, void** p, size_t bytes) {
+  *p = nullptr;
+  if (bytes == 0) bytes = 256;
+  hipError_t e = hipMalloc(p, bytes);
+  if (e != hipSuccess) {
+    cna_set_error(std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    return CNA_ENOMEM;
+  }
+  c->dev_bytes += (int64_t)bytes;
+  return 0;
+}
+int dev_free(cna_ctx* c, void* p, size_t bytes) {
+  if (p) {
+    (void)hipFree(p);
+    c->dev_bytes -= (int64_t)(bytes ? bytes : 256);
+  }
+  return 0;
+}
+int dev_reserve(cna_ctx* c, void** p, int64_t* cap, int64_t need) {
+  if (need <= *cap && *p) return 0;
+  if (*p) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(c, *p, (size_t)*cap);
+    *p = nullptr;
+    *cap = 0;
+  }
+  if (need < 256) need = 256;
+  CNA_TRY(dev_alloc(c, p, (size_t)need));
+  *cap = need;
+  return 0;
+}
+
+static hipEvent_t ev_get(cna_ctx* c) {
+  if (!c->ev_pool.empty()) {
+    hipEvent_t e = c->ev_pool.back();
+    c->ev_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void prof_begin(cna_ctx* c, int kid) {
+  ProfSpan s;
+  s.kid = kid;
+  s.a = ev_get(c);
+  s.b = ev_get(c);
+  (void)hipEventRecord(s.a, c->stream);
+  c->prof_pending.push_back(s);
+}
+void prof_end(cna_ctx* c, int kid) {
+  for (size_t i = c->prof_pending.size(); i-- > 0;) {
+    if (c->prof_pending[i].kid == kid) {
+      (void)hipEventRecord(c->prof_pending[i].b, c->stream);
+      return;
+    }
+  }
+}
+static void prof_flush(cna_ctx* c) {
+  if (c->prof_pending.empty()) return;
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& s : c->prof_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      c->prof_ms[s.kid] += ms;
+      c->prof_n[s.kid] += 1;
+    }
+    c->ev_pool.push_back(s.a);
+    c->ev_pool.push_back(s.b);
+  }
+  c->prof_pending.clear();
+}
+
+static const char* kKernelNames[CNA_K_COUNT] = {
+    "colsum", "nam_first", "nam_step", "batch_kurtosis", "zero_variance", "select", "resid_xb",
+    "standardize", "gram", "gram_reduce", "ncorrs", "null_local", "obs_counts", "percell_fdr",
+    "project_xb", "transpose", "rccl"};
+
+#define CHECK_CTX(c)                                        \
+  do {                                                      \
+    if (!(c)) CNA_FAIL(CNA_EINVAL, "null context");         \
+    HIP_TRY(hipSetDevice((c)->device));                     \
+  } while (0)
+
+// scratch layout helper: carve 256-byte aligned pieces out of c->scratch
+struct Carver {
+  char* base;
+  int64_t off = 0;
+  explicit Carver(void* p) : base((char*)p) {}
+  template <typename T>
+  T* take(int64_t count) {
+    T* r = (T*)(base + off);
+    off += round_up64((int64_t)sizeof(T) * count, 256);
+    return r;
+  }
+};
+static int64_t carve_bytes(std::initializer_list<int64_t> sizes) {
+  int64_t t = 0;
+  for (auto s : sizes) t += round_up64(s, 256);
+  return t;
+}
+
+
+// concatenate count_local doubles from every rank (rank order) into a host buffer
+static int ragged_gather(cna_ctx* c, const double* src_dev, int64_t count_local, double* out, int64_t n_expected) {
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, 256 * 2 + 8 * c->nranks));
+  int64_t* cnt_dev = (int64_t*)c->scratch;
+  std::vector<int64_t> cnt(c->nranks, 0);
+  cnt[c->rank] = count_local;
+  HIP_TRY(hipMemcpyAsync(cnt_dev, cnt.data(), 8 * c->nranks, hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(comm_allreduce_i64_sum(c, cnt_dev, c->nranks));
+  HIP_TRY(hipMemcpyAsync(cnt.data(), cnt_dev, 8 * c->nranks, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int64_t mx = 1, tot = 0;
+  for (auto v : cnt) { mx = std::max(mx, v); tot += v; }
+  if (tot != n_expected) CNA_FAIL(CNA_EINVAL, "ragged gather: expected total does not match the ranks' counts");
+  CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, 8 * mx * c->nranks));
+  double* all = (double*)c->scratch2;
+  if (count_local > 0)
+    HIP_TRY(hipMemcpyAsync(all + mx * c->rank, src_dev, 8 * count_local, hipMemcpyDeviceToDevice, c->stream));
+  CNA_TRY(comm_allgather_bytes(c, all + mx * c->rank, all, 8 * mx));
+  std::vector<double> host(mx * c->nranks);
+  HIP_TRY(hipMemcpyAsync(host.data(), all, 8 * mx * c->nranks, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  int64_t o = 0;
+  for (int r = 0; r < c->nranks; ++r) {
+    std::memcpy(out + o, host.data() + mx * r, 8 * cnt[r]);
+    o += cnt[r];
+  }
+  return 0;
+}
+
+extern "C" {
+
+const char* cna_last_error(void) { return g_err.c_str(); }
+int cna_abi_version(void) { return 1; }
+const char* cna_kernel_name(int k) { return (k >= 0 && k < CNA_K_COUNT) ? kKernelNames[k] : "?"; }
+
+int cna_device_count(int* count) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    cna_set_error(std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    return (int)e;
+  }
+  *count = n;
+  return 0;
+}
+
+int cna_ctx_create(int device, cna_ctx** out) {
+  if (!out) CNA_FAIL(CNA_EINVAL, "null out pointer");
+  *out = nullptr;
+  int n = 0;
+  CNA_TRY(cna_device_count(&n));
+  if (n <= 0) CNA_FAIL(CNA_EINVAL, "no HIP device visible: cna_amd has no CPU fallback");
+  if (device < 0 || device >= n) CNA_FAIL(CNA_EINVAL, "device index out of range");
+  HIP_TRY(hipSetDevice(device));
+  cna_ctx* c = new cna_ctx();
+  c->device = device;
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    cna_set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    return (int)e;
+  }
+  *out = c;
+  return 0;
+}
+
+int cna_ctx_destroy(cna_ctx* c) {
+  if (!c) return 0;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  prof_flush(c);
+  comm_destroy(c);
+  void* bufs[] = {c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+                  c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+int cna_ctx_sync(cna_ctx* c) {
+  CHECK_CTX(c);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int cna_ctx_device_bytes(cna_ctx* c, int64_t* bytes) {
+  if (!c || !bytes) CNA_FAIL(CNA_EINVAL, "null argument");
+  *bytes = c->dev_bytes;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------ graph
+int cna_graph_upload(cna_ctx* c, int64_t n_global, int64_t row0, int64_t n_local, const int64_t* indptr,
+                     const int32_t* indices, const void* data, int data_is_f64) {
+  CHECK_CTX(c);
+  if (n_global <= 0 || n_local < 0 || row0 < 0 || row0 + n_local > n_global || !indptr)
+    CNA_FAIL(CNA_EINVAL, "cna_graph_upload: bad shape");
+  const int64_t rpr = (n_global + c->nranks - 1) / c->nranks;
+  if (row0 != (int64_t)c->rank * rpr && !(n_local == 0))
+    CNA_FAIL(CNA_EINVAL, "cna_graph_upload: row0 must be rank*ceil(n/nranks)");
+  const int64_t want_local = std::max<int64_t>(0, std::min(rpr, n_global - (int64_t)c->rank * rpr));
+  if (n_local != want_local) CNA_FAIL(CNA_EINVAL, "cna_graph_upload: n_local must be the rank's block size");
+  if (indptr[0] != 0) CNA_FAIL(CNA_EINVAL, "cna_graph_upload: indptr must be rebased to start at 0");
+  const int64_t nnz = indptr[n_local];
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->indptr) dev_free(c, c->indptr, sizeof(int64_t) * (c->n_local + 1));
+  if (c->indices) dev_free(c, c->indices, sizeof(int32_t) * c->nnz);
+  if (c->data) dev_free(c, c->data, (c->data_f64 ? 8 : 4) * c->nnz);
+  if (c->colsum) dev_free(c, c->colsum, sizeof(double) * c->n_pad);
+  if (c->stat) dev_free(c, c->stat, sizeof(double) * c->n_pad);
+  c->indptr = nullptr; c->indices = nullptr; c->data = nullptr; c->colsum = nullptr; c->stat = nullptr;
+  c->n_global = n_global;
+  c->row0 = (int64_t)c->rank * rpr;
+  c->n_local = n_local;
+  c->rows_per_rank = rpr;
+  c->n_pad = rpr * c->nranks;
+  c->nnz = nnz;
+  c->data_f64 = data_is_f64 ? 1 : 0;
+  const size_t vb = data_is_f64 ? 8 : 4;
+  CNA_TRY(dev_alloc(c, (void**)&c->indptr, sizeof(int64_t) * (n_local + 1)));
+  CNA_TRY(dev_alloc(c, (void**)&c->indices, sizeof(int32_t) * nnz));
+  CNA_TRY(dev_alloc(c, (void**)&c->data, vb * nnz));
+  CNA_TRY(dev_alloc(c, (void**)&c->colsum, sizeof(double) * c->n_pad));
+  CNA_TRY(dev_alloc(c, (void**)&c->stat, sizeof(double) * c->n_pad));
+  HIP_TRY(hipMemcpy(c->indptr, indptr, sizeof(int64_t) * (n_local + 1), hipMemcpyHostToDevice));
+  if (nnz > 0) {
+    HIP_TRY(hipMemcpy(c->indices, indices, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->data, data, vb * nnz, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(hipMemset(c->stat, 0, sizeof(double) * c->n_pad));
+  c->have_colsum = false;
+  c->t_valid = false;
+  c->nam_valid = false;
+  c->x_valid = false;
+  c->ncorrs_valid = false;
+  c->steps_done = 0;
+  return 0;
+}
+
+int cna_colsums(cna_ctx* c, double self_weight) {
+  CHECK_CTX(c);
+  if (!c->indptr) CNA_FAIL(CNA_ESTATE, "cna_colsums before cna_graph_upload");
+  c->self_weight = self_weight;
+  CNA_TRY(launch_colsum(c));
+  CNA_TRY(comm_allreduce_f64_sum(c, c->colsum, (size_t)c->n_pad));
+  CNA_TRY(launch_add_scalar(c, c->colsum, c->n_global, self_weight));
+  c->have_colsum = true;
+  return 0;
+}
+
+int cna_fetch_colsums(cna_ctx* c, double* out) {
+  CHECK_CTX(c);
+  if (!c->have_colsum) CNA_FAIL(CNA_ESTATE, "colsums not computed");
+  HIP_TRY(hipMemcpyAsync(out, c->colsum, sizeof(double) * c->n_global, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+static int ensure_T(cna_ctx* c, int ld) {
+  const int64_t need = (int64_t)sizeof(double) * c->n_pad * ld;
+  if (need > c->t_cap || !c->T[0]) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 2; ++i) {
+      if (c->T[i]) dev_free(c, c->T[i], (size_t)c->t_cap);
+      c->T[i] = nullptr;
+    }
+    for (int i = 0; i < 2; ++i) {
+      CNA_TRY(dev_alloc(c, (void**)&c->T[i], (size_t)need));
+      HIP_TRY(hipMemsetAsync(c->T[i], 0, (size_t)need, c->stream));
+    }
+    c->t_cap = need;
+  }
+  return 0;
+}
+
+// -------------------------------------------------------------------------------- NAM
+int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const double* counts) {
+  CHECK_CTX(c);
+  if (!c->indptr) CNA_FAIL(CNA_ESTATE, "cna_set_samples before cna_graph_upload");
+  if (n_samples < 1 || n_samples > 512) CNA_FAIL(CNA_EINVAL, "n_samples must be in [1, 512]");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->sid) dev_free(c, c->sid, sizeof(int32_t) * c->n_global);
+  if (c->counts) dev_free(c, c->counts, sizeof(double) * c->N);
+  c->sid = nullptr; c->counts = nullptr;
+  c->N = n_samples;
+  c->ld = round_up(n_samples, 4);
+  CNA_TRY(dev_alloc(c, (void**)&c->sid, sizeof(int32_t) * c->n_global));
+  CNA_TRY(dev_alloc(c, (void**)&c->counts, sizeof(double) * n_samples));
+  HIP_TRY(hipMemcpy(c->sid, codes, sizeof(int32_t) * c->n_global, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->counts, counts, sizeof(double) * n_samples, hipMemcpyHostToDevice));
+  CNA_TRY(ensure_T(c, c->ld));
+  void* nm = c->nam;
+  CNA_TRY(dev_reserve(c, &nm, &c->nam_cap, (int64_t)sizeof(double) * std::max<int64_t>(c->n_local, 1) * c->ld));
+  c->nam = (double*)nm;
+  c->t_width = c->N;
+  c->t_ld = c->ld;
+  c->t_cur = 0;
+  c->steps_done = 0;
+  c->t_valid = false;
+  c->nam_valid = false;
+  c->x_valid = false;
+  return 0;
+}
+
+static int exchange_state(cna_ctx* c, double* T) {
+  if (c->nranks == 1) return 0;
+  const size_t block = sizeof(double) * (size_t)c->rows_per_rank * c->t_ld;
+  return comm_allgather_bytes(c, (char*)T + block * c->rank, T, block);
+}
+static int exchange_stat(cna_ctx* c) {
+  if (c->nranks == 1) return 0;
+  const size_t block = sizeof(double) * (size_t)c->rows_per_rank;
+  return comm_allgather_bytes(c, (char*)c->stat + block * c->rank, c->stat, block);
+}
+
+int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
+  CHECK_CTX(c);
+  if (!c->sid || !c->have_colsum) CNA_FAIL(CNA_ESTATE, "cna_nam_step needs cna_colsums and cna_set_samples");
+  if (c->t_ld != c->ld) CNA_FAIL(CNA_ESTATE, "state buffers hold a dense diffusion; call cna_set_samples again");
+  const bool first = c->steps_done == 0;
+  if (!first && !c->t_valid) CNA_FAIL(CNA_ESTATE, "previous step did not keep its state (may_continue=0)");
+  CNA_TRY(launch_nam_step(c, first, want_kurt != 0, may_continue != 0, may_stop != 0, false));
+  if (may_continue) {
+    CNA_TRY(exchange_state(c, c->T[c->t_cur ^ 1]));
+    c->t_cur ^= 1;
+  }
+  c->t_valid = may_continue != 0;
+  c->nam_valid = may_stop != 0;
+  c->steps_done += 1;
+  if (want_kurt) {
+    c->stat_space = CNA_MAT_NAM;
+    CNA_TRY(exchange_stat(c));
+  }
+  return 0;
+}
+
+int cna_fetch_cell_stat(cna_ctx* c, double* out, int64_t n_expected) {
+  CHECK_CTX(c);
+  if (c->stat_space == CNA_MAT_NAM) {
+    if (n_expected != c->n_global) CNA_FAIL(CNA_EINVAL, "cna_fetch_cell_stat: expected n_global entries");
+    HIP_TRY(hipMemcpyAsync(out, c->stat, sizeof(double) * c->n_global, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  if (c->stat_space != CNA_MAT_X) CNA_FAIL(CNA_ESTATE, "no per-cell statistic available");
+  if (c->nranks == 1) {
+    if (n_expected != c->nx) CNA_FAIL(CNA_EINVAL, "cna_fetch_cell_stat: expected nx entries");
+    HIP_TRY(hipMemcpyAsync(out, c->stat, sizeof(double) * c->nx, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  return ragged_gather(c, c->stat, c->nx, out, n_expected);
+}
+
+// --------------------------------------------------------------------- dense diffusion
+int cna_dense_load(cna_ctx* c, const double* s_local, int m) {
+  CHECK_CTX(c);
+  if (!c->have_colsum) CNA_FAIL(CNA_ESTATE, "cna_dense_load needs cna_colsums");
+  if (m < 1 || m > 512) CNA_FAIL(CNA_EINVAL, "dense state must have 1..512 columns");
+  const int ld = round_up(m, 4);
+  CNA_TRY(ensure_T(c, ld));
+  void* ds = c->dense_s;
+  CNA_TRY(dev_reserve(c, &ds, &c->dense_cap, (int64_t)sizeof(double) * std::max<int64_t>(c->n_local, 1) * ld));
+  c->dense_s = (double*)ds;
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, (int64_t)sizeof(double) * std::max<int64_t>(c->n_local, 1) * m));
+  HIP_TRY(hipMemcpyAsync(c->scratch, s_local, sizeof(double) * c->n_local * m, hipMemcpyHostToDevice, c->stream));
+  c->t_width = m;
+  c->t_ld = ld;
+  c->t_cur = 0;
+  CNA_TRY(launch_scale_rows(c, (const double*)c->scratch, c->T[0], m, ld));
+  CNA_TRY(exchange_state(c, c->T[0]));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->t_valid = true;
+  c->nam_valid = false;
+  c->steps_done = 1;  // never take the one-hot path
+  return 0;
+}
+
+int cna_dense_step(cna_ctx* c) {
+  CHECK_CTX(c);
+  if (!c->t_valid || !c->dense_s) CNA_FAIL(CNA_ESTATE, "cna_dense_step before cna_dense_load");
+  CNA_TRY(launch_nam_step(c, false, false, true, false, true));
+  CNA_TRY(exchange_state(c, c->T[c->t_cur ^ 1]));
+  c->t_cur ^= 1;
+  return 0;
+}
+
+int cna_dense_fetch(cna_ctx* c, double* out) {
+  CHECK_CTX(c);
+  if (!c->dense_s) CNA_FAIL(CNA_ESTATE, "no dense state");
+  if (c->n_local > 0)
+    HIP_TRY(hipMemcpy2DAsync(out, sizeof(double) * c->t_width, c->dense_s, sizeof(double) * c->t_ld,
+                             sizeof(double) * c->t_width, c->n_local, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------ QC / select
+int cna_batch_kurtosis(cna_ctx* c, int which, const int32_t* batch_codes, int n_batches) {
+  CHECK_CTX(c);
+  const double* mat;
+  int64_t rows;
+  int ncols, ld;
+  double* out;
+  if (which == CNA_MAT_NAM) {
+    if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+    mat = c->nam; rows = c->n_local; ncols = c->N; ld = c->ld; out = c->stat + c->row0;
+  } else if (which == CNA_MAT_X) {
+    if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+    mat = c->X; rows = c->nx; ncols = c->Nx; ld = c->ldx; out = c->stat;
+    if (c->nx > c->n_pad) CNA_FAIL(CNA_EINVAL, "X larger than the stat buffer");
+  } else {
+    CNA_FAIL(CNA_EINVAL, "bad matrix selector");
+  }
+  if (n_batches < 1) CNA_FAIL(CNA_EINVAL, "n_batches < 1");
+  std::vector<int32_t> order, boff(n_batches + 1, 0);
+  for (int s = 0; s < ncols; ++s)
+    if (batch_codes[s] >= 0 && batch_codes[s] < n_batches) boff[batch_codes[s] + 1]++;
+  for (int b = 0; b < n_batches; ++b) boff[b + 1] += boff[b];
+  order.resize(std::max(boff[n_batches], 1));
+  std::vector<int32_t> cur(boff.begin(), boff.end() - 1);
+  for (int s = 0; s < ncols; ++s)
+    if (batch_codes[s] >= 0 && batch_codes[s] < n_batches) order[cur[batch_codes[s]]++] = s;
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({(int64_t)4 * (int64_t)order.size(), 4 * (n_batches + 1)})));
+  Carver cv(c->scratch);
+  int32_t* order_dev = cv.take<int32_t>(order.size());
+  int32_t* boff_dev = cv.take<int32_t>(n_batches + 1);
+  HIP_TRY(hipMemcpyAsync(order_dev, order.data(), 4 * order.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(boff_dev, boff.data(), 4 * (n_batches + 1), hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(launch_batch_kurtosis(c, mat, rows, ncols, ld, order_dev, boff_dev, n_batches, out));
+  c->stat_space = which;
+  if (which == CNA_MAT_NAM) CNA_TRY(exchange_stat(c));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // host vectors go out of scope
+  return 0;
+}
+
+int cna_zero_variance(cna_ctx* c, const int32_t* colmap, int n_sel, uint8_t* flags_out, int64_t* n_zero_out) {
+  CHECK_CTX(c);
+  if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+  if (!colmap) n_sel = c->N;
+  if (n_sel < 1) CNA_FAIL(CNA_EINVAL, "no samples selected");
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({4 * (int64_t)n_sel, c->n_pad, 8})));
+  Carver cv(c->scratch);
+  int32_t* cm = cv.take<int32_t>(n_sel);
+  uint8_t* flags = cv.take<uint8_t>(c->n_pad);        // all cells; this rank fills [row0, row0+n_local)
+  unsigned long long* cnt = cv.take<unsigned long long>(1);
+  if (colmap) HIP_TRY(hipMemcpyAsync(cm, colmap, 4 * n_sel, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(cnt, 0, 8, c->stream));
+  HIP_TRY(hipMemsetAsync(flags, 0, c->n_pad, c->stream));
+  CNA_TRY(launch_zero_variance(c, colmap ? cm : nullptr, n_sel, flags + c->row0, cnt));
+  CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)cnt, 1));
+  unsigned long long h = 0;
+  HIP_TRY(hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n_zero_out) *n_zero_out = (int64_t)h;
+  if (flags_out) {
+    if (h == 0) {
+      std::memset(flags_out, 0, c->n_global);
+    } else {
+      if (c->nranks > 1)
+        CNA_TRY(comm_allgather_bytes(c, flags + c->rows_per_rank * c->rank, flags, (size_t)c->rows_per_rank));
+      HIP_TRY(hipMemcpyAsync(flags_out, flags, c->n_global, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+  }
+  return 0;
+}
+
+int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel) {
+  CHECK_CTX(c);
+  if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+  const int64_t nx = keep_idx ? n_keep : c->n_local;
+  const int Nx = colmap ? n_sel : c->N;
+  if (nx < 0 || nx > c->n_local || Nx < 1) CNA_FAIL(CNA_EINVAL, "cna_select: bad sizes");
+  c->nx = nx;
+  c->Nx = Nx;
+  c->ldx = round_up(Nx, 4);
+  void* xp = c->X;
+  CNA_TRY(dev_reserve(c, &xp, &c->x_cap, (int64_t)sizeof(double) * std::max<int64_t>(nx, 1) * c->ldx));
+  c->X = (double*)xp;
+  if (keep_idx) {
+    void* kp = c->keep_store;
+    CNA_TRY(dev_reserve(c, &kp, &c->keep_cap, 8 * std::max<int64_t>(nx, 1)));
+    c->keep_store = (int64_t*)kp;
+    HIP_TRY(hipMemcpyAsync(c->keep_store, keep_idx, 8 * nx, hipMemcpyHostToDevice, c->stream));
+    c->keep_idx = c->keep_store;
+  } else {
+    c->keep_idx = nullptr;   // identity: every local NAM row
+  }
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, 4 * (int64_t)Nx + 256));
+  int32_t* cm = (int32_t*)c->scratch;
+  if (colmap) HIP_TRY(hipMemcpyAsync(cm, colmap, 4 * Nx, hipMemcpyHostToDevice, c->stream));
+  int r = launch_select(c, colmap ? cm : nullptr);
+  CNA_TRY(r);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->x_valid = true;
+  c->x_from_nam = true;
+  c->ncorrs_valid = false;
+  return 0;
+}
+
+int cna_upload_x(cna_ctx* c, const double* x_local, int64_t n_rows, int n_cols) {
+  CHECK_CTX(c);
+  if (n_rows < 0 || n_cols < 1 || n_cols > 512) CNA_FAIL(CNA_EINVAL, "cna_upload_x: bad shape");
+  c->nx = n_rows;
+  c->Nx = n_cols;
+  c->ldx = round_up(n_cols, 4);
+  void* xp = c->X;
+  CNA_TRY(dev_reserve(c, &xp, &c->x_cap, (int64_t)sizeof(double) * std::max<int64_t>(n_rows, 1) * c->ldx));
+  c->X = (double*)xp;
+  HIP_TRY(hipMemsetAsync(c->X, 0, sizeof(double) * std::max<int64_t>(n_rows, 1) * c->ldx, c->stream));
+  if (n_rows > 0)
+    HIP_TRY(hipMemcpy2DAsync(c->X, sizeof(double) * c->ldx, x_local, sizeof(double) * n_cols,
+                             sizeof(double) * n_cols, n_rows, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->keep_idx = nullptr;
+  c->x_valid = true;
+  c->x_from_nam = false;
+  c->ncorrs_valid = false;
+  return 0;
+}
+
+// ------------------------------------------------------------------- residualise + PCA
+int cna_resid_apply(cna_ctx* c, const double* M, int center) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  const int Nx = c->Nx, ldx = c->ldx;
+  const int ldb = round_up(Nx, 16);
+  std::vector<double> B((size_t)ldx * ldb, 0.0);
+  for (int k = 0; k < Nx; ++k)
+    for (int j = 0; j < Nx; ++j) B[(size_t)k * ldb + j] = M ? M[(size_t)j * Nx + k] : (j == k ? 1.0 : 0.0);
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, (int64_t)sizeof(double) * ldx * ldb));
+  HIP_TRY(hipMemcpyAsync(c->scratch, B.data(), sizeof(double) * ldx * ldb, hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(launch_xb(c, (const double*)c->scratch, ldb, Nx, center != 0, c->X, ldx));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->ncorrs_valid = false;
+  return 0;
+}
+
+int cna_standardize(cna_ctx* c, int center) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  CNA_TRY(launch_standardize(c, center));
+  c->ncorrs_valid = false;
+  return 0;
+}
+
+int cna_gram(cna_ctx* c, double* G_out) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  const int Nx = c->Nx;
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, (int64_t)sizeof(double) * Nx * Nx));
+  double* G = (double*)c->scratch;
+  CNA_TRY(launch_gram(c, G));
+  CNA_TRY(comm_allreduce_f64_sum(c, G, (size_t)Nx * Nx));
+  HIP_TRY(hipMemcpyAsync(G_out, G, sizeof(double) * Nx * Nx, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int cna_project(cna_ctx* c, const double* W, int n_w, double* out_local) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  if (n_w < 1) CNA_FAIL(CNA_EINVAL, "n_w < 1");
+  const int Nx = c->Nx, ldx = c->ldx;
+  const int ldb = round_up(n_w, 16);
+  std::vector<double> B((size_t)ldx * ldb, 0.0);
+  for (int k = 0; k < Nx; ++k)
+    for (int j = 0; j < n_w; ++j) B[(size_t)k * ldb + j] = W[(size_t)k * n_w + j];
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, (int64_t)sizeof(double) * ldx * ldb));
+  HIP_TRY(hipMemcpyAsync(c->scratch, B.data(), sizeof(double) * ldx * ldb, hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, (int64_t)sizeof(double) * std::max<int64_t>(c->nx, 1) * ldb));
+  double* out = (double*)c->scratch2;
+  CNA_TRY(launch_xb(c, (const double*)c->scratch, ldb, n_w, false, out, ldb));
+  if (c->nx > 0)
+    HIP_TRY(hipMemcpy2DAsync(out_local, sizeof(double) * n_w, out, sizeof(double) * ldb, sizeof(double) * n_w,
+                             c->nx, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ------------------------------------------------------------------------- association
+int cna_ncorrs(cna_ctx* c, const double* y, double* out_local, double* max_abs) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  void* np = c->ncorrs;
+  CNA_TRY(dev_reserve(c, &np, &c->ncorrs_cap, 8 * std::max<int64_t>(c->nx, 1)));
+  c->ncorrs = (double*)np;
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({8 * (int64_t)c->Nx, 8})));
+  Carver cv(c->scratch);
+  double* yd = cv.take<double>(c->Nx);
+  unsigned long long* mb = cv.take<unsigned long long>(1);
+  HIP_TRY(hipMemcpyAsync(yd, y, 8 * c->Nx, hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(launch_ncorrs(c, yd, mb));
+  CNA_TRY(comm_allreduce_f64_max(c, (double*)mb, 1));
+  double m = 0.0;
+  HIP_TRY(hipMemcpyAsync(&m, mb, 8, hipMemcpyDeviceToHost, c->stream));
+  if (out_local && c->nx > 0)
+    HIP_TRY(hipMemcpyAsync(out_local, c->ncorrs, 8 * c->nx, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (max_abs) *max_abs = m;
+  c->ncorrs_valid = true;
+  return 0;
+}
+
+static void guess_from_thr(const double* thr, int T, double* thr0, double* inv_step) {
+  *thr0 = T > 0 ? thr[0] : 0.0;
+  const double step = T > 1 ? thr[1] - thr[0] : 0.0;
+  *inv_step = step > 0 ? 1.0 / step : 0.0;
+}
+
+int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int T, int64_t* tails_out) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  if (P < 1 || T < 1) CNA_FAIL(CNA_EINVAL, "cna_null_local: P and T must be positive");
+  for (int t = 1; t < T; ++t)
+    if (!(edges[t] >= edges[t - 1])) CNA_FAIL(CNA_EINVAL, "cna_null_local: edges must ascend");
+  const int Nx = c->Nx, ldx = c->ldx;
+  const int ldy = round_up(P, 64);
+  std::vector<double> Yp((size_t)ldx * ldy, 0.0);
+  for (int k = 0; k < Nx; ++k) std::memcpy(&Yp[(size_t)k * ldy], &Yc[(size_t)k * P], sizeof(double) * P);
+  // invert edges -> thresholds for the linear bin guess (exactness comes from the edge compares)
+  double th[2] = {0, 0};
+  for (int t = 0; t < std::min(T, 2); ++t) th[t] = std::sqrt(std::max(0.0, (edges[t] + 1e-8) / (1.0 - 1e-5)));
+  double thr0, inv_step;
+  guess_from_thr(th, T, &thr0, &inv_step);
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap,
+                      carve_bytes({(int64_t)sizeof(double) * ldx * ldy, 8 * (int64_t)T, 8 * (int64_t)P * T, 8 * (int64_t)P * T})));
+  Carver cv(c->scratch);
+  double* Yd = cv.take<double>((int64_t)ldx * ldy);
+  double* ed = cv.take<double>(T);
+  unsigned long long* hist = cv.take<unsigned long long>((int64_t)P * T);
+  int64_t* tails = cv.take<int64_t>((int64_t)P * T);
+  HIP_TRY(hipMemcpyAsync(Yd, Yp.data(), sizeof(double) * ldx * ldy, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(ed, edges, 8 * T, hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(launch_null_local(c, Yd, ldy, P, ed, T, thr0, inv_step, hist));
+  CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)P * T));
+  CNA_TRY(launch_suffix_sum(c, hist, P, T, tails));
+  HIP_TRY(hipMemcpyAsync(tails_out, tails, 8 * (size_t)P * T, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int cna_obs_counts(cna_ctx* c, const double* edges, const double* thr, int T, int64_t* ranks_out,
+                   int64_t* num_detected_out) {
+  CHECK_CTX(c);
+  if (!c->ncorrs_valid) CNA_FAIL(CNA_ESTATE, "cna_obs_counts needs cna_ncorrs");
+  if (T < 1) CNA_FAIL(CNA_EINVAL, "T < 1");
+  double thr0, inv_step;
+  guess_from_thr(thr, T, &thr0, &inv_step);
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({8 * (int64_t)T, 8 * (int64_t)T, 16 * (int64_t)T, 16 * (int64_t)T})));
+  Carver cv(c->scratch);
+  double* ed = cv.take<double>(T);
+  double* td = cv.take<double>(T);
+  unsigned long long* hist = cv.take<unsigned long long>(2 * T);
+  int64_t* tails = cv.take<int64_t>(2 * T);
+  HIP_TRY(hipMemcpyAsync(ed, edges, 8 * T, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(td, thr, 8 * T, hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(launch_obs_counts(c, ed, td, T, thr0, inv_step, hist));
+  CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)2 * T));
+  CNA_TRY(launch_suffix_sum(c, hist, 2, T, tails));
+  std::vector<int64_t> h(2 * T);
+  HIP_TRY(hipMemcpyAsync(h.data(), tails, 16 * T, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (ranks_out) std::memcpy(ranks_out, h.data(), 8 * T);
+  if (num_detected_out) std::memcpy(num_detected_out, h.data() + T, 8 * T);
+  return 0;
+}
+
+int cna_percell_fdr(cna_ctx* c, const double* thr, const double* runmin_fdr, int T, double* coef_out,
+                    double* fdr_out) {
+  CHECK_CTX(c);
+  if (!c->ncorrs_valid || !c->x_from_nam) CNA_FAIL(CNA_ESTATE, "cna_percell_fdr needs cna_select + cna_ncorrs");
+  const bool want_fdr = fdr_out && thr && runmin_fdr && T > 0;
+  double thr0 = 0, inv_step = 0;
+  if (want_fdr) guess_from_thr(thr, T, &thr0, &inv_step);
+  const int64_t Tn = want_fdr ? T : 1;
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({8 * Tn, 8 * Tn, 8 * c->n_pad, 8 * c->n_pad})));
+  Carver cv(c->scratch);
+  double* td = cv.take<double>(Tn);
+  double* rd = cv.take<double>(Tn);
+  double* coef = cv.take<double>(c->n_pad);
+  double* fdr = cv.take<double>(c->n_pad);
+  if (want_fdr) {
+    HIP_TRY(hipMemcpyAsync(td, thr, 8 * T, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(rd, runmin_fdr, 8 * T, hipMemcpyHostToDevice, c->stream));
+  }
+  CNA_TRY(launch_percell_fdr(c, td, rd, want_fdr ? T : 0, thr0, inv_step, coef + c->row0, want_fdr ? fdr + c->row0 : nullptr));
+  if (c->nranks > 1) {
+    const size_t block = 8 * (size_t)c->rows_per_rank;
+    CNA_TRY(comm_allgather_bytes(c, (char*)coef + block * c->rank, coef, block));
+    if (want_fdr) CNA_TRY(comm_allgather_bytes(c, (char*)fdr + block * c->rank, fdr, block));
+  }
+  if (coef_out) HIP_TRY(hipMemcpyAsync(coef_out, coef, 8 * c->n_global, hipMemcpyDeviceToHost, c->stream));
+  if (want_fdr) HIP_TRY(hipMemcpyAsync(fdr_out, fdr, 8 * c->n_global, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// -------------------------------------------------------------------------------- D2H
+int cna_matrix_shape(cna_ctx* c, int which, int64_t* n_rows_local, int* n_cols) {
+  if (!c) CNA_FAIL(CNA_EINVAL, "null context");
+  if (which == CNA_MAT_NAM) {
+    if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+    *n_rows_local = c->n_local; *n_cols = c->N;
+  } else if (which == CNA_MAT_X) {
+    if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+    *n_rows_local = c->nx; *n_cols = c->Nx;
+  } else {
+    CNA_FAIL(CNA_EINVAL, "bad matrix selector");
+  }
+  return 0;
+}
+
+int cna_fetch_matrix(cna_ctx* c, int which, double* out, int transposed) {
+  CHECK_CTX(c);
+  int64_t rows;
+  int cols;
+  CNA_TRY(cna_matrix_shape(c, which, &rows, &cols));
+  const double* src = which == CNA_MAT_NAM ? c->nam : c->X;
+  const int ld = which == CNA_MAT_NAM ? c->ld : c->ldx;
+  if (rows == 0) return 0;
+  if (transposed) {
+    CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, 8 * rows * cols));
+    CNA_TRY(launch_transpose(c, src, rows, cols, ld, (double*)c->scratch2));
+    HIP_TRY(hipMemcpyAsync(out, c->scratch2, 8 * rows * cols, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    HIP_TRY(hipMemcpy2DAsync(out, 8 * (size_t)cols, src, 8 * (size_t)ld, 8 * (size_t)cols, rows,
+                             hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int cna_allgather_host(cna_ctx* c, const double* local, int64_t count_local, double* out_all, int64_t count_total) {
+  CHECK_CTX(c);
+  if (count_local < 0 || count_total < count_local) CNA_FAIL(CNA_EINVAL, "cna_allgather_host: bad counts");
+  if (c->nranks == 1) {
+    if (count_total != count_local) CNA_FAIL(CNA_EINVAL, "cna_allgather_host: single rank but totals differ");
+    std::memcpy(out_all, local, 8 * count_local);
+    return 0;
+  }
+  void* tmp = nullptr;
+  CNA_TRY(dev_alloc(c, &tmp, 8 * std::max<int64_t>(count_local, 1)));
+  int r = 0;
+  if (count_local > 0) {
+    hipError_t e = hipMemcpyAsync(tmp, local, 8 * count_local, hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) { cna_set_error(hipGetErrorString(e)); r = (int)e; }
+  }
+  if (r == 0) r = ragged_gather(c, (const double*)tmp, count_local, out_all, count_total);
+  (void)hipStreamSynchronize(c->stream);
+  dev_free(c, tmp, 8 * std::max<int64_t>(count_local, 1));
+  return r;
+}
+
+// -------------------------------------------------------------------------- profiling
+int cna_prof_enable(cna_ctx* c, int on) {
+  if (!c) CNA_FAIL(CNA_EINVAL, "null context");
+  if (!on) prof_flush(c);
+  c->prof = on != 0;
+  return 0;
+}
+int cna_prof_reset(cna_ctx* c) {
+  if (!c) CNA_FAIL(CNA_EINVAL, "null context");
+  prof_flush(c);
+  for (int i = 0; i < CNA_K_COUNT; ++i) { c->prof_ms[i] = 0; c->prof_n[i] = 0; }
+  return 0;
+}
+int cna_prof_get(cna_ctx* c, int k, double* total_ms, int64_t* launches) {
+  if (!c || k < 0 || k >= CNA_K_COUNT) CNA_FAIL(CNA_EINVAL, "bad kernel id");
+  prof_flush(c);
+  if (total_ms) *total_ms = c->prof_ms[k];
+  if (launches) *launches = c->prof_n[k];
+  return 0;
+}
+
+}  // extern "C"

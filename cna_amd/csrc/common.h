@@ -1,0 +1,156 @@
+// Shared declarations of libcna_hip.so (gfx950 only).  See include/cna_hip.h for the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/cna_hip.h"
+
+#define WAVE 64
+
+void cna_set_error(const std::string& msg);
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t _e = (expr);                                                                \
+    if (_e != hipSuccess) {                                                                \
+      cna_set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" + __FILE__ +  \
+                    ":" + std::to_string(__LINE__) + ")");                               \
+      return (int)_e;                                                                      \
+    }                                                                                      \
+  } while (0)
+
+#define CNA_TRY(expr)            \
+  do {                           \
+    int _r = (expr);             \
+    if (_r != 0) return _r;      \
+  } while (0)
+
+#define CNA_FAIL(code, msg)      \
+  do {                           \
+    cna_set_error(msg);          \
+    return (code);               \
+  } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct ProfSpan {
+  int kid;
+  hipEvent_t a, b;
+};
+
+struct cna_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int64_t dev_bytes = 0;
+
+  // ---- communicator
+  int rank = 0, nranks = 1;
+  void* comm = nullptr;  // ncclComm_t
+
+  // ---- graph (local row block)
+  int64_t n_global = 0, row0 = 0, n_local = 0, rows_per_rank = 0, n_pad = 0, nnz = 0;
+  int64_t* indptr = nullptr;
+  int32_t* indices = nullptr;
+  void* data = nullptr;
+  int data_f64 = 0;
+  double self_weight = 1.0;
+  double* colsum = nullptr;  // n_pad, replicated
+  bool have_colsum = false;
+
+  // ---- samples
+  int N = 0, ld = 0;
+  int32_t* sid = nullptr;    // n_global
+  double* counts = nullptr;  // N
+
+  // ---- diffusion state: scaled state T = s/colsums for all global rows (neighbour gathers)
+  double* T[2] = {nullptr, nullptr};
+  int64_t t_cap = 0;  // doubles allocated per buffer
+  int t_cur = 0, t_width = 0, t_ld = 0, steps_done = 0;
+  bool t_valid = false;
+  double* dense_s = nullptr;  // unscaled local state of the dense diffusion (n_local x t_ld)
+  int64_t dense_cap = 0;
+
+  // ---- NAM (n_local x ld)
+  double* nam = nullptr;
+  int64_t nam_cap = 0;
+  bool nam_valid = false;
+
+  // ---- X (nx x ldx): selected NAM -> residualised NAM
+  double* X = nullptr;
+  int64_t x_cap = 0;
+  int64_t nx = 0;
+  int Nx = 0, ldx = 0;
+  int64_t* keep_idx = nullptr;    // active map: local NAM row of each X row; null = identity
+  int64_t* keep_store = nullptr;  // allocation behind keep_idx
+  int64_t keep_cap = 0;
+  bool x_valid = false, x_from_nam = false;
+
+  // ---- per-cell vectors
+  double* stat = nullptr;  // n_pad
+  int stat_space = -1;     // CNA_MAT_NAM / CNA_MAT_X
+  double* ncorrs = nullptr;
+  int64_t ncorrs_cap = 0;
+  bool ncorrs_valid = false;
+
+  // ---- scratch
+  void* scratch = nullptr;
+  int64_t scratch_cap = 0;
+  void* scratch2 = nullptr;
+  int64_t scratch2_cap = 0;
+
+  // ---- profiling
+  bool prof = false;
+  double prof_ms[CNA_K_COUNT] = {0};
+  int64_t prof_n[CNA_K_COUNT] = {0};
+  std::vector<ProfSpan> prof_pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+// profiling helpers (c_api.hip)
+void prof_begin(cna_ctx* c, int kid);
+void prof_end(cna_ctx* c, int kid);
+struct ProfScope {
+  cna_ctx* c;
+  int kid;
+  ProfScope(cna_ctx* c_, int k) : c(c_), kid(k) { if (c->prof) prof_begin(c, kid); }
+  ~ProfScope() { if (c->prof) prof_end(c, kid); }
+};
+
+int dev_alloc(cna_ctx* c, void** p, size_t bytes);
+int dev_free(cna_ctx* c, void* p, size_t bytes);
+// grow-only buffer: (re)allocates *p when cap < need (contents discarded)
+int dev_reserve(cna_ctx* c, void** p, int64_t* cap_bytes, int64_t need_bytes);
+
+// ---- collectives (comm.hip)
+int comm_allreduce_f64_sum(cna_ctx* c, double* buf, size_t count);
+int comm_allreduce_f64_max(cna_ctx* c, double* buf, size_t count);
+int comm_allreduce_i64_sum(cna_ctx* c, int64_t* buf, size_t count);
+int comm_allgather_bytes(cna_ctx* c, const void* send, void* recv, size_t bytes_per_rank);
+
+// ---- kernel launchers
+// diffuse.hip
+int launch_colsum(cna_ctx* c);
+int launch_add_scalar(cna_ctx* c, double* v, int64_t n, double s);
+int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool write_nam, bool dense);
+int launch_scale_rows(cna_ctx* c, const double* s_local, double* t_global, int m, int ld);
+// rows.hip
+int launch_batch_kurtosis(cna_ctx* c, const double* mat, int64_t rows, int ncols, int ld,
+                          const int32_t* order_dev, const int32_t* boff_dev, int n_batches, double* out);
+int launch_zero_variance(cna_ctx* c, const int32_t* colmap_dev, int n_sel, uint8_t* flags_dev,
+                         unsigned long long* count_dev);
+int launch_select(cna_ctx* c, const int32_t* colmap_dev);
+int launch_standardize(cna_ctx* c, int center);
+int launch_ncorrs(cna_ctx* c, const double* y_dev, unsigned long long* maxbits_dev);
+int launch_obs_counts(cna_ctx* c, const double* edges_dev, const double* thr_dev, int T, double thr0,
+                      double inv_step, unsigned long long* hist_dev /* 2*T */);
+int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, int64_t* tails);
+int launch_percell_fdr(cna_ctx* c, const double* thr_dev, const double* runmin_dev, int T, double thr0,
+                       double inv_step, double* coef_local, double* fdr_local);
+int launch_transpose(cna_ctx* c, const double* in, int64_t rows, int cols, int ld, double* out);
+// mfma.hip
+int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, double* out, int ld_out);
+int launch_gram(cna_ctx* c, double* G_dev);
+int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* edges_dev, int T,
+                      double thr0, double inv_step, unsigned long long* hist_dev);

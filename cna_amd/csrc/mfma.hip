@@ -1,0 +1,367 @@
+// Dense float64 contractions over the cell-major matrix X (cells x samples) on the gfx950
+// matrix cores, v_mfma_f64_16x16x4_f64:
+//   k_xb    OUT = (X [- rowmean]) . B     residualisation M.NAM (_nam.py:135,148), V = NAM^T U/sqrt(svs) (:106)
+//   k_gram  G   = X^T X                   NAM.dot(NAM.T) (_nam.py:105), contraction over cells
+//   k_null  fused |X.Yc|/N -> square -> threshold bin -> per-permutation histogram
+//           (_association.py:96-99 + _stats.py:34-62), never materialising cells x Nnull.
+//
+// Operand maps of __builtin_amdgcn_mfma_f64_16x16x4f64 (one f64 per lane for A and B):
+//   A[i][k]: i = lane & 15, k = lane >> 4        B[k][j]: k = lane >> 4, j = lane & 15
+//   D[r][j]: r = (lane >> 4) + 4*reg, j = lane & 15,  reg in 0..3
+#include "common.h"
+
+namespace {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ======================================================================== OUT = X . B
+// One wave owns a 16-cell tile: its rows are staged (and optionally centred) in a wave
+// private LDS panel, padded to ldp = ldx + 2 doubles so the A-fragment ds_read_b64 of 16
+// different rows is bank-conflict free.  B (K x ldb, ldb % 16 == 0, zero padded) is small
+// and L2 resident; its fragments are read straight from global as 128-byte row segments.
+__global__ __launch_bounds__(256) void k_xb(const double* __restrict__ X, int64_t nx, int Nx, int ldx,
+                                            const double* __restrict__ B, int ldb, int center,
+                                            double* __restrict__ out, int ld_out) {
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ldp = ldx + 2;
+  double* xp = sm + (size_t)wv * 16 * ldp;
+  const int64_t r0 = ((int64_t)blockIdx.x * 4 + wv) * 16;
+  for (int r = 0; r < 16; ++r) {
+    const int64_t gr = r0 + r;
+    for (int col = lane; col < ldx; col += 64) xp[r * ldp + col] = (gr < nx) ? X[gr * ldx + col] : 0.0;
+  }
+  __syncthreads();
+  if (center) {
+    for (int r = 0; r < 16; ++r) {
+      double s = 0.0;
+      for (int col = lane; col < Nx; col += 64) s += xp[r * ldp + col];
+      const double mean = wave_sum(s) / (double)Nx;
+      for (int col = lane; col < Nx; col += 64) xp[r * ldp + col] -= mean;
+    }
+  }
+  __syncthreads();
+  const int kq = ldx >> 2;
+  const int ai = lane & 15, ak = lane >> 4;
+  const int ntile = ldb >> 4;
+  for (int jt = 0; jt < ntile; ++jt) {
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    const double* bp = B + (size_t)ak * ldb + jt * 16 + ai;
+    const double* ap = xp + ai * ldp + ak;
+#pragma unroll 4
+    for (int q = 0; q < kq; ++q) {
+      const double a = ap[4 * q];
+      const double b = bp[(size_t)4 * q * ldb];
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+    const int col = jt * 16 + ai;
+    if (col < ld_out) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t gr = r0 + ak + 4 * r;
+        if (gr < nx) out[gr * ld_out + col] = acc[r];
+      }
+    }
+  }
+}
+
+// ======================================================================== G = X^T X
+// 8 waves per workgroup; the nt*(nt+1)/2 upper-triangular 16x16 tiles of G are dealt to the
+// waves (TPW accumulator tiles each, kept in registers for the whole kernel); the workgroup
+// streams 32-cell slabs of X through LDS and every wave feeds its tiles with 8 k-steps of 4
+// cells.  Per-workgroup partial tiles are written out and summed in a fixed order by
+// k_gram_reduce (deterministic; no float atomics).
+template <int TPW>
+__global__ __launch_bounds__(512) void k_gram(const double* __restrict__ X, int64_t nx, int ldx, int nt,
+                                              int ldp, int ntri, const int32_t* __restrict__ tiles,
+                                              double* __restrict__ partial) {
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ak = lane >> 4, ai = lane & 15;
+  v4d acc[TPW];
+  int off_i[TPW], off_j[TPW];
+  bool live[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int tix = (blockIdx.y * 8 + wv) * TPW + t;
+    live[t] = tix < ntri;
+    const int packed = live[t] ? __builtin_amdgcn_readfirstlane(tiles[tix]) : 0;
+    off_i[t] = (packed >> 16) * 16;
+    off_j[t] = (packed & 0xffff) * 16;
+  }
+  for (int i = tid; i < 32 * ldp; i += 512) sm[i] = 0.0;
+  const int64_t nslab = (nx + 31) / 32;
+  for (int64_t slab = blockIdx.x; slab < nslab; slab += gridDim.x) {
+    __syncthreads();
+    const int64_t r0 = slab * 32;
+    for (int r = wv; r < 32; r += 8) {
+      const int64_t gr = r0 + r;
+      for (int col = lane; col < ldx; col += 64) sm[r * ldp + col] = (gr < nx) ? X[gr * ldx + col] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int kq = 0; kq < 8; ++kq) {
+      const double* rowp = sm + (4 * kq + ak) * ldp + ai;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        if (live[t]) {
+          const double a = rowp[off_i[t]];
+          const double b = rowp[off_j[t]];
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    if (live[t]) {
+      const int tix = (blockIdx.y * 8 + wv) * TPW + t;
+      double* p = partial + ((size_t)blockIdx.x * ntri + tix) * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r * 64 + lane] = acc[t][r];
+    }
+  }
+}
+
+__global__ void k_gram_reduce(const double* __restrict__ partial, int nblocks, int ntri,
+                              const int32_t* __restrict__ tiles, int Nx, double* __restrict__ G) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ntri * 256) return;
+  const int tix = idx >> 8, e = idx & 255;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * ntri + tix) * 256 + e];
+  const int r = e >> 6, lane = e & 63;
+  const int packed = tiles[tix];
+  const int i = (packed >> 16) * 16 + (lane >> 4) + 4 * r;
+  const int j = (packed & 0xffff) * 16 + (lane & 15);
+  if (i < Nx && j < Nx) {
+    G[(size_t)i * Nx + j] = s;
+    G[(size_t)j * Nx + i] = s;
+  }
+}
+
+// ======================================================================== local null
+// grid = (row chunks, ceil(P/64)); 4 waves, wave w owns permutations 64*pt + 16*w .. +15 and
+// keeps that 16-column strip of Yc resident in registers (KQ doubles per lane) for the whole
+// kernel.  16-cell slabs of X stream through LDS (register prefetch of the next slab under
+// the MFMAs).  Epilogue per output: z = |acc|/N, z2 = z*z, h = #{t: edges[t] <= z2} found
+// from a linear guess + exact comparisons against the host-computed edges, then one LDS
+// atomic on a packed 16-bit counter (a chunk has < 65536 cells).  Counters are flushed with
+// integer global atomics -> bit-reproducible.
+template <int KQ>
+__global__ __launch_bounds__(256) void k_null(const double* __restrict__ X, int64_t nx, int Nx, int ldx,
+                                              int64_t chunk_rows, const double* __restrict__ Yc, int ldy,
+                                              int P, const double* __restrict__ edges, int T, double thr0,
+                                              double inv_step, unsigned long long* __restrict__ ghist) {
+  extern __shared__ double sm[];
+  constexpr int PF = (KQ + 7) / 8;      // double2 prefetch registers per thread
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ak = lane >> 4, ai = lane & 15;
+  const int ldp = ldx + 2;
+  const int HW = (T + 1) >> 1;
+  double* e_s = sm;                                   // T doubles (padded to even)
+  double* xt = sm + ((T + 1) & ~1);                   // 16 * ldp doubles
+  unsigned int* hist = (unsigned int*)(xt + 16 * ldp);  // 64 * HW words
+  for (int i = tid; i < T; i += 256) e_s[i] = edges[i];
+  for (int i = tid; i < 64 * HW; i += 256) hist[i] = 0u;
+
+  const int kq = ldx >> 2;
+  const int pt = blockIdx.y;
+  double b[KQ];
+  {
+    const double* bp = Yc + (size_t)ak * ldy + pt * 64 + wv * 16 + ai;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) b[q] = (q < kq) ? bp[(size_t)4 * q * ldy] : 0.0;
+  }
+  // per-thread prefetch slots: slab-relative element offsets of the double2 this thread moves
+  const int nd2 = (16 * ldx) >> 1;
+  int goff[PF], loff[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int f = tid + 256 * i;
+    const int e = 2 * f;
+    const int r = e / ldx;
+    goff[i] = (f < nd2) ? e : -1;
+    loff[i] = r * ldp + (e - r * ldx);
+  }
+  const int64_t row_begin = (int64_t)blockIdx.x * chunk_rows;
+  int64_t row_end = row_begin + chunk_rows;
+  if (row_end > nx) row_end = nx;
+  const double en = (double)Nx;
+  const double e0 = T > 0 ? edges[0] : __builtin_inf();
+
+  double2 pf[PF];
+  auto prefetch = [&](int64_t r0) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      pf[i] = make_double2(0.0, 0.0);
+      if (goff[i] >= 0) {
+        const int64_t g = r0 * ldx + goff[i];
+        if (g < row_end * (int64_t)ldx) pf[i] = *reinterpret_cast<const double2*>(X + g);
+      }
+    }
+  };
+  if (row_begin < row_end) prefetch(row_begin);
+  for (int64_t r0 = row_begin; r0 < row_end; r0 += 16) {
+    __syncthreads();                       // previous slab fully consumed
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+      if (goff[i] >= 0) *reinterpret_cast<double2*>(xt + loff[i]) = pf[i];
+    __syncthreads();
+    if (r0 + 16 < row_end) prefetch(r0 + 16);
+    v4d acc = {0.0, 0.0, 0.0, 0.0};
+    const double* ap = xt + ai * ldp + ak;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      if (q < kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * q], b[q], acc, 0, 0, 0);
+    }
+    unsigned int* hp = hist + (wv * 16 + ai) * HW;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const double z = __ddiv_rn(fabs(acc[r]), en);
+      const double z2 = z * z;
+      if (z2 >= e0) {
+        const double f = (z - thr0) * inv_step;
+        int h = (f >= (double)T) ? T : ((f > 0.0) ? (int)f + 1 : 1);
+        while (h < T && e_s[h] <= z2) ++h;
+        while (h > 1 && !(e_s[h - 1] <= z2)) --h;
+        const int bin = h - 1;
+        atomicAdd(&hp[bin >> 1], 1u << ((bin & 1) << 4));
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * HW; i += 256) {
+    const unsigned int w = hist[i];
+    if (w) {
+      const int pl = i / HW, hw = i - pl * HW;
+      const int p = pt * 64 + pl;
+      if (p < P) {
+        const unsigned int lo = w & 0xffffu, hi = w >> 16;
+        if (lo) atomicAdd(&ghist[(size_t)p * T + 2 * hw], (unsigned long long)lo);
+        if (hi && 2 * hw + 1 < T) atomicAdd(&ghist[(size_t)p * T + 2 * hw + 1], (unsigned long long)hi);
+      }
+    }
+  }
+}
+
+template <int TPW>
+int launch_gram_t(cna_ctx* c, int nt, int ldp, int ntri, const int32_t* tiles_dev, double* partial, int nblocks,
+                  size_t smem) {
+  const int npass = (ntri + 8 * TPW - 1) / (8 * TPW);
+  hipLaunchKernelGGL((k_gram<TPW>), dim3(nblocks, npass), dim3(512), smem, c->stream, c->X, c->nx, c->ldx, nt, ldp,
+                     ntri, tiles_dev, partial);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+template <int KQ>
+int launch_null_t(cna_ctx* c, dim3 grid, size_t smem, int64_t chunk_rows, const double* Yc, int ldy, int P,
+                  const double* edges, int T, double thr0, double inv_step, unsigned long long* hist) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_null<KQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_null<KQ>), grid, dim3(256), smem, c->stream, c->X, c->nx, c->Nx, c->ldx, chunk_rows, Yc,
+                     ldy, P, edges, T, thr0, inv_step, hist);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, double* out, int ld_out) {
+  (void)n_out;
+  if (c->nx == 0) return 0;
+  ProfScope ps(c, out == c->X ? CNA_K_RESID : CNA_K_PROJECT);
+  const size_t smem = sizeof(double) * 4 * 16 * (c->ldx + 2);
+  if (smem > 160 * 1024) CNA_FAIL(CNA_EINVAL, "too many samples for the residualisation kernel (max ~300)");
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_xb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int64_t ntile = (c->nx + 15) / 16;
+  const unsigned grid = (unsigned)((ntile + 3) / 4);
+  hipLaunchKernelGGL(k_xb, dim3(grid), dim3(256), smem, c->stream, c->X, c->nx, c->Nx, c->ldx, B_dev, ldb,
+                     center ? 1 : 0, out, ld_out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_gram(cna_ctx* c, double* G_dev) {
+  const int Nx = c->Nx;
+  const int nt = (Nx + 15) / 16;
+  const int ntri = nt * (nt + 1) / 2;
+  const int ldp = 16 * nt + ((nt & 1) ? 0 : 16);
+  const int tpw = (ntri + 7) / 8;
+  HIP_TRY(hipMemsetAsync(G_dev, 0, sizeof(double) * Nx * Nx, c->stream));
+  if (c->nx == 0) return 0;
+  // tile table (ti<<16 | tj), upper triangle, row-major
+  std::vector<int32_t> tiles;
+  for (int i = 0; i < nt; ++i)
+    for (int j = i; j < nt; ++j) tiles.push_back((i << 16) | j);
+  const int64_t nslab = (c->nx + 31) / 32;
+  const int nblocks = (int)(nslab < 512 ? nslab : 512);
+  const int64_t need = (int64_t)sizeof(int32_t) * ntri + 256 + (int64_t)sizeof(double) * nblocks * ntri * 256;
+  CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, need));
+  int32_t* tiles_dev = (int32_t*)c->scratch2;
+  double* partial = (double*)((char*)c->scratch2 + round_up64(sizeof(int32_t) * ntri, 256));
+  HIP_TRY(hipMemcpyAsync(tiles_dev, tiles.data(), sizeof(int32_t) * ntri, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // tiles vector goes out of scope
+  const size_t smem = sizeof(double) * 32 * ldp;
+  {
+    ProfScope ps(c, CNA_K_GRAM);
+    int r;
+    if (tpw <= 1) r = launch_gram_t<1>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem);
+    else if (tpw <= 2) r = launch_gram_t<2>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem);
+    else if (tpw <= 4) r = launch_gram_t<4>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem);
+    else if (tpw <= 8) r = launch_gram_t<8>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem);
+    else r = launch_gram_t<12>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem);   // extra passes beyond 96 tiles
+    CNA_TRY(r);
+  }
+  {
+    ProfScope ps(c, CNA_K_GRAM_REDUCE);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ntri), dim3(256), 0, c->stream, partial, nblocks, ntri,
+                       tiles_dev, Nx, G_dev);
+    HIP_TRY(hipGetLastError());
+  }
+  return 0;
+}
+
+int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* edges_dev, int T,
+                      double thr0, double inv_step, unsigned long long* hist_dev) {
+  HIP_TRY(hipMemsetAsync(hist_dev, 0, sizeof(unsigned long long) * (size_t)P * T, c->stream));
+  if (c->nx == 0 || P == 0 || T == 0) return 0;
+  const int kq = c->ldx / 4;
+  if (kq > 64) CNA_FAIL(CNA_EINVAL, "more than 256 samples are not supported by the local-null kernel yet");
+  const int nptile = (P + 63) / 64;
+  const int64_t ntile16 = (c->nx + 15) / 16;
+  int64_t nchunks = (1024 + nptile - 1) / nptile;
+  if (nchunks > ntile16) nchunks = ntile16;
+  int64_t chunk_rows = ((ntile16 + nchunks - 1) / nchunks) * 16;
+  if (chunk_rows > 65520) chunk_rows = 65520;
+  nchunks = (c->nx + chunk_rows - 1) / chunk_rows;
+  const int HW = (T + 1) / 2;
+  const size_t smem = sizeof(double) * (((T + 1) & ~1) + 16 * (c->ldx + 2)) + sizeof(unsigned int) * 64 * HW;
+  if (smem > 160 * 1024) CNA_FAIL(CNA_EINVAL, "local-null kernel: thresholds/samples exceed LDS");
+  dim3 grid((unsigned)nchunks, (unsigned)nptile);
+  ProfScope ps(c, CNA_K_NULL_LOCAL);
+  if (kq <= 16) return launch_null_t<16>(c, grid, smem, chunk_rows, Yc_dev, ldy, P, edges_dev, T, thr0, inv_step, hist_dev);
+  if (kq <= 32) return launch_null_t<32>(c, grid, smem, chunk_rows, Yc_dev, ldy, P, edges_dev, T, thr0, inv_step, hist_dev);
+  if (kq <= 52) return launch_null_t<52>(c, grid, smem, chunk_rows, Yc_dev, ldy, P, edges_dev, T, thr0, inv_step, hist_dev);
+  return launch_null_t<64>(c, grid, smem, chunk_rows, Yc_dev, ldy, P, edges_dev, T, thr0, inv_step, hist_dev);
+}

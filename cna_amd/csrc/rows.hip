@@ -1,0 +1,405 @@
+// Row-local (per-cell) kernels: QC statistics, selection, standardisation, neighbourhood
+// coefficients, observed threshold counts, per-cell FDR lookup, transpose for D2H.
+// All matrices are cell-major (one row per cell), so every statistic "over samples" is a
+// reduction inside one row: one wave per row, lanes across the sample axis.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ int64_t uniform64(int64_t v) {
+  int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+  int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+
+constexpr int MAXQ = 8;  // up to 512 columns per row
+
+// ---- _batch_kurtosis (_nam.py:78-82) -------------------------------------------------
+// order[] lists the sample columns grouped by batch (stable), boff[b]..boff[b+1] is batch b.
+// Lane b sums its batch's entries in sample order (the order numpy's mean walks them).
+__global__ __launch_bounds__(256) void k_batch_kurtosis(const double* __restrict__ mat, int64_t rows,
+                                                        int ncols, int ld, const int32_t* __restrict__ order,
+                                                        const int32_t* __restrict__ boff, int nb,
+                                                        double* __restrict__ out) {
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* xr = sm + (size_t)wv * ld;
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t base = (int64_t)blockIdx.x * 4; base < rows; base += nwaves) {
+    const int64_t row = base + wv;
+    const bool live = row < rows;
+    if (live)
+      for (int col = lane; col < ncols; col += 64) xr[col] = mat[row * ld + col];
+    __syncthreads();
+    double bm[4];
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int b = lane + 64 * q;
+      bm[q] = 0.0;
+      if (live && b < nb) {
+        const int s0 = boff[b], s1 = boff[b + 1];
+        double s = 0.0;
+        for (int m = s0; m < s1; ++m) s += xr[order[m]];
+        bm[q] = s / (double)(s1 - s0);
+        sum += bm[q];
+      }
+    }
+    const double n = (double)nb;
+    const double mean = wave_sum(sum) / n;
+    double d2s = 0.0, d4s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (lane + 64 * q < nb) {
+        const double d = bm[q] - mean;
+        const double d2 = d * d;
+        d2s += d2;
+        d4s += d2 * d2;
+      }
+    }
+    const double m2 = wave_sum(d2s) / n, m4 = wave_sum(d4s) / n;
+    const double em = 2.220446049250313e-16 * mean;
+    const double k = (m2 <= em * em) ? __builtin_nan("") : m4 / (m2 * m2);
+    if (live && lane == 0) out[row] = (k - 3.0) + 3.0;   // Fisher, then "+ 3" as the reference writes it
+    __syncthreads();
+  }
+}
+
+// ---- NAM.std(axis=0) == 0 over the selected samples (_association.py:182) -------------
+__global__ __launch_bounds__(256) void k_zero_variance(const double* __restrict__ nam, int64_t rows, int ld,
+                                                       const int32_t* __restrict__ colmap, int nsel,
+                                                       uint8_t* __restrict__ flags, unsigned long long* count) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < rows; row += nwaves) {
+    const double v0 = nam[row * ld + (colmap ? colmap[0] : 0)];
+    bool eq = true;
+    for (int c = lane; c < nsel; c += 64) {
+      const double v = nam[row * ld + (colmap ? colmap[c] : c)];
+      eq = eq && (v == v0);
+    }
+    const bool all_eq = __all(eq);
+    if (lane == 0) {
+      uint8_t f = 0;
+      if (all_eq) {
+        // pandas nanvar: avg = sum/N ; var = sum((avg - x)^2)/(N-1) -- zero iff avg == x
+        double s = 0.0;
+        for (int c = 0; c < nsel; ++c) s += v0;
+        const double avg = s / (double)nsel;
+        f = (avg - v0 == 0.0) ? 1 : 0;
+      }
+      flags[row] = f;
+      if (f) atomicAdd(count, 1ull);
+    }
+  }
+}
+
+// ---- X[i', c'] = NAM[keep[i'], colmap[c']] ---------------------------------------------
+__global__ void k_select(const double* __restrict__ nam, int ld, const int64_t* __restrict__ keep,
+                         const int32_t* __restrict__ colmap, double* __restrict__ X, int64_t nx, int Nx,
+                         int ldx) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nx * ldx) return;
+  const int64_t r = i / ldx;
+  const int c = (int)(i - r * ldx);
+  double v = 0.0;
+  if (c < Nx) {
+    const int64_t sr = keep ? keep[r] : r;
+    const int sc = colmap ? colmap[c] : c;
+    v = nam[sr * ld + sc];
+  }
+  X[i] = v;
+}
+
+// ---- X <- (X [- mean]) / std(ddof=1) per row (_nam.py:103-104,159) -----------------------
+__global__ __launch_bounds__(256) void k_standardize(double* __restrict__ X, int64_t nx, int Nx, int ldx,
+                                                     int center) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const double n = (double)Nx;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < nx; row += nwaves) {
+    double x[MAXQ];
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int col = lane + 64 * q;
+      x[q] = (col < Nx) ? X[row * ldx + col] : 0.0;
+      sum += x[q];
+    }
+    if (center) {
+      const double mean = wave_sum(sum) / n;
+      sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < MAXQ; ++q) {
+        if (lane + 64 * q < Nx) x[q] -= mean;
+        sum += x[q];
+      }
+    }
+    // pandas std: avg = sum/N ; sqrt(sum((avg-x)^2)/(N-1))
+    const double avg = wave_sum(sum) / n;
+    double ss = 0.0;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      if (lane + 64 * q < Nx) {
+        const double d = avg - x[q];
+        ss += d * d;
+      }
+    }
+    const double sd = sqrt(wave_sum(ss) / (n - 1.0));
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int col = lane + 64 * q;
+      if (col < Nx) X[row * ldx + col] = __ddiv_rn(x[q], sd);
+    }
+  }
+}
+
+// ---- ncorrs = (y[:,None]*NAMresid).mean(axis=0) (_association.py:77) -----------------------
+__global__ __launch_bounds__(256) void k_ncorrs(const double* __restrict__ X, int64_t nx, int Nx, int ldx,
+                                                const double* __restrict__ y, double* __restrict__ out,
+                                                unsigned long long* maxbits) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  double yv[MAXQ];
+#pragma unroll
+  for (int q = 0; q < MAXQ; ++q) yv[q] = (lane + 64 * q < Nx) ? y[lane + 64 * q] : 0.0;
+  double vmax = 0.0;
+  bool any_nan = false;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < nx; row += nwaves) {
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+      const int col = lane + 64 * q;
+      if (col < Nx) s += yv[q] * X[row * ldx + col];
+    }
+    const double v = wave_sum(s) / (double)Nx;
+    if (lane == 0) out[row] = v;
+    const double av = fabs(v);
+    if (av > vmax) vmax = av;
+    any_nan = any_nan || (v != v);
+  }
+  if (lane == 0) {
+    // non-negative doubles order like their bit patterns; NaN (0x7ff8...) sorts above +inf
+    unsigned long long bits = any_nan ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(vmax);
+    atomicMax(maxbits, bits);
+  }
+}
+
+// number of t in [0,T) with arr[t] <= x, arr ascending, starting from a guess
+__device__ __forceinline__ int count_le(const double* arr, int T, double x, int guess) {
+  int h = guess < 0 ? 0 : (guess > T ? T : guess);
+  while (h < T && arr[h] <= x) ++h;
+  while (h > 0 && !(arr[h - 1] <= x)) --h;
+  return h;
+}
+__device__ __forceinline__ int count_lt(const double* arr, int T, double x, int guess) {
+  int h = guess < 0 ? 0 : (guess > T ? T : guess);
+  while (h < T && arr[h] < x) ++h;
+  while (h > 0 && !(arr[h - 1] < x)) --h;
+  return h;
+}
+__device__ __forceinline__ int linear_guess(double z, double thr0, double inv_step, int T) {
+  if (!(z >= thr0)) return 0;
+  const double f = (z - thr0) * inv_step;
+  return f >= (double)T ? T : (int)f + 1;
+}
+
+// ---- ranks / num_detected of the observed coefficients (_stats.py:74, _association.py:108) --
+// hist[0..T)   : cells whose ncorr^2 falls in [edges[t], edges[t+1])   (suffix sum -> ranks)
+// hist[T..2T)  : cells with thr[t] < |ncorr| <= thr[t+1]               (suffix sum -> num_detected)
+__global__ __launch_bounds__(256) void k_obs_counts(const double* __restrict__ ncorrs, int64_t nx,
+                                                    const double* __restrict__ edges,
+                                                    const double* __restrict__ thr, int T, double thr0,
+                                                    double inv_step, unsigned long long* hist) {
+  extern __shared__ double smd[];
+  double* e_s = smd;
+  double* t_s = smd + T;
+  unsigned int* h_s = (unsigned int*)(smd + 2 * T);
+  for (int i = threadIdx.x; i < T; i += blockDim.x) {
+    e_s[i] = edges[i];
+    t_s[i] = thr[i];
+  }
+  for (int i = threadIdx.x; i < 2 * T; i += blockDim.x) h_s[i] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nx; i += stride) {
+    const double v = ncorrs[i];
+    const double z = fabs(v), z2 = v * v;
+    const int g = linear_guess(z, thr0, inv_step, T);
+    const int hr = count_le(e_s, T, z2, g);
+    const int hd = count_lt(t_s, T, z, g);
+    if (hr > 0) atomicAdd(&h_s[hr - 1], 1u);
+    if (hd > 0) atomicAdd(&h_s[T + hd - 1], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * T; i += blockDim.x)
+    if (h_s[i]) atomicAdd(&hist[i], (unsigned long long)h_s[i]);
+}
+
+// tails[p][t] = sum_{t' >= t} hist[p][t']
+__global__ void k_suffix_sum(const unsigned long long* __restrict__ hist, int P, int T,
+                             int64_t* __restrict__ tails) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  long long run = 0;
+  for (int t = T - 1; t >= 0; --t) {
+    run += (long long)hist[(size_t)p * T + t];
+    tails[(size_t)p * T + t] = run;
+  }
+}
+
+__global__ void k_fill(double* v, int64_t n, double x) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = x;
+}
+__global__ void k_scatter(const double* __restrict__ src, const int64_t* __restrict__ keep, int64_t nx,
+                          double* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nx) dst[keep ? keep[i] : i] = src[i];
+}
+// fdr_i = min{fdr_t : thr_t <= |coef_i|} else 1 (_association.py:234-237)
+__global__ void k_percell_fdr(const double* __restrict__ coef, int64_t n, const double* __restrict__ thr,
+                              const double* __restrict__ runmin, int T, double thr0, double inv_step,
+                              double* __restrict__ fdr) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double z = fabs(coef[i]);
+  const int h = count_le(thr, T, z, linear_guess(z, thr0, inv_step, T));
+  fdr[i] = h > 0 ? runmin[h - 1] : 1.0;
+}
+
+__global__ void k_transpose(const double* __restrict__ in, int64_t rows, int cols, int ld,
+                            double* __restrict__ out) {
+  __shared__ double tile[32][33];
+  const int64_t r0 = (int64_t)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+    const int64_t r = r0 + k;
+    const int c = c0 + threadIdx.x;
+    tile[k][threadIdx.x] = (r < rows && c < cols) ? in[r * ld + c] : 0.0;
+  }
+  __syncthreads();
+  for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+    const int c = c0 + k;
+    const int64_t r = r0 + threadIdx.x;
+    if (c < cols && r < rows) out[(int64_t)c * rows + r] = tile[threadIdx.x][k];
+  }
+}
+
+inline unsigned wave_grid(int64_t rows) {
+  const int64_t want = (rows + 3) / 4;
+  return (unsigned)(want < 4096 ? (want > 0 ? want : 1) : 4096);
+}
+
+}  // namespace
+
+int launch_batch_kurtosis(cna_ctx* c, const double* mat, int64_t rows, int ncols, int ld,
+                          const int32_t* order_dev, const int32_t* boff_dev, int n_batches, double* out) {
+  if (rows == 0) return 0;
+  if (n_batches > 256) CNA_FAIL(CNA_EINVAL, "more than 256 batches are not supported");
+  ProfScope ps(c, CNA_K_BATCH_KURT);
+  hipLaunchKernelGGL(k_batch_kurtosis, dim3(wave_grid(rows)), dim3(256), sizeof(double) * 4 * ld, c->stream,
+                     mat, rows, ncols, ld, order_dev, boff_dev, n_batches, out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_zero_variance(cna_ctx* c, const int32_t* colmap_dev, int n_sel, uint8_t* flags_dev,
+                         unsigned long long* count_dev) {
+  if (c->n_local == 0) return 0;
+  ProfScope ps(c, CNA_K_ZEROVAR);
+  hipLaunchKernelGGL(k_zero_variance, dim3(wave_grid(c->n_local)), dim3(256), 0, c->stream, c->nam,
+                     c->n_local, c->ld, colmap_dev, n_sel, flags_dev, count_dev);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_select(cna_ctx* c, const int32_t* colmap_dev) {
+  const int64_t tot = c->nx * c->ldx;
+  if (tot == 0) return 0;
+  ProfScope ps(c, CNA_K_SELECT);
+  hipLaunchKernelGGL(k_select, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nam, c->ld,
+                     c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_standardize(cna_ctx* c, int center) {
+  if (c->nx == 0) return 0;
+  if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 512 samples are not supported");
+  ProfScope ps(c, CNA_K_STANDARDIZE);
+  hipLaunchKernelGGL(k_standardize, dim3(wave_grid(c->nx)), dim3(256), 0, c->stream, c->X, c->nx, c->Nx,
+                     c->ldx, center);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_ncorrs(cna_ctx* c, const double* y_dev, unsigned long long* maxbits_dev) {
+  HIP_TRY(hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned long long), c->stream));
+  if (c->nx == 0) return 0;
+  if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 512 samples are not supported");
+  ProfScope ps(c, CNA_K_NCORRS);
+  const int64_t want = (c->nx + 3) / 4;
+  const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+  hipLaunchKernelGGL(k_ncorrs, dim3(grid), dim3(256), 0, c->stream, c->X, c->nx, c->Nx, c->ldx, y_dev,
+                     c->ncorrs, maxbits_dev);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_obs_counts(cna_ctx* c, const double* edges_dev, const double* thr_dev, int T, double thr0,
+                      double inv_step, unsigned long long* hist_dev) {
+  HIP_TRY(hipMemsetAsync(hist_dev, 0, sizeof(unsigned long long) * 2 * T, c->stream));
+  if (c->nx == 0 || T == 0) return 0;
+  ProfScope ps(c, CNA_K_OBS_COUNTS);
+  const int64_t want = (c->nx + 255) / 256;
+  const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
+  const size_t sm = sizeof(double) * 2 * T + sizeof(unsigned int) * 2 * T;
+  hipLaunchKernelGGL(k_obs_counts, dim3(grid), dim3(256), sm, c->stream, c->ncorrs, c->nx, edges_dev, thr_dev,
+                     T, thr0, inv_step, hist_dev);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, int64_t* tails) {
+  if (P == 0 || T == 0) return 0;
+  hipLaunchKernelGGL(k_suffix_sum, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, c->stream, hist, P, T, tails);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_percell_fdr(cna_ctx* c, const double* thr_dev, const double* runmin_dev, int T, double thr0,
+                       double inv_step, double* coef_local, double* fdr_local) {
+  const int64_t n = c->n_local;
+  if (n == 0) return 0;
+  ProfScope ps(c, CNA_K_PERCELL_FDR);
+  const unsigned g = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(k_fill, dim3(g), dim3(256), 0, c->stream, coef_local, n, __builtin_nan(""));
+  if (c->nx > 0)
+    hipLaunchKernelGGL(k_scatter, dim3((unsigned)((c->nx + 255) / 256)), dim3(256), 0, c->stream, c->ncorrs,
+                       c->keep_idx, c->nx, coef_local);
+  if (fdr_local)
+    hipLaunchKernelGGL(k_percell_fdr, dim3(g), dim3(256), 0, c->stream, coef_local, n, thr_dev, runmin_dev, T,
+                       thr0, inv_step, fdr_local);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_transpose(cna_ctx* c, const double* in, int64_t rows, int cols, int ld, double* out) {
+  if (rows == 0 || cols == 0) return 0;
+  ProfScope ps(c, CNA_K_TRANSPOSE);
+  dim3 grid((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32)), block(32, 8);
+  hipLaunchKernelGGL(k_transpose, grid, block, 0, c->stream, in, rows, cols, ld, out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,312 @@
+"""Device engine: thin, typed Python wrapper around one ``cna_ctx`` of libcna_hip.so.
+
+One Engine per process/GPU.  It owns the device-resident graph, diffusion state, NAM and
+working matrix; the host code in ``cna_amd.tools`` drives it step by step the way the
+reference drives numpy/scipy.  Nothing here computes on the CPU.
+"""
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _ffi
+from ._ffi import check, ptr, MAT_NAM, MAT_X
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Engine:
+    def __init__(self, device=None, rank=0, nranks=1, unique_id=None):
+        self.lib = _ffi.load()
+        if device is None:
+            device = int(os.environ.get('LOCAL_RANK', '0')) if nranks > 1 else 0
+        h = _ffi.c_ctx()
+        check(self.lib.cna_ctx_create(int(device), C.byref(h)), 'cna_ctx_create')
+        self.h = h
+        self.device = int(device)
+        self.rank, self.nranks = int(rank), int(nranks)
+        if nranks > 1:
+            if unique_id is None:
+                raise ValueError('nranks > 1 needs the RCCL unique id created by rank 0')
+            buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
+            check(self.lib.cna_comm_init(self.h, self.rank, self.nranks, C.cast(buf, C.c_void_p)), 'cna_comm_init')
+        self._graph_key = None
+        self._graph_ref = None
+        self._colsum_w = None
+        self.n = 0            # global cells
+        self.row0 = 0
+        self.n_local = 0
+        self.N = 0
+        self.x_rows_total = 0
+        self.x_epoch = 0      # bumped whenever the working matrix X is replaced
+        self.nam_epoch = 0    # bumped whenever a new NAM is started
+
+    # ---------------------------------------------------------------- lifetime
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.cna_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.cna_ctx_sync(self.h), 'cna_ctx_sync')
+
+    def device_bytes(self):
+        b = C.c_int64(0)
+        check(self.lib.cna_ctx_device_bytes(self.h, C.byref(b)), 'cna_ctx_device_bytes')
+        return b.value
+
+    @staticmethod
+    def new_unique_id():
+        lib = _ffi.load()
+        buf = (C.c_char * 128)()
+        check(lib.cna_comm_unique_id(C.cast(buf, C.c_void_p)), 'cna_comm_unique_id')
+        return bytes(buf)
+
+    # ---------------------------------------------------------------- graph
+    def block(self, n):
+        """Rows [r0, r1) of an n-cell problem owned by this rank (ceil split)."""
+        rpr = -(-n // self.nranks)
+        r0 = min(self.rank * rpr, n)
+        return r0, min(r0 + rpr, n)
+
+    @staticmethod
+    def _key(A):
+        return (id(A), A.shape, A.nnz, A.data.ctypes.data, A.indices.ctypes.data, A.indptr.ctypes.data,
+                str(A.data.dtype))
+
+    def ensure_graph(self, A):
+        """Upload the connectivities graph unless this very matrix is already resident."""
+        if not sp.issparse(A):
+            raise TypeError('connectivities must be a scipy.sparse matrix')
+        if not sp.isspmatrix_csr(A) and not isinstance(A, sp.csr_array):
+            A = sp.csr_matrix(A)
+        if A.shape[0] != A.shape[1]:
+            raise ValueError('connectivities must be square')
+        key = self._key(A)
+        if self._graph_key == key and self._graph_ref is not None and self._graph_ref() is A:
+            return False
+        n = A.shape[0]
+        r0, r1 = self.block(n)
+        lo, hi = int(A.indptr[r0]), int(A.indptr[r1])
+        indptr = np.ascontiguousarray(A.indptr[r0:r1 + 1].astype(np.int64) - lo)
+        indices = np.ascontiguousarray(A.indices[lo:hi], dtype=np.int32)
+        if A.data.dtype == np.float32:
+            data, f64 = np.ascontiguousarray(A.data[lo:hi]), 0
+        else:
+            data, f64 = np.ascontiguousarray(A.data[lo:hi], dtype=np.float64), 1
+        check(self.lib.cna_graph_upload(self.h, n, r0, r1 - r0, ptr(indptr), ptr(indices), ptr(data), f64),
+              'cna_graph_upload')
+        self.n, self.row0, self.n_local = n, r0, r1 - r0
+        self._graph_key = key
+        try:
+            self._graph_ref = weakref.ref(A)
+        except TypeError:
+            self._graph_ref = None
+        self._colsum_w = None
+        return True
+
+    def colsums(self, self_weight=1):
+        w = float(self_weight)
+        if self._colsum_w != w:
+            check(self.lib.cna_colsums(self.h, w), 'cna_colsums')
+            self._colsum_w = w
+
+    def fetch_colsums(self):
+        out = np.empty(self.n)
+        check(self.lib.cna_fetch_colsums(self.h, ptr(out)), 'cna_fetch_colsums')
+        return out
+
+    # ---------------------------------------------------------------- NAM
+    def set_samples(self, codes, n_samples, counts):
+        codes = np.ascontiguousarray(codes, dtype=np.int32)
+        if len(codes) != self.n:
+            raise ValueError('need one sample code per cell')
+        counts = _f64(counts)
+        check(self.lib.cna_set_samples(self.h, ptr(codes), int(n_samples), ptr(counts)), 'cna_set_samples')
+        self.N = int(n_samples)
+        self.nam_epoch += 1
+
+    def nam_step(self, want_kurt, may_continue, may_stop):
+        check(self.lib.cna_nam_step(self.h, int(bool(want_kurt)), int(bool(may_continue)), int(bool(may_stop))),
+              'cna_nam_step')
+
+    def cell_stat(self, n_expected):
+        out = np.empty(int(n_expected))
+        check(self.lib.cna_fetch_cell_stat(self.h, ptr(out), int(n_expected)), 'cna_fetch_cell_stat')
+        return out
+
+    # ---------------------------------------------------------------- dense diffusion
+    def dense_load(self, s_local):
+        s_local = _f64(s_local)
+        if s_local.ndim != 2 or s_local.shape[0] != self.n_local:
+            raise ValueError('dense state must be (local cells) x m')
+        check(self.lib.cna_dense_load(self.h, ptr(s_local), s_local.shape[1]), 'cna_dense_load')
+        self._dense_m = s_local.shape[1]
+
+    def dense_step(self):
+        check(self.lib.cna_dense_step(self.h), 'cna_dense_step')
+
+    def dense_fetch(self):
+        out = np.empty((self.n_local, self._dense_m))
+        check(self.lib.cna_dense_fetch(self.h, ptr(out)), 'cna_dense_fetch')
+        return out
+
+    # ---------------------------------------------------------------- QC / selection
+    def batch_kurtosis(self, which, batch_codes, n_batches):
+        bc = np.ascontiguousarray(batch_codes, dtype=np.int32)
+        check(self.lib.cna_batch_kurtosis(self.h, which, ptr(bc), int(n_batches)), 'cna_batch_kurtosis')
+
+    def zero_variance(self, colmap):
+        cm = None if colmap is None else np.ascontiguousarray(colmap, dtype=np.int32)
+        flags = np.zeros(self.n, dtype=np.uint8)
+        nz = C.c_int64(0)
+        check(self.lib.cna_zero_variance(self.h, ptr(cm), 0 if cm is None else len(cm), ptr(flags), C.byref(nz)),
+              'cna_zero_variance')
+        return flags.astype(bool), nz.value
+
+    def select(self, keep_global, colmap):
+        """keep_global: bool mask over all cells (or None = all); colmap: NAM column per output column."""
+        cm = None if colmap is None else np.ascontiguousarray(colmap, dtype=np.int32)
+        if keep_global is None:
+            idx, nk = None, 0
+            self.x_rows_total = self.n
+            self._x_local = self.n_local
+        else:
+            keep_global = np.asarray(keep_global, dtype=bool)
+            idx = np.ascontiguousarray(np.flatnonzero(keep_global[self.row0:self.row0 + self.n_local]), dtype=np.int64)
+            nk = len(idx)
+            self.x_rows_total = int(keep_global.sum())
+            self._x_local = nk
+        check(self.lib.cna_select(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm)), 'cna_select')
+        self.x_epoch += 1
+
+    def upload_x(self, x_local):
+        x_local = _f64(x_local)
+        check(self.lib.cna_upload_x(self.h, ptr(x_local), x_local.shape[0], x_local.shape[1]), 'cna_upload_x')
+        self._x_local = x_local.shape[0]
+        self.x_rows_total = x_local.shape[0]   # single-rank use (cna.tl.svd_nam)
+        self.x_epoch += 1
+
+    # ---------------------------------------------------------------- residualise + PCA
+    def resid_apply(self, M, center):
+        M = None if M is None else _f64(M)
+        check(self.lib.cna_resid_apply(self.h, ptr(M), int(bool(center))), 'cna_resid_apply')
+
+    def standardize(self, center=False):
+        check(self.lib.cna_standardize(self.h, int(bool(center))), 'cna_standardize')
+
+    def gram(self):
+        rows, cols = self.matrix_shape(MAT_X)
+        G = np.empty((cols, cols))
+        check(self.lib.cna_gram(self.h, ptr(G)), 'cna_gram')
+        return G
+
+    def project(self, W):
+        W = _f64(W)
+        rows, cols = self.matrix_shape(MAT_X)
+        out = np.empty((rows, W.shape[1]))
+        check(self.lib.cna_project(self.h, ptr(W), W.shape[1], ptr(out)), 'cna_project')
+        return out
+
+    # ---------------------------------------------------------------- association
+    def ncorrs(self, y, fetch=False):
+        y = _f64(y)
+        rows, cols = self.matrix_shape(MAT_X)
+        out = np.empty(rows) if fetch else None
+        m = C.c_double(0.0)
+        check(self.lib.cna_ncorrs(self.h, ptr(y), ptr(out), C.byref(m)), 'cna_ncorrs')
+        return out, m.value
+
+    def null_local(self, Yc, edges):
+        Yc = _f64(Yc)
+        edges = _f64(edges)
+        P, T = Yc.shape[1], len(edges)
+        tails = np.empty((P, T), dtype=np.int64)
+        check(self.lib.cna_null_local(self.h, ptr(Yc), P, ptr(edges), T, ptr(tails)), 'cna_null_local')
+        return tails
+
+    def obs_counts(self, edges, thr):
+        edges, thr = _f64(edges), _f64(thr)
+        T = len(thr)
+        ranks = np.empty(T, dtype=np.int64)
+        numdet = np.empty(T, dtype=np.int64)
+        check(self.lib.cna_obs_counts(self.h, ptr(edges), ptr(thr), T, ptr(ranks), ptr(numdet)), 'cna_obs_counts')
+        return ranks, numdet
+
+    def percell(self, thr=None, runmin=None):
+        coef = np.empty(self.n)
+        if thr is None:
+            check(self.lib.cna_percell_fdr(self.h, None, None, 0, ptr(coef), None), 'cna_percell_fdr')
+            return coef, None
+        thr, runmin = _f64(thr), _f64(runmin)
+        fdr = np.empty(self.n)
+        check(self.lib.cna_percell_fdr(self.h, ptr(thr), ptr(runmin), len(thr), ptr(coef), ptr(fdr)), 'cna_percell_fdr')
+        return coef, fdr
+
+    # ---------------------------------------------------------------- D2H
+    def matrix_shape(self, which):
+        r, c = C.c_int64(0), C.c_int(0)
+        check(self.lib.cna_matrix_shape(self.h, which, C.byref(r), C.byref(c)), 'cna_matrix_shape')
+        return r.value, c.value
+
+    def fetch_matrix(self, which, transposed=False):
+        rows, cols = self.matrix_shape(which)
+        out = np.empty((cols, rows) if transposed else (rows, cols))
+        check(self.lib.cna_fetch_matrix(self.h, which, ptr(out), int(bool(transposed))), 'cna_fetch_matrix')
+        return out
+
+    def gather_rows_host(self, local, n_total):
+        """Row blocks of every rank, concatenated in rank order (no-op on one GPU)."""
+        local = _f64(local)
+        if self.nranks == 1:
+            return local
+        cols = local.shape[1] if local.ndim == 2 else 1
+        out = np.empty((int(n_total), cols) if local.ndim == 2 else int(n_total))
+        check(self.lib.cna_allgather_host(self.h, ptr(local), local.size, ptr(out), out.size), 'cna_allgather_host')
+        return out
+
+    # ---------------------------------------------------------------- measurement
+    def prof_enable(self, on=True):
+        check(self.lib.cna_prof_enable(self.h, int(bool(on))), 'cna_prof_enable')
+
+    def prof_reset(self):
+        check(self.lib.cna_prof_reset(self.h), 'cna_prof_reset')
+
+    def prof(self):
+        """{kernel name: (total ms, launches)} for kernels launched while profiling was on."""
+        out = {}
+        for k, name in enumerate(_ffi.KERNELS):
+            ms, n = C.c_double(0.0), C.c_int64(0)
+            check(self.lib.cna_prof_get(self.h, k, C.byref(ms), C.byref(n)), 'cna_prof_get')
+            if n.value:
+                out[name] = (ms.value, n.value)
+        return out
+
+
+_default = None
+
+
+def get_engine():
+    """The process-wide engine (created on first use; one GPU per process)."""
+    global _default
+    if _default is None:
+        from . import dist
+        cfg = dist.current()
+        _default = Engine(device=cfg.get('device'), rank=cfg.get('rank', 0), nranks=cfg.get('nranks', 1),
+                          unique_id=cfg.get('unique_id'))
+    return _default
+
+
+def set_engine(engine):
+    global _default
+    _default = engine

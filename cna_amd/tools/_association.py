@@ -1,0 +1,247 @@
+"""Permutation-based association test between a sample-level phenotype and the NAM.
+
+Same call surface, result fields, warnings and error behaviour as the reference's
+``cna/tools/_association.py``.  Division of labour:
+
+  host (numpy, O(samples^2 x Nnull))      input checks, sample filter, M, LAPACK SVD of the
+                                          N x N Gram, permutation indices from numpy's legacy
+                                          RNG, batched global F-tests (_association.py:35-88)
+  device (HIP, O(cells x ...))            NAM, QC, residualisation, Gram, neighbourhood
+                                          coefficients (:77), local null correlations fused with
+                                          the tail counting of _stats.py:34-62 (:96-103),
+                                          observed ranks / num_detected (:105-108),
+                                          data.obs columns incl. the per-cell FDR lookup (:230-237)
+"""
+import warnings
+
+import numpy as np
+import pandas as pd
+
+from .. import _ffi
+from ..engine import get_engine
+from ._nam import LazyNamespace, _nam_device, _qc_device, _resid_device, _gather_rows
+from ._out import select_output
+from ._stats import conditional_permutation, grouplevel_permutation, default_ks, minp_stats
+
+
+def _association(engine, U, M, r, y, batches, donorids, cell_index, ks=None, Nnull=1000,
+                 force_permute_all=False, local_test=True, seed=None, show_progress=False):
+    """Reference ``_association`` (_association.py:10-129) against the residualised NAM held by
+    ``engine`` (cells x samples).  ``U``: samples x samples PCs, ``M``: conditioning projector."""
+    out = select_output(show_progress)
+    if seed is not None:
+        np.random.seed(seed)
+    if force_permute_all:
+        batches = np.ones(len(y))
+
+    y = (y - y.mean()) / y.std()
+    n = len(y)
+    if ks is None:
+        ks = default_ks(n)
+    if max(ks) + r >= n:
+        raise ValueError(
+            'Maximum number of PCs plus number of covariates must be less than n-1. ' +
+            f'Currently it is {max(ks)+r} while n is {n}. Either reduce the number of covariates ' +
+            'or reduce the number of PCs to consider using the optional argument ks=[...].')
+    ks_arr = np.asarray(ks)
+    Mv = np.asarray(M, dtype=np.float64)
+
+    # observed statistic
+    best, pv, r2v = minp_stats(y[:, None], Mv, U, ks_arr, r)
+    k, p, r2 = ks[best[0]], pv[0], r2v[0]
+    if k == max(ks):
+        warnings.warn(('data supported use of {} NAM PCs, which is the maximum considered. ' +
+                       'Consider allowing more PCs by using the "ks" argument.').format(k))
+
+    # coefficients and r2 of the chosen model
+    ycond = pd.Series(Mv.dot(y), index=getattr(M, 'index', None))
+    ycond /= ycond.std()
+    beta = U[:, :k].T.dot(ycond.values)
+    yhat = U[:, :k].dot(beta)
+    r2_perpc = (beta / np.sqrt(ycond.values.dot(ycond.values))) ** 2
+
+    # neighbourhood coefficients: correlation of each cell's residualised NAM row with y
+    _, maxabs = engine.ncorrs(y, fetch=False)
+
+    # null phenotypes and the global p-value
+    if donorids is not None:
+        y_ = grouplevel_permutation(donorids, y, Nnull)
+    else:
+        y_ = conditional_permutation(batches, y, Nnull)
+    _, nullminps, nullr2s = minp_stats(y_, Mv, U, ks_arr, r)
+    hits = (nullminps <= p + 1e-8).sum()
+    pfinal = (hits + 1) / (Nnull + 1)
+    if hits == 0:
+        warnings.warn('global association p-value attained minimal possible value. ' +
+                      'Consider increasing Nnull')
+
+    fdrs, fdr_5p_t, fdr_10p_t = None, None, None
+    thresholds = fdr_vals = None
+    if local_test:
+        print('computing neighborhood-level FDRs', file=out)
+        Nloc = min(1000, Nnull)
+        ycond_ = Mv.dot(y_[:, :Nloc])
+        ycond_ /= ycond_.std(axis=0, ddof=1)
+        maxcorr = max(maxabs, 0.001)
+        thresholds = np.arange(maxcorr / 4, maxcorr, maxcorr / 400)
+        z2 = thresholds ** 2
+        edges = z2 - 1e-8 - 1e-5 * z2                        # tail_counts' bin edges (_stats.py:47)
+        tails = engine.null_local(ycond_, edges)              # Nloc x T, never cells x Nloc
+        ranks, num_detected = engine.obs_counts(edges, thresholds)
+        with np.errstate(all='ignore'):
+            fdr_vals = (tails / ranks[None, :]).mean(axis=0)
+        fdrs = pd.DataFrame({'threshold': thresholds, 'fdr': fdr_vals, 'num_detected': num_detected})
+        if np.min(fdrs.fdr) > 0.05:
+            fdr_5p_t = None
+        else:
+            fdr_5p_t = fdrs[fdrs.fdr <= 0.05].iloc[0].threshold
+        if np.min(fdrs.fdr) > 0.1:
+            fdr_10p_t = None
+        else:
+            fdr_10p_t = fdrs[fdrs.fdr <= 0.1].iloc[0].threshold
+
+    # data.obs columns (all cells) and, from them, the coefficients of the kept cells
+    if fdrs is not None:
+        with np.errstate(invalid='ignore'):
+            runmin = np.fmin.accumulate(fdr_vals)
+        coef_all, fdr_all = engine.percell(thresholds, runmin)
+    else:
+        coef_all, fdr_all = engine.percell(None, None)
+
+    res = {'p': pfinal, 'nullminps': nullminps, 'k': k, 'fdrs': fdrs, 'fdr_5p_t': fdr_5p_t,
+           'fdr_10p_t': fdr_10p_t, 'yresid_hat': yhat, 'yresid': ycond, 'ks': ks, 'beta': beta, 'r2': r2,
+           'r2_perpc': r2_perpc, 'nullr2_mean': nullr2s.mean(), 'nullr2_std': nullr2s.std()}
+    return res, coef_all, fdr_all
+
+
+def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size):
+    """Input validation and the sample filter (reference _association.py:131-173): same
+    exception types, messages and printed warnings."""
+    for name, val, kind, label in (('y', y, pd.Series, 'Series'), ('batches', batches, pd.Series, 'Series'),
+                                   ('covs', covs, pd.DataFrame, 'DataFrame'),
+                                   ('donorids', donorids, pd.Series, 'Series')):
+        if (name == 'y' or val is not None) and not isinstance(val, kind):
+            raise TypeError(f"'{name}' must be a pandas {label}, but got {type(val)}")
+    sids_in_data = set(data.obs[sid_name])
+    if not set(y.index).issubset(sids_in_data):
+        print("WARNING: index of 'y' contains values not present in 'data[sid_name]'. These samples will be ignored.")
+    if not sids_in_data.issubset(set(y.index)):
+        raise ValueError("'data[sid_name]' contains values not present in the index of 'y'.")
+    if batches is not None and donorids is not None:
+        raise ValueError('We do not currently support conditioning on batch ' +
+                         'while also accounting for multiple samples per donor')
+    if batches is None:
+        batches = pd.Series(np.ones(len(y)), index=y.index)
+
+    present = y.index.isin(data.obs[sid_name].unique())
+    if covs is not None:
+        filter_samples = ~(y.isna() | covs.isna().any(axis=1)) & present
+        if donorids is not None:
+            print('WARNING: We currently do not account for multiple samples per donor ' +
+                  'when conditioning on covariates. This conditioning may therefore account ' +
+                  'only incompletely for the covariates of interest. We expect this to make ' +
+                  'only minor differences in most cases, but we have not investigated it formally')
+    else:
+        filter_samples = ~np.isnan(y) & present
+
+    N = filter_samples.sum()
+    if N < 10 and not allow_low_sample_size:
+        raise ValueError(
+            'You are supplying phenotype information on fewer than 10 samples. This may lead to ' +
+            'poor power at low sample sizes because our null distribution is one in which each ' +
+            'sample\'s single-cell profile is unchanged but the sample labels are randomly ' +
+            'assigned. If you want to run an analysis at this sample size despite the possibility of low ' +
+            'power, you can do so by invoking the association(...) function with the argument ' +
+            'allow_low_sample_size=True.')
+    return batches, filter_samples
+
+
+def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
+                            show_progress, **kwargs):
+    """Reference compute_nam_and_reindex (_association.py:175-191) on the device: build the NAM,
+    QC it, put the sample axis in ``y.index`` order restricted to ``filter_samples``, drop the
+    cells whose remaining entries have zero variance.  Leaves the selected NAM in the engine's
+    working matrix and returns the bookkeeping the caller needs."""
+    out = select_output(show_progress)
+    nam_kwargs = {k: v for k, v in kwargs.items() if k in ('self_weight',)}
+    print('computing NAM', file=out)
+    labels, _ = _nam_device(engine, data, sid_name, nsteps=nsteps, show_progress=show_progress, **nam_kwargs)
+    kept = _qc_device(engine, labels, batches, show_progress=show_progress)
+
+    # NAM.reindex(y.index)[filter_samples]: boolean-Series indexing aligns on the index
+    positions = pd.Series(np.arange(len(y)), index=y.index)[filter_samples].values
+    sample_index = y.index[positions]
+    colmap = labels.get_indexer(sample_index)
+    if (colmap < 0).any():
+        raise ValueError('the sample filter selects samples that have no cells in data; ' +
+                         'make sure y, covs, batches and donorids share one index order')
+    zero_var, nzero = engine.zero_variance(colmap)
+    if nzero:
+        kept = kept & ~zero_var
+    engine.select(None if kept.all() else kept, colmap)
+    return (kept, pd.Index(sample_index, name=sid_name), colmap,
+            batches.reindex(y.index),
+            covs.reindex(y.index) if covs is not None else None,
+            donorids.reindex(y.index) if donorids is not None else None,
+            filter_samples.reindex(y.index))
+
+
+def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=None, key_added='coef',
+                max_frac_pcs=0.15, nsteps=None, show_progress=False, allow_low_sample_size=False,
+                return_full=False, ridges=None, engine=None, **kwargs):
+    """cna.tl.association (reference _association.py:193-242).
+
+    Returns the global p-value, or with ``return_full=True`` the full result namespace
+    (same field names and types as upstream; the three cells x samples sized frames --
+    ``nam``, ``namresid``, ``namresid_nbhdXpc`` -- are copied off the GPU when first read).
+    Writes ``data.obs[key_added]`` and ``data.obs[key_added + '_fdr']``."""
+    out = select_output(show_progress)
+    engine = engine or get_engine()
+    extra = set(kwargs) - {'Nnull', 'force_permute_all', 'local_test', 'seed', 'self_weight'}
+    if extra or 'self_weight' in kwargs:
+        # upstream forwards **kwargs to _association(), which rejects anything else
+        bad = sorted(extra | ({'self_weight'} & set(kwargs)))[0]
+        raise TypeError(f"_association() got an unexpected keyword argument '{bad}'")
+
+    batches, filter_samples = check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size)
+    kept, sample_index, colmap, batches, covs, donorids, filter_samples = compute_nam_and_reindex(
+        engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps, show_progress)
+    cell_index = data.obs.index[kept]
+    nam_epoch = engine.nam_epoch
+
+    N = filter_samples.sum()
+    npcs = min(N, max([10] + [int(max_frac_pcs * N)] + [ks if ks is not None else []][0]))
+    res, U = _resid_device(engine, sample_index, cell_index,
+                           covs[filter_samples] if covs is not None else covs,
+                           batches[filter_samples] if batches is not None else batches,
+                           npcs=npcs, ridges=ridges, show_progress=show_progress)
+
+    print('performing association test', file=out)
+    res_, coef_all, fdr_all = _association(
+        engine, U, res.M, res.r, y[filter_samples].values, batches[filter_samples].values,
+        donorids[filter_samples].values if donorids is not None else None, cell_index,
+        show_progress=show_progress, ks=ks, **kwargs)
+    res.__dict__.update(res_)
+    res.ncorrs = pd.Series(coef_all[kept], index=cell_index)
+    res.kept = kept
+
+    def fetch_nam():
+        if engine.nam_epoch != nam_epoch:
+            raise RuntimeError('res.nam lives on the GPU and a later cna_amd call has replaced it; '
+                               'read it (or call res.materialize()) before running the next analysis')
+        full = _gather_rows(engine, engine.fetch_matrix(_ffi.MAT_NAM), engine.n)
+        return pd.DataFrame(full[kept][:, colmap].T, index=sample_index, columns=cell_index)
+
+    res._defer('nam', fetch_nam)
+
+    if key_added in data.obs:
+        warnings.warn(f"Key '{key_added}' already exists in data.obs. Overwriting.")
+    data.obs[key_added] = coef_all
+    if res.fdrs is None:
+        # upstream dereferences res.fdrs here and dies when local_test=False (_association.py:235)
+        raise AttributeError("'NoneType' object has no attribute 'loc'")
+    data.obs[f'{key_added}_fdr'] = fdr_all
+
+    if return_full:
+        return res
+    return res.p

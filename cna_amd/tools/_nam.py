@@ -1,0 +1,333 @@
+"""NAM construction, QC and residualisation/PCA -- host orchestration over the HIP engine.
+
+Mirrors the public surface of the reference's ``cna/tools/_nam.py`` (names, arguments,
+return types, progress text); the cells-sized arithmetic is done by libcna_hip.so:
+
+  reference step (file:line)                               device entry point
+  colsums = A.sum(axis=0)+w            _nam.py:28          cna_colsums
+  s <- A.(s/colsums)+w*s/colsums       _nam.py:33          cna_nam_step / cna_dense_step
+  median_i kurtosis_j(s/C)             _nam.py:59          cna_nam_step(want_kurt) + host median
+  _batch_kurtosis                      _nam.py:78-82       cna_batch_kurtosis
+  NAM_ = M.(NAM - mean)                _nam.py:122-148     cna_resid_apply
+  NAM_ /= std                          _nam.py:159         cna_standardize
+  NAM.dot(NAM.T)                       _nam.py:105         cna_gram     (N x N SVD stays in LAPACK)
+  V = NAM^T U / sqrt(svs)              _nam.py:106         cna_project  (lazy)
+
+Device matrices are cells x samples; DataFrames handed back to the caller are transposed to
+the reference's samples x cells on the way out.
+"""
+import warnings
+from argparse import Namespace
+
+import numpy as np
+import pandas as pd
+import scipy.sparse as sp
+
+from .. import _ffi
+from ..engine import get_engine
+from ._out import select_output
+
+DEFAULT_RIDGES = [1e5, 1e4, 1e3, 1e2, 1e1, 1e0, 1e-1, 1e-2, 1e-3, 1e-4, 0]
+
+
+class LazyNamespace(Namespace):
+    """Result namespace whose cells-sized fields are fetched from the device on first access
+    (SURVEY.md §8f.1).  ``isinstance(res, argparse.Namespace)`` holds; a lazily provided
+    attribute appears in ``vars(res)`` once it has been read."""
+
+    def _defer(self, name, thunk):
+        self.__dict__.setdefault('_lazy', {})[name] = thunk
+
+    def __getattr__(self, name):
+        lazy = self.__dict__.get('_lazy', {})
+        if name in lazy:
+            value = lazy.pop(name)()
+            setattr(self, name, value)
+            return value
+        raise AttributeError(name)
+
+    def materialize(self):
+        for name in list(self.__dict__.get('_lazy', {})):
+            getattr(self, name)
+        return self
+
+
+def get_connectivity(data):
+    """The kNN graph of an AnnData-like object (reference _nam.py:12-19).  anndata >= 0.7.2
+    keeps it in ``obsp``; objects from older versions only have ``uns['neighbors']``."""
+    obsp = getattr(data, 'obsp', None)
+    if obsp is not None and 'connectivities' in obsp:
+        return obsp['connectivities']
+    return data.uns['neighbors']['connectivities']
+
+
+def _as_csr(a):
+    if sp.isspmatrix_csr(a) or isinstance(a, getattr(sp, 'csr_array', ())):
+        return a
+    return sp.csr_matrix(a)
+
+
+def sample_codes(col):
+    """Column order of ``pd.get_dummies(obs[sid])`` (_nam.py:51): category order for a
+    categorical column (unused categories included), sorted unique labels otherwise."""
+    if isinstance(col.dtype, pd.CategoricalDtype):
+        return np.asarray(col.cat.codes, dtype=np.int32), pd.Index(col.cat.categories)
+    codes, uniques = pd.factorize(col, sort=True)
+    return codes.astype(np.int32), pd.Index(uniques)
+
+
+def _column_r2(a, b):
+    # R(A,B)**2 of _nam.py:47-49 (diagnostic print only).  The reference's operands are DataFrames,
+    # so the covariance is a population moment but both std() calls are pandas' ddof=1.
+    with np.errstate(all='ignore'):
+        r = ((a - a.mean(axis=0)) * (b - b.mean(axis=0))).mean(axis=0) / a.std(axis=0, ddof=1) / b.std(axis=0, ddof=1)
+    return r ** 2
+
+
+def _prepare_graph(engine, data, self_weight):
+    A = _as_csr(get_connectivity(data))
+    engine.ensure_graph(A)
+    engine.colsums(self_weight)
+    return A
+
+
+# --------------------------------------------------------------------------- diffusion API
+def diffuse_stepwise(data, s, maxnsteps=15, show_progress=False, self_weight=1, engine=None):
+    """Generator over random-walk steps of a dense cells x m state (reference _nam.py:21-34).
+    Yields an ndarray (or a DataFrame when ``s`` is one) after every step."""
+    out = select_output(show_progress)
+    engine = engine or get_engine()
+    _prepare_graph(engine, data, self_weight)
+    frame = s if isinstance(s, pd.DataFrame) else None
+    arr = np.asarray(s, dtype=np.float64)
+    if arr.ndim != 2:
+        raise ValueError('s must be 2-dimensional (cells x columns)')
+    r0, r1 = engine.block(arr.shape[0])
+    engine.dense_load(arr[r0:r1])
+    for i in range(maxnsteps):
+        print('\ttaking step', i + 1, file=out)
+        engine.dense_step()
+        cur = _gather_rows(engine, engine.dense_fetch(), arr.shape[0])
+        yield pd.DataFrame(cur, index=frame.index, columns=frame.columns) if frame is not None else cur
+
+
+def _gather_rows(engine, local, n):
+    if engine.nranks == 1:
+        return local
+    return engine.gather_rows_host(local, n)
+
+
+def diffuse(data, s, nsteps, show_progress=False, self_weight=1, engine=None):
+    """State after ``nsteps`` steps (reference _nam.py:36-41)."""
+    for s in diffuse_stepwise(data, s, maxnsteps=nsteps, show_progress=show_progress,
+                              self_weight=self_weight, engine=engine):
+        pass
+    return s
+
+
+# --------------------------------------------------------------------------- NAM on device
+def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1, show_progress=False):
+    """Reference ``_nam`` (_nam.py:44-76) with the state resident on the GPU.  On return the
+    engine holds NAM = (s/C) (cells x samples); returns (labels, steps taken)."""
+    out = select_output(show_progress)
+    _prepare_graph(engine, data, self_weight)
+    codes, labels = sample_codes(data.obs[sid_name])
+    N = len(labels)
+    C = np.bincount(codes[codes >= 0], minlength=N).astype(np.float64)
+    engine.set_samples(codes, N, C)
+    n = engine.n
+
+    need_kurt = (nsteps is None) or show_progress
+    prevmedkurt = np.inf
+    old = None
+    taken = 0
+    for i in range(maxnsteps):
+        last_for_sure = (nsteps is not None and i + 1 == nsteps) or (i + 1 == maxnsteps)
+        may_stop = last_for_sure or show_progress or (nsteps is None and i + 1 >= 3)
+        engine.nam_step(need_kurt, not last_for_sure, may_stop)
+        taken = i + 1
+        if need_kurt:
+            with np.errstate(all='ignore'):
+                medkurt = np.median(engine.cell_stat(n))
+            if show_progress:
+                # R2(t, t-1) is scale free per column, so NAM = s/C serves as s (_nam.py:60)
+                cur = engine.fetch_matrix(_ffi.MAT_NAM)
+                cur = _gather_rows(engine, cur, n)
+                R2 = _column_r2(cur, old if old is not None else np.zeros_like(cur))
+                old = cur
+                print('\tmedian kurtosis:', medkurt + 3, file=out)
+                with np.errstate(all='ignore'):
+                    print('\t20th percentile R2(t,t-1):', np.percentile(R2, 20), file=out)
+        if nsteps is None:
+            if prevmedkurt - medkurt < 3 and i + 1 >= 3:
+                print('stopping after', i + 1, 'steps', file=out)
+                break
+            prevmedkurt = medkurt
+        elif i + 1 == nsteps:
+            break
+    return labels, taken
+
+
+def _batch_codes(batches, index):
+    """Integer code per sample of ``index`` in ``np.unique(batches)`` order (what the
+    reference iterates over in _batch_kurtosis, _nam.py:79-82); NaN -> -1."""
+    b = batches.reindex(index) if isinstance(batches, pd.Series) else pd.Series(np.asarray(batches), index=index)
+    vals = b.values
+    try:
+        isnan = pd.isna(vals)
+    except TypeError:
+        isnan = np.zeros(len(vals), dtype=bool)
+    uniq = np.unique(vals[~isnan])
+    codes = np.full(len(vals), -1, dtype=np.int32)
+    codes[~isnan] = np.searchsorted(uniq, vals[~isnan])
+    return codes, len(uniq)
+
+
+def _qc_device(engine, labels, batches, show_progress=False):
+    """Reference ``_qc_nam`` (_nam.py:85-99) -> bool keep mask over all cells."""
+    out = select_output(show_progress)
+    if len(np.unique(batches)) == 1:
+        return np.repeat(True, engine.n)
+    codes, nb = _batch_codes(batches, labels)
+    engine.batch_kurtosis(_ffi.MAT_NAM, codes, nb)
+    kurtoses = engine.cell_stat(engine.n)
+    threshold = max(6, 2 * np.median(kurtoses))
+    print('throwing out neighborhoods with batch kurtosis >=', threshold, file=out)
+    with np.errstate(invalid='ignore'):
+        keep = kurtoses < threshold
+    print('keeping', keep.sum(), 'neighborhoods', file=out)
+    return keep
+
+
+def nam(data, sid_name, batches=None, nsteps=None, self_weight=1, max_frac_pcs=0.15, suffix='', ks=None,
+        show_progress=False, engine=None, **kwargs):
+    """Neighborhood abundance matrix and QC mask (reference _nam.py:179-193).
+
+    Returns ``(DataFrame samples x kept cells, bool keep[n_cells])``.  ``max_frac_pcs``,
+    ``suffix``, ``ks`` and extra keywords are accepted and ignored exactly as upstream."""
+    out = select_output(show_progress)
+    engine = engine or get_engine()
+    if batches is None:
+        u = data.obs[sid_name].unique()
+        batches = pd.Series(np.ones(len(u)), index=u)
+    print('computing NAM', file=out)
+    labels, _ = _nam_device(engine, data, sid_name, nsteps=nsteps, self_weight=self_weight,
+                            show_progress=show_progress)
+    keep = _qc_device(engine, labels, batches, show_progress=show_progress)
+    full = _gather_rows(engine, engine.fetch_matrix(_ffi.MAT_NAM), engine.n)   # cells x samples
+    index = pd.Index(labels, name=sid_name)
+    frame = pd.DataFrame(full[keep].T, index=index, columns=data.obs.index[keep], dtype=float)
+    return frame, keep
+
+
+# ------------------------------------------------------------------ residualise + PCA
+def _pc_names(n):
+    return ['PC' + str(i) for i in range(1, n + 1)]
+
+
+def svd_nam(NAM, engine=None):
+    """PCA of a samples x cells NAM through its Gram matrix (reference _nam.py:102-115):
+    returns ``(U DataFrame, svs Series, V DataFrame)``."""
+    engine = engine or get_engine()
+    X = np.ascontiguousarray(np.asarray(NAM, dtype=np.float64).T)      # cells x samples
+    engine.upload_x(X)
+    engine.standardize(center=True)
+    G = engine.gram()
+    U, svs, _ = np.linalg.svd(G)
+    with np.errstate(all='ignore'):
+        V = engine.project(U / np.sqrt(svs))
+    names = _pc_names(U.shape[1])
+    index = NAM.index if isinstance(NAM, pd.DataFrame) else None
+    columns = NAM.columns if isinstance(NAM, pd.DataFrame) else None
+    return (pd.DataFrame(U, index=index, columns=names),
+            pd.Series(svs, index=names),
+            pd.DataFrame(V, index=columns, columns=names))
+
+
+def _resid_device(engine, sample_index, cell_index, covs, batches, ridges=None, npcs=None, show_progress=False):
+    """Reference ``_resid_nam`` (_nam.py:118-177) applied to the engine's working matrix X
+    (cells x samples, already restricted to ``sample_index`` / ``cell_index``)."""
+    out = select_output(show_progress)
+    N = len(sample_index)
+    if covs is None:
+        covs = pd.DataFrame(np.ones((N, 0)), index=sample_index)
+    else:
+        covs = (covs - covs.mean(axis=0)) / covs.std(axis=0)
+
+    if batches is None or len(np.unique(batches)) == 1:
+        C = covs
+        if len(C.T) == 0:
+            M = pd.DataFrame(np.eye(N), columns=sample_index, index=sample_index)
+            # M = I: centring + division by the std is one row-local pass
+            engine.standardize(center=True)
+        else:
+            M = np.eye(N) - C.dot(np.linalg.solve(C.T.dot(C), C.T))
+            M.columns = M.index
+            engine.resid_apply(M.values, center=True)
+            engine.standardize(center=False)
+    else:
+        B = pd.get_dummies(batches)
+        B = (B - B.mean(axis=0)) / B.std(axis=0)
+        C = pd.concat([B, covs], axis=1)
+        if ridges is None:
+            ridges = DEFAULT_RIDGES
+        bcodes, nb = _batch_codes(batches, sample_index)
+        first = True
+        for ridge in ridges:
+            L = np.diag([1] * len(B.T) + [0] * (len(C.T) - len(B.T)))
+            M = np.eye(N) - C.dot(np.linalg.solve(C.T.dot(C) + ridge * len(C) * L, C.T))
+            M.columns = M.index
+            engine.resid_apply(np.asarray(M.values, dtype=np.float64), center=first)
+            first = False
+            engine.batch_kurtosis(_ffi.MAT_X, bcodes, nb)
+            kurtoses = engine.cell_stat(engine.x_rows_total)
+            med = np.median(kurtoses)
+            print('\twith ridge', ridge, 'median batch kurtosis = ', med, file=out)
+            if med <= 6:
+                break
+        if first:   # empty ridge list: only centring applies
+            engine.resid_apply(None, center=True)
+        engine.standardize(center=False)
+
+    # svd_nam re-centres / re-standardises (_nam.py:103-104); X is already standardised, so
+    # that is an identity up to 1 ulp and the Gram matrix is taken of X directly.
+    G = engine.gram()
+    U, svs, _ = np.linalg.svd(G)
+    names = _pc_names(N)
+    if npcs is None:
+        npcs = N
+    n_cells = engine.x_rows_total
+
+    res = LazyNamespace()
+    res.M = M
+    res.r = len(C.T)
+    res.namresid_sampleXpc = pd.DataFrame(U, index=sample_index, columns=names)
+    svs_s = pd.Series(svs, index=names)
+    res.namresid_svs = svs_s[:npcs]
+    res.namresid_varexp = svs_s / len(U) / n_cells
+
+    epoch = engine.x_epoch
+
+    def _still_resident():
+        if engine.x_epoch != epoch:
+            raise RuntimeError('this result field lives on the GPU and a later cna_amd call has replaced it; '
+                               'read it (or call res.materialize()) before running the next analysis')
+
+    def fetch_namresid():
+        _still_resident()
+        if engine.nranks == 1:
+            full_t = engine.fetch_matrix(_ffi.MAT_X, transposed=True)           # samples x cells
+        else:
+            full_t = _gather_rows(engine, engine.fetch_matrix(_ffi.MAT_X), n_cells).T
+        return pd.DataFrame(full_t, index=sample_index, columns=cell_index)
+
+    def fetch_V():
+        _still_resident()
+        with np.errstate(all='ignore'):
+            V = engine.project(U / np.sqrt(svs))
+        V = _gather_rows(engine, V, n_cells)
+        return pd.DataFrame(V, index=cell_index, columns=names)
+
+    res._defer('namresid', fetch_namresid)
+    res._defer('namresid_nbhdXpc', fetch_V)
+    return res, U

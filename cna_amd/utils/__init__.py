@@ -1,0 +1,3 @@
+from .multisample import obs_to_sample
+
+__all__ = ['obs_to_sample']

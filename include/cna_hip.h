@@ -1,0 +1,171 @@
+/*
+ * cna_hip.h -- C ABI of libcna_hip.so: the MI355X (gfx950) hot path of covarying
+ * neighborhood analysis (reference: immunogenomics/cna 0.2.3).
+ *
+ * The reference is pure Python and has no FFI of its own; the boundary a
+ * maintainer binds is therefore this library, called from the Python host through ctypes
+ * (cna_amd/_ffi.py; INTEGRATION.md shows the stub a reference maintainer would add).
+ * Every entry point names the reference lines it replaces (paths under
+ * /root/reference/src/cna/tools/).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / numpy types;
+ *   - every function returns 0 on success, a hipError_t (>0) or a CNA_E* code (<0) otherwise,
+ *     with a human-readable message available from cna_last_error() (thread local);
+ *   - the caller owns every host buffer; the library owns all device memory until
+ *     cna_ctx_destroy();  one context per host thread; all work is issued on the context's
+ *     own HIP stream and entry points that return host data synchronise that stream;
+ *   - matrices on the device are "cell-major": one row per cell (neighbourhood), one column
+ *     per sample, float64, leading dimension rounded up to a multiple of 4 with zero padding
+ *     (the reference's frames are the transpose, samples x cells);
+ *   - multi-GPU: one process per GPU; a context owns the contiguous block of graph rows
+ *     [row0, row0+n_local) and the same rows of every matrix; sample-space objects are
+ *     replicated.  Collectives (RCCL) are internal to the entry points that need them.
+ */
+#ifndef CNA_HIP_H
+#define CNA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cna_ctx cna_ctx;
+
+#define CNA_EINVAL  (-1)   /* bad argument / call order */
+#define CNA_ENOMEM  (-2)
+#define CNA_ERCCL   (-3)   /* RCCL failure or librccl.so not loadable */
+#define CNA_ESTATE  (-4)   /* required earlier step missing */
+
+/* matrix selectors for cna_matrix_shape / cna_fetch_matrix */
+#define CNA_MAT_NAM   0    /* NAM after diffusion, all local cells x all samples           */
+#define CNA_MAT_X     1    /* working matrix: selected NAM, then residualised NAM in place */
+
+/* kernel ids for the profiling counters (cna_prof_get) */
+enum {
+  CNA_K_COLSUM = 0, CNA_K_NAM_FIRST, CNA_K_NAM_STEP, CNA_K_BATCH_KURT, CNA_K_ZEROVAR,
+  CNA_K_SELECT, CNA_K_RESID, CNA_K_STANDARDIZE, CNA_K_GRAM, CNA_K_GRAM_REDUCE, CNA_K_NCORRS,
+  CNA_K_NULL_LOCAL, CNA_K_OBS_COUNTS, CNA_K_PERCELL_FDR, CNA_K_PROJECT, CNA_K_TRANSPOSE,
+  CNA_K_ALLGATHER, CNA_K_COUNT
+};
+
+/* ---- library / context ------------------------------------------------------------- */
+const char* cna_last_error(void);
+int  cna_abi_version(void);
+int  cna_device_count(int* count);
+int  cna_ctx_create(int device, cna_ctx** out);
+int  cna_ctx_destroy(cna_ctx* ctx);
+int  cna_ctx_sync(cna_ctx* ctx);
+/* bytes of device memory currently held by the context */
+int  cna_ctx_device_bytes(cna_ctx* ctx, int64_t* bytes);
+
+/* ---- multi-GPU (RCCL over xGMI) ------------------------------------------------------ */
+/* rank 0 creates a 128-byte id and ships it to the other ranks by any host channel */
+int  cna_comm_unique_id(void* id128);
+int  cna_comm_init(cna_ctx* ctx, int rank, int nranks, const void* id128);
+
+/* ---- graph: data.obsp['connectivities'] (_nam.py:12-19,25) ---------------------------- */
+/* CSR rows [row0, row0+n_local) of the n_global x n_global kNN graph.  indptr has n_local+1
+ * entries rebased so indptr[0]==0; column indices are global.  data is float32 (what scanpy
+ * emits) or float64.  Replaces the scipy.sparse object the reference reads. */
+int  cna_graph_upload(cna_ctx* ctx, int64_t n_global, int64_t row0, int64_t n_local,
+                      const int64_t* indptr, const int32_t* indices,
+                      const void* data, int data_is_f64);
+/* colsums = A.sum(axis=0) + self_weight (_nam.py:28), float64, all-reduced over ranks */
+int  cna_colsums(cna_ctx* ctx, double self_weight);
+int  cna_fetch_colsums(cna_ctx* ctx, double* out_n_global);
+
+/* ---- NAM construction (_nam.py:44-76) ------------------------------------------------ */
+/* codes[i] = column of cell i in pd.get_dummies(obs[sid]) (_nam.py:51), for ALL n_global cells;
+ * counts[c] = cells per sample C (_nam.py:54). */
+int  cna_set_samples(cna_ctx* ctx, const int32_t* codes, int n_samples, const double* counts);
+/* One diffusion step s <- A.(s/colsums) + w*s/colsums (_nam.py:31-34) of the sample indicators.
+ * The first call after cna_set_samples starts from the one-hot matrix.
+ *   want_kurt : also produce per-cell kurtosis over samples of s/C (_nam.py:59), readable with
+ *               cna_fetch_cell_stat;
+ *   may_continue : keep the scaled state for another step (exchanged across ranks);
+ *   may_stop  : also write NAM = s/C (_nam.py:73) so the walk can end here. */
+int  cna_nam_step(cna_ctx* ctx, int want_kurt, int may_continue, int may_stop);
+/* per-cell statistic of the last kernel that produced one (kurtosis / batch kurtosis),
+ * gathered over ranks: out has n_global entries (CNA_MAT_NAM rows) or n_x_total (CNA_MAT_X) */
+int  cna_fetch_cell_stat(cna_ctx* ctx, double* out, int64_t n_expected);
+
+/* cna.tl.diffuse / diffuse_stepwise on an arbitrary dense cells x m state (_nam.py:21-41):
+ * load the local rows, step, fetch the local rows (unscaled state s). */
+int  cna_dense_load(cna_ctx* ctx, const double* s_local, int m);
+int  cna_dense_step(cna_ctx* ctx);
+int  cna_dense_fetch(cna_ctx* ctx, double* s_local_out);
+
+/* ---- QC / selection (_nam.py:78-99, _association.py:175-191) --------------------------- */
+/* _batch_kurtosis (_nam.py:78-82) of matrix `which`: per cell, Pearson kurtosis over the
+ * per-batch means; batch_codes[s] in [0,n_batches) per column of that matrix. */
+int  cna_batch_kurtosis(cna_ctx* ctx, int which, const int32_t* batch_codes, int n_batches);
+/* cells whose NAM entries are constant over the selected samples (NAM.std(axis=0)==0,
+ * _association.py:182): flags (1 byte per cell, all n_global cells, gathered over ranks) and
+ * their total number. colmap NULL = all samples. */
+int  cna_zero_variance(cna_ctx* ctx, const int32_t* colmap, int n_sel, uint8_t* flags_out,
+                       int64_t* n_zero_out);
+/* X[i', c'] = NAM[keep_idx[i'], colmap[c']]  (NAM.reindex(y.index)[filter], iloc[:, keep], drop;
+ * _nam.py:99, _association.py:178-185).  keep_idx: local row indices, NULL = all rows. */
+int  cna_select(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_keep,
+                const int32_t* colmap, int n_sel);
+/* upload a cells x samples matrix as X (cna.tl.svd_nam on a user NAM, _nam.py:102) */
+int  cna_upload_x(cna_ctx* ctx, const double* x_local, int64_t n_rows, int n_cols);
+
+/* ---- residualisation + PCA (_nam.py:102-177) ------------------------------------------ */
+/* X <- (X - rowmean(X))  if center  (_nam.py:122);  then X <- X . M^T if M != NULL
+ * (_nam.py:135,148; M is n_cols x n_cols row-major). */
+int  cna_resid_apply(cna_ctx* ctx, const double* M, int center);
+/* X <- X / std(X over samples, ddof=1)  (_nam.py:159); center!=0 subtracts the mean first
+ * (svd_nam's own re-standardisation, _nam.py:103-104). */
+int  cna_standardize(cna_ctx* ctx, int center);
+/* G = X^T X over all cells of all ranks (NAM.dot(NAM.T), _nam.py:105), n_cols x n_cols row-major */
+int  cna_gram(cna_ctx* ctx, double* G_out);
+/* out = X . W  (V = NAM^T U / sqrt(svs), _nam.py:106; W = U/sqrt(svs), n_cols x n_w row-major),
+ * local rows, row-major n_x_local x n_w */
+int  cna_project(cna_ctx* ctx, const double* W, int n_w, double* out_local);
+
+/* ---- association (_association.py:77-120, _stats.py:34-83) ----------------------------- */
+/* ncorrs = (y[:,None]*NAMresid).mean(axis=0) (_association.py:77); kept on the device and
+ * optionally copied out (local rows); max_abs = max|ncorrs| over all ranks (_association.py:101). */
+int  cna_ncorrs(cna_ctx* ctx, const double* y, double* out_local, double* max_abs);
+/* Local null: for P' permuted, conditioned, standardised phenotypes Yc (n_cols x P row-major,
+ * _association.py:96-97) count, per permutation p and threshold t,
+ *   tails[p][t] = #{cells i : (|X_i . Yc_p| / n_cols)^2 >= edges[t]}
+ * = tail_counts(thresholds, nullncorrs) of _stats.py:34-62 with
+ * edges[t] = thr_t^2 - 1e-8 - 1e-5*thr_t^2 (ascending).  The cells x P' matrix of
+ * _association.py:99 is never materialised.  tails_out is P x T int64, summed over ranks. */
+int  cna_null_local(cna_ctx* ctx, const double* Yc, int P, const double* edges, int T,
+                    int64_t* tails_out);
+/* ranks[t] = #{i : ncorrs_i^2 >= edges[t]} (_stats.py:74) and
+ * num_detected[t] = #{i : |ncorrs_i| > thr[t]} (_association.py:108), summed over ranks */
+int  cna_obs_counts(cna_ctx* ctx, const double* edges, const double* thr, int T,
+                    int64_t* ranks_out, int64_t* num_detected_out);
+/* data.obs[key] and data.obs[key+'_fdr'] (_association.py:230-237) for ALL n_global cells:
+ * coef = NaN for cells not kept else ncorrs; fdr = min{fdr_t : thr_t <= |coef|} else 1.
+ * runmin_fdr[t] = min(fdr[0..t]).  kept rows are the ones given to cna_select. */
+int  cna_percell_fdr(cna_ctx* ctx, const double* thr, const double* runmin_fdr, int T,
+                     double* coef_out_global, double* fdr_out_global);
+
+/* ---- device -> host for the lazily materialised result fields (a20) -------------------- */
+int  cna_matrix_shape(cna_ctx* ctx, int which, int64_t* n_rows_local, int* n_cols);
+/* transposed!=0 writes samples x cells (the reference's orientation), else cells x samples */
+int  cna_fetch_matrix(cna_ctx* ctx, int which, double* out, int transposed);
+
+/* concatenate count_local doubles from every rank, in rank order, into out_all on every rank
+ * (row blocks of the lazily fetched matrices when the job spans several GPUs) */
+int  cna_allgather_host(cna_ctx* ctx, const double* local, int64_t count_local, double* out_all,
+                        int64_t count_total);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* HIP-event timing of every kernel launch on the context's stream (bench.py roofline) */
+int  cna_prof_enable(cna_ctx* ctx, int on);
+int  cna_prof_reset(cna_ctx* ctx);
+int  cna_prof_get(cna_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
+const char* cna_kernel_name(int kernel_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CNA_HIP_H */

@@ -79,7 +79,7 @@ def row_kurtosis(x):
     m2 = d2.mean(axis=1)
     m4 = (d2 * d2).mean(axis=1)
     with np.errstate(all='ignore'):
-        zero = m2 <= (np.finfo(np.float64).resolution * mean[:, 0]) ** 2
+        zero = m2 <= (np.finfo(np.float64).eps * mean[:, 0]) ** 2
         out = np.where(zero, np.nan, m4 / m2 ** 2)
     return out - 3.0
 
@@ -88,7 +88,7 @@ def column_r2(a, b):
     """R(A,B)^2 per column (_nam.py:47-49,60): population moments, NaN when a column of
     B is constant (first step: old_s = 0)."""
     with np.errstate(all='ignore'):
-        r = ((a - a.mean(axis=0)) * (b - b.mean(axis=0))).mean(axis=0) / a.std(axis=0) / b.std(axis=0)
+        r = ((a - a.mean(axis=0)) * (b - b.mean(axis=0))).mean(axis=0) / a.std(axis=0, ddof=1) / b.std(axis=0, ddof=1)
     return r ** 2
 
 

@@ -1,0 +1,224 @@
+"""TEST DOUBLE for cna_amd.engine.Engine, built from the CPU oracle.
+
+Lives under tests/ on purpose: it lets the CPU test-suite exercise the *host* logic of
+cna_amd.tools (input checks, sample reindexing, ridge schedule, permutation null, result
+fields, row-block sharding and the collectives it needs) without a GPU, and lets
+world_size-2 gloo tests check that a sharded run equals an unsharded one.  The product never
+imports this file and has no CPU path of its own.
+
+Collectives: ``coll`` is None (single rank) or an object with allreduce_sum(ndarray),
+allreduce_max(float) and allgather(ndarray rows) -- see GlooColl below.
+"""
+import numpy as np
+import scipy.sparse as sp
+
+from oracle import cna_oracle as orc
+
+MAT_NAM, MAT_X = 0, 1
+
+
+class GlooColl:
+    """Host collectives over torch.distributed (gloo) for the sharded CPU tests."""
+
+    def __init__(self):
+        import torch.distributed as td
+        self.td = td
+        self.rank, self.nranks = td.get_rank(), td.get_world_size()
+
+    def allreduce_sum(self, a):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(a).copy())
+        self.td.all_reduce(t)
+        return t.numpy()
+
+    def allreduce_max(self, v):
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float64)
+        self.td.all_reduce(t, op=self.td.ReduceOp.MAX)
+        return float(t[0])
+
+    def allgather(self, a):
+        box = [None] * self.nranks
+        self.td.all_gather_object(box, np.ascontiguousarray(a))
+        return np.concatenate(box, axis=0)
+
+
+class FakeEngine:
+    def __init__(self, coll=None):
+        self.coll = coll
+        self.rank = coll.rank if coll else 0
+        self.nranks = coll.nranks if coll else 1
+        self.n = self.row0 = self.n_local = self.N = 0
+        self.x_rows_total = 0
+        self.x_epoch = self.nam_epoch = 0
+        self.calls = []
+
+    # -- collectives
+    def _sum(self, a):
+        return self.coll.allreduce_sum(a) if self.coll else a
+
+    def _gather(self, a):
+        return self.coll.allgather(a) if self.coll else a
+
+    def gather_rows_host(self, local, n_total):
+        out = self._gather(local)
+        assert out.shape[0] == n_total
+        return out
+
+    def block(self, n):
+        rpr = -(-n // self.nranks)
+        r0 = min(self.rank * rpr, n)
+        return r0, min(r0 + rpr, n)
+
+    # -- graph
+    def ensure_graph(self, A):
+        A = sp.csr_matrix(A)
+        self.n = A.shape[0]
+        r0, r1 = self.block(self.n)
+        self.row0, self.n_local = r0, r1 - r0
+        self.A_local = A[r0:r1].astype(np.float64)
+        self._w = None
+        return True
+
+    def colsums(self, self_weight=1):
+        part = np.asarray(self.A_local.sum(axis=0)).ravel()
+        self.colsum = self._sum(part) + self_weight
+        self.w = self_weight
+
+    def fetch_colsums(self):
+        return self.colsum.copy()
+
+    # -- NAM
+    def set_samples(self, codes, n_samples, counts):
+        self.codes = np.asarray(codes)
+        self.N = int(n_samples)
+        self.counts = np.asarray(counts, dtype=np.float64)
+        S = np.zeros((self.n, self.N))
+        S[np.arange(self.n), self.codes] = 1.0
+        self.S = S
+        self.steps = 0
+        self.nam_epoch += 1
+
+    def _step(self, S):
+        c = self.colsum[:, None]
+        T = S / c
+        loc = slice(self.row0, self.row0 + self.n_local)
+        new_local = self.A_local.dot(T) + self.w * S[loc] / c[loc]
+        return new_local
+
+    def nam_step(self, want_kurt, may_continue, may_stop):
+        self.calls.append(('nam_step', bool(want_kurt), bool(may_continue), bool(may_stop)))
+        new_local = self._step(self.S)
+        self.S = self._gather(new_local)
+        self.steps += 1
+        with np.errstate(all='ignore'):
+            if may_stop:
+                self.nam = new_local / self.counts
+            if want_kurt:
+                self.stat = orc.row_kurtosis(self.S / self.counts)
+
+    def cell_stat(self, n_expected):
+        assert len(self.stat) == n_expected
+        return self.stat.copy()
+
+    # -- dense diffusion
+    def dense_load(self, s_local):
+        self.D = self._gather(np.asarray(s_local, dtype=np.float64))
+
+    def dense_step(self):
+        self.D_local = self._step(self.D)
+        self.D = self._gather(self.D_local)
+
+    def dense_fetch(self):
+        return self.D_local.copy()
+
+    # -- QC / selection
+    def batch_kurtosis(self, which, batch_codes, n_batches):
+        mat = self.nam if which == MAT_NAM else self.X
+        bc = np.asarray(batch_codes)
+        with np.errstate(all='ignore'):
+            local = orc.batch_kurtosis(mat, bc, n_batches)
+        self.stat = self._gather(local)
+
+    def zero_variance(self, colmap):
+        sub = self.nam if colmap is None else self.nam[:, np.asarray(colmap)]
+        with np.errstate(all='ignore'):
+            flags = sub.std(axis=1, ddof=1) == 0
+        flags = self._gather(flags.astype(np.uint8)).astype(bool)
+        return flags, int(flags.sum())
+
+    def select(self, keep_global, colmap):
+        loc = slice(self.row0, self.row0 + self.n_local)
+        rows = self.nam if keep_global is None else self.nam[np.asarray(keep_global, dtype=bool)[loc]]
+        self.X = rows if colmap is None else rows[:, np.asarray(colmap)]
+        self.X = np.array(self.X)
+        self.keep_local = None if keep_global is None else np.asarray(keep_global, dtype=bool)[loc]
+        self.x_rows_total = self.n if keep_global is None else int(np.sum(keep_global))
+        self.x_epoch += 1
+
+    def upload_x(self, x_local):
+        self.X = np.array(x_local, dtype=np.float64)
+        self.x_rows_total = self.X.shape[0]
+        self.x_epoch += 1
+
+    # -- residualise + PCA
+    def resid_apply(self, M, center):
+        if center:
+            self.X = self.X - self.X.mean(axis=1, keepdims=True)
+        if M is not None:
+            self.X = self.X.dot(np.asarray(M).T)
+
+    def standardize(self, center=False):
+        if center:
+            self.X = self.X - self.X.mean(axis=1, keepdims=True)
+        with np.errstate(all='ignore'):
+            self.X = self.X / self.X.std(axis=1, ddof=1)[:, None]
+
+    def gram(self):
+        return self._sum(self.X.T.dot(self.X))
+
+    def project(self, W):
+        return self.X.dot(np.asarray(W))
+
+    # -- association
+    def ncorrs(self, y, fetch=False):
+        self.nc = (self.X * np.asarray(y)[None, :]).sum(axis=1) / self.X.shape[1]
+        m = np.abs(self.nc).max() if len(self.nc) else 0.0
+        if self.coll:
+            m = self.coll.allreduce_max(m)
+        return (self.nc.copy() if fetch else None), float(m)
+
+    def null_local(self, Yc, edges):
+        z2 = (np.abs(self.X.dot(Yc)) / self.X.shape[1]) ** 2
+        tails = np.array([[(z2[:, p] >= e).sum() for e in edges] for p in range(Yc.shape[1])], dtype=np.int64)
+        return self._sum(tails)
+
+    def obs_counts(self, edges, thr):
+        z = np.abs(self.nc)
+        ranks = np.array([(self.nc ** 2 >= e).sum() for e in edges], dtype=np.int64)
+        numdet = np.array([(z > t).sum() for t in thr], dtype=np.int64)
+        return self._sum(ranks), self._sum(numdet)
+
+    def percell(self, thr=None, runmin=None):
+        coef = np.full(self.n_local, np.nan)
+        if self.keep_local is None:
+            coef[:] = self.nc
+        else:
+            coef[self.keep_local] = self.nc
+        coef = self._gather(coef)
+        if thr is None:
+            return coef, None
+        idx = np.searchsorted(thr, np.abs(coef), side='right') - 1
+        fdr = np.ones(len(coef))
+        ok = (idx >= 0) & ~np.isnan(coef)
+        fdr[ok] = np.asarray(runmin)[idx[ok]]
+        return coef, fdr
+
+    # -- D2H
+    def matrix_shape(self, which):
+        m = self.nam if which == MAT_NAM else self.X
+        return m.shape
+
+    def fetch_matrix(self, which, transposed=False):
+        m = self.nam if which == MAT_NAM else self.X
+        return np.array(m.T if transposed else m)

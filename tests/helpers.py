@@ -59,3 +59,74 @@ def relerr(a, b):
     b = np.asarray(b, dtype=np.float64)
     scale = max(np.nanmax(np.abs(b)), 1e-300) if b.size else 1.0
     return float(np.nanmax(np.abs(a - b)) / scale) if a.size else 0.0
+
+
+# --------------------------------------------------------------------------------------
+# running the product API on a fixture and comparing with the reference's outputs
+def run_product(case, engine, **overrides):
+    """cna_amd.tl.association on a golden case; returns (result or None, exception or None, warnings)."""
+    import warnings
+    import cna_amd as cna
+    call = dict(case['call'])
+    call.update(overrides)
+    res, err = None, None
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter('always')
+        try:
+            res = cna.tl.association(case['data'], case['y'], case['sid_name'], batches=case['batches'],
+                                     covs=case['covs'], donorids=case['donorids'], return_full=True,
+                                     engine=engine, **call)
+        except Exception as e:   # noqa: BLE001 - mirrored reference behaviour is checked by the caller
+            err = e
+    msgs = [str(w.message) for w in wl if issubclass(w.category, UserWarning)]
+    return res, err, msgs
+
+
+def assert_matches_golden(res, data, z, tol=1e-5, check_lazy=True):
+    """Every result field of SURVEY.md §8a a20 against the reference's values.
+    ints / masks exact; floats within `tol` relative (BASELINE.json: 1e-5)."""
+    import pytest
+    assert int(res.k) == int(z['k'])
+    assert np.array_equal(np.asarray(res.ks), z['ks'])
+    assert int(res.r) == int(z['r'])
+    assert np.array_equal(res.kept, z['kept'])
+    assert float(res.p) == pytest.approx(float(z['p']), rel=1e-12)
+    assert relerr(res.ncorrs.values, z['ncorrs']) < tol
+    assert relerr(res.M.values, z['M']) < tol
+    assert relerr(res.nullminps, z['nullminps']) < tol * 10
+    assert relerr(res.namresid_svs.values, z['svs']) < tol
+    assert relerr(res.namresid_varexp.values, z['varexp']) < tol
+    assert relerr(np.asarray(res.yresid), z['yresid']) < tol
+    assert float(res.r2) == pytest.approx(float(z['r2']), rel=tol * 10)
+    assert float(res.nullr2_mean) == pytest.approx(float(z['nullr2_mean']), rel=tol * 10)
+    assert float(res.nullr2_std) == pytest.approx(float(z['nullr2_std']), rel=tol * 10)
+    kk = int(z['k'])
+    U, Uref = sign_align(res.namresid_sampleXpc.values, z['U'], kk)
+    assert relerr(U, Uref) < 1e-4
+    assert relerr(np.abs(res.beta), np.abs(z['beta'])) < 1e-4
+    assert relerr(res.r2_perpc, z['r2_perpc']) < 1e-4
+    assert relerr(np.abs(res.yresid_hat), np.abs(z['yresid_hat'])) < 1e-4
+    np.testing.assert_allclose(data.obs['coef'].values, z['obs_coef'], rtol=0,
+                               atol=tol * np.nanmax(np.abs(z['obs_coef'])), equal_nan=True)
+    if 'fdr_fdr' in z:
+        f = res.fdrs
+        T = min(len(f), len(z['fdr_threshold']))
+        assert abs(len(f) - len(z['fdr_threshold'])) <= 1 and T >= 300
+        assert relerr(f.threshold.values[:T], z['fdr_threshold'][:T]) < tol
+        assert np.array_equal(f.num_detected.values[:T], z['fdr_num_detected'][:T])
+        assert relerr(f.fdr.values[:T], z['fdr_fdr'][:T]) < tol * 10
+        for key in ('fdr_5p_t', 'fdr_10p_t'):
+            ref = float(z[key])
+            got = getattr(res, key)
+            if np.isnan(ref):
+                assert got is None
+            else:
+                assert got == pytest.approx(ref, rel=tol)
+        np.testing.assert_allclose(data.obs['coef_fdr'].values, z['obs_coef_fdr'], rtol=tol * 10, atol=1e-12)
+    if check_lazy:
+        assert list(res.nam.index) == z['nam_index'].tolist()
+        assert relerr(res.nam.values, z['nam']) < tol
+        assert relerr(res.namresid.values, z['namresid']) < tol
+        V, Vref = sign_align(res.namresid_nbhdXpc.values, z['V'], kk)
+        assert relerr(V, Vref) < 1e-4
+        assert res.nam.shape == z['nam'].shape and list(res.nam.columns) == list(data.obs.index[z['kept']])

@@ -1,0 +1,302 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against (a) the CPU oracle on the same seeded inputs, (b) the golden vectors captured from the
+reference, (c) size-independent properties at larger sizes.
+
+Tolerances: integers / masks / step counts exact; floats 1e-5 relative versus the reference
+(BASELINE.json north_star), and much tighter (1e-10) versus the float64 oracle since both
+evaluate the same float64 formulas.
+"""
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse as sp
+
+from helpers import golden_names, load_case, run_product, assert_matches_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+NAMES = golden_names()
+
+
+@pytest.fixture(scope='module')
+def eng():
+    from cna_amd.engine import get_engine
+    return get_engine()
+
+
+@pytest.fixture(scope='module')
+def orc():
+    from oracle import cna_oracle
+    return cna_oracle
+
+
+def test_native_library_is_what_runs(eng):
+    import ctypes as C
+    from cna_amd import _ffi
+    assert _ffi._lib is not None and _ffi.LIB_PATH.endswith('cna_amd/libcna_hip.so')
+    with open('/proc/self/maps') as f:
+        assert 'libcna_hip.so' in f.read()
+    n = C.c_int(0)
+    assert _ffi.load().cna_device_count(C.byref(n)) == 0 and n.value >= 1
+
+
+# ------------------------------------------------------------------ kernel by kernel vs oracle
+def _setup_nam(eng, orc, case, nsteps=3, want_kurt=True):
+    from cna_amd.tools._nam import sample_codes
+    A = sp.csr_matrix(case['data'].obsp['connectivities'])
+    eng.ensure_graph(case['data'].obsp['connectivities'])
+    eng.colsums(1)
+    codes, labels = sample_codes(case['data'].obs[case['sid_name']])
+    N = len(labels)
+    C = np.bincount(codes, minlength=N).astype(float)
+    eng.set_samples(codes, N, C)
+    return A, codes, N
+
+
+@pytest.mark.parametrize('name', ['c01_plain_f32', 'c05_ks_f64', 'c14_selfweight_autostop_unsorted'])
+def test_diffusion_steps_vs_oracle_and_golden(eng, orc, name):
+    from cna_amd import _ffi
+    case = load_case(name)
+    z = case['z']
+    A, codes, N = _setup_nam(eng, orc, case)
+    cs = eng.fetch_colsums()
+    np.testing.assert_allclose(cs, orc.column_sums(A, 1, 'f64'), rtol=1e-15)
+    S = np.zeros((A.shape[0], N), dtype=bool)
+    S[np.arange(A.shape[0]), codes] = True
+    s = S
+    colsums = orc.column_sums(A, 1, 'f64')
+    nst = len(z['steps'])
+    for i in range(nst):
+        s = orc.diffusion_step(A, s, colsums, 1, first_onehot=(i == 0), mode='f64')
+        eng.nam_step(True, i + 1 < nst, True)
+        got = eng.fetch_matrix(_ffi.MAT_NAM)
+        want = s / S.sum(axis=0)
+        assert relerr(got, want) < 1e-13, (i, relerr(got, want))
+        assert relerr(got, z['steps'][i] / S.sum(axis=0)) < 1e-5          # the reference itself
+        kurt = eng.cell_stat(A.shape[0])
+        np.testing.assert_allclose(kurt, orc.row_kurtosis(want), rtol=1e-9, atol=1e-12)
+        assert np.median(kurt) == pytest.approx(z['steps_medkurt'][i], rel=1e-5)
+    # the walk is column-stochastic: every sample's row of the (samples x cells) NAM sums to 1
+    got = eng.fetch_matrix(_ffi.MAT_NAM)
+    np.testing.assert_allclose(got.sum(axis=0), 1.0, rtol=1e-10)
+
+
+def test_dense_diffusion_and_self_weight(eng, orc):
+    import cna_amd as cna
+    case = load_case('c01_plain_f32')
+    z = case['z']
+    A = sp.csr_matrix(case['data'].obsp['connectivities'])
+    for w, key in ((1, 'diffuse_out_2'), (0.5, 'diffuse_out_2_sw05')):
+        out = cna.tl.diffuse(case['data'], z['diffuse_in'], 2, self_weight=w)
+        assert relerr(out, orc.diffuse(A, z['diffuse_in'], 2, self_weight=w, mode='f64')) < 1e-14
+        assert relerr(out, z[key]) < 1e-5
+    # a single column, and a DataFrame in -> DataFrame out, generator semantics
+    one = z['diffuse_in'][:, :1]
+    assert relerr(cna.tl.diffuse(case['data'], one, 3), orc.diffuse(A, one, 3, mode='f64')) < 1e-14
+    steps = list(cna.tl.diffuse_stepwise(case['data'], pd.DataFrame(z['diffuse_in']), maxnsteps=2))
+    assert len(steps) == 2 and isinstance(steps[1], pd.DataFrame)
+    assert relerr(steps[1].values, z['diffuse_out_2']) < 1e-5
+    case = load_case('c14_selfweight_autostop_unsorted')
+    NAM, keep = cna.tl.nam(case['data'], case['sid_name'], nsteps=2, self_weight=2)
+    assert relerr(NAM.values, case['z']['tlnam_sw2']) < 1e-5 and keep.all()
+
+
+@pytest.mark.parametrize('name', ['c03_covs_batches', 'c12_batchy_qc'])
+def test_tl_nam_qc(eng, name):
+    import cna_amd as cna
+    case = load_case(name)
+    z = case['z']
+    NAM, keep = cna.tl.nam(case['data'], case['sid_name'], batches=case['batches'], nsteps=3)
+    assert np.array_equal(keep, z['tlnam_keep'])
+    assert NAM.shape == z['tlnam'].shape and relerr(NAM.values, z['tlnam']) < 1e-5
+    assert list(NAM.index) == z['tlnam_index'].tolist()
+
+
+def _random_x(rs, n, N):
+    return rs.randn(n, N) * rs.rand(1, N) + rs.randn(n, 1)
+
+
+@pytest.mark.parametrize('n,N', [(1000, 20), (777, 50), (513, 3), (300, 130), (257, 200), (64, 256), (5, 17)])
+def test_dense_row_kernels_vs_numpy(eng, orc, n, N):
+    from cna_amd import _ffi
+    rs = np.random.RandomState(n + N)
+    X = _random_x(rs, n, N)
+    # standardize(center) == svd_nam's re-standardisation
+    eng.upload_x(X)
+    eng.standardize(center=True)
+    Xc = X - X.mean(axis=1, keepdims=True)
+    Xs = Xc / Xc.std(axis=1, ddof=1)[:, None]
+    got = eng.fetch_matrix(_ffi.MAT_X)
+    assert relerr(got, Xs) < 1e-13
+    assert relerr(eng.fetch_matrix(_ffi.MAT_X, transposed=True), Xs.T) < 1e-13
+    # Gram on the matrix cores
+    G = eng.gram()
+    assert relerr(G, Xs.T.dot(Xs)) < 1e-12
+    assert np.array_equal(G, G.T)
+    # projection X.W (V = NAM^T U / sqrt(svs)); asymmetric W catches a transposed operand
+    W = rs.randn(N, N)
+    assert relerr(eng.project(W), Xs.dot(W)) < 1e-12
+    W2 = rs.randn(N, 5)
+    assert relerr(eng.project(W2), Xs.dot(W2)) < 1e-12
+    # residualisation (X - mean).M^T with an asymmetric M, then in place a second time (ridge loop)
+    eng.upload_x(X)
+    M = rs.randn(N, N)
+    eng.resid_apply(M, center=True)
+    want = Xc.dot(M.T)
+    assert relerr(eng.fetch_matrix(_ffi.MAT_X), want) < 1e-12
+    M2 = rs.randn(N, N)
+    eng.resid_apply(M2, center=False)
+    want = want.dot(M2.T)
+    assert relerr(eng.fetch_matrix(_ffi.MAT_X), want) < 1e-12
+    eng.standardize(center=False)
+    want = want / want.std(axis=1, ddof=1)[:, None]
+    assert relerr(eng.fetch_matrix(_ffi.MAT_X), want) < 1e-12
+    # batch kurtosis of the working matrix
+    nb = min(7, N)
+    bc = np.arange(N) % nb
+    eng.batch_kurtosis(_ffi.MAT_X, bc, nb)
+    np.testing.assert_allclose(eng.cell_stat(n), orc.batch_kurtosis(want, bc, nb), rtol=1e-9)
+    # neighbourhood coefficients
+    y = rs.randn(N)
+    nc, m = eng.ncorrs(y, fetch=True)
+    ref = (want * y[None, :]).sum(axis=1) / N
+    assert relerr(nc, ref) < 1e-12 and m == pytest.approx(np.abs(ref).max(), rel=1e-12)
+
+
+@pytest.mark.parametrize('n,N,P', [(3000, 20, 100), (2049, 50, 200), (1000, 100, 70), (600, 200, 130),
+                                   (100, 256, 64), (16, 12, 5)])
+def test_local_null_counts_are_exact(eng, n, N, P):
+    """tails / ranks / num_detected are integers: they must equal a brute-force count."""
+    from cna_amd import _ffi
+    rs = np.random.RandomState(n + N + P)
+    X = rs.randn(n, N)
+    X = (X - X.mean(axis=1, keepdims=True))
+    X /= X.std(axis=1, ddof=1)[:, None]
+    eng.upload_x(X)
+    y = rs.randn(N)
+    nc, maxabs = eng.ncorrs(y, fetch=True)
+    Yc = rs.randn(N, P)
+    Yc /= Yc.std(axis=0, ddof=1)
+    maxcorr = max(maxabs, 0.001)
+    thr = np.arange(maxcorr / 4, maxcorr, maxcorr / 400)
+    edges = thr ** 2 - 1e-8 - 1e-5 * thr ** 2
+    tails = eng.null_local(Yc, edges)
+    z2 = (np.abs(X.dot(Yc)) / N) ** 2
+    want = np.array([len(v) - np.searchsorted(v, edges, side='left') for v in np.sort(z2, axis=0).T])
+    # a value within 1 ulp of an edge may land on either side: allow a handful of off-by-ones
+    diff = np.abs(tails - want)
+    assert diff.max() <= 1 and diff.sum() <= 3, (diff.max(), diff.sum())
+    assert (np.diff(tails, axis=1) <= 0).all() and tails.max() <= n
+    ranks, numdet = eng.obs_counts(edges, thr)
+    assert np.array_equal(ranks, [(nc ** 2 >= e).sum() for e in edges])
+    assert np.array_equal(numdet, [(np.abs(nc) > t).sum() for t in thr])
+
+
+def test_percell_lookup(eng, orc):
+    case = load_case('c12_batchy_qc')
+    res, err, _ = run_product(case, eng)
+    assert err is None
+    coef = case['data'].obs['coef'].values
+    fdr = case['data'].obs['coef_fdr'].values
+    assert np.isnan(coef[~res.kept]).all() and (fdr[~res.kept] == 1).all()
+    want = orc.percell_fdr(coef, res.fdrs.threshold.values, res.fdrs.fdr.values)
+    np.testing.assert_allclose(fdr, want, rtol=1e-14)
+
+
+# ----------------------------------------------------------------------- end to end vs reference
+@pytest.mark.parametrize('name', NAMES)
+def test_association_matches_reference(eng, name):
+    case = load_case(name)
+    z = case['z']
+    res, err, msgs = run_product(case, eng)
+    if z['raised'].item():
+        assert err is not None and type(err).__name__ + ': ' + str(err) == z['raised'].item()
+        np.testing.assert_allclose(case['data'].obs['coef'].values, z['obs_coef'], rtol=0,
+                                   atol=1e-5 * np.nanmax(np.abs(z['obs_coef'])), equal_nan=True)
+        return
+    assert err is None, repr(err)
+    assert_matches_golden(res, case['data'], z, tol=1e-5)
+
+
+@pytest.mark.parametrize('name', ['c01_plain_f32', 'c03_covs_batches', 'c09_y_nan_extra_reordered', 'c15_ridges_custom'])
+def test_association_matches_f64_oracle_tightly(eng, orc, name):
+    case = load_case(name)
+    res, err, _ = run_product(case, eng)
+    assert err is None
+    ref = orc.association(case['data'], case['y'], case['sid_name'], batches=case['batches'], covs=case['covs'],
+                          donorids=case['donorids'], mode='f64', **case['call'])
+    assert int(res.k) == ref['k'] and res.p == ref['p'] and np.array_equal(res.kept, ref['kept'])
+    assert relerr(res.nam.values.T, ref['nam']) < 1e-13
+    assert relerr(res.namresid.values.T, ref['namresid']) < 1e-10
+    assert relerr(res.ncorrs.values, ref['ncorrs']) < 1e-10
+    assert relerr(res.namresid_svs.values, ref['svs']) < 1e-10
+    assert relerr(res.nullminps, ref['nullminps']) < 1e-8
+    T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
+    assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T])
+    np.testing.assert_allclose(res.fdrs.fdr.values[:T], ref['fdrs']['fdr'][:T], rtol=1e-9, atol=1e-13)
+
+
+def test_svd_nam_public(eng):
+    import cna_amd as cna
+    z = load_case('c01_plain_f32')['z']
+    nam_df = pd.DataFrame(z['nam'], index=z['nam_index'].tolist())
+    U, svs, V = cna.tl.svd_nam(nam_df)
+    assert relerr(svs.values, z['svd_svs']) < 1e-6
+    from helpers import sign_align
+    a, b = sign_align(U.values, z['svd_U'], 5)
+    assert relerr(a, b) < 1e-5
+    a, b = sign_align(V.values, z['svd_V'], 5)
+    assert relerr(a, b) < 1e-5
+
+
+# -------------------------------------------------------------------------- edge cases / properties
+def test_isolated_and_heavy_rows(eng, orc):
+    """cells without neighbours, a row with > 64 neighbours (multi-chunk), N not a multiple of 4."""
+    from cna_amd import _ffi
+    rs = np.random.RandomState(3)
+    n, N = 400, 7
+    A = sp.random(n, n, density=0.02, random_state=rs, format='lil', dtype=np.float64)
+    A[5, :] = 0
+    A[:, 5] = 0                       # isolated cell
+    A[9, :] = rs.rand(n)              # 399 neighbours
+    A[9, 5] = 0
+    A = sp.csr_matrix(A)
+    A.setdiag(0)
+    A.eliminate_zeros()
+    A = A.astype(np.float32)
+    codes = rs.randint(0, N, n).astype(np.int32)
+    obs = pd.DataFrame({'id': codes})
+    data = type('D', (), {'obs': obs, 'obsp': {'connectivities': A}, 'uns': {}})()
+    import cna_amd as cna
+    NAM, keep = cna.tl.nam(data, 'id', nsteps=3)
+    ref = orc.build_nam(A, codes, N, nsteps=3, mode='f64')
+    assert relerr(NAM.values.T, ref['nam']) < 1e-13 and keep.all()
+    # the isolated cell keeps all its mass in its own sample
+    row = NAM.values[:, 5] * np.bincount(codes, minlength=N)
+    assert row[codes[5]] == pytest.approx(1.0) and np.count_nonzero(row) == 1
+
+
+def test_properties_at_scale(eng):
+    """size-independent properties on a larger synthetic problem (oracle-free)."""
+    import cna_amd as cna
+    from cna_amd import synth
+    data, meta = synth.make_dataset(60000, 50, k=30, seed=5, n_covs=2)
+    res = cna.tl.association(data, meta['y'], 'id', covs=meta['covs'], nsteps=3, Nnull=500, seed=1, return_full=True)
+    nam = res.nam.values                                   # samples x cells
+    np.testing.assert_allclose(nam.sum(axis=1), 1.0, rtol=1e-9)      # column-stochastic walk
+    X = res.namresid.values
+    assert np.abs(X.mean(axis=0)).max() < 1e-10
+    np.testing.assert_allclose(X.std(axis=0, ddof=1), 1.0, rtol=1e-10)
+    # residualised NAM is orthogonal to the covariates
+    cz = (meta['covs'] - meta['covs'].mean()) / meta['covs'].std()
+    assert np.abs(cz.values.T.dot(X)).max() < 1e-8
+    U = res.namresid_sampleXpc.values
+    np.testing.assert_allclose(U.T.dot(U), np.eye(U.shape[1]), atol=1e-10)
+    np.testing.assert_allclose(U.dot(np.diag(res.namresid_varexp.values * 50 * X.shape[1])).dot(U.T), X.dot(X.T),
+                               rtol=1e-7, atol=1e-6 * X.shape[1])
+    f = res.fdrs
+    assert (np.diff(f.num_detected.values) <= 0).all()
+    assert f.num_detected.values[0] == (np.abs(res.ncorrs.values) > f.threshold.values[0]).sum()
+    yz = (meta['y'].values - meta['y'].values.mean()) / meta['y'].values.std()
+    np.testing.assert_allclose(res.ncorrs.values, yz.dot(X) / 50, rtol=1e-9, atol=1e-12)
+    assert 1 / 501 <= res.p <= 1 and len(res.nullminps) == 500

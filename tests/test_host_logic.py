@@ -1,0 +1,159 @@
+"""Host-side logic of cna_amd.tools on CPU: the real orchestration code driven through a
+test double of the device engine (tests/fake_engine.py, oracle arithmetic).  Checks that
+input validation, sample reindexing/filtering, QC, the ridge schedule, the permutation
+null, result fields, warnings and progress text reproduce the reference's golden outputs.
+The HIP kernels themselves are checked on the GPU (tests/test_gpu_parity.py)."""
+import contextlib
+import io
+import re
+
+import numpy as np
+import pandas as pd
+import pytest
+
+import cna_amd as cna
+from fake_engine import FakeEngine
+from helpers import golden_names, load_case, run_product, assert_matches_golden, relerr
+
+NAMES = golden_names()
+
+
+@pytest.mark.parametrize('name', NAMES)
+def test_association_host_logic(name):
+    case = load_case(name)
+    z = case['z']
+    res, err, msgs = run_product(case, FakeEngine())
+    if z['raised'].item():
+        assert err is not None and type(err).__name__ == z['raised'].item().split(':')[0]
+        assert str(err) == z['raised'].item().split(': ', 1)[1]
+        np.testing.assert_allclose(case['data'].obs['coef'].values, z['obs_coef'], rtol=0,
+                                   atol=1e-5 * np.nanmax(np.abs(z['obs_coef'])), equal_nan=True)
+        return
+    assert err is None, repr(err)
+    assert_matches_golden(res, case['data'], z)
+    import json
+    ref_msgs = [m for m in json.loads(z['warnings'].item()) if 'already exists' not in m]
+    assert [m for m in msgs if 'already exists' not in m] == ref_msgs
+
+
+def _numbers(text):
+    return [float(x) for x in re.findall(r'[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?|nan', text)]
+
+
+@pytest.mark.parametrize('name', ['c01_plain_f32', 'c02_covs_autostop', 'c03_covs_batches', 'c12_batchy_qc',
+                                  'c15_ridges_custom'])
+def test_progress_text(name):
+    case = load_case(name)
+    ref = case['z']['stdout'].item()
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        cna.tl.association(case['data'], case['y'], case['sid_name'], batches=case['batches'], covs=case['covs'],
+                           donorids=case['donorids'], show_progress=True, engine=FakeEngine(), **case['call'])
+    got = buf.getvalue()
+    strip = lambda s: re.sub(r'[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?|nan', '#', s)
+    assert strip(got) == strip(ref)
+    a, b = np.array(_numbers(got)), np.array(_numbers(ref))
+    np.testing.assert_allclose(a, b, rtol=1e-5, equal_nan=True)
+
+
+def test_ridge_loop_runs_the_whole_schedule():
+    case = load_case('c16_ridge_loop')
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        cna.tl.association(case['data'], case['y'], case['sid_name'], batches=case['batches'], covs=case['covs'],
+                           show_progress=True, engine=FakeEngine(), **case['call'])
+    ref_lines = [l for l in case['z']['stdout'].item().splitlines() if 'with ridge' in l]
+    got_lines = [l for l in buf.getvalue().splitlines() if 'with ridge' in l]
+    assert len(got_lines) == len(ref_lines) == 11
+    # the last ridges regress the batch effect down to rounding noise: compare the stable ones
+    for g, r in list(zip(got_lines, ref_lines))[:8]:
+        assert _numbers(g)[0] == _numbers(r)[0]
+        assert _numbers(g)[1] == pytest.approx(_numbers(r)[1], rel=1e-6)
+
+
+def test_tl_nam_and_svd_and_diffuse():
+    case = load_case('c12_batchy_qc')
+    z = case['z']
+    NAM, keep = cna.tl.nam(case['data'], case['sid_name'], batches=case['batches'], nsteps=3, engine=FakeEngine())
+    assert isinstance(NAM, pd.DataFrame) and NAM.index.name == case['sid_name']
+    assert np.array_equal(keep, z['tlnam_keep'])
+    assert relerr(NAM.values, z['tlnam']) < 1e-5
+    assert list(NAM.columns) == list(case['data'].obs.index[keep])
+
+    case = load_case('c01_plain_f32')
+    z = case['z']
+    eng = FakeEngine()
+    out = cna.tl.diffuse(case['data'], z['diffuse_in'], 2, engine=eng)
+    assert isinstance(out, np.ndarray) and relerr(out, z['diffuse_out_2']) < 1e-6
+    out = cna.tl.diffuse(case['data'], z['diffuse_in'], 2, self_weight=0.5, engine=eng)
+    assert relerr(out, z['diffuse_out_2_sw05']) < 1e-6
+    steps = list(cna.tl.diffuse_stepwise(case['data'], pd.DataFrame(z['diffuse_in']), maxnsteps=2, engine=eng))
+    assert len(steps) == 2 and isinstance(steps[0], pd.DataFrame)
+    nam_df = pd.DataFrame(z['nam'], index=z['nam_index'].tolist())
+    U, svs, V = cna.tl.svd_nam(nam_df, engine=eng)
+    assert relerr(svs.values, z['svd_svs']) < 1e-6
+    assert list(U.columns[:2]) == ['PC1', 'PC2'] and list(U.index) == list(nam_df.index)
+    assert V.shape == z['svd_V'].shape
+
+    case = load_case('c14_selfweight_autostop_unsorted')
+    NAM, _ = cna.tl.nam(case['data'], case['sid_name'], nsteps=2, self_weight=2, engine=FakeEngine())
+    assert relerr(NAM.values, case['z']['tlnam_sw2']) < 1e-5
+
+
+def test_autostop_step_flags():
+    """nsteps=None: every step from the 3rd on must be allowed to be the last one."""
+    case = load_case('c02_covs_autostop')
+    eng = FakeEngine()
+    cna.tl.association(case['data'], case['y'], case['sid_name'], covs=case['covs'], engine=eng, **case['call'])
+    steps = [c for c in eng.calls if c[0] == 'nam_step']
+    assert len(steps) == case['z']['stdout'].item().count('median kurtosis')
+    assert all(c[1] for c in steps)                    # kurtosis needed for the stop rule
+    assert [c[3] for c in steps] == [False, False] + [True] * (len(steps) - 2)
+
+
+def test_input_validation_matches_reference_messages():
+    case = load_case('c01_plain_f32')
+    d, y = case['data'], case['y']
+    eng = FakeEngine()
+    with pytest.raises(TypeError, match="'y' must be a pandas Series"):
+        cna.tl.association(d, y.values, 'id', engine=eng)
+    with pytest.raises(TypeError, match="'covs' must be a pandas DataFrame"):
+        cna.tl.association(d, y, 'id', covs=y, engine=eng)
+    with pytest.raises(TypeError, match="'batches' must be a pandas Series"):
+        cna.tl.association(d, y, 'id', batches=y.values, engine=eng)
+    with pytest.raises(ValueError, match="contains values not present in the index of 'y'"):
+        cna.tl.association(d, y.iloc[:-1], 'id', engine=eng)
+    with pytest.raises(ValueError, match='do not currently support conditioning on batch'):
+        cna.tl.association(d, y, 'id', batches=y, donorids=y, engine=eng)
+    few = y.copy()
+    few.iloc[5:] = np.nan
+    with pytest.raises(ValueError, match='fewer than 10 samples'):
+        cna.tl.association(d, few, 'id', engine=eng)
+    with pytest.raises(ValueError, match='Maximum number of PCs plus number of covariates'):
+        cna.tl.association(d, y, 'id', ks=[20], nsteps=1, engine=eng)
+    with pytest.raises(TypeError, match="unexpected keyword argument 'self_weight'"):
+        cna.tl.association(d, y, 'id', self_weight=2, engine=eng)
+    with pytest.warns(UserWarning, match="Key 'coef' already exists"):
+        cna.tl.association(d, y, 'id', nsteps=1, Nnull=10, seed=0, engine=eng)
+        cna.tl.association(d, y, 'id', nsteps=1, Nnull=10, seed=0, engine=eng)
+
+
+def test_lazy_fields_guard_against_stale_device_state():
+    case = load_case('c01_plain_f32')
+    eng = FakeEngine()
+    res = cna.tl.association(case['data'], case['y'], 'id', return_full=True, engine=eng, **case['call'])
+    _ = res.namresid                    # read while resident: fine
+    cna.tl.association(case['data'], case['y'], 'id', engine=eng, **case['call'])
+    with pytest.raises(RuntimeError, match='later cna_amd call'):
+        _ = res.namresid_nbhdXpc
+    with pytest.raises(RuntimeError, match='later cna_amd call'):
+        _ = res.nam
+
+
+def test_obs_to_sample():
+    obs = pd.DataFrame({'id': [2, 2, 1, 1, 1], 'age': [10., 10., 30., 30., 30.], 'x': [1., 3., 0., 3., 6.]})
+    d = type('D', (), {'obs': obs})()
+    out = cna.ut.obs_to_sample(d, ['age', 'x'], 'id')
+    assert list(out.index) == [2, 1]
+    assert out.loc[1, 'x'] == 3.0 and out.loc[2, 'age'] == 10.0
+    assert cna.ut.obs_to_sample(d, 'x', 'id', aggregate='max').loc[1, 'x'] == 6.0
