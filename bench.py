@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cells*permutations / second of an end-to-end ``cna.tl.association``
+(BASELINE.json metric) on synthetic data, HIP path, graph resident in HBM.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C2|C3|C4w]
+
+A *step* is one full association() call -- NAM diffusion (3 steps) -> QC/selection ->
+residualisation -> Gram/SVD -> global permutation test -> fused local null + FDRs ->
+data.obs write-back -- on one synthetic dataset.  At N=1 the workload is BASELINE.json
+configs[1] ("C2": 200k cells, 50 samples, k=30, nsteps=3, Nnull=1000).  With N>1 (launched
+by torch.distributed.run, one rank per GPU) the cells axis is sharded by row blocks with a
+fixed 200k cells per GPU (weak scaling); RCCL carries the state exchange between diffusion
+steps and the small all-reduces.
+
+Prints ONE JSON line on rank 0 (see the repo's bench contract) with two extra objects:
+  roofline     for the kernel that dominates the timed region (HIP-event timed in this run)
+  cpu_baseline the CPU oracle timed here on a bounded sample of the same workload (N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F64_MFMA_PEAK_TF = 78.6      # AMD MI355X datasheet: FP64 matrix 78.6 TFLOP/s (the guide lists no f64 row)
+
+WORKLOADS = {
+    # name: (cells per GPU, samples, kNN k, nsteps, Nnull)
+    'C2': (200_000, 50, 30, 3, 1000),
+    'C3': (1_000_000, 100, 30, 3, 1000),
+    'C4w': (250_000, 200, 30, 3, 1000),     # 8 GPUs x 250k = BASELINE config 4
+}
+
+
+def algorithmic_work(kernel, n, nnz, N, P, T, wA):
+    """Algorithmic bytes / flops of ONE launch (DESIGN.md 'Kernels')."""
+    ld = (N + 3) // 4 * 4
+    if kernel == 'nam_step':
+        return 'hbm', nnz * (4 + wA) + 8 * (n + 1) + 8 * n + 2 * 8 * n * N
+    if kernel == 'nam_first':
+        return 'hbm', nnz * (4 + wA) + 8 * (n + 1) + n * (4 + 8) + 8 * n * N
+    if kernel == 'null_local':
+        return 'mfma', 2.0 * n * N * P
+    if kernel == 'gram':
+        return 'mfma', 2.0 * n * N * N
+    if kernel in ('resid_xb', 'project_xb'):
+        return 'mfma', 2.0 * n * N * N
+    if kernel == 'colsum':
+        return 'hbm', nnz * (4 + wA) + 8 * n
+    if kernel in ('standardize',):
+        return 'hbm', 2 * 8 * n * ld
+    if kernel in ('select',):
+        return 'hbm', 2 * 8 * n * ld
+    if kernel in ('ncorrs', 'zero_variance'):
+        return 'hbm', 8 * n * ld + 8 * n
+    return 'hbm', 8 * n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-cells', type=int, default=100_000)
+    ap.add_argument('--profile-host', default=None, help='write a cProfile of 3 extra steps to this file')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
+    td = None
+    if world > 1:
+        import torch
+        import torch.distributed as td
+        torch.cuda.set_device(local_rank)
+        td.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        from cna_amd import dist
+        dist.init_from_torch(device=local_rank)
+
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.engine import get_engine
+    from cna_amd.tools._nam import get_connectivity
+
+    cells_per_gpu, N, k, nsteps, Nnull = WORKLOADS[args.workload]
+    n = cells_per_gpu * world
+    t0 = time.time()
+    data, meta = synth.make_dataset(n, N, k=k, seed=0)
+    t_gen = time.time() - t0
+    A = get_connectivity(data)
+    nnz = int(A.nnz)
+    y = meta['y']
+    eng = get_engine()
+    kw = dict(nsteps=nsteps, Nnull=Nnull, seed=0)
+
+    def sync():
+        eng.sync()
+        if td is not None:
+            import torch
+            torch.cuda.synchronize()
+            td.barrier()
+            torch.cuda.synchronize()
+
+    # graph H2D + first call (also the PCIe-inclusive single-call time, reported separately)
+    sync()
+    t0 = time.perf_counter()
+    p_first = cna.tl.association(data, y, 'id', **kw)
+    sync()
+    t_cold = time.perf_counter() - t0
+    for _ in range(max(args.warmup - 1, 0)):
+        cna.tl.association(data, y, 'id', **kw)
+
+    eng.prof_reset()
+    eng.prof_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        p_last = cna.tl.association(data, y, 'id', **kw)
+    sync()
+    dt = time.perf_counter() - t0
+    eng.prof_enable(False)
+    prof = eng.prof()
+    if td is not None:
+        import torch
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        dt = float(t[0])
+    assert p_first == p_last
+
+    if args.profile_host and rank == 0:
+        import cProfile
+        import io
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for _ in range(3):
+            cna.tl.association(data, y, 'id', **kw)
+        pr.disable()
+        buf = io.StringIO()
+        pstats.Stats(pr, stream=buf).sort_stats('tottime').print_stats(45)
+        with open(args.profile_host, 'w') as f:
+            f.write(buf.getvalue())
+
+    if rank != 0:
+        if td is not None:
+            td.destroy_process_group()
+        return
+
+    ms_per_step = dt / args.steps * 1e3
+    value = n * Nnull * args.steps / dt
+    wA = A.data.dtype.itemsize
+    T = 300
+    n_loc = eng.n_local
+    nnz_loc = int(A.indptr[eng.row0 + n_loc] - A.indptr[eng.row0])
+    kernels = {}
+    for name, (ms, cnt) in prof.items():
+        bound, work = algorithmic_work(name, n_loc, nnz_loc, N, min(1000, Nnull), T, wA)
+        avg_s = ms / cnt * 1e-3
+        ach = work / avg_s / (1e9 if bound == 'hbm' else 1e12)
+        peak = HBM_PEAK_GBS if bound == 'hbm' else F64_MFMA_PEAK_TF
+        kernels[name] = dict(total_ms=round(ms, 4), launches=cnt, avg_us=round(ms / cnt * 1e3, 2), bound=bound,
+                             achieved=round(ach, 3), peak=peak, unit='GB/s' if bound == 'hbm' else 'TFLOP/s',
+                             frac=round(ach / peak, 4))
+    dom = max((k_ for k_ in kernels if k_ != 'rccl'), key=lambda k_: kernels[k_]['total_ms'])
+    kd = kernels[dom]
+    roofline = dict(kernel=dom, bound=kd['bound'], achieved=kd['achieved'], peak=kd['peak'], unit=kd['unit'],
+                    frac=kd['frac'], traffic=None, avg_us=kd['avg_us'], launches_per_step=kd['launches'] // args.steps)
+    gpu_ms_per_step = sum(v['total_ms'] for v in kernels.values()) / args.steps
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import cna_oracle as orc
+        ns = min(args.cpu_sample_cells, n)
+        sdata, smeta = synth.make_dataset(ns, N, k=k, seed=0)
+        t0 = time.perf_counter()
+        ref = orc.association(sdata, smeta['y'], 'id', mode='reference', **kw)
+        t_cpu = time.perf_counter() - t0
+        try:
+            from threadpoolctl import threadpool_info
+            threads = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
+        except Exception:
+            threads = os.cpu_count()
+        cpu = dict(value=round(ns * Nnull / t_cpu, 1), unit='cell*perm/s', cores=int(threads), kind='port',
+                   seconds=round(t_cpu, 2), host_cpus=os.cpu_count(),
+                   sample='oracle/cna_oracle.py association(mode=reference) on %d cells x %d samples, k=%d, '
+                          'nsteps=%d, Nnull=%d (same generator, seed 0); numpy/scipy vectorised port, '
+                          'BLAS threads as listed' % (ns, N, k, nsteps, Nnull))
+
+    out = {
+        'metric': 'cells*permutations/sec end-to-end cna.tl.association',
+        'value': round(value, 1), 'unit': 'cell*perm/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': '%s: %d cells (%d per GPU) x %d samples, k=%d kNN (%.1f nnz/row, float32 CSR), '
+                               'nsteps=%d, Nnull=%d, local FDR pass on' % (args.workload, n, cells_per_gpu, N, k,
+                                                                          nnz / n, nsteps, Nnull),
+                   'parallelism': 'cells sharded in %d row block(s)' % world, 'p_value': p_last},
+        'roofline': roofline,
+        'cpu_baseline': cpu,
+        'gpu_kernel_ms_per_step': round(gpu_ms_per_step, 3),
+        'host_ms_per_step': round(ms_per_step - gpu_ms_per_step, 3),
+        'first_call_ms_incl_graph_h2d': round(t_cold * 1e3, 1),
+        'dataset_gen_s': round(t_gen, 1),
+        'kernels': kernels,
+    }
+    print(json.dumps(out))
+    if td is not None:
+        td.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -297,15 +297,19 @@ int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const doubl
   if (!c->indptr) CNA_FAIL(CNA_ESTATE, "cna_set_samples before cna_graph_upload");
   if (n_samples < 1 || n_samples > 512) CNA_FAIL(CNA_EINVAL, "n_samples must be in [1, 512]");
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (c->sid) dev_free(c, c->sid, sizeof(int32_t) * c->n_global);
-  if (c->counts) dev_free(c, c->counts, sizeof(double) * c->N);
-  c->sid = nullptr; c->counts = nullptr;
+  if (!c->sid || !c->counts || c->N != n_samples || c->sid_n != c->n_global) {
+    if (c->sid) dev_free(c, c->sid, sizeof(int32_t) * c->sid_n);
+    if (c->counts) dev_free(c, c->counts, sizeof(double) * c->N);
+    c->sid = nullptr; c->counts = nullptr;
+    CNA_TRY(dev_alloc(c, (void**)&c->sid, sizeof(int32_t) * c->n_global));
+    CNA_TRY(dev_alloc(c, (void**)&c->counts, sizeof(double) * n_samples));
+    c->sid_n = c->n_global;
+  }
   c->N = n_samples;
   c->ld = round_up(n_samples, 4);
-  CNA_TRY(dev_alloc(c, (void**)&c->sid, sizeof(int32_t) * c->n_global));
-  CNA_TRY(dev_alloc(c, (void**)&c->counts, sizeof(double) * n_samples));
-  HIP_TRY(hipMemcpy(c->sid, codes, sizeof(int32_t) * c->n_global, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->counts, counts, sizeof(double) * n_samples, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpyAsync(c->sid, codes, sizeof(int32_t) * c->n_global, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->counts, counts, sizeof(double) * n_samples, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   CNA_TRY(ensure_T(c, c->ld));
   void* nm = c->nam;
   CNA_TRY(dev_reserve(c, &nm, &c->nam_cap, (int64_t)sizeof(double) * std::max<int64_t>(c->n_local, 1) * c->ld));
@@ -604,10 +608,10 @@ int cna_ncorrs(cna_ctx* c, const double* y, double* out_local, double* max_abs) 
   void* np = c->ncorrs;
   CNA_TRY(dev_reserve(c, &np, &c->ncorrs_cap, 8 * std::max<int64_t>(c->nx, 1)));
   c->ncorrs = (double*)np;
-  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({8 * (int64_t)c->Nx, 8})));
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({8 * (int64_t)c->Nx, 8 * 2049})));
   Carver cv(c->scratch);
   double* yd = cv.take<double>(c->Nx);
-  unsigned long long* mb = cv.take<unsigned long long>(1);
+  unsigned long long* mb = cv.take<unsigned long long>(2049);
   HIP_TRY(hipMemcpyAsync(yd, y, 8 * c->Nx, hipMemcpyHostToDevice, c->stream));
   CNA_TRY(launch_ncorrs(c, yd, mb));
   CNA_TRY(comm_allreduce_f64_max(c, (double*)mb, 1));
@@ -637,11 +641,27 @@ int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int
   const int ldy = round_up(P, 64);
   std::vector<double> Yp((size_t)ldx * ldy, 0.0);
   for (int k = 0; k < Nx; ++k) std::memcpy(&Yp[(size_t)k * ldy], &Yc[(size_t)k * P], sizeof(double) * P);
-  // invert edges -> thresholds for the linear bin guess (exactness comes from the edge compares)
-  double th[2] = {0, 0};
-  for (int t = 0; t < std::min(T, 2); ++t) th[t] = std::sqrt(std::max(0.0, (edges[t] + 1e-8) / (1.0 - 1e-5)));
+  // cut[t] = smallest double a >= 0 with fl(fl(a/N)^2) >= edges[t]: the reference's test on
+  // z^2 = (|x.yc|/N)^2 (_association.py:99, _stats.py:47-54) moved onto the raw dot product.
+  // Both roundings are monotone, so a bisection over the bit patterns of the positive doubles
+  // finds the exact switch point.
+  std::vector<double> cuts(T);
+  const double dn = (double)Nx;
+  for (int t = 0; t < T; ++t) {
+    const double e = edges[t];
+    auto ok = [&](double a) { volatile double z = a / dn; volatile double z2 = z * z; return z2 >= e; };
+    if (e <= 0.0 || ok(0.0)) { cuts[t] = 0.0; continue; }
+    uint64_t lo = 0, hi = 0x7ff0000000000000ull;          // lo fails, hi (+inf) passes
+    while (hi - lo > 1) {
+      const uint64_t mid = lo + (hi - lo) / 2;
+      double a;
+      std::memcpy(&a, &mid, 8);
+      if (ok(a)) hi = mid; else lo = mid;
+    }
+    std::memcpy(&cuts[t], &hi, 8);
+  }
   double thr0, inv_step;
-  guess_from_thr(th, T, &thr0, &inv_step);
+  guess_from_thr(cuts.data(), T, &thr0, &inv_step);
   CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap,
                       carve_bytes({(int64_t)sizeof(double) * ldx * ldy, 8 * (int64_t)T, 8 * (int64_t)P * T, 8 * (int64_t)P * T})));
   Carver cv(c->scratch);
@@ -650,7 +670,7 @@ int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int
   unsigned long long* hist = cv.take<unsigned long long>((int64_t)P * T);
   int64_t* tails = cv.take<int64_t>((int64_t)P * T);
   HIP_TRY(hipMemcpyAsync(Yd, Yp.data(), sizeof(double) * ldx * ldy, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(ed, edges, 8 * T, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(ed, cuts.data(), 8 * T, hipMemcpyHostToDevice, c->stream));
   CNA_TRY(launch_null_local(c, Yd, ldy, P, ed, T, thr0, inv_step, hist));
   CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)P * T));
   CNA_TRY(launch_suffix_sum(c, hist, P, T, tails));

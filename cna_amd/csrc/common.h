@@ -62,6 +62,7 @@ struct cna_ctx {
   // ---- samples
   int N = 0, ld = 0;
   int32_t* sid = nullptr;    // n_global
+  int64_t sid_n = 0;
   double* counts = nullptr;  // N
 
   // ---- diffusion state: scaled state T = s/colsums for all global rows (neighbour gathers)
@@ -154,3 +155,34 @@ int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, 
 int launch_gram(cna_ctx* c, double* G_dev);
 int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* edges_dev, int T,
                       double thr0, double inv_step, unsigned long long* hist_dev);
+
+// ---- device helpers shared by the kernel files
+#ifdef __HIPCC__
+// Sum over the 64 lanes of a wave, result in every lane.  Four DPP steps (xor 1, xor 2, mirror
+// within 8, mirror within 16) give every lane its 16-lane row total without touching LDS
+// (ds_bpermute-based __shfl_xor costs two LDS round trips per step for a double); the four
+// row totals are then combined through scalar reads.  Fixed order -> deterministic.
+__device__ __forceinline__ double dpp_add(double v, const int ctrl_sel) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  int lo2, hi2;
+  switch (ctrl_sel) {
+    case 0: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+    case 1: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+    case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break; // row_half_mirror
+    default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break; // row_mirror
+  }
+  return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double wave_sum(double v) {
+  v = dpp_add(v, 0);
+  v = dpp_add(v, 1);
+  v = dpp_add(v, 2);
+  v = dpp_add(v, 3);
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+#endif

@@ -46,12 +46,6 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {
   return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
 // logical row-block of this workgroup: XCD x (= blockIdx % 8, observed dispatch) walks the
 // contiguous range [x*cpx, (x+1)*cpx); a pure speed choice, any placement is correct.
 __device__ __forceinline__ int64_t xcd_logical_block() {
@@ -164,11 +158,12 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
     const int jl = ok ? a.idx[e] : 0;
     const double al = ok ? (double)val[e] : 0.0;
     const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
-    for (int l = 0; l < cnt; l += 8) {
-      double t[8][NQ];
-      double av[8];
+    constexpr int U = (NQ <= 2) ? 16 : 8;      // neighbour rows in flight per wave
+    for (int l = 0; l < cnt; l += U) {
+      double t[U][NQ];
+      double av[U];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < U; ++u) {
         const bool on = (l + u) < cnt;
         const int lu = on ? (l + u) : l;
         const int64_t j = __builtin_amdgcn_readlane(jl, lu);
@@ -180,7 +175,7 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
         }
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < U; ++u) {
         if ((l + u) < cnt) {
 #pragma unroll
           for (int q = 0; q < NQ; ++q) acc[q] = __dadd_rn(acc[q], __dmul_rn(av[u], t[u][q]));

@@ -14,12 +14,6 @@ namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
 // ======================================================================== OUT = X . B
 // One wave owns a 16-cell tile: its rows are staged (and optionally centred) in a wave
 // private LDS panel, padded to ldp = ldx + 2 doubles so the A-fragment ds_read_b64 of 16
@@ -133,64 +127,81 @@ __global__ __launch_bounds__(512) void k_gram(const double* __restrict__ X, int6
   }
 }
 
-__global__ void k_gram_reduce(const double* __restrict__ partial, int nblocks, int ntri,
-                              const int32_t* __restrict__ tiles, int Nx, double* __restrict__ G) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= ntri * 256) return;
-  const int tix = idx >> 8, e = idx & 255;
+__global__ __launch_bounds__(1024) void k_gram_reduce(const double* __restrict__ partial, int nblocks, int ntri,
+                                                      const int32_t* __restrict__ tiles, int Nx,
+                                                      double* __restrict__ G) {
+  // block = 64 accumulator lanes x 16 strided groups of workgroup partials; fixed summation
+  // order (group-strided, then groups 0..15) -> bit-reproducible
+  __shared__ double red[16][64];
+  const int tix = blockIdx.x >> 2, r = blockIdx.x & 3;
+  const int lane = threadIdx.x, g = threadIdx.y;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += partial[((size_t)b * ntri + tix) * 256 + e];
-  const int r = e >> 6, lane = e & 63;
-  const int packed = tiles[tix];
-  const int i = (packed >> 16) * 16 + (lane >> 4) + 4 * r;
-  const int j = (packed & 0xffff) * 16 + (lane & 15);
-  if (i < Nx && j < Nx) {
-    G[(size_t)i * Nx + j] = s;
-    G[(size_t)j * Nx + i] = s;
+  for (int b = g; b < nblocks; b += 16) s += partial[((size_t)b * ntri + tix) * 256 + r * 64 + lane];
+  red[g][lane] = s;
+  __syncthreads();
+  if (g == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][lane];
+    const int packed = tiles[tix];
+    const int i = (packed >> 16) * 16 + (lane >> 4) + 4 * r;
+    const int j = (packed & 0xffff) * 16 + (lane & 15);
+    if (i < Nx && j < Nx) {
+      G[(size_t)i * Nx + j] = t;
+      G[(size_t)j * Nx + i] = t;
+    }
   }
 }
 
 // ======================================================================== local null
-// grid = (row chunks, ceil(P/64)); 4 waves, wave w owns permutations 64*pt + 16*w .. +15 and
-// keeps that 16-column strip of Yc resident in registers (KQ doubles per lane) for the whole
-// kernel.  16-cell slabs of X stream through LDS (register prefetch of the next slab under
-// the MFMAs).  Epilogue per output: z = |acc|/N, z2 = z*z, h = #{t: edges[t] <= z2} found
-// from a linear guess + exact comparisons against the host-computed edges, then one LDS
-// atomic on a packed 16-bit counter (a chunk has < 65536 cells).  Counters are flushed with
-// integer global atomics -> bit-reproducible.
-template <int KQ>
-__global__ __launch_bounds__(256) void k_null(const double* __restrict__ X, int64_t nx, int Nx, int ldx,
+// grid = (row chunks, ceil(P/64)); 8 waves.  Wave w owns permutations 64*pt + 16*(w&3) .. +15 and
+// keeps that 16-column strip of Yc in registers (KQ doubles per lane) for the whole kernel;
+// waves 0-3 take the first half of each slab of cells, waves 4-7 the second half, TS 16-cell
+// tiles each (independent accumulators, so the 64-cycle f64 MFMAs of one tile hide the
+// dependent-issue latency of the other).  Slabs of 32*TS cells stream through LDS with a
+// register prefetch of the next slab under the MFMAs.
+//
+// Epilogue.  The reference bins z^2 = (|x.yc|/N)^2 against edges[t] (_stats.py:47-54).  Both
+// roundings are monotone in |x.yc|, so the host converts every edge into the smallest double
+// cut[t] with fl(fl(cut/N)^2) >= edges[t]; counting cut[t] <= |acc| is then *exactly* the
+// reference's count and costs one compare instead of a division and a square per element.
+// A linear guess + two exact compares finds the bin; counters are packed 16-bit pairs in LDS
+// (a chunk has < 65536 cells) and are flushed with integer global atomics -> bit-reproducible.
+template <int KQ, int TS>
+__global__ __launch_bounds__(512) void k_null(const double* __restrict__ X, int64_t nx, int ldx,
                                               int64_t chunk_rows, const double* __restrict__ Yc, int ldy,
-                                              int P, const double* __restrict__ edges, int T, double thr0,
+                                              int P, const double* __restrict__ cuts, int T, double cut0,
                                               double inv_step, unsigned long long* __restrict__ ghist) {
   extern __shared__ double sm[];
-  constexpr int PF = (KQ + 7) / 8;      // double2 prefetch registers per thread
+  constexpr int ROWS = 32 * TS;
+  constexpr int PF = (ROWS * KQ * 4 / 2 + 511) / 512;   // double2 prefetch registers per thread
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip = wv & 3, half = wv >> 2;
   const int ak = lane >> 4, ai = lane & 15;
   const int ldp = ldx + 2;
   const int HW = (T + 1) >> 1;
-  double* e_s = sm;                                   // T doubles (padded to even)
-  double* xt = sm + ((T + 1) & ~1);                   // 16 * ldp doubles
-  unsigned int* hist = (unsigned int*)(xt + 16 * ldp);  // 64 * HW words
-  for (int i = tid; i < T; i += 256) e_s[i] = edges[i];
-  for (int i = tid; i < 64 * HW; i += 256) hist[i] = 0u;
+  const int TP = (T + 2) & ~1;                           // cuts + inf sentinel, even
+  double* c_s = sm;
+  double* xt = sm + TP;                                  // ROWS * ldp doubles
+  unsigned int* hist = (unsigned int*)(xt + ROWS * ldp);  // 64 * HW words
+  for (int i = tid; i < TP; i += 512) c_s[i] = i < T ? cuts[i] : __builtin_inf();
+  for (int i = tid; i < 64 * HW; i += 512) hist[i] = 0u;
 
   const int kq = ldx >> 2;
   const int pt = blockIdx.y;
   double b[KQ];
   {
-    const double* bp = Yc + (size_t)ak * ldy + pt * 64 + wv * 16 + ai;
+    const double* bp = Yc + (size_t)ak * ldy + pt * 64 + strip * 16 + ai;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) b[q] = (q < kq) ? bp[(size_t)4 * q * ldy] : 0.0;
   }
-  // per-thread prefetch slots: slab-relative element offsets of the double2 this thread moves
-  const int nd2 = (16 * ldx) >> 1;
+  const int nd2 = (ROWS * ldx) >> 1;
   int goff[PF], loff[PF];
 #pragma unroll
   for (int i = 0; i < PF; ++i) {
-    const int f = tid + 256 * i;
+    const int f = tid + 512 * i;
     const int e = 2 * f;
     const int r = e / ldx;
     goff[i] = (f < nd2) ? e : -1;
@@ -199,8 +210,8 @@ __global__ __launch_bounds__(256) void k_null(const double* __restrict__ X, int6
   const int64_t row_begin = (int64_t)blockIdx.x * chunk_rows;
   int64_t row_end = row_begin + chunk_rows;
   if (row_end > nx) row_end = nx;
-  const double en = (double)Nx;
-  const double e0 = T > 0 ? edges[0] : __builtin_inf();
+  const int64_t lim = row_end * (int64_t)ldx;
+  const double Tm1 = (double)(T - 1);
 
   double2 pf[PF];
   auto prefetch = [&](int64_t r0) {
@@ -209,41 +220,49 @@ __global__ __launch_bounds__(256) void k_null(const double* __restrict__ X, int6
       pf[i] = make_double2(0.0, 0.0);
       if (goff[i] >= 0) {
         const int64_t g = r0 * ldx + goff[i];
-        if (g < row_end * (int64_t)ldx) pf[i] = *reinterpret_cast<const double2*>(X + g);
+        if (g < lim) pf[i] = *reinterpret_cast<const double2*>(X + g);
       }
     }
   };
   if (row_begin < row_end) prefetch(row_begin);
-  for (int64_t r0 = row_begin; r0 < row_end; r0 += 16) {
+  unsigned int* hp = hist + (strip * 16 + ai) * HW;
+  for (int64_t r0 = row_begin; r0 < row_end; r0 += ROWS) {
     __syncthreads();                       // previous slab fully consumed
 #pragma unroll
     for (int i = 0; i < PF; ++i)
       if (goff[i] >= 0) *reinterpret_cast<double2*>(xt + loff[i]) = pf[i];
     __syncthreads();
-    if (r0 + 16 < row_end) prefetch(r0 + 16);
-    v4d acc = {0.0, 0.0, 0.0, 0.0};
-    const double* ap = xt + ai * ldp + ak;
+    if (r0 + ROWS < row_end) prefetch(r0 + ROWS);
+    v4d acc[TS];
+#pragma unroll
+    for (int t = 0; t < TS; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* ap = xt + (half * 16 * TS + ai) * ldp + ak;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
-      if (q < kq) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[4 * q], b[q], acc, 0, 0, 0);
-    }
-    unsigned int* hp = hist + (wv * 16 + ai) * HW;
+      if (q < kq) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const double z = __ddiv_rn(fabs(acc[r]), en);
-      const double z2 = z * z;
-      if (z2 >= e0) {
-        const double f = (z - thr0) * inv_step;
-        int h = (f >= (double)T) ? T : ((f > 0.0) ? (int)f + 1 : 1);
-        while (h < T && e_s[h] <= z2) ++h;
-        while (h > 1 && !(e_s[h - 1] <= z2)) --h;
-        const int bin = h - 1;
-        atomicAdd(&hp[bin >> 1], 1u << ((bin & 1) << 4));
+        for (int t = 0; t < TS; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[t * 16 * ldp + 4 * q], b[q], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double x = fabs(acc[t][r]);
+        if (x >= cut0 && r0 + (half * TS + t) * 16 + ak + 4 * r < row_end) {
+          const double f = (x - cut0) * inv_step;
+          int h = (f >= Tm1) ? T : (int)f + 1;           // candidate #{cuts <= x}, in [1, T]
+          while (c_s[h] <= x) ++h;                         // c_s[T] = +inf stops the walk
+          while (c_s[h - 1] > x) --h;                      // c_s[0] <= x holds
+          const int bin = h - 1;
+          atomicAdd(&hp[bin >> 1], 1u << ((bin & 1) << 4));
+        }
       }
     }
   }
   __syncthreads();
-  for (int i = tid; i < 64 * HW; i += 256) {
+  for (int i = tid; i < 64 * HW; i += 512) {
     const unsigned int w = hist[i];
     if (w) {
       const int pl = i / HW, hw = i - pl * HW;
@@ -267,16 +286,16 @@ int launch_gram_t(cna_ctx* c, int nt, int ldp, int ntri, const int32_t* tiles_de
   return 0;
 }
 
-template <int KQ>
+template <int KQ, int TS>
 int launch_null_t(cna_ctx* c, dim3 grid, size_t smem, int64_t chunk_rows, const double* Yc, int ldy, int P,
-                  const double* edges, int T, double thr0, double inv_step, unsigned long long* hist) {
+                  const double* cuts, int T, double cut0, double inv_step, unsigned long long* hist) {
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_null<KQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_null<KQ, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_null<KQ>), grid, dim3(256), smem, c->stream, c->X, c->nx, c->Nx, c->ldx, chunk_rows, Yc,
-                     ldy, P, edges, T, thr0, inv_step, hist);
+  hipLaunchKernelGGL((k_null<KQ, TS>), grid, dim3(512), smem, c->stream, c->X, c->nx, c->ldx, chunk_rows, Yc, ldy,
+                     P, cuts, T, cut0, inv_step, hist);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -335,33 +354,41 @@ int launch_gram(cna_ctx* c, double* G_dev) {
   }
   {
     ProfScope ps(c, CNA_K_GRAM_REDUCE);
-    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ntri), dim3(256), 0, c->stream, partial, nblocks, ntri,
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ntri * 4), dim3(64, 16), 0, c->stream, partial, nblocks, ntri,
                        tiles_dev, Nx, G_dev);
     HIP_TRY(hipGetLastError());
   }
   return 0;
 }
 
-int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* edges_dev, int T,
-                      double thr0, double inv_step, unsigned long long* hist_dev) {
+int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* cuts_dev, int T,
+                      double cut0, double inv_step, unsigned long long* hist_dev) {
   HIP_TRY(hipMemsetAsync(hist_dev, 0, sizeof(unsigned long long) * (size_t)P * T, c->stream));
   if (c->nx == 0 || P == 0 || T == 0) return 0;
   const int kq = c->ldx / 4;
   if (kq > 64) CNA_FAIL(CNA_EINVAL, "more than 256 samples are not supported by the local-null kernel yet");
-  const int nptile = (P + 63) / 64;
-  const int64_t ntile16 = (c->nx + 15) / 16;
-  int64_t nchunks = (1024 + nptile - 1) / nptile;
-  if (nchunks > ntile16) nchunks = ntile16;
-  int64_t chunk_rows = ((ntile16 + nchunks - 1) / nchunks) * 16;
-  if (chunk_rows > 65520) chunk_rows = 65520;
-  nchunks = (c->nx + chunk_rows - 1) / chunk_rows;
   const int HW = (T + 1) / 2;
-  const size_t smem = sizeof(double) * (((T + 1) & ~1) + 16 * (c->ldx + 2)) + sizeof(unsigned int) * 64 * HW;
+  const size_t fixed = sizeof(double) * ((T + 2) & ~1) + sizeof(unsigned int) * 64 * HW;
+  const size_t slab64 = sizeof(double) * 64 * (c->ldx + 2), slab32 = slab64 / 2;
+  const int TS = (fixed + slab64 <= 150 * 1024) ? 2 : 1;
+  const size_t smem = fixed + (TS == 2 ? slab64 : slab32);
   if (smem > 160 * 1024) CNA_FAIL(CNA_EINVAL, "local-null kernel: thresholds/samples exceed LDS");
+  const int ROWS = 32 * TS;
+  const int nptile = (P + 63) / 64;
+  const int64_t nslab = (c->nx + ROWS - 1) / ROWS;
+  int64_t nchunks = (1024 + nptile - 1) / nptile;
+  if (nchunks > nslab) nchunks = nslab;
+  int64_t chunk_rows = ((nslab + nchunks - 1) / nchunks) * ROWS;
+  if (chunk_rows > 65472) chunk_rows = 65472;            // 16-bit packed counters; multiple of 64
+  nchunks = (c->nx + chunk_rows - 1) / chunk_rows;
   dim3 grid((unsigned)nchunks, (unsigned)nptile);
   ProfScope ps(c, CNA_K_NULL_LOCAL);
-  if (kq <= 16) return launch_null_t<16>(c, grid, smem, chunk_rows, Yc_dev, ldy, P, edges_dev, T, thr0, inv_step, hist_dev);
-  if (kq <= 32) return launch_null_t<32>(c, grid, smem, chunk_rows, Yc_dev, ldy, P, edges_dev, T, thr0, inv_step, hist_dev);
-  if (kq <= 52) return launch_null_t<52>(c, grid, smem, chunk_rows, Yc_dev, ldy, P, edges_dev, T, thr0, inv_step, hist_dev);
-  return launch_null_t<64>(c, grid, smem, chunk_rows, Yc_dev, ldy, P, edges_dev, T, thr0, inv_step, hist_dev);
+#define NULL_CASE(KQV)                                                                                        \
+  return TS == 2 ? launch_null_t<KQV, 2>(c, grid, smem, chunk_rows, Yc_dev, ldy, P, cuts_dev, T, cut0, inv_step, hist_dev) \
+                 : launch_null_t<KQV, 1>(c, grid, smem, chunk_rows, Yc_dev, ldy, P, cuts_dev, T, cut0, inv_step, hist_dev)
+  if (kq <= 16) { NULL_CASE(16); }
+  if (kq <= 32) { NULL_CASE(32); }
+  if (kq <= 52) { NULL_CASE(52); }
+  NULL_CASE(64);
+#undef NULL_CASE
 }

@@ -6,12 +6,6 @@
 
 namespace {
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-
 __device__ __forceinline__ int64_t uniform64(int64_t v) {
   int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
   int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
@@ -120,79 +114,123 @@ __global__ void k_select(const double* __restrict__ nam, int ld, const int64_t* 
 }
 
 // ---- X <- (X [- mean]) / std(ddof=1) per row (_nam.py:103-104,159) -----------------------
+// A wave walks RPW rows at a time: all their loads are issued before the first reduction so
+// the dependent shuffle chains of one row hide under the memory latency of the others.
+template <int NQ>
 __global__ __launch_bounds__(256) void k_standardize(double* __restrict__ X, int64_t nx, int Nx, int ldx,
                                                      int center) {
+  constexpr int RPW = 4;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
   const double n = (double)Nx;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < nx; row += nwaves) {
-    double x[MAXQ];
-    double sum = 0.0;
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wv) * RPW; base < nx; base += stride) {
+    double x[RPW][NQ];
+    double sum[RPW];
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      const int col = lane + 64 * q;
-      x[q] = (col < Nx) ? X[row * ldx + col] : 0.0;
-      sum += x[q];
-    }
-    if (center) {
-      const double mean = wave_sum(sum) / n;
-      sum = 0.0;
+    for (int r = 0; r < RPW; ++r) {
+      sum[r] = 0.0;
 #pragma unroll
-      for (int q = 0; q < MAXQ; ++q) {
-        if (lane + 64 * q < Nx) x[q] -= mean;
-        sum += x[q];
+      for (int q = 0; q < NQ; ++q) {
+        const int col = lane + 64 * q;
+        x[r][q] = (col < Nx && base + r < nx) ? X[(base + r) * ldx + col] : 0.0;
+        sum[r] += x[r][q];
       }
     }
-    // pandas std: avg = sum/N ; sqrt(sum((avg-x)^2)/(N-1))
-    const double avg = wave_sum(sum) / n;
-    double ss = 0.0;
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      if (lane + 64 * q < Nx) {
-        const double d = avg - x[q];
-        ss += d * d;
+    for (int r = 0; r < RPW; ++r) {
+      if (center) {
+        const double mean = wave_sum(sum[r]) / n;
+        sum[r] = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          if (lane + 64 * q < Nx) x[r][q] -= mean;
+          sum[r] += x[r][q];
+        }
       }
-    }
-    const double sd = sqrt(wave_sum(ss) / (n - 1.0));
+      // pandas std: avg = sum/N ; sqrt(sum((avg-x)^2)/(N-1))
+      const double avg = wave_sum(sum[r]) / n;
+      double ss = 0.0;
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      const int col = lane + 64 * q;
-      if (col < Nx) X[row * ldx + col] = __ddiv_rn(x[q], sd);
+      for (int q = 0; q < NQ; ++q) {
+        if (lane + 64 * q < Nx) {
+          const double d = avg - x[r][q];
+          ss += d * d;
+        }
+      }
+      const double sd = sqrt(wave_sum(ss) / (n - 1.0));
+      if (base + r < nx) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int col = lane + 64 * q;
+          if (col < Nx) X[(base + r) * ldx + col] = __ddiv_rn(x[r][q], sd);
+        }
+      }
     }
   }
 }
 
 // ---- ncorrs = (y[:,None]*NAMresid).mean(axis=0) (_association.py:77) -----------------------
+template <int NQ>
 __global__ __launch_bounds__(256) void k_ncorrs(const double* __restrict__ X, int64_t nx, int Nx, int ldx,
                                                 const double* __restrict__ y, double* __restrict__ out,
-                                                unsigned long long* maxbits) {
+                                                unsigned long long* __restrict__ blockmax) {
+  constexpr int RPW = 4;
+  __shared__ unsigned long long wmax[4];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
-  double yv[MAXQ];
+  const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+  double yv[NQ];
 #pragma unroll
-  for (int q = 0; q < MAXQ; ++q) yv[q] = (lane + 64 * q < Nx) ? y[lane + 64 * q] : 0.0;
+  for (int q = 0; q < NQ; ++q) yv[q] = (lane + 64 * q < Nx) ? y[lane + 64 * q] : 0.0;
   double vmax = 0.0;
   bool any_nan = false;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < nx; row += nwaves) {
-    double s = 0.0;
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wv) * RPW; base < nx; base += stride) {
+    double s[RPW];
 #pragma unroll
-    for (int q = 0; q < MAXQ; ++q) {
-      const int col = lane + 64 * q;
-      if (col < Nx) s += yv[q] * X[row * ldx + col];
+    for (int r = 0; r < RPW; ++r) {
+      s[r] = 0.0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int col = lane + 64 * q;
+        if (col < Nx && base + r < nx) s[r] += yv[q] * X[(base + r) * ldx + col];
+      }
     }
-    const double v = wave_sum(s) / (double)Nx;
-    if (lane == 0) out[row] = v;
-    const double av = fabs(v);
-    if (av > vmax) vmax = av;
-    any_nan = any_nan || (v != v);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const double v = wave_sum(s[r]) / (double)Nx;
+      if (base + r < nx) {
+        if (lane == 0) out[base + r] = v;
+        const double av = fabs(v);
+        if (av > vmax) vmax = av;
+        any_nan = any_nan || (v != v);
+      }
+    }
   }
-  if (lane == 0) {
-    // non-negative doubles order like their bit patterns; NaN (0x7ff8...) sorts above +inf
-    unsigned long long bits = any_nan ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(vmax);
-    atomicMax(maxbits, bits);
+  // non-negative doubles order like their bit patterns; NaN (0x7ff8...) sorts above +inf.
+  // One slot per workgroup, folded by k_max_fold: 8192 same-address atomics cost ~80 us.
+  if (lane == 0)
+    wmax[wv] = any_nan ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(vmax);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long m = wmax[0];
+    for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
+    blockmax[blockIdx.x] = m;
   }
+}
+
+__global__ __launch_bounds__(256) void k_max_fold(const unsigned long long* __restrict__ blockmax, int nblocks,
+                                                  unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long sm[256];
+  unsigned long long m = 0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) m = blockmax[i] > m ? blockmax[i] : m;
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o && sm[threadIdx.x + o] > sm[threadIdx.x]) sm[threadIdx.x] = sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sm[0];
 }
 
 // number of t in [0,T) with arr[t] <= x, arr ascending, starting from a guess
@@ -338,21 +376,32 @@ int launch_standardize(cna_ctx* c, int center) {
   if (c->nx == 0) return 0;
   if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 512 samples are not supported");
   ProfScope ps(c, CNA_K_STANDARDIZE);
-  hipLaunchKernelGGL(k_standardize, dim3(wave_grid(c->nx)), dim3(256), 0, c->stream, c->X, c->nx, c->Nx,
-                     c->ldx, center);
+  const unsigned grid = wave_grid((c->nx + 3) / 4);
+  switch ((c->Nx + 63) / 64) {
+#define STD_CASE(Q) case Q: hipLaunchKernelGGL(k_standardize<Q>, dim3(grid), dim3(256), 0, c->stream, c->X, c->nx, c->Nx, c->ldx, center); break
+    STD_CASE(1); STD_CASE(2); STD_CASE(3); STD_CASE(4);
+    default: hipLaunchKernelGGL(k_standardize<MAXQ>, dim3(grid), dim3(256), 0, c->stream, c->X, c->nx, c->Nx, c->ldx, center);
+#undef STD_CASE
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
 int launch_ncorrs(cna_ctx* c, const double* y_dev, unsigned long long* maxbits_dev) {
+  // maxbits_dev[0] = result, maxbits_dev[1 ..] = per-workgroup partials (caller reserves 2049 words)
   HIP_TRY(hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned long long), c->stream));
   if (c->nx == 0) return 0;
   if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 512 samples are not supported");
   ProfScope ps(c, CNA_K_NCORRS);
-  const int64_t want = (c->nx + 3) / 4;
+  const int64_t want = (c->nx + 15) / 16;
   const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
-  hipLaunchKernelGGL(k_ncorrs, dim3(grid), dim3(256), 0, c->stream, c->X, c->nx, c->Nx, c->ldx, y_dev,
-                     c->ncorrs, maxbits_dev);
+  switch ((c->Nx + 63) / 64) {
+#define NC_CASE(Q) case Q: hipLaunchKernelGGL(k_ncorrs<Q>, dim3(grid), dim3(256), 0, c->stream, c->X, c->nx, c->Nx, c->ldx, y_dev, c->ncorrs, maxbits_dev + 1); break
+    NC_CASE(1); NC_CASE(2); NC_CASE(3); NC_CASE(4);
+    default: hipLaunchKernelGGL(k_ncorrs<MAXQ>, dim3(grid), dim3(256), 0, c->stream, c->X, c->nx, c->Nx, c->ldx, y_dev, c->ncorrs, maxbits_dev + 1);
+#undef NC_CASE
+  }
+  hipLaunchKernelGGL(k_max_fold, dim3(1), dim3(256), 0, c->stream, maxbits_dev + 1, (int)grid, maxbits_dev);
   HIP_TRY(hipGetLastError());
   return 0;
 }

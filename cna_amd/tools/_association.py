@@ -19,7 +19,7 @@ import pandas as pd
 
 from .. import _ffi
 from ..engine import get_engine
-from ._nam import LazyNamespace, _nam_device, _qc_device, _resid_device, _gather_rows
+from ._nam import LazyNamespace, _nam_device, _qc_device, _resid_device, _gather_rows, sample_codes
 from ._out import select_output
 from ._stats import conditional_permutation, grouplevel_permutation, default_ks, minp_stats
 
@@ -114,18 +114,21 @@ def _association(engine, U, M, r, y, batches, donorids, cell_index, ks=None, Nnu
     return res, coef_all, fdr_all
 
 
-def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size):
+def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size, sids_present=None):
     """Input validation and the sample filter (reference _association.py:131-173): same
-    exception types, messages and printed warnings."""
+    exception types, messages and printed warnings.  ``sids_present``: the distinct sample ids
+    of the cells if the caller already has them (one hash pass over the cells instead of three)."""
     for name, val, kind, label in (('y', y, pd.Series, 'Series'), ('batches', batches, pd.Series, 'Series'),
                                    ('covs', covs, pd.DataFrame, 'DataFrame'),
                                    ('donorids', donorids, pd.Series, 'Series')):
         if (name == 'y' or val is not None) and not isinstance(val, kind):
             raise TypeError(f"'{name}' must be a pandas {label}, but got {type(val)}")
-    sids_in_data = set(data.obs[sid_name])
-    if not set(y.index).issubset(sids_in_data):
+    if sids_present is None:
+        sids_present = pd.unique(data.obs[sid_name])
+    present = y.index.isin(sids_present)
+    if not present.all():
         print("WARNING: index of 'y' contains values not present in 'data[sid_name]'. These samples will be ignored.")
-    if not sids_in_data.issubset(set(y.index)):
+    if not pd.Index(sids_present).isin(y.index).all():
         raise ValueError("'data[sid_name]' contains values not present in the index of 'y'.")
     if batches is not None and donorids is not None:
         raise ValueError('We do not currently support conditioning on batch ' +
@@ -133,7 +136,6 @@ def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_si
     if batches is None:
         batches = pd.Series(np.ones(len(y)), index=y.index)
 
-    present = y.index.isin(data.obs[sid_name].unique())
     if covs is not None:
         filter_samples = ~(y.isna() | covs.isna().any(axis=1)) & present
         if donorids is not None:
@@ -157,7 +159,7 @@ def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_si
 
 
 def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
-                            show_progress, **kwargs):
+                            show_progress, codes_labels=None, **kwargs):
     """Reference compute_nam_and_reindex (_association.py:175-191) on the device: build the NAM,
     QC it, put the sample axis in ``y.index`` order restricted to ``filter_samples``, drop the
     cells whose remaining entries have zero variance.  Leaves the selected NAM in the engine's
@@ -165,7 +167,8 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     out = select_output(show_progress)
     nam_kwargs = {k: v for k, v in kwargs.items() if k in ('self_weight',)}
     print('computing NAM', file=out)
-    labels, _ = _nam_device(engine, data, sid_name, nsteps=nsteps, show_progress=show_progress, **nam_kwargs)
+    labels, _ = _nam_device(engine, data, sid_name, nsteps=nsteps, show_progress=show_progress,
+                            codes_labels=codes_labels, **nam_kwargs)
     kept = _qc_device(engine, labels, batches, show_progress=show_progress)
 
     # NAM.reindex(y.index)[filter_samples]: boolean-Series indexing aligns on the index
@@ -203,10 +206,17 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
         bad = sorted(extra | ({'self_weight'} & set(kwargs)))[0]
         raise TypeError(f"_association() got an unexpected keyword argument '{bad}'")
 
-    batches, filter_samples = check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size)
+    # factorise the per-cell sample ids once; validation and NAM construction share the result
+    codes, labels = sample_codes(data.obs[sid_name])
+    used = np.bincount(codes[codes >= 0], minlength=len(labels)) > 0
+    batches, filter_samples = check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size,
+                                           sids_present=labels[used] if isinstance(y, pd.Series) else None)
     kept, sample_index, colmap, batches, covs, donorids, filter_samples = compute_nam_and_reindex(
-        engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps, show_progress)
-    cell_index = data.obs.index[kept]
+        engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps, show_progress,
+        codes_labels=(codes, labels))
+    def cell_index():
+        # names of the kept cells: only needed for the frames of a full result
+        return data.obs.index if kept.all() else data.obs.index[kept]
     nam_epoch = engine.nam_epoch
 
     N = filter_samples.sum()
@@ -219,10 +229,10 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
     print('performing association test', file=out)
     res_, coef_all, fdr_all = _association(
         engine, U, res.M, res.r, y[filter_samples].values, batches[filter_samples].values,
-        donorids[filter_samples].values if donorids is not None else None, cell_index,
+        donorids[filter_samples].values if donorids is not None else None, None,
         show_progress=show_progress, ks=ks, **kwargs)
     res.__dict__.update(res_)
-    res.ncorrs = pd.Series(coef_all[kept], index=cell_index)
+    res._defer('ncorrs', lambda: pd.Series(coef_all if kept.all() else coef_all[kept], index=cell_index()))
     res.kept = kept
 
     def fetch_nam():
@@ -230,7 +240,7 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
             raise RuntimeError('res.nam lives on the GPU and a later cna_amd call has replaced it; '
                                'read it (or call res.materialize()) before running the next analysis')
         full = _gather_rows(engine, engine.fetch_matrix(_ffi.MAT_NAM), engine.n)
-        return pd.DataFrame(full[kept][:, colmap].T, index=sample_index, columns=cell_index)
+        return pd.DataFrame(full[kept][:, colmap].T, index=sample_index, columns=cell_index())
 
     res._defer('nam', fetch_nam)
 
@@ -243,5 +253,6 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
     data.obs[f'{key_added}_fdr'] = fdr_all
 
     if return_full:
+        res.ncorrs   # eager, like upstream; the three cells x samples frames stay lazy
         return res
     return res.p

@@ -29,6 +29,22 @@ from ._out import select_output
 
 DEFAULT_RIDGES = [1e5, 1e4, 1e3, 1e2, 1e1, 1e0, 1e-1, 1e-2, 1e-3, 1e-4, 0]
 
+try:   # optional: keeps LAPACK from fanning a 50 x 50 SVD out over every core of a big host
+    from threadpoolctl import ThreadpoolController as _TPC
+    _blas_pool = _TPC()
+except Exception:   # pragma: no cover - threadpoolctl not installed
+    _blas_pool = None
+
+
+def _small_svd(G):
+    """np.linalg.svd of the samples x samples Gram (_nam.py:105).  Same LAPACK routine as the
+    reference (so PC signs agree); run on one BLAS thread when the matrix is small, where the
+    threaded driver costs ~100x the arithmetic (measured: 25 ms vs 0.2 ms at N=50 on a 256-core host)."""
+    if _blas_pool is not None and G.shape[0] <= 512:
+        with _blas_pool.limit(limits=1, user_api='blas'):
+            return np.linalg.svd(G)
+    return np.linalg.svd(G)
+
 
 class LazyNamespace(Namespace):
     """Result namespace whose cells-sized fields are fetched from the device on first access
@@ -126,12 +142,13 @@ def diffuse(data, s, nsteps, show_progress=False, self_weight=1, engine=None):
 
 
 # --------------------------------------------------------------------------- NAM on device
-def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1, show_progress=False):
+def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1, show_progress=False,
+                codes_labels=None):
     """Reference ``_nam`` (_nam.py:44-76) with the state resident on the GPU.  On return the
     engine holds NAM = (s/C) (cells x samples); returns (labels, steps taken)."""
     out = select_output(show_progress)
     _prepare_graph(engine, data, self_weight)
-    codes, labels = sample_codes(data.obs[sid_name])
+    codes, labels = codes_labels if codes_labels is not None else sample_codes(data.obs[sid_name])
     N = len(labels)
     C = np.bincount(codes[codes >= 0], minlength=N).astype(np.float64)
     engine.set_samples(codes, N, C)
@@ -233,7 +250,7 @@ def svd_nam(NAM, engine=None):
     engine.upload_x(X)
     engine.standardize(center=True)
     G = engine.gram()
-    U, svs, _ = np.linalg.svd(G)
+    U, svs, _ = _small_svd(G)
     with np.errstate(all='ignore'):
         V = engine.project(U / np.sqrt(svs))
     names = _pc_names(U.shape[1])
@@ -242,6 +259,10 @@ def svd_nam(NAM, engine=None):
     return (pd.DataFrame(U, index=index, columns=names),
             pd.Series(svs, index=names),
             pd.DataFrame(V, index=columns, columns=names))
+
+
+def _names(index_or_thunk):
+    return index_or_thunk() if callable(index_or_thunk) else index_or_thunk
 
 
 def _resid_device(engine, sample_index, cell_index, covs, batches, ridges=None, npcs=None, show_progress=False):
@@ -292,7 +313,7 @@ def _resid_device(engine, sample_index, cell_index, covs, batches, ridges=None, 
     # svd_nam re-centres / re-standardises (_nam.py:103-104); X is already standardised, so
     # that is an identity up to 1 ulp and the Gram matrix is taken of X directly.
     G = engine.gram()
-    U, svs, _ = np.linalg.svd(G)
+    U, svs, _ = _small_svd(G)
     names = _pc_names(N)
     if npcs is None:
         npcs = N
@@ -319,14 +340,14 @@ def _resid_device(engine, sample_index, cell_index, covs, batches, ridges=None, 
             full_t = engine.fetch_matrix(_ffi.MAT_X, transposed=True)           # samples x cells
         else:
             full_t = _gather_rows(engine, engine.fetch_matrix(_ffi.MAT_X), n_cells).T
-        return pd.DataFrame(full_t, index=sample_index, columns=cell_index)
+        return pd.DataFrame(full_t, index=sample_index, columns=_names(cell_index))
 
     def fetch_V():
         _still_resident()
         with np.errstate(all='ignore'):
             V = engine.project(U / np.sqrt(svs))
         V = _gather_rows(engine, V, n_cells)
-        return pd.DataFrame(V, index=cell_index, columns=names)
+        return pd.DataFrame(V, index=_names(cell_index), columns=names)
 
     res._defer('namresid', fetch_namresid)
     res._defer('namresid_nbhdXpc', fetch_V)

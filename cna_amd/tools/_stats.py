@@ -8,7 +8,7 @@ phenotype matrix goes to the device.  The cells-sized work of _stats.py:34-83 (t
 empirical FDRs) lives in the HIP kernels (cna_null_local / cna_obs_counts).
 """
 import numpy as np
-import scipy.stats as st
+import scipy.special as sc
 
 
 def conditional_permutation(B, Y, num):
@@ -58,16 +58,21 @@ def minp_stats(Z, M, U, ks, r):
     ssered = np.einsum('ij,ij->j', Zc, Zc)
     kmax = int(max(ks))
     Bt = U[:, :kmax].T.dot(Zc)                      # kmax x P projections
-    ps = np.empty((len(ks), Z.shape[1]))
-    r2s = np.empty_like(ps)
+    ssefull = np.empty((len(ks), Z.shape[1]))
     for a, k in enumerate(ks):
         fit = U[:, :k].dot(Bt[:k])
         resid = fit - Zc
-        ssefull = np.einsum('ij,ij->j', resid, resid)
-        with np.errstate(all='ignore'):
-            f = ((ssered - ssefull) / k) / (ssefull / n)
-            ps[a] = st.f.sf(f, k, n - (1 + r + k))
-            r2s[a] = 1 - ssefull / ssered
+        ssefull[a] = np.einsum('ij,ij->j', resid, resid)
+    kcol = np.asarray(ks, dtype=np.float64)[:, None]
+    with np.errstate(all='ignore'):
+        f = ((ssered - ssefull) / kcol) / (ssefull / n)
+        # scipy.stats.f.sf(f, k, dfd) is special.fdtrc(k, dfd, f) inside the support, 1 at or
+        # below it and NaN for non-positive degrees of freedom; one ufunc call instead of
+        # len(ks) trips through the rv_continuous argument machinery.
+        dfd = n - (1 + r + kcol)
+        ps = np.where(f <= 0, 1.0, sc.fdtrc(kcol, dfd, f))
+        ps = np.where((dfd > 0) & ~np.isnan(f), ps, np.nan)
+        r2s = 1 - ssefull / ssered
     best = np.nanargmin(ps, axis=0)
     cols = np.arange(Z.shape[1])
     return best, ps[best, cols], r2s[best, cols]
