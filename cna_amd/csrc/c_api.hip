@@ -186,7 +186,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   prof_flush(c);
   comm_destroy(c);
   void* bufs[] = {c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
-                  c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2};
+                  c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -247,6 +247,7 @@ int cna_graph_upload(cna_ctx* c, int64_t n_global, int64_t row0, int64_t n_local
   }
   HIP_TRY(hipMemset(c->stat, 0, sizeof(double) * c->n_pad));
   c->have_colsum = false;
+  c->cellinfo_valid = false;
   c->t_valid = false;
   c->nam_valid = false;
   c->x_valid = false;
@@ -263,6 +264,7 @@ int cna_colsums(cna_ctx* c, double self_weight) {
   CNA_TRY(comm_allreduce_f64_sum(c, c->colsum, (size_t)c->n_pad));
   CNA_TRY(launch_add_scalar(c, c->colsum, c->n_global, self_weight));
   c->have_colsum = true;
+  c->cellinfo_valid = false;
   return 0;
 }
 
@@ -275,7 +277,8 @@ int cna_fetch_colsums(cna_ctx* c, double* out) {
 }
 
 static int ensure_T(cna_ctx* c, int ld) {
-  const int64_t need = (int64_t)sizeof(double) * c->n_pad * ld;
+  // + 64 doubles: the gather kernel lets lanes past the row width read into the following row
+  const int64_t need = (int64_t)sizeof(double) * (c->n_pad * ld + 64);
   if (need > c->t_cap || !c->T[0]) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 2; ++i) {
@@ -310,6 +313,7 @@ int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const doubl
   HIP_TRY(hipMemcpyAsync(c->sid, codes, sizeof(int32_t) * c->n_global, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->counts, counts, sizeof(double) * n_samples, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  c->cellinfo_valid = false;
   CNA_TRY(ensure_T(c, c->ld));
   void* nm = c->nam;
   CNA_TRY(dev_reserve(c, &nm, &c->nam_cap, (int64_t)sizeof(double) * std::max<int64_t>(c->n_local, 1) * c->ld));

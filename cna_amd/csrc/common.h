@@ -64,6 +64,9 @@ struct cna_ctx {
   int32_t* sid = nullptr;    // n_global
   int64_t sid_n = 0;
   double* counts = nullptr;  // N
+  void* cellinfo = nullptr;  // n_global x {1/colsums, sid}: one gather per edge in the first step
+  int64_t cellinfo_cap = 0;
+  bool cellinfo_valid = false;
 
   // ---- diffusion state: scaled state T = s/colsums for all global rows (neighbour gathers)
   double* T[2] = {nullptr, nullptr};

@@ -12,8 +12,15 @@
 // Workgroup -> row mapping is XCD-aware: each of the 8 XCDs walks a contiguous range of
 // rows so the neighbour rows it gathers stay in that XCD's 4 MiB L2.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
+
+struct CellInfo {      // one gather per edge in the first step
+  double inv_colsum;
+  int32_t sid;
+  int32_t pad;
+};
 
 struct StepArgs {
   const int64_t* indptr;
@@ -46,37 +53,38 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {
   return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
-// logical row-block of this workgroup: XCD x (= blockIdx % 8, observed dispatch) walks the
-// contiguous range [x*cpx, (x+1)*cpx); a pure speed choice, any placement is correct.
-__device__ __forceinline__ int64_t xcd_logical_block() {
-  const int64_t cpx = gridDim.x >> 3;
-  return (int64_t)(blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-}
+// write-out shared by both step kernels: s[] holds the new unscaled state of one row; element k
+// of lane `lane` is column col_of(lane, k)
+struct ColStride1 {   // one double per lane: col = lane + 64*k
+  __device__ static int col(int lane, int k) { return lane + 64 * k; }
+};
+struct ColPair {      // double2 per lane: cols 2*(lane + 64*(k/2)) + (k&1)
+  __device__ static int col(int lane, int k) { return 2 * (lane + 64 * (k >> 1)) + (k & 1); }
+};
 
-// write-out shared by both step kernels: s[] holds the new unscaled state of one row
-template <int NQ>
+template <int NV, typename CM>
 __device__ __forceinline__ void finish_row(const StepArgs& a, int64_t row, int64_t grow, int lane,
-                                           const double (&s)[NQ]) {
+                                           const double (&s)[NV]) {
   const double cs = a.colsum[grow];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int col = lane + 64 * q;
+  for (int k = 0; k < NV; ++k) {
+    const int col = CM::col(lane, k);
     if (col < a.ld) {
       const bool in = col < a.width;
-      if (a.write_t) a.Tout[grow * a.ld + col] = in ? __ddiv_rn(s[q], cs) : 0.0;
-      if (a.dense_out) a.dense_out[row * a.ld + col] = in ? s[q] : 0.0;
+      if (a.write_t) a.Tout[grow * a.ld + col] = in ? __ddiv_rn(s[k], cs) : 0.0;
+      if (a.dense_out) a.dense_out[row * a.ld + col] = in ? s[k] : 0.0;
     }
   }
   if (a.write_nam || a.want_kurt) {
-    double x[NQ];
+    double x[NV];
     double sum = 0.0;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int col = lane + 64 * q;
+    for (int k = 0; k < NV; ++k) {
+      const int col = CM::col(lane, k);
       const bool in = col < a.width;
-      x[q] = in ? __ddiv_rn(s[q], a.counts[col]) : 0.0;     // s / C   (_nam.py:59,73)
-      if (a.write_nam && col < a.ld) a.nam[row * a.ld + col] = x[q];
-      sum += x[q];
+      x[k] = in ? __ddiv_rn(s[k], a.counts[col]) : 0.0;     // s / C   (_nam.py:59,73)
+      if (a.write_nam && col < a.ld) a.nam[row * a.ld + col] = x[k];
+      sum += x[k];
     }
     if (a.want_kurt) {
       // scipy.stats.kurtosis(s/C, axis=1): Fisher, biased (_nam.py:59)
@@ -84,10 +92,9 @@ __device__ __forceinline__ void finish_row(const StepArgs& a, int64_t row, int64
       const double mean = wave_sum(sum) / n;
       double d2s = 0.0, d4s = 0.0;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int col = lane + 64 * q;
-        if (col < a.width) {
-          const double d = x[q] - mean;
+      for (int k = 0; k < NV; ++k) {
+        if (CM::col(lane, k) < a.width) {
+          const double d = x[k] - mean;
           const double d2 = d * d;
           d2s += d2;
           d4s += d2 * d2;
@@ -96,101 +103,149 @@ __device__ __forceinline__ void finish_row(const StepArgs& a, int64_t row, int64
       const double m2 = wave_sum(d2s) / n;
       const double m4 = wave_sum(d4s) / n;
       const double em = 2.220446049250313e-16 * mean;
-      const double k = (m2 <= em * em) ? __builtin_nan("") : m4 / (m2 * m2);
-      if (lane == 0) a.stat[grow] = k - 3.0;
+      const double k4 = (m2 <= em * em) ? __builtin_nan("") : m4 / (m2 * m2);
+      if (lane == 0) a.stat[grow] = k4 - 3.0;
     }
   }
 }
 
-// first step: the input is the one-hot sample indicator, so a neighbour contributes
-// A[i,j]/colsums[j] to column sid[j] only -- read 4 B of sid per edge, not an N-wide row.
+template <typename VT>
+__device__ __forceinline__ void load_edges(const StepArgs& a, int64_t start, int64_t end, int lane, int& jl,
+                                           double& al) {
+  const int64_t e = start + lane;
+  const bool ok = e < end;
+  jl = ok ? a.idx[e] : 0;
+  al = ok ? (double)((const VT*)a.val)[e] : 0.0;
+}
+
+// Workgroup -> rows: 4 consecutive rows per workgroup (one per wave); XCD x (= blockIdx % 8,
+// observed dispatch) walks the contiguous block range [x*cpx, (x+1)*cpx) so the neighbour rows
+// it gathers stay in its own 4 MiB L2 (+4 % measured; a pure speed choice).
+__device__ __forceinline__ int64_t my_row(int wv) {
+  const int64_t cpx = gridDim.x >> 3;
+  const int64_t blk = (int64_t)(blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+  return uniform64(blk * 4 + wv);
+}
+
+// First step: the input is the one-hot sample indicator, so neighbour j contributes
+// A[i,j] * (1/colsums[j]) to column sid[j] only.  One 16-byte record {1/colsums, sid} per cell
+// makes that a single gather per edge; every lane takes one edge and adds its term into the
+// wave's LDS accumulator row with ds_add_f64 (edges of one row rarely share a sample, and
+// same-address adds of one instruction retire in lane order, i.e. CSR order).
 template <typename VT, int NQ>
-__global__ __launch_bounds__(256) void k_nam_first(StepArgs a) {
+__global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* __restrict__ info) {
+  extern __shared__ double sm[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row = uniform64(xcd_logical_block() * 4 + wv);
+  double* accl = sm + (size_t)wv * 64 * NQ;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) accl[lane + 64 * q] = 0.0;
+  const int64_t row = my_row(wv);
   if (row >= a.n_local) return;
   const int64_t grow = a.row0 + row;
   const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
-  const VT* __restrict__ val = (const VT*)a.val;
-  double acc[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
   for (int64_t base = start; base < end; base += 64) {
-    const int64_t e = base + lane;
-    const bool ok = e < end;
-    const int j = ok ? a.idx[e] : 0;
-    const int cj = ok ? a.sid[j] : -1;
-    const double v = ok ? __dmul_rn((double)val[e], __ddiv_rn(1.0, a.colsum[j])) : 0.0;
-    const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
-    for (int l = 0; l < cnt; ++l) {
-      const int c = __builtin_amdgcn_readlane(cj, l);
-      const double vv = readlane_d(v, l);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        if (lane + 64 * q == c) acc[q] = __dadd_rn(acc[q], vv);
+    int jl;
+    double al;
+    load_edges<VT>(a, base, end, lane, jl, al);
+    if (base + lane < end) {
+      const CellInfo ci = info[jl];
+      if (ci.sid >= 0) unsafeAtomicAdd(&accl[ci.sid], __dmul_rn(al, ci.inv_colsum));
     }
   }
-  const int sid_i = a.sid[grow];
+  const CellInfo me = info[grow];
   const double self = __ddiv_rn(a.w, a.colsum[grow]);        // (w*1)/colsums[i]
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   double s[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) s[q] = __dadd_rn(acc[q], (lane + 64 * q == sid_i) ? self : 0.0);
-  finish_row<NQ>(a, row, grow, lane, s);
+  for (int q = 0; q < NQ; ++q) s[q] = __dadd_rn(accl[lane + 64 * q], (lane + 64 * q == me.sid) ? self : 0.0);
+  finish_row<NQ, ColStride1>(a, row, grow, lane, s);
 }
 
-template <typename VT, int NQ>
+// Steps >= 2: gather-accumulate over neighbour rows of the scaled state T.  Each lane owns two
+// adjacent columns and gathers them with one 16-byte load (measured: the L2 -> L1 gather path
+// saturates near 12 TB/s of useful bytes on this chip whatever the instruction mix; 16-byte
+// lanes cost half the load instructions of 8-byte ones, -18 % time at N=100).  Neighbour index
+// and weight travel lane -> SGPR by v_readlane, the row base T + j*ld is scalar arithmetic, and
+// products / sums are unfused and in CSR order (scipy's csr_matvecs rounding sequence).
+template <typename VT, int NQ2>
 __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
+  constexpr int U = 8;                          // neighbour rows in flight per wave (8 beats 16 and 32)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row = uniform64(xcd_logical_block() * 4 + wv);
+  const int64_t row = my_row(wv);
   if (row >= a.n_local) return;
   const int64_t grow = a.row0 + row;
   const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
-  const VT* __restrict__ val = (const VT*)a.val;
-  const double* __restrict__ Tin = a.Tin;
-  double acc[NQ];
+  const double2* __restrict__ Tin = (const double2*)a.Tin;
+  const int ld2 = a.ld >> 1;
+  bool act[NQ2];
+  unsigned off[NQ2];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+  for (int q = 0; q < NQ2; ++q) {
+    act[q] = lane + 64 * q < ld2;
+    off[q] = act[q] ? (unsigned)(lane + 64 * q) : 0u;
+  }
+  double2 acc[NQ2];
+#pragma unroll
+  for (int q = 0; q < NQ2; ++q) acc[q] = make_double2(0.0, 0.0);
   for (int64_t base = start; base < end; base += 64) {
-    const int64_t e = base + lane;
-    const bool ok = e < end;
-    const int jl = ok ? a.idx[e] : 0;
-    const double al = ok ? (double)val[e] : 0.0;
+    int jl;
+    double al;
+    load_edges<VT>(a, base, end, lane, jl, al);
     const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
-    constexpr int U = (NQ <= 2) ? 16 : 8;      // neighbour rows in flight per wave
-    for (int l = 0; l < cnt; l += U) {
-      double t[U][NQ];
-      double av[U];
+    int l = 0;
+    for (; l + U <= cnt; l += U) {
+      double2 t[U][NQ2];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool on = (l + u) < cnt;
-        const int lu = on ? (l + u) : l;
-        const int64_t j = __builtin_amdgcn_readlane(jl, lu);
-        av[u] = readlane_d(al, lu);
+        const int j = __builtin_amdgcn_readlane(jl, l + u);
+        const double2* __restrict__ rowp = Tin + (int64_t)j * ld2;
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-          const int col = lane + 64 * q;
-          t[u][q] = (on && col < a.width) ? Tin[j * a.ld + col] : 0.0;
-        }
+        for (int q = 0; q < NQ2; ++q) t[u][q] = act[q] ? rowp[off[q]] : make_double2(0.0, 0.0);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        if ((l + u) < cnt) {
+        const double av = readlane_d(al, l + u);
 #pragma unroll
-          for (int q = 0; q < NQ; ++q) acc[q] = __dadd_rn(acc[q], __dmul_rn(av[u], t[u][q]));
+        for (int q = 0; q < NQ2; ++q) {
+          acc[q].x = __dadd_rn(acc[q].x, __dmul_rn(av, t[u][q].x));
+          acc[q].y = __dadd_rn(acc[q].y, __dmul_rn(av, t[u][q].y));
         }
       }
     }
-  }
-  double s[NQ];
+    for (; l < cnt; ++l) {                       // ragged tail
+      const int j = __builtin_amdgcn_readlane(jl, l);
+      const double av = readlane_d(al, l);
+      const double2* __restrict__ rowp = Tin + (int64_t)j * ld2;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int col = lane + 64 * q;
-    const double own = (col < a.width) ? Tin[grow * a.ld + col] : 0.0;
-    s[q] = __dadd_rn(acc[q], __dmul_rn(a.w, own));           // + w*s/colsums  (exact for w=1)
+      for (int q = 0; q < NQ2; ++q) {
+        const double2 t = act[q] ? rowp[off[q]] : make_double2(0.0, 0.0);
+        acc[q].x = __dadd_rn(acc[q].x, __dmul_rn(av, t.x));
+        acc[q].y = __dadd_rn(acc[q].y, __dmul_rn(av, t.y));
+      }
+    }
   }
-  finish_row<NQ>(a, row, grow, lane, s);
+  double s[2 * NQ2];
+#pragma unroll
+  for (int q = 0; q < NQ2; ++q) {
+    const double2 own = act[q] ? Tin[grow * ld2 + off[q]] : make_double2(0.0, 0.0);
+    s[2 * q] = __dadd_rn(acc[q].x, __dmul_rn(a.w, own.x));          // + w*s/colsums  (exact for w=1)
+    s[2 * q + 1] = __dadd_rn(acc[q].y, __dmul_rn(a.w, own.y));
+  }
+  finish_row<2 * NQ2, ColPair>(a, row, grow, lane, s);
+}
+
+__global__ void k_cellinfo(const double* __restrict__ colsum, const int32_t* __restrict__ sid, int64_t n,
+                           CellInfo* __restrict__ info) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    CellInfo ci;
+    ci.inv_colsum = __ddiv_rn(1.0, colsum[i]);      // s/colsums of the one-hot state (_nam.py:33)
+    ci.sid = sid[i];
+    ci.pad = 0;
+    info[i] = ci;
+  }
 }
 
 template <typename VT>
@@ -218,30 +273,42 @@ __global__ void k_scale_rows(const double* __restrict__ s, const double* __restr
 }
 
 template <typename VT, int NQ>
-int launch_step_t(cna_ctx* c, bool first, const StepArgs& a) {
-  const int64_t nblk = (c->n_local + 3) / 4;
-  const int64_t cpx = (nblk + 7) / 8;
-  dim3 grid((unsigned)(cpx * 8)), block(256);
-  if (first)
-    hipLaunchKernelGGL((k_nam_first<VT, NQ>), grid, block, 0, c->stream, a);
-  else
-    hipLaunchKernelGGL((k_nam_step<VT, NQ>), grid, block, 0, c->stream, a);
-  HIP_TRY(hipGetLastError());
+int launch_first_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
+  hipLaunchKernelGGL((k_nam_first<VT, NQ>), grid, dim3(256), sizeof(double) * 4 * 64 * NQ, c->stream, a,
+                     (const CellInfo*)c->cellinfo);
+  return 0;
+}
+template <typename VT, int NQ2>
+int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
+  hipLaunchKernelGGL((k_nam_step<VT, NQ2>), grid, dim3(256), 0, c->stream, a);
   return 0;
 }
 
 template <typename VT>
 int launch_step_q(cna_ctx* c, bool first, const StepArgs& a) {
-  const int nq = (a.ld + 63) / 64;
-  switch (nq) {
-    case 1: return launch_step_t<VT, 1>(c, first, a);
-    case 2: return launch_step_t<VT, 2>(c, first, a);
-    case 3: return launch_step_t<VT, 3>(c, first, a);
-    case 4: return launch_step_t<VT, 4>(c, first, a);
-    case 5: case 6: return launch_step_t<VT, 6>(c, first, a);
-    case 7: case 8: return launch_step_t<VT, 8>(c, first, a);
-    default: CNA_FAIL(CNA_EINVAL, "more than 512 samples / state columns are not supported");
+  const int64_t nblk = (c->n_local + 3) / 4;
+  const int64_t cpx = (nblk + 7) / 8;
+  dim3 grid((unsigned)(cpx * 8));
+  if (a.ld > 512) CNA_FAIL(CNA_EINVAL, "more than 512 samples / state columns are not supported");
+  if (first) {
+    switch ((a.ld + 63) / 64) {
+      case 1: launch_first_t<VT, 1>(c, a, grid); break;
+      case 2: launch_first_t<VT, 2>(c, a, grid); break;
+      case 3: launch_first_t<VT, 3>(c, a, grid); break;
+      case 4: launch_first_t<VT, 4>(c, a, grid); break;
+      case 5: case 6: launch_first_t<VT, 6>(c, a, grid); break;
+      default: launch_first_t<VT, 8>(c, a, grid); break;
+    }
+  } else {
+    switch ((a.ld / 2 + 63) / 64) {
+      case 1: launch_step_t<VT, 1>(c, a, grid); break;
+      case 2: launch_step_t<VT, 2>(c, a, grid); break;
+      case 3: launch_step_t<VT, 3>(c, a, grid); break;
+      default: launch_step_t<VT, 4>(c, a, grid); break;
+    }
   }
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 }  // namespace
@@ -272,6 +339,15 @@ int launch_add_scalar(cna_ctx* c, double* v, int64_t n, double s) {
 
 int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool write_nam, bool dense) {
   if (c->n_local == 0) return 0;
+  if (first && !c->cellinfo_valid) {
+    void* p = c->cellinfo;
+    CNA_TRY(dev_reserve(c, &p, &c->cellinfo_cap, (int64_t)sizeof(CellInfo) * c->n_global));
+    c->cellinfo = p;
+    hipLaunchKernelGGL(k_cellinfo, dim3((unsigned)((c->n_global + 255) / 256)), dim3(256), 0, c->stream, c->colsum,
+                       c->sid, c->n_global, (CellInfo*)c->cellinfo);
+    HIP_TRY(hipGetLastError());
+    c->cellinfo_valid = true;
+  }
   ProfScope ps(c, first ? CNA_K_NAM_FIRST : CNA_K_NAM_STEP);
   StepArgs a;
   a.indptr = c->indptr;

@@ -9,6 +9,8 @@
 //   A[i][k]: i = lane & 15, k = lane >> 4        B[k][j]: k = lane >> 4, j = lane & 15
 //   D[r][j]: r = (lane >> 4) + 4*reg, j = lane & 15,  reg in 0..3
 #include "common.h"
+#include <array>
+#include <utility>
 
 namespace {
 
@@ -168,95 +170,100 @@ __global__ __launch_bounds__(1024) void k_gram_reduce(const double* __restrict__
 // A linear guess + two exact compares finds the bin; counters are packed 16-bit pairs in LDS
 // (a chunk has < 65536 cells) and are flushed with integer global atomics -> bit-reproducible.
 template <int KQ, int TS>
-__global__ __launch_bounds__(512) void k_null(const double* __restrict__ X, int64_t nx, int ldx,
-                                              int64_t chunk_rows, const double* __restrict__ Yc, int ldy,
-                                              int P, const double* __restrict__ cuts, int T, double cut0,
-                                              double inv_step, unsigned long long* __restrict__ ghist) {
+__global__ __launch_bounds__(512) void k_null(const double* __restrict__ X, int64_t nx, int64_t chunk_rows,
+                                              const double* __restrict__ Yc, int ldy, int P,
+                                              const double* __restrict__ cuts, int T, double cut0,
+                                              float inv_step, unsigned long long* __restrict__ ghist) {
+  // KQ is the exact number of k-steps: the leading dimension of X is 4*KQ
   extern __shared__ double sm[];
   constexpr int ROWS = 32 * TS;
-  constexpr int PF = (ROWS * KQ * 4 / 2 + 511) / 512;   // double2 prefetch registers per thread
+  constexpr int LDX = 4 * KQ, LDP = LDX + 2;
+  constexpr int ND2 = ROWS * LDX / 2;                    // double2 elements per slab
+  constexpr int PF = (ND2 + 511) / 512;                  // double2 prefetch registers per thread
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int strip = wv & 3, half = wv >> 2;
   const int ak = lane >> 4, ai = lane & 15;
-  const int ldp = ldx + 2;
-  const int HW = (T + 1) >> 1;
+  const int HW = ((T + 1) >> 1) | 1;                     // odd row stride: the 16 strips' counters spread over all banks
   const int TP = (T + 2) & ~1;                           // cuts + inf sentinel, even
   double* c_s = sm;
-  double* xt = sm + TP;                                  // ROWS * ldp doubles
-  unsigned int* hist = (unsigned int*)(xt + ROWS * ldp);  // 64 * HW words
+  double* xt = sm + TP;                                  // ROWS * LDP doubles
+  unsigned int* hist = (unsigned int*)(xt + ROWS * LDP);  // 64 * HW words
   for (int i = tid; i < TP; i += 512) c_s[i] = i < T ? cuts[i] : __builtin_inf();
   for (int i = tid; i < 64 * HW; i += 512) hist[i] = 0u;
 
-  const int kq = ldx >> 2;
   const int pt = blockIdx.y;
   double b[KQ];
   {
     const double* bp = Yc + (size_t)ak * ldy + pt * 64 + strip * 16 + ai;
 #pragma unroll
-    for (int q = 0; q < KQ; ++q) b[q] = (q < kq) ? bp[(size_t)4 * q * ldy] : 0.0;
+    for (int q = 0; q < KQ; ++q) b[q] = bp[(size_t)4 * q * ldy];
   }
-  const int nd2 = (ROWS * ldx) >> 1;
-  int goff[PF], loff[PF];
+  // prefetch slots: slab-relative element offset (global) and padded offset (LDS) of each double2
+  unsigned goff[PF], loff[PF];
 #pragma unroll
   for (int i = 0; i < PF; ++i) {
-    const int f = tid + 512 * i;
-    const int e = 2 * f;
-    const int r = e / ldx;
-    goff[i] = (f < nd2) ? e : -1;
-    loff[i] = r * ldp + (e - r * ldx);
+    const unsigned f = tid + 512u * i;
+    const unsigned e = 2u * f;
+    const unsigned r = e / LDX;
+    goff[i] = (f < (unsigned)ND2) ? e : 0xffffffffu;
+    loff[i] = r * LDP + (e - r * LDX);
   }
   const int64_t row_begin = (int64_t)blockIdx.x * chunk_rows;
   int64_t row_end = row_begin + chunk_rows;
   if (row_end > nx) row_end = nx;
-  const int64_t lim = row_end * (int64_t)ldx;
-  const double Tm1 = (double)(T - 1);
+  const int Tm1 = T - 1;
 
   double2 pf[PF];
   auto prefetch = [&](int64_t r0) {
+    const double* __restrict__ slab = X + r0 * LDX;      // uniform base, 32-bit lane offsets
+    const int64_t left = (row_end - r0) * LDX;
+    const unsigned lim = left > (int64_t)(ROWS * LDX) ? (unsigned)(ROWS * LDX) : (unsigned)left;
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       pf[i] = make_double2(0.0, 0.0);
-      if (goff[i] >= 0) {
-        const int64_t g = r0 * ldx + goff[i];
-        if (g < lim) pf[i] = *reinterpret_cast<const double2*>(X + g);
-      }
+      if (goff[i] < lim) pf[i] = *reinterpret_cast<const double2*>(slab + goff[i]);
     }
   };
   if (row_begin < row_end) prefetch(row_begin);
-  unsigned int* hp = hist + (strip * 16 + ai) * HW;
+  const unsigned hp = (unsigned)((strip * 16 + ai) * HW);   // this lane's counter row (word index)
   for (int64_t r0 = row_begin; r0 < row_end; r0 += ROWS) {
     __syncthreads();                       // previous slab fully consumed
 #pragma unroll
     for (int i = 0; i < PF; ++i)
-      if (goff[i] >= 0) *reinterpret_cast<double2*>(xt + loff[i]) = pf[i];
+      if (goff[i] != 0xffffffffu) *reinterpret_cast<double2*>(xt + loff[i]) = pf[i];
     __syncthreads();
     if (r0 + ROWS < row_end) prefetch(r0 + ROWS);
     v4d acc[TS];
 #pragma unroll
     for (int t = 0; t < TS; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const double* ap = xt + (half * 16 * TS + ai) * ldp + ak;
+    const double* ap = xt + (half * 16 * TS + ai) * LDP + ak;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
-      if (q < kq) {
 #pragma unroll
-        for (int t = 0; t < TS; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[t * 16 * ldp + 4 * q], b[q], acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < TS; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[t * 16 * LDP + 4 * q], b[q], acc[t], 0, 0, 0);
     }
+    // rows past row_end were staged as zeros and cut0 > 0, so they never count
 #pragma unroll
     for (int t = 0; t < TS; ++t) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const double x = fabs(acc[t][r]);
-        if (x >= cut0 && r0 + (half * TS + t) * 16 + ak + 4 * r < row_end) {
-          const double f = (x - cut0) * inv_step;
-          int h = (f >= Tm1) ? T : (int)f + 1;           // candidate #{cuts <= x}, in [1, T]
-          while (c_s[h] <= x) ++h;                         // c_s[T] = +inf stops the walk
-          while (c_s[h - 1] > x) --h;                      // c_s[0] <= x holds
-          const int bin = h - 1;
-          atomicAdd(&hp[bin >> 1], 1u << ((bin & 1) << 4));
+        if (x >= cut0) {
+          // linear guess in float (the cuts are evenly spaced to ~1e-5), exact fix-up in double
+          const int g = (int)((float)(x - cut0) * inv_step);
+          int h = (g < Tm1 ? g : Tm1) + 1;                 // candidate #{cuts <= x}, in [1, T]
+          const double c0 = c_s[h - 1], c1 = c_s[h];       // c_s[T] = +inf
+          h += (c1 <= x) ? 1 : 0;
+          h -= (c0 > x) ? 1 : 0;
+          if (c_s[h] <= x || c_s[h - 1] > x) {             // guess off by more than one: walk (rare)
+            while (c_s[h] <= x) ++h;
+            while (c_s[h - 1] > x) --h;
+          }
+          const unsigned bin = (unsigned)(h - 1);
+          atomicAdd(&hist[hp + (bin >> 1)], (bin & 1u) ? 0x10000u : 1u);
         }
       }
     }
@@ -294,11 +301,21 @@ int launch_null_t(cna_ctx* c, dim3 grid, size_t smem, int64_t chunk_rows, const 
     HIP_TRY(hipFuncSetAttribute((const void*)k_null<KQ, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_null<KQ, TS>), grid, dim3(512), smem, c->stream, c->X, c->nx, c->ldx, chunk_rows, Yc, ldy,
-                     P, cuts, T, cut0, inv_step, hist);
+  hipLaunchKernelGGL((k_null<KQ, TS>), grid, dim3(512), smem, c->stream, c->X, c->nx, chunk_rows, Yc, ldy, P, cuts,
+                     T, cut0, (float)inv_step, hist);
   HIP_TRY(hipGetLastError());
   return 0;
 }
+
+// one instantiation per exact k-depth (ceil(N/4), N <= 256) so the MFMA loop has no guards
+typedef int (*null_launch_fn)(cna_ctx*, dim3, size_t, int64_t, const double*, int, int, const double*, int, double,
+                              double, unsigned long long*);
+template <int TS, int... KQ>
+constexpr std::array<null_launch_fn, sizeof...(KQ)> null_table(std::integer_sequence<int, KQ...>) {
+  return {{&launch_null_t<KQ + 1, TS>...}};
+}
+const auto kNullTS2 = null_table<2>(std::make_integer_sequence<int, 54>{});   // KQ 1..54
+const auto kNullTS1 = null_table<1>(std::make_integer_sequence<int, 64>{});   // KQ 1..64
 
 }  // namespace
 
@@ -367,10 +384,11 @@ int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const do
   if (c->nx == 0 || P == 0 || T == 0) return 0;
   const int kq = c->ldx / 4;
   if (kq > 64) CNA_FAIL(CNA_EINVAL, "more than 256 samples are not supported by the local-null kernel yet");
-  const int HW = (T + 1) / 2;
+  if (!(cut0 > 0.0)) CNA_FAIL(CNA_EINVAL, "local-null kernel needs strictly positive thresholds");
+  const int HW = ((T + 1) / 2) | 1;
   const size_t fixed = sizeof(double) * ((T + 2) & ~1) + sizeof(unsigned int) * 64 * HW;
   const size_t slab64 = sizeof(double) * 64 * (c->ldx + 2), slab32 = slab64 / 2;
-  const int TS = (fixed + slab64 <= 150 * 1024) ? 2 : 1;
+  const int TS = (kq <= 54 && fixed + slab64 <= 150 * 1024) ? 2 : 1;
   const size_t smem = fixed + (TS == 2 ? slab64 : slab32);
   if (smem > 160 * 1024) CNA_FAIL(CNA_EINVAL, "local-null kernel: thresholds/samples exceed LDS");
   const int ROWS = 32 * TS;
@@ -383,12 +401,6 @@ int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const do
   nchunks = (c->nx + chunk_rows - 1) / chunk_rows;
   dim3 grid((unsigned)nchunks, (unsigned)nptile);
   ProfScope ps(c, CNA_K_NULL_LOCAL);
-#define NULL_CASE(KQV)                                                                                        \
-  return TS == 2 ? launch_null_t<KQV, 2>(c, grid, smem, chunk_rows, Yc_dev, ldy, P, cuts_dev, T, cut0, inv_step, hist_dev) \
-                 : launch_null_t<KQV, 1>(c, grid, smem, chunk_rows, Yc_dev, ldy, P, cuts_dev, T, cut0, inv_step, hist_dev)
-  if (kq <= 16) { NULL_CASE(16); }
-  if (kq <= 32) { NULL_CASE(32); }
-  if (kq <= 52) { NULL_CASE(52); }
-  NULL_CASE(64);
-#undef NULL_CASE
+  null_launch_fn fn = TS == 2 ? kNullTS2[kq - 1] : kNullTS1[kq - 1];
+  return fn(c, grid, smem, chunk_rows, Yc_dev, ldy, P, cuts_dev, T, cut0, inv_step, hist_dev);
 }

@@ -284,16 +284,21 @@ __global__ __launch_bounds__(256) void k_obs_counts(const double* __restrict__ n
     if (h_s[i]) atomicAdd(&hist[i], (unsigned long long)h_s[i]);
 }
 
-// tails[p][t] = sum_{t' >= t} hist[p][t']
-__global__ void k_suffix_sum(const unsigned long long* __restrict__ hist, int P, int T,
-                             int64_t* __restrict__ tails) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  long long run = 0;
-  for (int t = T - 1; t >= 0; --t) {
-    run += (long long)hist[(size_t)p * T + t];
-    tails[(size_t)p * T + t] = run;
+// tails[p][t] = sum_{t' >= t} hist[p][t']: one workgroup per permutation, Hillis-Steele suffix
+// scan in LDS (integers -> exact in any order)
+__global__ __launch_bounds__(512) void k_suffix_sum(const unsigned long long* __restrict__ hist, int P, int T,
+                                                    int64_t* __restrict__ tails) {
+  __shared__ long long buf[2][512];
+  const int p = blockIdx.x, t = threadIdx.x;
+  int cur = 0;
+  buf[0][t] = t < T ? (long long)hist[(size_t)p * T + t] : 0;
+  __syncthreads();
+  for (int o = 1; o < 512; o <<= 1) {
+    buf[cur ^ 1][t] = buf[cur][t] + (t + o < 512 ? buf[cur][t + o] : 0);
+    cur ^= 1;
+    __syncthreads();
   }
+  if (t < T) tails[(size_t)p * T + t] = buf[cur][t];
 }
 
 __global__ void k_fill(double* v, int64_t n, double x) {
@@ -422,7 +427,8 @@ int launch_obs_counts(cna_ctx* c, const double* edges_dev, const double* thr_dev
 
 int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, int64_t* tails) {
   if (P == 0 || T == 0) return 0;
-  hipLaunchKernelGGL(k_suffix_sum, dim3((unsigned)((P + 63) / 64)), dim3(64), 0, c->stream, hist, P, T, tails);
+  if (T > 512) CNA_FAIL(CNA_EINVAL, "more than 512 FDR thresholds are not supported");
+  hipLaunchKernelGGL(k_suffix_sum, dim3((unsigned)P), dim3(512), 0, c->stream, hist, P, T, tails);
   HIP_TRY(hipGetLastError());
   return 0;
 }

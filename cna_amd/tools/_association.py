@@ -19,22 +19,54 @@ import pandas as pd
 
 from .. import _ffi
 from ..engine import get_engine
-from ._nam import LazyNamespace, _nam_device, _qc_device, _resid_device, _gather_rows, sample_codes
+from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_device, _gather_rows, sample_codes,
+                   _small_svd, _defer_pcs)
 from ._out import select_output
 from ._stats import conditional_permutation, grouplevel_permutation, default_ks, minp_stats
 
 
-def _association(engine, U, M, r, y, batches, donorids, cell_index, ks=None, Nnull=1000,
-                 force_permute_all=False, local_test=True, seed=None, show_progress=False):
-    """Reference ``_association`` (_association.py:10-129) against the residualised NAM held by
-    ``engine`` (cells x samples).  ``U``: samples x samples PCs, ``M``: conditioning projector."""
-    out = select_output(show_progress)
+_pool = None
+
+
+def _background():
+    """One helper thread: lets a blocking device call (ctypes drops the GIL) run while the
+    host does sample-space numpy work.  Never more than one engine call is in flight."""
+    global _pool
+    if _pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='cna-device')
+    return _pool
+
+
+def _draw_null(y, batches, donorids, Nnull=1000, force_permute_all=False, seed=None):
+    """Host-only head of the reference's ``_association`` (_association.py:15-22,79-83):
+    seed numpy's global RNG, standardise y (ddof=0) and draw the permuted phenotypes.
+    It needs nothing from the device, so the caller runs it while the diffusion kernels
+    execute; the RNG is consumed by nothing else in between, so the draws are the same."""
     if seed is not None:
         np.random.seed(seed)
     if force_permute_all:
         batches = np.ones(len(y))
-
     y = (y - y.mean()) / y.std()
+    if donorids is not None:
+        y_ = grouplevel_permutation(donorids, y, Nnull)
+    else:
+        y_ = conditional_permutation(batches, y, Nnull)
+    return y, y_
+
+
+def _association(engine, G, res, y, y_, ks=None, Nnull=1000, local_test=True, show_progress=False,
+                 npcs=None, n_cells=None):
+    """Body of the reference's ``_association`` (_association.py:24-129) against the
+    residualised NAM held by ``engine`` (cells x samples).  ``G`` is its samples x samples Gram
+    matrix, ``res`` the namespace from the residualisation (M, r), ``y`` / ``y_`` the
+    standardised phenotype and its permutations.
+
+    Ordering: the local-null kernel is started first and runs on the GPU while LAPACK's SVD of
+    G and the global F-tests run here; the values, warnings and progress text are those of the
+    reference's sequential order."""
+    out = select_output(show_progress)
+    M, r = res.M, res.r
     n = len(y)
     if ks is None:
         ks = default_ks(n)
@@ -43,42 +75,15 @@ def _association(engine, U, M, r, y, batches, donorids, cell_index, ks=None, Nnu
             'Maximum number of PCs plus number of covariates must be less than n-1. ' +
             f'Currently it is {max(ks)+r} while n is {n}. Either reduce the number of covariates ' +
             'or reduce the number of PCs to consider using the optional argument ks=[...].')
+    if y_ is None:   # grouplevel_permutation refused (it printed why); upstream dies on y_.T
+        raise AttributeError("'NoneType' object has no attribute 'T'")
     ks_arr = np.asarray(ks)
     Mv = np.asarray(M, dtype=np.float64)
 
-    # observed statistic
-    best, pv, r2v = minp_stats(y[:, None], Mv, U, ks_arr, r)
-    k, p, r2 = ks[best[0]], pv[0], r2v[0]
-    if k == max(ks):
-        warnings.warn(('data supported use of {} NAM PCs, which is the maximum considered. ' +
-                       'Consider allowing more PCs by using the "ks" argument.').format(k))
-
-    # coefficients and r2 of the chosen model
-    ycond = pd.Series(Mv.dot(y), index=getattr(M, 'index', None))
-    ycond /= ycond.std()
-    beta = U[:, :k].T.dot(ycond.values)
-    yhat = U[:, :k].dot(beta)
-    r2_perpc = (beta / np.sqrt(ycond.values.dot(ycond.values))) ** 2
-
-    # neighbourhood coefficients: correlation of each cell's residualised NAM row with y
+    # neighbourhood coefficients (device) -> thresholds -> start the local null (device, async)
     _, maxabs = engine.ncorrs(y, fetch=False)
-
-    # null phenotypes and the global p-value
-    if donorids is not None:
-        y_ = grouplevel_permutation(donorids, y, Nnull)
-    else:
-        y_ = conditional_permutation(batches, y, Nnull)
-    _, nullminps, nullr2s = minp_stats(y_, Mv, U, ks_arr, r)
-    hits = (nullminps <= p + 1e-8).sum()
-    pfinal = (hits + 1) / (Nnull + 1)
-    if hits == 0:
-        warnings.warn('global association p-value attained minimal possible value. ' +
-                      'Consider increasing Nnull')
-
-    fdrs, fdr_5p_t, fdr_10p_t = None, None, None
-    thresholds = fdr_vals = None
+    pending = thresholds = edges = None
     if local_test:
-        print('computing neighborhood-level FDRs', file=out)
         Nloc = min(1000, Nnull)
         ycond_ = Mv.dot(y_[:, :Nloc])
         ycond_ /= ycond_.std(axis=0, ddof=1)
@@ -86,32 +91,74 @@ def _association(engine, U, M, r, y, batches, donorids, cell_index, ks=None, Nnu
         thresholds = np.arange(maxcorr / 4, maxcorr, maxcorr / 400)
         z2 = thresholds ** 2
         edges = z2 - 1e-8 - 1e-5 * z2                        # tail_counts' bin edges (_stats.py:47)
-        tails = engine.null_local(ycond_, edges)              # Nloc x T, never cells x Nloc
+        pending = _background().submit(engine.null_local, ycond_, edges)   # Nloc x T, never cells x Nloc
+
+    try:
+        # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105)
+        U, svs, _ = _small_svd(G)
+        names = ['PC' + str(i) for i in range(1, len(U) + 1)]
+        res.namresid_sampleXpc = pd.DataFrame(U, index=M.index, columns=names)
+        svs_s = pd.Series(svs, index=names)
+        res.namresid_svs = svs_s[:npcs if npcs is not None else len(U)]
+        res.namresid_varexp = svs_s / len(U) / n_cells
+
+        # observed statistic
+        best, pv, r2v = minp_stats(y[:, None], Mv, U, ks_arr, r)
+        k, p, r2 = ks[best[0]], pv[0], r2v[0]
+        if k == max(ks):
+            warnings.warn(('data supported use of {} NAM PCs, which is the maximum considered. ' +
+                           'Consider allowing more PCs by using the "ks" argument.').format(k))
+
+        # coefficients and r2 of the chosen model
+        ycond = pd.Series(Mv.dot(y), index=getattr(M, 'index', None))
+        ycond /= ycond.std()
+        beta = U[:, :k].T.dot(ycond.values)
+        yhat = U[:, :k].dot(beta)
+        r2_perpc = (beta / np.sqrt(ycond.values.dot(ycond.values))) ** 2
+
+        # global p-value from the null phenotypes
+        _, nullminps, nullr2s = minp_stats(y_, Mv, U, ks_arr, r)
+        hits = (nullminps <= p + 1e-8).sum()
+        pfinal = (hits + 1) / (Nnull + 1)
+        if hits == 0:
+            warnings.warn('global association p-value attained minimal possible value. ' +
+                          'Consider increasing Nnull')
+    except BaseException:
+        if pending is not None:
+            pending.result()          # never leave a device call running behind an exception
+        raise
+
+    fdr_vals = None
+    fdr_5p_t = fdr_10p_t = None
+    if local_test:
+        print('computing neighborhood-level FDRs', file=out)
+        tails = pending.result()
         ranks, num_detected = engine.obs_counts(edges, thresholds)
         with np.errstate(all='ignore'):
             fdr_vals = (tails / ranks[None, :]).mean(axis=0)
-        fdrs = pd.DataFrame({'threshold': thresholds, 'fdr': fdr_vals, 'num_detected': num_detected})
-        if np.min(fdrs.fdr) > 0.05:
-            fdr_5p_t = None
-        else:
-            fdr_5p_t = fdrs[fdrs.fdr <= 0.05].iloc[0].threshold
-        if np.min(fdrs.fdr) > 0.1:
-            fdr_10p_t = None
-        else:
-            fdr_10p_t = fdrs[fdrs.fdr <= 0.1].iloc[0].threshold
+        with np.errstate(invalid='ignore'):
+            if not np.min(fdr_vals) > 0.05:
+                fdr_5p_t = thresholds[np.flatnonzero(fdr_vals <= 0.05)[0]]
+            if not np.min(fdr_vals) > 0.1:
+                fdr_10p_t = thresholds[np.flatnonzero(fdr_vals <= 0.1)[0]]
+        res._defer('fdrs', lambda: pd.DataFrame({'threshold': thresholds, 'fdr': fdr_vals,
+                                                 'num_detected': num_detected}))
+    else:
+        res.fdrs = None
 
     # data.obs columns (all cells) and, from them, the coefficients of the kept cells
-    if fdrs is not None:
+    if fdr_vals is not None:
         with np.errstate(invalid='ignore'):
             runmin = np.fmin.accumulate(fdr_vals)
         coef_all, fdr_all = engine.percell(thresholds, runmin)
     else:
         coef_all, fdr_all = engine.percell(None, None)
 
-    res = {'p': pfinal, 'nullminps': nullminps, 'k': k, 'fdrs': fdrs, 'fdr_5p_t': fdr_5p_t,
-           'fdr_10p_t': fdr_10p_t, 'yresid_hat': yhat, 'yresid': ycond, 'ks': ks, 'beta': beta, 'r2': r2,
-           'r2_perpc': r2_perpc, 'nullr2_mean': nullr2s.mean(), 'nullr2_std': nullr2s.std()}
-    return res, coef_all, fdr_all
+    res.__dict__.update({'p': pfinal, 'nullminps': nullminps, 'k': k, 'fdr_5p_t': fdr_5p_t,
+                         'fdr_10p_t': fdr_10p_t, 'yresid_hat': yhat, 'yresid': ycond, 'ks': ks, 'beta': beta,
+                         'r2': r2, 'r2_perpc': r2_perpc, 'nullr2_mean': nullr2s.mean(),
+                         'nullr2_std': nullr2s.std()})
+    return coef_all, fdr_all, U, svs
 
 
 def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size, sids_present=None):
@@ -159,11 +206,13 @@ def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_si
 
 
 def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
-                            show_progress, codes_labels=None, **kwargs):
+                            show_progress, codes_labels=None, overlap=None, **kwargs):
     """Reference compute_nam_and_reindex (_association.py:175-191) on the device: build the NAM,
     QC it, put the sample axis in ``y.index`` order restricted to ``filter_samples``, drop the
     cells whose remaining entries have zero variance.  Leaves the selected NAM in the engine's
-    working matrix and returns the bookkeeping the caller needs."""
+    working matrix and returns the bookkeeping the caller needs.  ``overlap``: a host-only
+    callable run after the diffusion kernels have been queued and before their first result is
+    needed; its return value is passed through."""
     out = select_output(show_progress)
     nam_kwargs = {k: v for k, v in kwargs.items() if k in ('self_weight',)}
     print('computing NAM', file=out)
@@ -178,15 +227,17 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     if (colmap < 0).any():
         raise ValueError('the sample filter selects samples that have no cells in data; ' +
                          'make sure y, covs, batches and donorids share one index order')
+    batches = batches.reindex(y.index)
+    covs = covs.reindex(y.index) if covs is not None else None
+    donorids = donorids.reindex(y.index) if donorids is not None else None
+    filter_samples = filter_samples.reindex(y.index)
+    extra = overlap(batches, donorids, filter_samples) if overlap is not None else None
+
     zero_var, nzero = engine.zero_variance(colmap)
     if nzero:
         kept = kept & ~zero_var
     engine.select(None if kept.all() else kept, colmap)
-    return (kept, pd.Index(sample_index, name=sid_name), colmap,
-            batches.reindex(y.index),
-            covs.reindex(y.index) if covs is not None else None,
-            donorids.reindex(y.index) if donorids is not None else None,
-            filter_samples.reindex(y.index))
+    return (kept, pd.Index(sample_index, name=sid_name), colmap, batches, covs, donorids, filter_samples, extra)
 
 
 def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=None, key_added='coef',
@@ -205,15 +256,25 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
         # upstream forwards **kwargs to _association(), which rejects anything else
         bad = sorted(extra | ({'self_weight'} & set(kwargs)))[0]
         raise TypeError(f"_association() got an unexpected keyword argument '{bad}'")
+    Nnull = kwargs.get('Nnull', 1000)
 
     # factorise the per-cell sample ids once; validation and NAM construction share the result
     codes, labels = sample_codes(data.obs[sid_name])
     used = np.bincount(codes[codes >= 0], minlength=len(labels)) > 0
     batches, filter_samples = check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size,
                                            sids_present=labels[used] if isinstance(y, pd.Series) else None)
-    kept, sample_index, colmap, batches, covs, donorids, filter_samples = compute_nam_and_reindex(
-        engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps, show_progress,
-        codes_labels=(codes, labels))
+
+    def draw(batches_, donorids_, filter_):
+        # host-only: runs while the diffusion kernels are executing
+        return _draw_null(y[filter_].values, batches_[filter_].values,
+                          donorids_[filter_].values if donorids_ is not None else None,
+                          Nnull=Nnull, force_permute_all=kwargs.get('force_permute_all', False),
+                          seed=kwargs.get('seed'))
+
+    kept, sample_index, colmap, batches, covs, donorids, filter_samples, (y_std, y_null) = \
+        compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
+                                show_progress, codes_labels=(codes, labels), overlap=draw)
+
     def cell_index():
         # names of the kept cells: only needed for the frames of a full result
         return data.obs.index if kept.all() else data.obs.index[kept]
@@ -221,17 +282,16 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
 
     N = filter_samples.sum()
     npcs = min(N, max([10] + [int(max_frac_pcs * N)] + [ks if ks is not None else []][0]))
-    res, U = _resid_device(engine, sample_index, cell_index,
+    res, G = _resid_device(engine, sample_index, cell_index,
                            covs[filter_samples] if covs is not None else covs,
                            batches[filter_samples] if batches is not None else batches,
-                           npcs=npcs, ridges=ridges, show_progress=show_progress)
+                           ridges=ridges, show_progress=show_progress)
 
     print('performing association test', file=out)
-    res_, coef_all, fdr_all = _association(
-        engine, U, res.M, res.r, y[filter_samples].values, batches[filter_samples].values,
-        donorids[filter_samples].values if donorids is not None else None, None,
-        show_progress=show_progress, ks=ks, **kwargs)
-    res.__dict__.update(res_)
+    coef_all, fdr_all, U, svs = _association(engine, G, res, y_std, y_null, ks=ks, Nnull=Nnull,
+                                             local_test=kwargs.get('local_test', True),
+                                             show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_total)
+    _defer_pcs(res, engine, U, svs, cell_index)
     res._defer('ncorrs', lambda: pd.Series(coef_all if kept.all() else coef_all[kept], index=cell_index()))
     res.kept = kept
 
@@ -247,12 +307,12 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
     if key_added in data.obs:
         warnings.warn(f"Key '{key_added}' already exists in data.obs. Overwriting.")
     data.obs[key_added] = coef_all
-    if res.fdrs is None:
+    if fdr_all is None:
         # upstream dereferences res.fdrs here and dies when local_test=False (_association.py:235)
         raise AttributeError("'NoneType' object has no attribute 'loc'")
     data.obs[f'{key_added}_fdr'] = fdr_all
 
     if return_full:
-        res.ncorrs   # eager, like upstream; the three cells x samples frames stay lazy
+        res.ncorrs, res.fdrs   # eager, like upstream; the three cells x samples frames stay lazy
         return res
     return res.p

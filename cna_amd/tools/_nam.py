@@ -265,7 +265,7 @@ def _names(index_or_thunk):
     return index_or_thunk() if callable(index_or_thunk) else index_or_thunk
 
 
-def _resid_device(engine, sample_index, cell_index, covs, batches, ridges=None, npcs=None, show_progress=False):
+def _resid_device(engine, sample_index, cell_index, covs, batches, ridges=None, show_progress=False):
     """Reference ``_resid_nam`` (_nam.py:118-177) applied to the engine's working matrix X
     (cells x samples, already restricted to ``sample_index`` / ``cell_index``)."""
     out = select_output(show_progress)
@@ -311,44 +311,44 @@ def _resid_device(engine, sample_index, cell_index, covs, batches, ridges=None, 
         engine.standardize(center=False)
 
     # svd_nam re-centres / re-standardises (_nam.py:103-104); X is already standardised, so
-    # that is an identity up to 1 ulp and the Gram matrix is taken of X directly.
+    # that is an identity up to 1 ulp and the Gram matrix is taken of X directly.  The SVD of
+    # G itself is left to the caller, which overlaps it with device work.
     G = engine.gram()
-    U, svs, _ = _small_svd(G)
-    names = _pc_names(N)
-    if npcs is None:
-        npcs = N
-    n_cells = engine.x_rows_total
-
     res = LazyNamespace()
     res.M = M
     res.r = len(C.T)
-    res.namresid_sampleXpc = pd.DataFrame(U, index=sample_index, columns=names)
-    svs_s = pd.Series(svs, index=names)
-    res.namresid_svs = svs_s[:npcs]
-    res.namresid_varexp = svs_s / len(U) / n_cells
-
     epoch = engine.x_epoch
-
-    def _still_resident():
-        if engine.x_epoch != epoch:
-            raise RuntimeError('this result field lives on the GPU and a later cna_amd call has replaced it; '
-                               'read it (or call res.materialize()) before running the next analysis')
+    n_cells = engine.x_rows_total
 
     def fetch_namresid():
-        _still_resident()
+        _still_resident(engine, epoch)
         if engine.nranks == 1:
             full_t = engine.fetch_matrix(_ffi.MAT_X, transposed=True)           # samples x cells
         else:
             full_t = _gather_rows(engine, engine.fetch_matrix(_ffi.MAT_X), n_cells).T
         return pd.DataFrame(full_t, index=sample_index, columns=_names(cell_index))
 
+    res._defer('namresid', fetch_namresid)
+    return res, G
+
+
+def _still_resident(engine, epoch):
+    if engine.x_epoch != epoch:
+        raise RuntimeError('this result field lives on the GPU and a later cna_amd call has replaced it; '
+                           'read it (or call res.materialize()) before running the next analysis')
+
+
+def _defer_pcs(res, engine, U, svs, cell_index):
+    """namresid_nbhdXpc: V = NAM^T U / sqrt(svs) (_nam.py:106), computed on the device when read."""
+    epoch = engine.x_epoch
+    n_cells = engine.x_rows_total
+    names = _pc_names(len(U))
+
     def fetch_V():
-        _still_resident()
+        _still_resident(engine, epoch)
         with np.errstate(all='ignore'):
             V = engine.project(U / np.sqrt(svs))
         V = _gather_rows(engine, V, n_cells)
         return pd.DataFrame(V, index=_names(cell_index), columns=names)
 
-    res._defer('namresid', fetch_namresid)
     res._defer('namresid_nbhdXpc', fetch_V)
-    return res, U
