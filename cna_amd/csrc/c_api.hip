@@ -664,8 +664,18 @@ int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int
     }
     std::memcpy(&cuts[t], &hi, 8);
   }
-  double thr0, inv_step;
-  guess_from_thr(cuts.data(), T, &thr0, &inv_step);
+  // the cuts are (nearly) an arithmetic progression: cut0 + t*step.  eps bounds, in steps, how far
+  // any cut is from that line; the kernel trusts floor((x-cut0)/step) outside +-eps of a cut.
+  const double cut0 = cuts[0];
+  double inv_step = 0.0, eps = 2.0;                      // eps >= 1: always walk the table
+  if (T >= 3 && cuts[T - 1] > cuts[0]) {
+    const double step = (cuts[T - 1] - cuts[0]) / (T - 1);
+    double dev = 0.0;
+    for (int t = 0; t < T; ++t) dev = std::max(dev, std::fabs(cuts[t] - (cut0 + t * step)) / step);
+    inv_step = 1.0 / step;
+    eps = 2.0 * dev + 1e-9;
+    if (!(eps < 0.25)) { eps = 2.0; }
+  }
   CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap,
                       carve_bytes({(int64_t)sizeof(double) * ldx * ldy, 8 * (int64_t)T, 8 * (int64_t)P * T, 8 * (int64_t)P * T})));
   Carver cv(c->scratch);
@@ -675,7 +685,7 @@ int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int
   int64_t* tails = cv.take<int64_t>((int64_t)P * T);
   HIP_TRY(hipMemcpyAsync(Yd, Yp.data(), sizeof(double) * ldx * ldy, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(ed, cuts.data(), 8 * T, hipMemcpyHostToDevice, c->stream));
-  CNA_TRY(launch_null_local(c, Yd, ldy, P, ed, T, thr0, inv_step, hist));
+  CNA_TRY(launch_null_local(c, Yd, ldy, P, ed, T, cut0, inv_step, eps, hist));
   CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)P * T));
   CNA_TRY(launch_suffix_sum(c, hist, P, T, tails));
   HIP_TRY(hipMemcpyAsync(tails_out, tails, 8 * (size_t)P * T, hipMemcpyDeviceToHost, c->stream));

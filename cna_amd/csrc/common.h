@@ -156,8 +156,8 @@ int launch_transpose(cna_ctx* c, const double* in, int64_t rows, int cols, int l
 // mfma.hip
 int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, double* out, int ld_out);
 int launch_gram(cna_ctx* c, double* G_dev);
-int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* edges_dev, int T,
-                      double thr0, double inv_step, unsigned long long* hist_dev);
+int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* cuts_dev, int T,
+                      double cut0, double inv_step, double eps, unsigned long long* hist_dev);
 
 // ---- device helpers shared by the kernel files
 #ifdef __HIPCC__

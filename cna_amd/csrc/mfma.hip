@@ -10,6 +10,7 @@
 //   D[r][j]: r = (lane >> 4) + 4*reg, j = lane & 15,  reg in 0..3
 #include "common.h"
 #include <array>
+#include <cstdlib>
 #include <utility>
 
 namespace {
@@ -169,11 +170,11 @@ __global__ __launch_bounds__(1024) void k_gram_reduce(const double* __restrict__
 // reference's count and costs one compare instead of a division and a square per element.
 // A linear guess + two exact compares finds the bin; counters are packed 16-bit pairs in LDS
 // (a chunk has < 65536 cells) and are flushed with integer global atomics -> bit-reproducible.
-template <int KQ, int TS>
+template <int KQ, int TS, int MODE = 0>
 __global__ __launch_bounds__(512) void k_null(const double* __restrict__ X, int64_t nx, int64_t chunk_rows,
                                               const double* __restrict__ Yc, int ldy, int P,
                                               const double* __restrict__ cuts, int T, double cut0,
-                                              float inv_step, unsigned long long* __restrict__ ghist) {
+                                              double inv_step, double eps, unsigned long long* __restrict__ ghist) {
   // KQ is the exact number of k-steps: the leading dimension of X is 4*KQ
   extern __shared__ double sm[];
   constexpr int ROWS = 32 * TS;
@@ -186,11 +187,11 @@ __global__ __launch_bounds__(512) void k_null(const double* __restrict__ X, int6
   const int strip = wv & 3, half = wv >> 2;
   const int ak = lane >> 4, ai = lane & 15;
   const int HW = ((T + 1) >> 1) | 1;                     // odd row stride: the 16 strips' counters spread over all banks
-  const int TP = (T + 2) & ~1;                           // cuts + inf sentinel, even
+  const int TP = (T + 4) & ~1;                           // 0, cuts[0..T), +inf, +inf (even count)
   double* c_s = sm;
   double* xt = sm + TP;                                  // ROWS * LDP doubles
   unsigned int* hist = (unsigned int*)(xt + ROWS * LDP);  // 64 * HW words
-  for (int i = tid; i < TP; i += 512) c_s[i] = i < T ? cuts[i] : __builtin_inf();
+  for (int i = tid; i < TP; i += 512) c_s[i] = i == 0 ? 0.0 : (i <= T ? cuts[i - 1] : __builtin_inf());
   for (int i = tid; i < 64 * HW; i += 512) hist[i] = 0u;
 
   const int pt = blockIdx.y;
@@ -213,12 +214,13 @@ __global__ __launch_bounds__(512) void k_null(const double* __restrict__ X, int6
   const int64_t row_begin = (int64_t)blockIdx.x * chunk_rows;
   int64_t row_end = row_begin + chunk_rows;
   if (row_end > nx) row_end = nx;
-  const int Tm1 = T - 1;
 
-  double2 pf[PF];
-  auto prefetch = [&](int64_t r0) {
+  // register prefetch two slabs ahead (pfA: even slabs, pfB: odd): one slab of MFMAs is shorter
+  // than an L2/Infinity-Cache round trip under load
+  double2 pfA[PF], pfB[PF];
+  auto prefetch = [&](double2 (&pf)[PF], int64_t r0) {
     const double* __restrict__ slab = X + r0 * LDX;      // uniform base, 32-bit lane offsets
-    const int64_t left = (row_end - r0) * LDX;
+    const int64_t left = r0 < row_end ? (row_end - r0) * LDX : 0;
     const unsigned lim = left > (int64_t)(ROWS * LDX) ? (unsigned)(ROWS * LDX) : (unsigned)left;
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
@@ -226,46 +228,79 @@ __global__ __launch_bounds__(512) void k_null(const double* __restrict__ X, int6
       if (goff[i] < lim) pf[i] = *reinterpret_cast<const double2*>(slab + goff[i]);
     }
   };
-  if (row_begin < row_end) prefetch(row_begin);
   const unsigned hp = (unsigned)((strip * 16 + ai) * HW);   // this lane's counter row (word index)
-  for (int64_t r0 = row_begin; r0 < row_end; r0 += ROWS) {
+  // Output -> counter.  c_s[k] (k>=1) = cuts[k-1], c_s[0] = 0, c_s[T+1..] = +inf; the count of an
+  // output is h = #{k in 1..T : c_s[k] <= x}.  The cuts are an arithmetic progression to within
+  // `eps` steps (the host measures the worst deviation), so h = floor((x-cut0)/step) + 1 is exact
+  // unless x lies within eps of a cut -- only those outputs (and the last bin) consult the table.
+  // Rows past row_end were staged as zeros and cut0 > 0, so they never count.
+  auto count = [&](double v) {
+    const double x = fabs(v);
+    if (x >= cut0) {
+      const double f = (x - cut0) * inv_step;
+      const double fl = floor(f);
+      const double fr = f - fl;
+      int h = (fl < (double)(T - 1)) ? (int)fl + 1 : T;
+      if (!(fl < (double)(T - 1) && fr > eps && fr < 1.0 - eps)) {   // near a cut or in the top bin: exact walk
+        while (c_s[h + 1] <= x) ++h;                                  // c_s[T+1] = +inf
+        while (c_s[h] > x) --h;                                       // c_s[1] = cut0 <= x
+      }
+      const unsigned bin = (unsigned)(h - 1);
+      atomicAdd(&hist[hp + (bin >> 1)], (bin & 1u) ? 0x10000u : 1u);
+    }
+  };
+  auto count_all = [&](const v4d (&acc)[TS]) {
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) count(acc[t][r]);
+    }
+  };
+  const double* ap = xt + (half * 16 * TS + ai) * LDP + ak;
+  auto stage = [&](double2 (&pf)[PF], int64_t r0) {
     __syncthreads();                       // previous slab fully consumed
 #pragma unroll
     for (int i = 0; i < PF; ++i)
       if (goff[i] != 0xffffffffu) *reinterpret_cast<double2*>(xt + loff[i]) = pf[i];
     __syncthreads();
-    if (r0 + ROWS < row_end) prefetch(r0 + ROWS);
+    prefetch(pf, r0 + 2 * ROWS);           // this register set is free again: fetch two slabs ahead
+  };
+  auto slab = [&]() {
     v4d acc[TS];
 #pragma unroll
     for (int t = 0; t < TS; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const double* ap = xt + (half * 16 * TS + ai) * LDP + ak;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
 #pragma unroll
-      for (int t = 0; t < TS; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[t * 16 * LDP + 4 * q], b[q], acc[t], 0, 0, 0);
-    }
-    // rows past row_end were staged as zeros and cut0 > 0, so they never count
-#pragma unroll
-    for (int t = 0; t < TS; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double x = fabs(acc[t][r]);
-        if (x >= cut0) {
-          // linear guess in float (the cuts are evenly spaced to ~1e-5), exact fix-up in double
-          const int g = (int)((float)(x - cut0) * inv_step);
-          int h = (g < Tm1 ? g : Tm1) + 1;                 // candidate #{cuts <= x}, in [1, T]
-          const double c0 = c_s[h - 1], c1 = c_s[h];       // c_s[T] = +inf
-          h += (c1 <= x) ? 1 : 0;
-          h -= (c0 > x) ? 1 : 0;
-          if (c_s[h] <= x || c_s[h - 1] > x) {             // guess off by more than one: walk (rare)
-            while (c_s[h] <= x) ++h;
-            while (c_s[h - 1] > x) --h;
-          }
-          const unsigned bin = (unsigned)(h - 1);
-          atomicAdd(&hist[hp + (bin >> 1)], (bin & 1u) ? 0x10000u : 1u);
+      for (int t = 0; t < TS; ++t) {
+        if (MODE == 2) {
+          if (q < 2) acc[t][q] += ap[t * 16 * LDP + 4 * q] * b[q];       // experiment: no matrix work
+        } else {
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[t * 16 * LDP + 4 * q], b[q], acc[t], 0, 0, 0);
         }
       }
+    }
+    if (MODE == 1) {                                                     // experiment: no counting
+      double z = 0.0;
+#pragma unroll
+      for (int t = 0; t < TS; ++t) z += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+      if (z == 123.456) atomicAdd(&hist[hp], 1u);
+    } else {
+      count_all(acc);
+    }
+  };
+  if (row_begin < row_end) {
+    prefetch(pfA, row_begin);
+    prefetch(pfB, row_begin + ROWS);
+    for (int64_t r0 = row_begin;;) {
+      stage(pfA, r0);
+      slab();
+      r0 += ROWS;
+      if (r0 >= row_end) break;
+      stage(pfB, r0);
+      slab();
+      r0 += ROWS;
+      if (r0 >= row_end) break;
     }
   }
   __syncthreads();
@@ -295,21 +330,21 @@ int launch_gram_t(cna_ctx* c, int nt, int ldp, int ntri, const int32_t* tiles_de
 
 template <int KQ, int TS>
 int launch_null_t(cna_ctx* c, dim3 grid, size_t smem, int64_t chunk_rows, const double* Yc, int ldy, int P,
-                  const double* cuts, int T, double cut0, double inv_step, unsigned long long* hist) {
+                  const double* cuts, int T, double cut0, double inv_step, double eps, unsigned long long* hist) {
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_null<KQ, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   hipLaunchKernelGGL((k_null<KQ, TS>), grid, dim3(512), smem, c->stream, c->X, c->nx, chunk_rows, Yc, ldy, P, cuts,
-                     T, cut0, (float)inv_step, hist);
+                     T, cut0, inv_step, eps, hist);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
 // one instantiation per exact k-depth (ceil(N/4), N <= 256) so the MFMA loop has no guards
 typedef int (*null_launch_fn)(cna_ctx*, dim3, size_t, int64_t, const double*, int, int, const double*, int, double,
-                              double, unsigned long long*);
+                              double, double, unsigned long long*);
 template <int TS, int... KQ>
 constexpr std::array<null_launch_fn, sizeof...(KQ)> null_table(std::integer_sequence<int, KQ...>) {
   return {{&launch_null_t<KQ + 1, TS>...}};
@@ -379,14 +414,14 @@ int launch_gram(cna_ctx* c, double* G_dev) {
 }
 
 int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* cuts_dev, int T,
-                      double cut0, double inv_step, unsigned long long* hist_dev) {
+                      double cut0, double inv_step, double eps, unsigned long long* hist_dev) {
   HIP_TRY(hipMemsetAsync(hist_dev, 0, sizeof(unsigned long long) * (size_t)P * T, c->stream));
   if (c->nx == 0 || P == 0 || T == 0) return 0;
   const int kq = c->ldx / 4;
   if (kq > 64) CNA_FAIL(CNA_EINVAL, "more than 256 samples are not supported by the local-null kernel yet");
   if (!(cut0 > 0.0)) CNA_FAIL(CNA_EINVAL, "local-null kernel needs strictly positive thresholds");
   const int HW = ((T + 1) / 2) | 1;
-  const size_t fixed = sizeof(double) * ((T + 2) & ~1) + sizeof(unsigned int) * 64 * HW;
+  const size_t fixed = sizeof(double) * ((T + 4) & ~1) + sizeof(unsigned int) * 64 * HW;
   const size_t slab64 = sizeof(double) * 64 * (c->ldx + 2), slab32 = slab64 / 2;
   const int TS = (kq <= 54 && fixed + slab64 <= 150 * 1024) ? 2 : 1;
   const size_t smem = fixed + (TS == 2 ? slab64 : slab32);
@@ -402,5 +437,17 @@ int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const do
   dim3 grid((unsigned)nchunks, (unsigned)nptile);
   ProfScope ps(c, CNA_K_NULL_LOCAL);
   null_launch_fn fn = TS == 2 ? kNullTS2[kq - 1] : kNullTS1[kq - 1];
-  return fn(c, grid, smem, chunk_rows, Yc_dev, ldy, P, cuts_dev, T, cut0, inv_step, hist_dev);
+  if (const char* dbg = getenv("CNA_NULL_DEBUG")) {                      // experiments, N=50 only
+    if (kq == 13 && TS == 2 && atoi(dbg) == 1) {
+      hipLaunchKernelGGL((k_null<13, 2, 1>), grid, dim3(512), smem, c->stream, c->X, c->nx, chunk_rows, Yc_dev, ldy, P,
+                         cuts_dev, T, cut0, inv_step, eps, hist_dev);
+      return 0;
+    }
+    if (kq == 13 && TS == 2 && atoi(dbg) == 2) {
+      hipLaunchKernelGGL((k_null<13, 2, 2>), grid, dim3(512), smem, c->stream, c->X, c->nx, chunk_rows, Yc_dev, ldy, P,
+                         cuts_dev, T, cut0, inv_step, eps, hist_dev);
+      return 0;
+    }
+  }
+  return fn(c, grid, smem, chunk_rows, Yc_dev, ldy, P, cuts_dev, T, cut0, inv_step, eps, hist_dev);
 }
