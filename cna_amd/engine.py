@@ -29,9 +29,9 @@ class Engine:
         self.h = h
         self.device = int(device)
         self.rank, self.nranks = int(rank), int(nranks)
-        if nranks > 1:
-            if unique_id is None:
-                raise ValueError('nranks > 1 needs the RCCL unique id created by rank 0')
+        if nranks > 1 and unique_id is None:
+            raise ValueError('nranks > 1 needs the RCCL unique id created by rank 0')
+        if unique_id is not None:   # also with one rank: every collective then really goes through RCCL
             buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
             check(self.lib.cna_comm_init(self.h, self.rank, self.nranks, C.cast(buf, C.c_void_p)), 'cna_comm_init')
         self._graph_key = None

@@ -300,3 +300,18 @@ def test_properties_at_scale(eng):
     yz = (meta['y'].values - meta['y'].values.mean()) / meta['y'].values.std()
     np.testing.assert_allclose(res.ncorrs.values, yz.dot(X) / 50, rtol=1e-9, atol=1e-12)
     assert 1 / 501 <= res.p <= 1 and len(res.nullminps) == 500
+
+
+def test_rccl_path_with_one_rank(orc):
+    """The collectives of the sharded path (all-reduce / all-gather through librccl.so) on a
+    one-rank communicator: same answers as without a communicator."""
+    from cna_amd.engine import Engine
+    case = load_case('c12_batchy_qc')
+    e = Engine(device=0, rank=0, nranks=1, unique_id=Engine.new_unique_id())
+    try:
+        res, err, _ = run_product(case, e)
+        assert err is None, repr(err)
+        assert_matches_golden(res, case['data'], case['z'], tol=1e-5)
+        prof_names = e.prof()
+    finally:
+        e.close()
