@@ -38,6 +38,18 @@ WORKLOADS = {
 }
 
 
+def usable_cpus():
+    """CPUs this process may use: cgroup v2 quota if set, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def algorithmic_work(kernel, n, nnz, N, P, T, wA):
     """Algorithmic bytes / flops of ONE launch (DESIGN.md 'Kernels')."""
     ld = (N + 3) // 4 * 4
@@ -90,6 +102,7 @@ def main():
 
     import cna_amd as cna
     from cna_amd import synth
+    cna.tune_host_allocator()       # host-side: no mmap/munmap churn for per-cell numpy temporaries
     from cna_amd.engine import get_engine
     from cna_amd.tools._nam import get_connectivity
 
@@ -183,14 +196,20 @@ def main():
         from oracle import cna_oracle as orc
         ns = min(args.cpu_sample_cells, n)
         sdata, smeta = synth.make_dataset(ns, N, k=k, seed=0)
-        t0 = time.perf_counter()
-        ref = orc.association(sdata, smeta['y'], 'id', mode='reference', **kw)
-        t_cpu = time.perf_counter() - t0
+        # give the CPU path the cores this container may actually use (cgroup quota), not the
+        # host's core count: oversubscribed BLAS threads only get the process throttled
+        threads = usable_cpus()
         try:
-            from threadpoolctl import threadpool_info
-            threads = max([i.get('num_threads', 1) for i in threadpool_info()] or [1])
+            from threadpoolctl import threadpool_limits
+            limiter = threadpool_limits(limits=threads, user_api='blas')
         except Exception:
-            threads = os.cpu_count()
+            import contextlib
+            limiter = contextlib.nullcontext()
+        with limiter:
+            orc.association(sdata, smeta['y'], 'id', mode='reference', **dict(kw, Nnull=50))   # warm caches
+            t0 = time.perf_counter()
+            ref = orc.association(sdata, smeta['y'], 'id', mode='reference', **kw)
+            t_cpu = time.perf_counter() - t0
         cpu = dict(value=round(ns * Nnull / t_cpu, 1), unit='cell*perm/s', cores=int(threads), kind='port',
                    seconds=round(t_cpu, 2), host_cpus=os.cpu_count(),
                    sample='oracle/cna_oracle.py association(mode=reference) on %d cells x %d samples, k=%d, '

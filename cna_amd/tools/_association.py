@@ -20,7 +20,7 @@ import pandas as pd
 from .. import _ffi
 from ..engine import get_engine
 from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_device, _gather_rows, sample_codes,
-                   _small_svd, _defer_pcs)
+                   _small_svd, _defer_pcs, host_blas_threads)
 from ._out import select_output
 from ._stats import conditional_permutation, grouplevel_permutation, default_ks, minp_stats
 
@@ -249,6 +249,13 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
     (same field names and types as upstream; the three cells x samples sized frames --
     ``nam``, ``namresid``, ``namresid_nbhdXpc`` -- are copied off the GPU when first read).
     Writes ``data.obs[key_added]`` and ``data.obs[key_added + '_fdr']``."""
+    with host_blas_threads(1):
+        return _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added, max_frac_pcs, nsteps,
+                                 show_progress, allow_low_sample_size, return_full, ridges, engine, **kwargs)
+
+
+def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added, max_frac_pcs, nsteps,
+                      show_progress, allow_low_sample_size, return_full, ridges, engine, **kwargs):
     out = select_output(show_progress)
     engine = engine or get_engine()
     extra = set(kwargs) - {'Nnull', 'force_permute_all', 'local_test', 'seed', 'self_weight'}
@@ -260,7 +267,8 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
 
     # factorise the per-cell sample ids once; validation and NAM construction share the result
     codes, labels = sample_codes(data.obs[sid_name])
-    used = np.bincount(codes[codes >= 0], minlength=len(labels)) > 0
+    counts = np.bincount(codes if codes.min(initial=0) >= 0 else codes[codes >= 0], minlength=len(labels))
+    used = counts > 0
     batches, filter_samples = check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size,
                                            sids_present=labels[used] if isinstance(y, pd.Series) else None)
 
@@ -273,7 +281,7 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
 
     kept, sample_index, colmap, batches, covs, donorids, filter_samples, (y_std, y_null) = \
         compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
-                                show_progress, codes_labels=(codes, labels), overlap=draw)
+                                show_progress, codes_labels=(codes, labels, counts), overlap=draw)
 
     def cell_index():
         # names of the kept cells: only needed for the frames of a full result

@@ -36,13 +36,23 @@ except Exception:   # pragma: no cover - threadpoolctl not installed
     _blas_pool = None
 
 
+import contextlib
+
+
+def host_blas_threads(limit=1):
+    """Context manager: run the host's sample-space linear algebra (N x N, N x Nnull) on `limit`
+    BLAS threads.  These matrices are tiny; a threaded BLAS fans them out over every core it
+    sees, its idle workers spin, and under a container CPU quota that spinning gets the whole
+    process throttled (measured on the GPU box: 25 ms for a 50 x 50 SVD, and 50 ms stalls at
+    random places, with 64 OpenBLAS threads under a 16-CPU cgroup quota)."""
+    if _blas_pool is None:
+        return contextlib.nullcontext()
+    return _blas_pool.limit(limits=limit, user_api='blas')
+
+
 def _small_svd(G):
-    """np.linalg.svd of the samples x samples Gram (_nam.py:105).  Same LAPACK routine as the
-    reference (so PC signs agree); run on one BLAS thread when the matrix is small, where the
-    threaded driver costs ~100x the arithmetic (measured: 25 ms vs 0.2 ms at N=50 on a 256-core host)."""
-    if _blas_pool is not None and G.shape[0] <= 512:
-        with _blas_pool.limit(limits=1, user_api='blas'):
-            return np.linalg.svd(G)
+    """np.linalg.svd of the samples x samples Gram (_nam.py:105): the same LAPACK routine as the
+    reference, so PC signs agree."""
     return np.linalg.svd(G)
 
 
@@ -88,8 +98,15 @@ def sample_codes(col):
     categorical column (unused categories included), sorted unique labels otherwise."""
     if isinstance(col.dtype, pd.CategoricalDtype):
         return np.asarray(col.cat.codes, dtype=np.int32), pd.Index(col.cat.categories)
-    codes, uniques = pd.factorize(col, sort=True)
-    return codes.astype(np.int32), pd.Index(uniques)
+    # factorize in order of appearance, then rank the (few) labels: pandas' sort=True re-maps the
+    # per-cell codes through a generic take that is several times slower than the hashing itself
+    codes, uniques = pd.factorize(col)
+    uniques = pd.Index(uniques)
+    order = uniques.argsort()
+    rank = np.empty(len(order) + 1, dtype=np.int32)
+    rank[order] = np.arange(len(order), dtype=np.int32)
+    rank[-1] = -1                                   # NaN ids (code -1) stay -1
+    return rank[codes], uniques[order]
 
 
 def _column_r2(a, b):
@@ -148,9 +165,13 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
     engine holds NAM = (s/C) (cells x samples); returns (labels, steps taken)."""
     out = select_output(show_progress)
     _prepare_graph(engine, data, self_weight)
-    codes, labels = codes_labels if codes_labels is not None else sample_codes(data.obs[sid_name])
+    if codes_labels is not None and len(codes_labels) == 3:
+        codes, labels, counts = codes_labels
+    else:
+        codes, labels = codes_labels if codes_labels is not None else sample_codes(data.obs[sid_name])
+        counts = np.bincount(codes if codes.min(initial=0) >= 0 else codes[codes >= 0], minlength=len(labels))
     N = len(labels)
-    C = np.bincount(codes[codes >= 0], minlength=N).astype(np.float64)
+    C = counts.astype(np.float64)
     engine.set_samples(codes, N, C)
     n = engine.n
 
@@ -250,7 +271,8 @@ def svd_nam(NAM, engine=None):
     engine.upload_x(X)
     engine.standardize(center=True)
     G = engine.gram()
-    U, svs, _ = _small_svd(G)
+    with host_blas_threads(1):
+        U, svs, _ = _small_svd(G)
     with np.errstate(all='ignore'):
         V = engine.project(U / np.sqrt(svs))
     names = _pc_names(U.shape[1])

@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import warnings; warnings.simplefilter('ignore')
 import cna_amd as cna
+if os.environ.get('TUNE', '1') == '1': print('tuned', cna.tune_host_allocator())
 from cna_amd import synth
 from cna_amd.engine import get_engine, Engine
 
