@@ -83,6 +83,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-cells', type=int, default=100_000)
     ap.add_argument('--profile-host', default=None, help='write a cProfile of 3 extra steps to this file')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='take the torch.distributed + RCCL code path even with one rank (plumbing check)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -92,13 +94,15 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
     td = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch
         import torch.distributed as td
         torch.cuda.set_device(local_rank)
-        td.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        td.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank), rank=rank, world_size=world)
         from cna_amd import dist
-        dist.init_from_torch(device=local_rank)
+        dist.init_from_torch(device=local_rank, always_comm=args.force_dist)
 
     import cna_amd as cna
     from cna_amd import synth

@@ -38,6 +38,7 @@ struct StepArgs {
   int width, ld;
   double w;
   int want_kurt, write_t, write_nam;
+  int xcd_chunk;
 };
 
 __device__ __forceinline__ double readlane_d(double v, int l) {
@@ -121,9 +122,13 @@ __device__ __forceinline__ void load_edges(const StepArgs& a, int64_t start, int
 // Workgroup -> rows: 4 consecutive rows per workgroup (one per wave); XCD x (= blockIdx % 8,
 // observed dispatch) walks the contiguous block range [x*cpx, (x+1)*cpx) so the neighbour rows
 // it gathers stay in its own 4 MiB L2 (+4 % measured; a pure speed choice).
-__device__ __forceinline__ int64_t my_row(int wv) {
-  const int64_t cpx = gridDim.x >> 3;
-  const int64_t blk = (int64_t)(blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+__device__ __forceinline__ int64_t my_row(int wv, int chunk) {
+  // chunk = consecutive workgroups (4 rows each) one XCD takes before the next XCD's chunk begins;
+  // chunk = gridDim/8 gives every XCD one contiguous eighth of the rows (best when a cluster of
+  // cells fits the 4 MiB L2), a small chunk keeps all XCDs inside one window of rows (best when it
+  // only fits the 256 MiB Infinity Cache)
+  const int64_t b = blockIdx.x >> 3, x = blockIdx.x & 7;
+  const int64_t blk = (b / chunk) * (8 * (int64_t)chunk) + x * chunk + (b % chunk);
   return uniform64(blk * 4 + wv);
 }
 
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
   double* accl = sm + (size_t)wv * 64 * NQ;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) accl[lane + 64 * q] = 0.0;
-  const int64_t row = my_row(wv);
+  const int64_t row = my_row(wv, a.xcd_chunk);
   if (row >= a.n_local) return;
   const int64_t grow = a.row0 + row;
   const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
   constexpr int U = 8;                          // neighbour rows in flight per wave (8 beats 16 and 32)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row = my_row(wv);
+  const int64_t row = my_row(wv, a.xcd_chunk);
   if (row >= a.n_local) return;
   const int64_t grow = a.row0 + row;
   const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
@@ -285,9 +290,15 @@ int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
 }
 
 template <typename VT>
-int launch_step_q(cna_ctx* c, bool first, const StepArgs& a) {
+int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
   const int64_t nblk = (c->n_local + 3) / 4;
-  const int64_t cpx = (nblk + 7) / 8;
+  int64_t cpx = (nblk + 7) / 8;
+  StepArgs a = a_in;
+  // measured (tools/kbench.py): one contiguous eighth per XCD is best at 200k x 50 (+4 % over
+  // round-robin) and within 2 % of every chunk size at 1M x 100
+  int64_t chunk = cpx;
+  cpx = (cpx + chunk - 1) / chunk * chunk;      // whole chunks per XCD
+  a.xcd_chunk = (int)chunk;
   dim3 grid((unsigned)(cpx * 8));
   if (a.ld > 512) CNA_FAIL(CNA_EINVAL, "more than 512 samples / state columns are not supported");
   if (first) {

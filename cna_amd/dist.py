@@ -15,6 +15,7 @@ def init(rank, nranks, unique_id=None, device=None):
     global _cfg
     if nranks > 1 and unique_id is None:
         raise ValueError('unique_id required when nranks > 1 (create it on rank 0 with new_unique_id())')
+    # with one rank a unique_id is optional: when given, collectives still go through RCCL
     _cfg = dict(rank=int(rank), nranks=int(nranks), unique_id=unique_id,
                 device=int(device) if device is not None else None)
     from . import engine
@@ -30,7 +31,7 @@ def new_unique_id():
     return Engine.new_unique_id()
 
 
-def init_from_torch(device=None):
+def init_from_torch(device=None, always_comm=False):
     """Broadcast the RCCL id over an existing torch.distributed process group."""
     import torch.distributed as td
     if not td.is_initialized():
@@ -39,7 +40,7 @@ def init_from_torch(device=None):
     if device is None:
         device = int(os.environ.get('LOCAL_RANK', rank))
     uid = None
-    if nranks > 1:
+    if nranks > 1 or always_comm:
         box = [new_unique_id() if rank == 0 else None]
         td.broadcast_object_list(box, src=0)
         uid = box[0]

@@ -48,9 +48,8 @@ def minp_stats(Z, M, U, ks, r):
 
     Restates _reg/_stats/_minp_stats (_association.py:35-61): condition on covariates
     (M.z), scale by the ddof=1 std, regress on the first k sample-PCs for each k in ks,
-    F-test against the null model, keep the k with the smallest p.  Because U is
-    orthonormal, ||Uk Uk^T z - z||^2 is evaluated directly from the fitted values as the
-    reference does.  Returns (index into ks, p, r2) per column.
+    F-test against the null model, keep the k with the smallest p.
+    Returns (index into ks, p, r2) per column.
     """
     n = Z.shape[0]
     Zc = M.dot(Z)
@@ -58,11 +57,10 @@ def minp_stats(Z, M, U, ks, r):
     ssered = np.einsum('ij,ij->j', Zc, Zc)
     kmax = int(max(ks))
     Bt = U[:, :kmax].T.dot(Zc)                      # kmax x P projections
-    ssefull = np.empty((len(ks), Z.shape[1]))
-    for a, k in enumerate(ks):
-        fit = U[:, :k].dot(Bt[:k])
-        resid = fit - Zc
-        ssefull[a] = np.einsum('ij,ij->j', resid, resid)
+    # ||Uk Uk^T z - z||^2 = ||z||^2 - sum_{j<k} (U_j.z)^2 for orthonormal U: one cumulative sum
+    # serves every k (agrees with forming the fitted values to ~1e-16/(1-r2))
+    fitted = np.cumsum(Bt * Bt, axis=0)
+    ssefull = ssered[None, :] - fitted[np.asarray(ks, dtype=int) - 1]
     kcol = np.asarray(ks, dtype=np.float64)[:, None]
     with np.errstate(all='ignore'):
         f = ((ssered - ssefull) / kcol) / (ssefull / n)
