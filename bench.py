@@ -30,6 +30,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_MFMA_PEAK_TF = 78.6      # AMD MI355X datasheet: FP64 matrix 78.6 TFLOP/s (the guide lists no f64 row)
 
+# HBM-side traffic per launch from rocprofv3 PMC passes of THIS bench command (profiles/r01_pmc_summary.txt,
+# tools/pmc_run.sh): bytes = 2 * FETCH_SIZE KB + WRITE_SIZE KB.  The factor 2 on FETCH_SIZE is the guide's
+# gfx950 correction, re-calibrated here on k_ncorrs (streams the 83.2 MB matrix once, FETCH_SIZE reads 41.6 MB).
+# Counted at the L2's fabric side, i.e. Infinity-Cache hits included.  Only valid for the profiled workload.
+PMC_TRAFFIC = {
+    ('C2', 'nam_step'): 2 * 513694e3 + 84650e3,
+    ('C2', 'nam_first'): 2 * 37894e3 + 81250e3,
+    ('C2', 'null_local'): 2 * 147138e3 + 52217e3,
+}
+
 WORKLOADS = {
     # name: (cells per GPU, samples, kNN k, nsteps, Nnull)
     'C2': (200_000, 50, 30, 3, 1000),
@@ -192,7 +202,8 @@ def main():
     dom = max((k_ for k_ in kernels if k_ != 'rccl'), key=lambda k_: kernels[k_]['total_ms'])
     kd = kernels[dom]
     roofline = dict(kernel=dom, bound=kd['bound'], achieved=kd['achieved'], peak=kd['peak'], unit=kd['unit'],
-                    frac=kd['frac'], traffic=None, avg_us=kd['avg_us'], launches_per_step=kd['launches'] // args.steps)
+                    frac=kd['frac'], traffic=PMC_TRAFFIC.get((args.workload, dom)) if world == 1 else None,
+                    traffic_source='profiles/r01_pmc_summary.txt (rocprofv3 --pmc, same command)', avg_us=kd['avg_us'], launches_per_step=kd['launches'] // args.steps)
     gpu_ms_per_step = sum(v['total_ms'] for v in kernels.values()) / args.steps
 
     cpu = None
