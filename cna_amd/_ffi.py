@@ -47,6 +47,10 @@ SIGNATURES = {
     'cna_project': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p]),
     'cna_ncorrs': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, c_f64p]),
     'cna_null_local': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'cna_condition_phenotypes': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int]),
+    'cna_null_local_resident': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'cna_global_test': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
     'cna_obs_counts': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'cna_percell_fdr': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'cna_matrix_shape': (C.c_int, [c_ctx, C.c_int, c_i64p, C.POINTER(C.c_int)]),
@@ -61,7 +65,7 @@ SIGNATURES = {
 MAT_NAM, MAT_X = 0, 1
 KERNELS = ['colsum', 'nam_first', 'nam_step', 'batch_kurtosis', 'zero_variance', 'select', 'resid_xb',
            'standardize', 'gram', 'gram_reduce', 'ncorrs', 'null_local', 'obs_counts', 'percell_fdr',
-           'project_xb', 'transpose', 'rccl']
+           'project_xb', 'transpose', 'rccl', 'condition', 'global_test']
 
 _lib = None
 

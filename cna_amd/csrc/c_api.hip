@@ -85,7 +85,7 @@ static void prof_flush(cna_ctx* c) {
 static const char* kKernelNames[CNA_K_COUNT] = {
     "colsum", "nam_first", "nam_step", "batch_kurtosis", "zero_variance", "select", "resid_xb",
     "standardize", "gram", "gram_reduce", "ncorrs", "null_local", "obs_counts", "percell_fdr",
-    "project_xb", "transpose", "rccl"};
+    "project_xb", "transpose", "rccl", "condition", "global_test"};
 
 #define CHECK_CTX(c)                                        \
   do {                                                      \
@@ -186,7 +186,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   prof_flush(c);
   comm_destroy(c);
   void* bufs[] = {c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
-                  c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo};
+                  c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -635,21 +635,15 @@ static void guess_from_thr(const double* thr, int T, double* thr0, double* inv_s
   *inv_step = step > 0 ? 1.0 / step : 0.0;
 }
 
-int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int T, int64_t* tails_out) {
-  CHECK_CTX(c);
-  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
-  if (P < 1 || T < 1) CNA_FAIL(CNA_EINVAL, "cna_null_local: P and T must be positive");
-  for (int t = 1; t < T; ++t)
-    if (!(edges[t] >= edges[t - 1])) CNA_FAIL(CNA_EINVAL, "cna_null_local: edges must ascend");
-  const int Nx = c->Nx, ldx = c->ldx;
-  const int ldy = round_up(P, 64);
-  std::vector<double> Yp((size_t)ldx * ldy, 0.0);
-  for (int k = 0; k < Nx; ++k) std::memcpy(&Yp[(size_t)k * ldy], &Yc[(size_t)k * P], sizeof(double) * P);
-  // cut[t] = smallest double a >= 0 with fl(fl(a/N)^2) >= edges[t]: the reference's test on
-  // z^2 = (|x.yc|/N)^2 (_association.py:99, _stats.py:47-54) moved onto the raw dot product.
-  // Both roundings are monotone, so a bisection over the bit patterns of the positive doubles
-  // finds the exact switch point.
-  std::vector<double> cuts(T);
+// cut[t] = smallest double a >= 0 with fl(fl(a/N)^2) >= edges[t]: the reference's test on
+// z^2 = (|x.yc|/N)^2 (_association.py:99, _stats.py:47-54) moved onto the raw dot product.  Both
+// roundings are monotone, so a bisection over the bit patterns of the positive doubles finds the
+// exact switch point.  The cuts are (nearly) an arithmetic progression cut0 + t*step; eps bounds,
+// in steps, how far any cut is from that line (the kernel trusts floor((x-cut0)/step) outside
+// +-eps of a cut and walks the table otherwise).
+static void exact_cuts(const double* edges, int T, int Nx, std::vector<double>& cuts, double* cut0,
+                       double* inv_step, double* eps) {
+  cuts.resize(T);
   const double dn = (double)Nx;
   for (int t = 0; t < T; ++t) {
     const double e = edges[t];
@@ -664,31 +658,115 @@ int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int
     }
     std::memcpy(&cuts[t], &hi, 8);
   }
-  // the cuts are (nearly) an arithmetic progression: cut0 + t*step.  eps bounds, in steps, how far
-  // any cut is from that line; the kernel trusts floor((x-cut0)/step) outside +-eps of a cut.
-  const double cut0 = cuts[0];
-  double inv_step = 0.0, eps = 2.0;                      // eps >= 1: always walk the table
+  *cut0 = cuts[0];
+  *inv_step = 0.0;
+  *eps = 2.0;                                             // eps >= 1: always walk the table
   if (T >= 3 && cuts[T - 1] > cuts[0]) {
     const double step = (cuts[T - 1] - cuts[0]) / (T - 1);
     double dev = 0.0;
-    for (int t = 0; t < T; ++t) dev = std::max(dev, std::fabs(cuts[t] - (cut0 + t * step)) / step);
-    inv_step = 1.0 / step;
-    eps = 2.0 * dev + 1e-9;
-    if (!(eps < 0.25)) { eps = 2.0; }
+    for (int t = 0; t < T; ++t) dev = std::max(dev, std::fabs(cuts[t] - (*cut0 + t * step)) / step);
+    *inv_step = 1.0 / step;
+    *eps = 2.0 * dev + 1e-9;
+    if (!(*eps < 0.25)) *eps = 2.0;
   }
-  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap,
-                      carve_bytes({(int64_t)sizeof(double) * ldx * ldy, 8 * (int64_t)T, 8 * (int64_t)P * T, 8 * (int64_t)P * T})));
+}
+
+static int ensure_zc(cna_ctx* c, int P) {
+  const int ldy = round_up(P, 64) + 64;   // one spare tile: a resident read may start at any column
+  void* p = c->zc;
+  CNA_TRY(dev_reserve(c, &p, &c->zc_cap, (int64_t)sizeof(double) * c->ldx * ldy));
+  c->zc = (double*)p;
+  HIP_TRY(hipMemsetAsync(c->zc, 0, sizeof(double) * c->ldx * ldy, c->stream));   // zero pads (rows >= Nx, cols >= P)
+  c->zc_ld = ldy;
+  c->zc_cols = P;
+  c->zc_rows = c->Nx;
+  return 0;
+}
+
+static int null_local_on_resident(cna_ctx* c, int col0, int P, const double* edges, int T, int64_t* tails_out) {
+  if (P < 1 || T < 1) CNA_FAIL(CNA_EINVAL, "cna_null_local: P and T must be positive");
+  for (int t = 1; t < T; ++t)
+    if (!(edges[t] >= edges[t - 1])) CNA_FAIL(CNA_EINVAL, "cna_null_local: edges must ascend");
+  if (!c->zc || col0 < 0 || col0 + P > c->zc_cols || c->zc_rows != c->Nx)
+    CNA_FAIL(CNA_ESTATE, "no conditioned phenotypes resident for these columns");
+  std::vector<double> cuts;
+  double cut0, inv_step, eps;
+  exact_cuts(edges, T, c->Nx, cuts, &cut0, &inv_step, &eps);
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({8 * (int64_t)T, 8 * (int64_t)P * T, 8 * (int64_t)P * T})));
   Carver cv(c->scratch);
-  double* Yd = cv.take<double>((int64_t)ldx * ldy);
   double* ed = cv.take<double>(T);
   unsigned long long* hist = cv.take<unsigned long long>((int64_t)P * T);
   int64_t* tails = cv.take<int64_t>((int64_t)P * T);
-  HIP_TRY(hipMemcpyAsync(Yd, Yp.data(), sizeof(double) * ldx * ldy, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(ed, cuts.data(), 8 * T, hipMemcpyHostToDevice, c->stream));
-  CNA_TRY(launch_null_local(c, Yd, ldy, P, ed, T, cut0, inv_step, eps, hist));
+  // columns beyond col0+P inside the last 64-wide tile are other phenotypes: the kernel only
+  // flushes counters of p < P, and reads stay inside the zero-padded leading dimension
+  CNA_TRY(launch_null_local(c, c->zc + col0, c->zc_ld, P, ed, T, cut0, inv_step, eps, hist));
   CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)P * T));
   CNA_TRY(launch_suffix_sum(c, hist, P, T, tails));
   HIP_TRY(hipMemcpyAsync(tails_out, tails, 8 * (size_t)P * T, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int T, int64_t* tails_out) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  if (P < 1) CNA_FAIL(CNA_EINVAL, "cna_null_local: P must be positive");
+  CNA_TRY(ensure_zc(c, P));
+  HIP_TRY(hipMemcpy2DAsync(c->zc, sizeof(double) * c->zc_ld, Yc, sizeof(double) * P, sizeof(double) * P, c->Nx,
+                           hipMemcpyHostToDevice, c->stream));
+  return null_local_on_resident(c, 0, P, edges, T, tails_out);
+}
+
+int cna_null_local_resident(cna_ctx* c, int col0, int P, const double* edges, int T, int64_t* tails_out) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  return null_local_on_resident(c, col0, P, edges, T, tails_out);
+}
+
+int cna_condition_phenotypes(cna_ctx* c, const double* M, const double* Y, int P) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  if (P < 1) CNA_FAIL(CNA_EINVAL, "P must be positive");
+  const int N = c->Nx;
+  if (N < 2) CNA_FAIL(CNA_EINVAL, "need at least two samples");
+  CNA_TRY(ensure_zc(c, P));
+  void* g = c->gt;
+  CNA_TRY(dev_reserve(c, &g, &c->gt_cap, carve_bytes({8 * (int64_t)N * N, 8 * (int64_t)N * P})));
+  c->gt = g;
+  Carver cv(c->gt);
+  double* Md = cv.take<double>((int64_t)N * N);
+  double* Yd = cv.take<double>((int64_t)N * P);
+  HIP_TRY(hipMemcpyAsync(Md, M, 8 * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(Yd, Y, 8 * (size_t)N * P, hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(launch_condition(c, Md, Yd, N, P, c->zc, c->zc_ld));
+  HIP_TRY(hipStreamSynchronize(c->stream));               // host buffers may be released
+  return 0;
+}
+
+int cna_global_test(cna_ctx* c, const double* U, int kmax, const int32_t* ks, int K, int r, double* minp_out,
+                    double* r2_out, int32_t* kidx_out) {
+  CHECK_CTX(c);
+  if (!c->zc || c->zc_cols < 1 || c->zc_rows != c->Nx) CNA_FAIL(CNA_ESTATE, "cna_global_test needs cna_condition_phenotypes");
+  const int N = c->Nx, P = c->zc_cols;
+  if (kmax < 1 || kmax > N || K < 1) CNA_FAIL(CNA_EINVAL, "cna_global_test: bad kmax / K");
+  for (int a = 0; a < K; ++a)
+    if (ks[a] < 1 || ks[a] > kmax) CNA_FAIL(CNA_EINVAL, "cna_global_test: ks must lie in [1, kmax]");
+  void* g = c->gt;
+  CNA_TRY(dev_reserve(c, &g, &c->gt_cap, carve_bytes({8 * (int64_t)N * kmax, 4 * (int64_t)K, 8 * (int64_t)P, 8 * (int64_t)P, 4 * (int64_t)P})));
+  c->gt = g;
+  Carver cv(c->gt);
+  double* Ud = cv.take<double>((int64_t)N * kmax);
+  int32_t* ksd = cv.take<int32_t>(K);
+  double* mp = cv.take<double>(P);
+  double* r2 = cv.take<double>(P);
+  int32_t* ki = cv.take<int32_t>(P);
+  HIP_TRY(hipMemcpyAsync(Ud, U, 8 * (size_t)N * kmax, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(ksd, ks, 4 * (size_t)K, hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(launch_global_test(c, c->zc, c->zc_ld, N, P, Ud, kmax, ksd, K, r, mp, r2, ki));
+  HIP_TRY(hipMemcpyAsync(minp_out, mp, 8 * (size_t)P, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(r2_out, r2, 8 * (size_t)P, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(kidx_out, ki, 4 * (size_t)P, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }

@@ -98,6 +98,13 @@ struct cna_ctx {
   int64_t ncorrs_cap = 0;
   bool ncorrs_valid = false;
 
+  // ---- resident conditioned phenotypes Zc (ldx x zc_ld), zc_cols valid columns
+  double* zc = nullptr;
+  int64_t zc_cap = 0;
+  int zc_ld = 0, zc_cols = 0, zc_rows = 0;
+  void* gt = nullptr;        // global-test staging (U, ks, outputs)
+  int64_t gt_cap = 0;
+
   // ---- scratch
   void* scratch = nullptr;
   int64_t scratch_cap = 0;
@@ -158,6 +165,11 @@ int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, 
 int launch_gram(cna_ctx* c, double* G_dev);
 int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* cuts_dev, int T,
                       double cut0, double inv_step, double eps, unsigned long long* hist_dev);
+
+// stats.hip
+int launch_condition(cna_ctx* c, const double* M_dev, const double* Y_dev, int N, int P, double* Zc_dev, int ldy);
+int launch_global_test(cna_ctx* c, const double* Zc_dev, int ldy, int N, int P, const double* U_dev, int kmax,
+                       const int32_t* ks_dev, int K, int r, double* minp_dev, double* r2_dev, int32_t* kidx_dev);
 
 // ---- device helpers shared by the kernel files
 #ifdef __HIPCC__

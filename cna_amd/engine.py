@@ -235,6 +235,31 @@ class Engine:
         check(self.lib.cna_null_local(self.h, ptr(Yc), P, ptr(edges), T, ptr(tails)), 'cna_null_local')
         return tails
 
+    def condition(self, M, Y):
+        """Zc = M.Y / std(M.Y, ddof=1) per column, kept on the device (column 0: observed phenotype)."""
+        M, Y = _f64(M), _f64(Y)
+        check(self.lib.cna_condition_phenotypes(self.h, ptr(M), ptr(Y), Y.shape[1]), 'cna_condition_phenotypes')
+        self._zc_cols = Y.shape[1]
+
+    def null_local_resident(self, col0, P, edges):
+        edges = _f64(edges)
+        T = len(edges)
+        tails = np.empty((int(P), T), dtype=np.int64)
+        check(self.lib.cna_null_local_resident(self.h, int(col0), int(P), ptr(edges), T, ptr(tails)),
+              'cna_null_local_resident')
+        return tails
+
+    def global_test(self, U, ks, r):
+        """min-p F-test of every resident phenotype column -> (index into ks, p, r2) arrays."""
+        ks = np.ascontiguousarray(ks, dtype=np.int32)
+        kmax = int(ks.max())
+        Uk = _f64(U[:, :kmax])
+        P = self._zc_cols
+        minp, r2, kidx = np.empty(P), np.empty(P), np.empty(P, dtype=np.int32)
+        check(self.lib.cna_global_test(self.h, ptr(Uk), kmax, ptr(ks), len(ks), int(r), ptr(minp), ptr(r2), ptr(kidx)),
+              'cna_global_test')
+        return kidx, minp, r2
+
     def obs_counts(self, edges, thr):
         edges, thr = _f64(edges), _f64(thr)
         T = len(thr)

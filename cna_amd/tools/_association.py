@@ -80,59 +80,60 @@ def _association(engine, G, res, y, y_, ks=None, Nnull=1000, local_test=True, sh
     ks_arr = np.asarray(ks)
     Mv = np.asarray(M, dtype=np.float64)
 
-    # neighbourhood coefficients (device) -> thresholds -> start the local null (device, async)
+    # phenotypes -> device: Zc = M.[y, y_] / std (ddof=1), resident for both tests
+    engine.condition(Mv, np.column_stack([y, y_]))
+    # neighbourhood coefficients -> thresholds -> start the local null (device, asynchronous)
     _, maxabs = engine.ncorrs(y, fetch=False)
     pending = thresholds = edges = None
     if local_test:
         Nloc = min(1000, Nnull)
-        ycond_ = Mv.dot(y_[:, :Nloc])
-        ycond_ /= ycond_.std(axis=0, ddof=1)
         maxcorr = max(maxabs, 0.001)
         thresholds = np.arange(maxcorr / 4, maxcorr, maxcorr / 400)
         z2 = thresholds ** 2
         edges = z2 - 1e-8 - 1e-5 * z2                        # tail_counts' bin edges (_stats.py:47)
-        pending = _background().submit(engine.null_local, ycond_, edges)   # Nloc x T, never cells x Nloc
+        # Nloc x T tail counts from columns 1..Nloc of Zc; cells x Nloc is never materialised
+        pending = _background().submit(engine.null_local_resident, 1, Nloc, edges)
 
+    tails = None
     try:
-        # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105)
+        # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105), under the local-null kernel
         U, svs, _ = _small_svd(G)
         names = ['PC' + str(i) for i in range(1, len(U) + 1)]
         res.namresid_sampleXpc = pd.DataFrame(U, index=M.index, columns=names)
         svs_s = pd.Series(svs, index=names)
         res.namresid_svs = svs_s[:npcs if npcs is not None else len(U)]
         res.namresid_varexp = svs_s / len(U) / n_cells
-
-        # observed statistic
-        best, pv, r2v = minp_stats(y[:, None], Mv, U, ks_arr, r)
-        k, p, r2 = ks[best[0]], pv[0], r2v[0]
-        if k == max(ks):
-            warnings.warn(('data supported use of {} NAM PCs, which is the maximum considered. ' +
-                           'Consider allowing more PCs by using the "ks" argument.').format(k))
-
-        # coefficients and r2 of the chosen model
-        ycond = pd.Series(Mv.dot(y), index=getattr(M, 'index', None))
-        ycond /= ycond.std()
-        beta = U[:, :k].T.dot(ycond.values)
-        yhat = U[:, :k].dot(beta)
-        r2_perpc = (beta / np.sqrt(ycond.values.dot(ycond.values))) ** 2
-
-        # global p-value from the null phenotypes
-        _, nullminps, nullr2s = minp_stats(y_, Mv, U, ks_arr, r)
-        hits = (nullminps <= p + 1e-8).sum()
-        pfinal = (hits + 1) / (Nnull + 1)
-        if hits == 0:
-            warnings.warn('global association p-value attained minimal possible value. ' +
-                          'Consider increasing Nnull')
-    except BaseException:
+    finally:
         if pending is not None:
-            pending.result()          # never leave a device call running behind an exception
-        raise
+            tails = pending.result()      # one device call at a time; also never leave it running
+
+    # global test of the observed phenotype and of every permutation (device F-tests)
+    best, pv, r2v = engine.global_test(U, ks_arr, r)
+    if (best < 0).any():
+        raise ValueError('All-NaN slice encountered')        # np.nanargmin in _minp_stats
+    k, p, r2 = ks[best[0]], pv[0], r2v[0]
+    if k == max(ks):
+        warnings.warn(('data supported use of {} NAM PCs, which is the maximum considered. ' +
+                       'Consider allowing more PCs by using the "ks" argument.').format(k))
+
+    # coefficients and r2 of the chosen model
+    ycond = pd.Series(Mv.dot(y), index=getattr(M, 'index', None))
+    ycond /= ycond.std()
+    beta = U[:, :k].T.dot(ycond.values)
+    yhat = U[:, :k].dot(beta)
+    r2_perpc = (beta / np.sqrt(ycond.values.dot(ycond.values))) ** 2
+
+    nullminps, nullr2s = pv[1:], r2v[1:]
+    hits = (nullminps <= p + 1e-8).sum()
+    pfinal = (hits + 1) / (Nnull + 1)
+    if hits == 0:
+        warnings.warn('global association p-value attained minimal possible value. ' +
+                      'Consider increasing Nnull')
 
     fdr_vals = None
     fdr_5p_t = fdr_10p_t = None
     if local_test:
         print('computing neighborhood-level FDRs', file=out)
-        tails = pending.result()
         ranks, num_detected = engine.obs_counts(edges, thresholds)
         with np.errstate(all='ignore'):
             fdr_vals = (tails / ranks[None, :]).mean(axis=0)

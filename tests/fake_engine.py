@@ -193,6 +193,19 @@ class FakeEngine:
         tails = np.array([[(z2[:, p] >= e).sum() for e in edges] for p in range(Yc.shape[1])], dtype=np.int64)
         return self._sum(tails)
 
+    def condition(self, M, Y):
+        Zc = np.asarray(M).dot(np.asarray(Y))
+        self.Zc = Zc / Zc.std(axis=0, ddof=1)
+        self._M = np.asarray(M)
+        self._Y = np.asarray(Y)
+
+    def null_local_resident(self, col0, P, edges):
+        return self.null_local(self.Zc[:, col0:col0 + P], edges)
+
+    def global_test(self, U, ks, r):
+        kix, p, r2 = orc.minp_stats(self._Y, self._M, np.asarray(U), np.asarray(ks), r)
+        return kix.astype(np.int32), p, r2
+
     def obs_counts(self, edges, thr):
         z = np.abs(self.nc)
         ranks = np.array([(self.nc ** 2 >= e).sum() for e in edges], dtype=np.int64)

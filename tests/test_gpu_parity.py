@@ -315,3 +315,39 @@ def test_rccl_path_with_one_rank(orc):
         prof_names = e.prof()
     finally:
         e.close()
+
+
+@pytest.mark.parametrize('N,P,r,ks', [(50, 1001, 0, [1, 2, 3, 4]), (24, 37, 2, [2, 5]), (200, 300, 5, [4, 8, 12, 16]),
+                                       (12, 5, 0, [1]), (130, 64, 1, [3, 26])])
+def test_global_test_matches_scipy(eng, N, P, r, ks):
+    """Device F-tests (incomplete-beta continued fraction) against scipy's fdtrc through the
+    host restatement of _minp_stats; includes strong signals (p down to ~1e-60)."""
+    from cna_amd.tools._stats import minp_stats
+    rs = np.random.RandomState(N + P)
+    X = rs.randn(4 * N, N)
+    eng.upload_x(X)                                   # only to define the sample axis
+    Q, _ = np.linalg.qr(rs.randn(N, N))
+    U = Q                                             # orthonormal "PCs"
+    C = rs.randn(N, max(r, 1))
+    M = np.eye(N) - C.dot(np.linalg.solve(C.T.dot(C), C.T)) if r else np.eye(N)
+    Y = rs.randn(N, P)
+    Y[:, 0] = 8 * U[:, 0] + 0.05 * rs.randn(N)        # a column almost inside the span of PC1
+    Y[:, 1] = U[:, :max(ks)].dot(rs.randn(max(ks))) + 1e-3 * rs.randn(N)
+    eng.condition(M, Y)
+    kidx, p, r2 = eng.global_test(U, ks, r)
+    kidx_ref, p_ref, r2_ref = minp_stats(Y, M, U, np.asarray(ks), r)
+    assert np.array_equal(kidx, kidx_ref)
+    np.testing.assert_allclose(p, p_ref, rtol=1e-9, atol=0)
+    np.testing.assert_allclose(r2, r2_ref, rtol=1e-9, atol=1e-13)
+    assert p.min() < 1e-8
+    # the resident matrix also feeds the local null: same counts as uploading the columns
+    Zc = M.dot(Y)
+    Zc /= Zc.std(axis=0, ddof=1)
+    y = rs.randn(N)
+    _, m = eng.ncorrs(y)
+    thr = np.arange(m / 4, m, m / 400)
+    edges = thr ** 2 - 1e-8 - 1e-5 * thr ** 2
+    Pl = min(P - 1, 70)
+    a = eng.null_local_resident(1, Pl, edges)
+    b = eng.null_local(np.ascontiguousarray(Zc[:, 1:1 + Pl]), edges)
+    assert np.abs(a - b).max() <= 1
