@@ -98,11 +98,6 @@ def _association(engine, G, res, y, y_, ks=None, Nnull=1000, local_test=True, sh
     try:
         # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105), under the local-null kernel
         U, svs, _ = _small_svd(G)
-        names = ['PC' + str(i) for i in range(1, len(U) + 1)]
-        res.namresid_sampleXpc = pd.DataFrame(U, index=M.index, columns=names)
-        svs_s = pd.Series(svs, index=names)
-        res.namresid_svs = svs_s[:npcs if npcs is not None else len(U)]
-        res.namresid_varexp = svs_s / len(U) / n_cells
     finally:
         if pending is not None:
             tails = pending.result()      # one device call at a time; also never leave it running
@@ -117,11 +112,19 @@ def _association(engine, G, res, y, y_, ks=None, Nnull=1000, local_test=True, sh
                        'Consider allowing more PCs by using the "ks" argument.').format(k))
 
     # coefficients and r2 of the chosen model
-    ycond = pd.Series(Mv.dot(y), index=getattr(M, 'index', None))
-    ycond /= ycond.std()
-    beta = U[:, :k].T.dot(ycond.values)
+    ycond_v = Mv.dot(y)
+    ycond_v = ycond_v / ycond_v.std(ddof=1)
+    beta = U[:, :k].T.dot(ycond_v)
     yhat = U[:, :k].dot(beta)
-    r2_perpc = (beta / np.sqrt(ycond.values.dot(ycond.values))) ** 2
+    r2_perpc = (beta / np.sqrt(ycond_v.dot(ycond_v))) ** 2
+
+    # sample-space frames of the result are only built when somebody reads them
+    def _names():
+        return ['PC' + str(i) for i in range(1, len(U) + 1)]
+    res._defer('namresid_sampleXpc', lambda: pd.DataFrame(U, index=M.index, columns=_names()))
+    res._defer('namresid_svs', lambda: pd.Series(svs, index=_names())[:npcs if npcs is not None else len(U)])
+    res._defer('namresid_varexp', lambda: pd.Series(svs, index=_names()) / len(U) / n_cells)
+    res._defer('yresid', lambda: pd.Series(ycond_v, index=getattr(M, 'index', None)))
 
     nullminps, nullr2s = pv[1:], r2v[1:]
     hits = (nullminps <= p + 1e-8).sum()
@@ -156,7 +159,7 @@ def _association(engine, G, res, y, y_, ks=None, Nnull=1000, local_test=True, sh
         coef_all, fdr_all = engine.percell(None, None)
 
     res.__dict__.update({'p': pfinal, 'nullminps': nullminps, 'k': k, 'fdr_5p_t': fdr_5p_t,
-                         'fdr_10p_t': fdr_10p_t, 'yresid_hat': yhat, 'yresid': ycond, 'ks': ks, 'beta': beta,
+                         'fdr_10p_t': fdr_10p_t, 'yresid_hat': yhat, 'ks': ks, 'beta': beta,
                          'r2': r2, 'r2_perpc': r2_perpc, 'nullr2_mean': nullr2s.mean(),
                          'nullr2_std': nullr2s.std()})
     return coef_all, fdr_all, U, svs
@@ -322,6 +325,8 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     data.obs[f'{key_added}_fdr'] = fdr_all
 
     if return_full:
-        res.ncorrs, res.fdrs   # eager, like upstream; the three cells x samples frames stay lazy
+        # everything but the three cells x samples frames is materialised now, like upstream
+        for name in ('ncorrs', 'fdrs', 'namresid_sampleXpc', 'namresid_svs', 'namresid_varexp', 'yresid'):
+            getattr(res, name)
         return res
     return res.p

@@ -351,3 +351,32 @@ def test_global_test_matches_scipy(eng, N, P, r, ks):
     a = eng.null_local_resident(1, Pl, edges)
     b = eng.null_local(np.ascontiguousarray(Zc[:, 1:1 + Pl]), edges)
     assert np.abs(a - b).max() <= 1
+
+
+@pytest.mark.parametrize('n,N,extra', [(3000, 70, {}), (2500, 130, dict(n_covs=3)), (2000, 200, dict(n_covs=2, n_batches=4)),
+                                       (1500, 256, {}), (4000, 33, dict(n_batches=9, n_covs=1))])
+def test_association_wide_sample_axis_vs_oracle(eng, orc, n, N, extra):
+    """end to end at sample counts the golden fixtures do not reach (several 64-lane chunks per row,
+    deep k-loops in the MFMA kernels, every local-null instantiation family), against the f64 oracle."""
+    import cna_amd as cna
+    from cna_amd import synth
+    import warnings
+    data, meta = synth.make_dataset(n, N, k=15, seed=n + N, **extra)
+    kw = dict(nsteps=3, Nnull=130, seed=5)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        res = cna.tl.association(data, meta['y'], 'id', covs=meta['covs'], batches=meta['batches'], return_full=True, **kw)
+        ref = orc.association(data, meta['y'], 'id', covs=meta['covs'], batches=meta['batches'], mode='f64', **kw)
+    assert int(res.k) == ref['k'] and res.p == ref['p'] and np.array_equal(res.kept, ref['kept'])
+    assert relerr(res.nam.values.T, ref['nam']) < 1e-13
+    assert relerr(res.namresid.values.T, ref['namresid']) < 1e-9
+    assert relerr(res.ncorrs.values, ref['ncorrs']) < 1e-9
+    assert relerr(res.namresid_svs.values, ref['svs']) < 1e-9
+    np.testing.assert_allclose(res.nullminps, ref['nullminps'], rtol=1e-7)
+    T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
+    assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T])
+    np.testing.assert_allclose(res.fdrs.fdr.values[:T], ref['fdrs']['fdr'][:T], rtol=1e-8, atol=1e-13)
+    np.testing.assert_allclose(data.obs['coef_fdr'].values, ref['obs_coef_fdr'], rtol=1e-8, atol=1e-13)
+    from helpers import sign_align
+    V, Vref = sign_align(res.namresid_nbhdXpc.values, ref['V'], int(res.k))
+    assert relerr(V, Vref) < 1e-6
