@@ -48,7 +48,7 @@ SIGNATURES = {
     'cna_ncorrs': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, c_f64p]),
     'cna_null_local': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'cna_condition_phenotypes': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int]),
-    'cna_null_local_resident': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'cna_null_local_resident': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'cna_global_test': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     'cna_obs_counts': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -186,7 +186,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   prof_flush(c);
   comm_destroy(c);
   void* bufs[] = {c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
-                  c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt};
+                  c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -683,7 +683,8 @@ static int ensure_zc(cna_ctx* c, int P) {
   return 0;
 }
 
-static int null_local_on_resident(cna_ctx* c, int col0, int P, const double* edges, int T, int64_t* tails_out) {
+static int null_local_on_resident(cna_ctx* c, int col0, int P, const double* edges, int T, int64_t* tails_out,
+                                  int64_t* sums_out) {
   if (P < 1 || T < 1) CNA_FAIL(CNA_EINVAL, "cna_null_local: P and T must be positive");
   for (int t = 1; t < T; ++t)
     if (!(edges[t] >= edges[t - 1])) CNA_FAIL(CNA_EINVAL, "cna_null_local: edges must ascend");
@@ -692,18 +693,23 @@ static int null_local_on_resident(cna_ctx* c, int col0, int P, const double* edg
   std::vector<double> cuts;
   double cut0, inv_step, eps;
   exact_cuts(edges, T, c->Nx, cuts, &cut0, &inv_step, &eps);
-  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({8 * (int64_t)T, 8 * (int64_t)P * T, 8 * (int64_t)P * T})));
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({8 * (int64_t)T, 8 * (int64_t)P * T, 8 * (int64_t)P * T, 8 * (int64_t)T})));
   Carver cv(c->scratch);
   double* ed = cv.take<double>(T);
   unsigned long long* hist = cv.take<unsigned long long>((int64_t)P * T);
   int64_t* tails = cv.take<int64_t>((int64_t)P * T);
+  int64_t* sums = cv.take<int64_t>(T);
   HIP_TRY(hipMemcpyAsync(ed, cuts.data(), 8 * T, hipMemcpyHostToDevice, c->stream));
   // columns beyond col0+P inside the last 64-wide tile are other phenotypes: the kernel only
   // flushes counters of p < P, and reads stay inside the zero-padded leading dimension
   CNA_TRY(launch_null_local(c, c->zc + col0, c->zc_ld, P, ed, T, cut0, inv_step, eps, hist));
   CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)P * T));
   CNA_TRY(launch_suffix_sum(c, hist, P, T, tails));
-  HIP_TRY(hipMemcpyAsync(tails_out, tails, 8 * (size_t)P * T, hipMemcpyDeviceToHost, c->stream));
+  if (tails_out) HIP_TRY(hipMemcpyAsync(tails_out, tails, 8 * (size_t)P * T, hipMemcpyDeviceToHost, c->stream));
+  if (sums_out) {
+    CNA_TRY(launch_tail_sums(c, tails, P, T, sums));
+    HIP_TRY(hipMemcpyAsync(sums_out, sums, 8 * (size_t)T, hipMemcpyDeviceToHost, c->stream));
+  }
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -715,13 +721,14 @@ int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int
   CNA_TRY(ensure_zc(c, P));
   HIP_TRY(hipMemcpy2DAsync(c->zc, sizeof(double) * c->zc_ld, Yc, sizeof(double) * P, sizeof(double) * P, c->Nx,
                            hipMemcpyHostToDevice, c->stream));
-  return null_local_on_resident(c, 0, P, edges, T, tails_out);
+  return null_local_on_resident(c, 0, P, edges, T, tails_out, nullptr);
 }
 
-int cna_null_local_resident(cna_ctx* c, int col0, int P, const double* edges, int T, int64_t* tails_out) {
+int cna_null_local_resident(cna_ctx* c, int col0, int P, const double* edges, int T, int64_t* tails_out,
+                            int64_t* tail_sums_out) {
   CHECK_CTX(c);
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
-  return null_local_on_resident(c, col0, P, edges, T, tails_out);
+  return null_local_on_resident(c, col0, P, edges, T, tails_out, tail_sums_out);
 }
 
 int cna_condition_phenotypes(cna_ctx* c, const double* M, const double* Y, int P) {

@@ -110,6 +110,9 @@ struct cna_ctx {
   int64_t scratch_cap = 0;
   void* scratch2 = nullptr;
   int64_t scratch2_cap = 0;
+  int gram_tiles_nt = -1;        // upper-triangular tile table of the Gram kernel (depends on nt only)
+  void* gram_tiles_ptr = nullptr;
+  int64_t gram_tiles_cap = 0;
 
   // ---- profiling
   bool prof = false;
@@ -157,6 +160,7 @@ int launch_ncorrs(cna_ctx* c, const double* y_dev, unsigned long long* maxbits_d
 int launch_obs_counts(cna_ctx* c, const double* edges_dev, const double* thr_dev, int T, double thr0,
                       double inv_step, unsigned long long* hist_dev /* 2*T */);
 int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, int64_t* tails);
+int launch_tail_sums(cna_ctx* c, const int64_t* tails, int P, int T, int64_t* sums);
 int launch_percell_fdr(cna_ctx* c, const double* thr_dev, const double* runmin_dev, int T, double thr0,
                        double inv_step, double* coef_local, double* fdr_local);
 int launch_transpose(cna_ctx* c, const double* in, int64_t rows, int cols, int ld, double* out);

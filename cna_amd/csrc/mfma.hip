@@ -387,12 +387,17 @@ int launch_gram(cna_ctx* c, double* G_dev) {
     for (int j = i; j < nt; ++j) tiles.push_back((i << 16) | j);
   const int64_t nslab = (c->nx + 31) / 32;
   const int nblocks = (int)(nslab < 512 ? nslab : 512);
-  const int64_t need = (int64_t)sizeof(int32_t) * ntri + 256 + (int64_t)sizeof(double) * nblocks * ntri * 256;
-  CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, need));
-  int32_t* tiles_dev = (int32_t*)c->scratch2;
-  double* partial = (double*)((char*)c->scratch2 + round_up64(sizeof(int32_t) * ntri, 256));
-  HIP_TRY(hipMemcpyAsync(tiles_dev, tiles.data(), sizeof(int32_t) * ntri, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));  // tiles vector goes out of scope
+  CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, (int64_t)sizeof(double) * nblocks * ntri * 256));
+  double* partial = (double*)c->scratch2;
+  if (c->gram_tiles_nt != nt) {                          // the tile table depends on nt only: upload once
+    void* tp = c->gram_tiles_ptr;
+    CNA_TRY(dev_reserve(c, &tp, &c->gram_tiles_cap, (int64_t)sizeof(int32_t) * ntri));
+    c->gram_tiles_ptr = tp;
+    HIP_TRY(hipMemcpyAsync(tp, tiles.data(), sizeof(int32_t) * ntri, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));            // tiles vector goes out of scope
+    c->gram_tiles_nt = nt;
+  }
+  int32_t* tiles_dev = (int32_t*)c->gram_tiles_ptr;
   const size_t smem = sizeof(double) * 32 * ldp;
   {
     ProfScope ps(c, CNA_K_GRAM);

@@ -301,6 +301,15 @@ __global__ __launch_bounds__(512) void k_suffix_sum(const unsigned long long* __
   if (t < T) tails[(size_t)p * T + t] = buf[cur][t];
 }
 
+// sums[t] = sum_p tails[p][t]  (the FDR is mean_p(tails[p][t]/ranks[t]), _stats.py:79-80)
+__global__ void k_tail_sums(const int64_t* __restrict__ tails, int P, int T, int64_t* __restrict__ sums) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  long long s = 0;
+  for (int p = 0; p < P; ++p) s += tails[(size_t)p * T + t];
+  sums[t] = s;
+}
+
 __global__ void k_fill(double* v, int64_t n, double x) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = x;
@@ -429,6 +438,13 @@ int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, 
   if (P == 0 || T == 0) return 0;
   if (T > 512) CNA_FAIL(CNA_EINVAL, "more than 512 FDR thresholds are not supported");
   hipLaunchKernelGGL(k_suffix_sum, dim3((unsigned)P), dim3(512), 0, c->stream, hist, P, T, tails);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_tail_sums(cna_ctx* c, const int64_t* tails, int P, int T, int64_t* sums) {
+  if (T == 0) return 0;
+  hipLaunchKernelGGL(k_tail_sums, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, c->stream, tails, P, T, sums);
   HIP_TRY(hipGetLastError());
   return 0;
 }

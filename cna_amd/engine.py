@@ -241,13 +241,16 @@ class Engine:
         check(self.lib.cna_condition_phenotypes(self.h, ptr(M), ptr(Y), Y.shape[1]), 'cna_condition_phenotypes')
         self._zc_cols = Y.shape[1]
 
-    def null_local_resident(self, col0, P, edges):
+    def null_local_resident(self, col0, P, edges, sums_only=False):
+        """Tail counts of the local null on resident columns: P x T matrix, or (sums_only) its sum
+        over permutations, which is all the FDR formula needs."""
         edges = _f64(edges)
         T = len(edges)
-        tails = np.empty((int(P), T), dtype=np.int64)
-        check(self.lib.cna_null_local_resident(self.h, int(col0), int(P), ptr(edges), T, ptr(tails)),
+        tails = None if sums_only else np.empty((int(P), T), dtype=np.int64)
+        sums = np.empty(T, dtype=np.int64) if sums_only else None
+        check(self.lib.cna_null_local_resident(self.h, int(col0), int(P), ptr(edges), T, ptr(tails), ptr(sums)),
               'cna_null_local_resident')
-        return tails
+        return sums if sums_only else tails
 
     def global_test(self, U, ks, r):
         """min-p F-test of every resident phenotype column -> (index into ks, p, r2) arrays."""

@@ -91,16 +91,17 @@ def _association(engine, G, res, y, y_, ks=None, Nnull=1000, local_test=True, sh
         thresholds = np.arange(maxcorr / 4, maxcorr, maxcorr / 400)
         z2 = thresholds ** 2
         edges = z2 - 1e-8 - 1e-5 * z2                        # tail_counts' bin edges (_stats.py:47)
-        # Nloc x T tail counts from columns 1..Nloc of Zc; cells x Nloc is never materialised
-        pending = _background().submit(engine.null_local_resident, 1, Nloc, edges)
+        # tail counts from columns 1..Nloc of Zc, summed over permutations on the device; neither
+        # cells x Nloc nor Nloc x T ever reaches the host
+        pending = _background().submit(engine.null_local_resident, 1, Nloc, edges, True)
 
-    tails = None
+    tail_sums = None
     try:
         # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105), under the local-null kernel
         U, svs, _ = _small_svd(G)
     finally:
         if pending is not None:
-            tails = pending.result()      # one device call at a time; also never leave it running
+            tail_sums = pending.result()  # one device call at a time; also never leave it running
 
     # global test of the observed phenotype and of every permutation (device F-tests)
     best, pv, r2v = engine.global_test(U, ks_arr, r)
@@ -139,7 +140,8 @@ def _association(engine, G, res, y, y_, ks=None, Nnull=1000, local_test=True, sh
         print('computing neighborhood-level FDRs', file=out)
         ranks, num_detected = engine.obs_counts(edges, thresholds)
         with np.errstate(all='ignore'):
-            fdr_vals = (tails / ranks[None, :]).mean(axis=0)
+            # mean over permutations of tails/ranks (_stats.py:79-80) from the per-threshold sums
+            fdr_vals = tail_sums / ranks / Nloc
         with np.errstate(invalid='ignore'):
             if not np.min(fdr_vals) > 0.05:
                 fdr_5p_t = thresholds[np.flatnonzero(fdr_vals <= 0.05)[0]]

@@ -142,14 +142,16 @@ int  cna_null_local(cna_ctx* ctx, const double* Yc, int P, const double* edges, 
  * cna_condition_phenotypes: Y is n_cols x P row-major (observed phenotype in column 0, the
  * permuted ones after it, _association.py:80-83); computes, per column, zcond = M.z / std(M.z, ddof=1)
  * (_association.py:51-52,96-97) and keeps the result on the device.
- * cna_null_local_resident: cna_null_local on columns [col0, col0+P) of that resident matrix.
+ * cna_null_local_resident: cna_null_local on columns [col0, col0+P) of that resident matrix;
+ * tails_out (P x T) and tail_sums_out (T: sum over permutations, all the FDR needs) may each be NULL.
  * cna_global_test: _reg/_stats/_minp_stats (_association.py:35-61) for every resident column:
  * U is n_cols x kmax row-major (first kmax sample-PCs), ks[K] the PC counts tried, r the number
  * of conditioning columns; out: min over k of the F-test p-value (scipy.stats.f.sf semantics),
  * its r2 and the index of the chosen k (-1 when every p is NaN).  All three are replicated work
  * on every rank (sample space). */
 int  cna_condition_phenotypes(cna_ctx* ctx, const double* M, const double* Y, int P);
-int  cna_null_local_resident(cna_ctx* ctx, int col0, int P, const double* edges, int T, int64_t* tails_out);
+int  cna_null_local_resident(cna_ctx* ctx, int col0, int P, const double* edges, int T, int64_t* tails_out,
+                             int64_t* tail_sums_out);
 int  cna_global_test(cna_ctx* ctx, const double* U, int kmax, const int32_t* ks, int K, int r,
                      double* minp_out, double* r2_out, int32_t* kidx_out);
 /* ranks[t] = #{i : ncorrs_i^2 >= edges[t]} (_stats.py:74) and

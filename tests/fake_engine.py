@@ -199,8 +199,9 @@ class FakeEngine:
         self._M = np.asarray(M)
         self._Y = np.asarray(Y)
 
-    def null_local_resident(self, col0, P, edges):
-        return self.null_local(self.Zc[:, col0:col0 + P], edges)
+    def null_local_resident(self, col0, P, edges, sums_only=False):
+        tails = self.null_local(self.Zc[:, col0:col0 + P], edges)
+        return tails.sum(axis=0) if sums_only else tails
 
     def global_test(self, U, ks, r):
         kix, p, r2 = orc.minp_stats(self._Y, self._M, np.asarray(U), np.asarray(ks), r)
