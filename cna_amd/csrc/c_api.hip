@@ -649,7 +649,20 @@ static void exact_cuts(const double* edges, int T, int Nx, std::vector<double>& 
     const double e = edges[t];
     auto ok = [&](double a) { volatile double z = a / dn; volatile double z2 = z * z; return z2 >= e; };
     if (e <= 0.0 || ok(0.0)) { cuts[t] = 0.0; continue; }
+    // bracket the switch point around N*sqrt(e) (a few ulps wide), then bisect the bit patterns
     uint64_t lo = 0, hi = 0x7ff0000000000000ull;          // lo fails, hi (+inf) passes
+    const double guess = dn * std::sqrt(e);
+    uint64_t g;
+    std::memcpy(&g, &guess, 8);
+    if (guess > 0.0 && g > 64 && g < hi - 64) {
+      double a;
+      uint64_t b = g - 64;
+      std::memcpy(&a, &b, 8);
+      if (!ok(a)) lo = b;
+      b = g + 64;
+      std::memcpy(&a, &b, 8);
+      if (ok(a)) hi = b;
+    }
     while (hi - lo > 1) {
       const uint64_t mid = lo + (hi - lo) / 2;
       double a;

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Timeline of one association() step: every Engine call with enter/exit times and the gaps between them."""
+import sys, os, time, threading
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, warnings
+warnings.simplefilter('ignore')
+import cna_amd as cna
+cna.tune_host_allocator()
+from cna_amd import synth
+from cna_amd.engine import get_engine, Engine
+n, N = int(sys.argv[1]) if len(sys.argv) > 1 else 200000, int(sys.argv[2]) if len(sys.argv) > 2 else 50
+data, meta = synth.make_dataset(n, N, k=30, seed=0)
+eng = get_engine(); kw = dict(nsteps=3, Nnull=1000, seed=0)
+for _ in range(4): cna.tl.association(data, meta['y'], 'id', **kw)
+ev = []
+for name in dir(Engine):
+    if name.startswith('_') or name in ('block', 'prof', 'close'): continue
+    fn = getattr(Engine, name)
+    if not callable(fn) or isinstance(fn, staticmethod): continue
+    def mk(fn, name):
+        def w(self, *a, **k):
+            t0 = time.perf_counter(); r = fn(self, *a, **k); ev.append((t0, time.perf_counter(), name, threading.current_thread().name[:4])); return r
+        return w
+    setattr(Engine, name, mk(fn, name))
+t0 = time.perf_counter(); cna.tl.association(data, meta['y'], 'id', **kw); t1 = time.perf_counter()
+ev.sort()
+print('step %.3f ms' % ((t1 - t0) * 1e3))
+last = t0
+for a, b, name, th in ev:
+    print('%8.3f  +%6.3f gap  %-22s %6.3f ms  [%s]' % ((a - t0) * 1e3, (a - last) * 1e3, name, (b - a) * 1e3, th))
+    if th == 'Main': last = b
+print('%8.3f  +%6.3f gap  end' % ((t1 - t0) * 1e3, (t1 - last) * 1e3))
