@@ -32,6 +32,7 @@ SIGNATURES = {
     'cna_colsums': (C.c_int, [c_ctx, C.c_double]),
     'cna_fetch_colsums': (C.c_int, [c_ctx, C.c_void_p]),
     'cna_set_samples': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p]),
+    'cna_restart_nam': (C.c_int, [c_ctx]),
     'cna_nam_step': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int]),
     'cna_fetch_cell_stat': (C.c_int, [c_ctx, C.c_void_p, C.c_int64]),
     'cna_dense_load': (C.c_int, [c_ctx, C.c_void_p, C.c_int]),
@@ -40,15 +41,20 @@ SIGNATURES = {
     'cna_batch_kurtosis': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int]),
     'cna_zero_variance': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, c_i64p]),
     'cna_select': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
+    'cna_select_standardized': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, c_i64p]),
     'cna_upload_x': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_int]),
     'cna_resid_apply': (C.c_int, [c_ctx, C.c_void_p, C.c_int]),
     'cna_standardize': (C.c_int, [c_ctx, C.c_int]),
     'cna_gram': (C.c_int, [c_ctx, C.c_void_p]),
+    'cna_gram_launch': (C.c_int, [c_ctx]),
+    'cna_gram_fetch': (C.c_int, [c_ctx, C.c_void_p]),
     'cna_project': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p]),
     'cna_ncorrs': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, c_f64p]),
     'cna_null_local': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'cna_condition_phenotypes': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int]),
     'cna_null_local_resident': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    'cna_null_local_launch': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
+    'cna_null_local_fetch': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),
     'cna_global_test': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     'cna_obs_counts': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

@@ -51,18 +51,18 @@ static hipEvent_t ev_get(cna_ctx* c) {
   (void)hipEventCreate(&e);
   return e;
 }
-void prof_begin(cna_ctx* c, int kid) {
+void prof_begin(cna_ctx* c, int kid, hipStream_t st) {
   ProfSpan s;
   s.kid = kid;
   s.a = ev_get(c);
   s.b = ev_get(c);
-  (void)hipEventRecord(s.a, c->stream);
+  (void)hipEventRecord(s.a, st);
   c->prof_pending.push_back(s);
 }
-void prof_end(cna_ctx* c, int kid) {
+void prof_end(cna_ctx* c, int kid, hipStream_t st) {
   for (size_t i = c->prof_pending.size(); i-- > 0;) {
     if (c->prof_pending[i].kid == kid) {
-      (void)hipEventRecord(c->prof_pending[i].b, c->stream);
+      (void)hipEventRecord(c->prof_pending[i].b, st);
       return;
     }
   }
@@ -70,6 +70,7 @@ void prof_end(cna_ctx* c, int kid) {
 static void prof_flush(cna_ctx* c) {
   if (c->prof_pending.empty()) return;
   (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->copy_stream);
   for (auto& s : c->prof_pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
@@ -170,6 +171,9 @@ int cna_ctx_create(int device, cna_ctx** out) {
   cna_ctx* c = new cna_ctx();
   c->device = device;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->gram_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->null_done, hipEventDisableTiming);
   if (e != hipSuccess) {
     delete c;
     cna_set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -186,11 +190,15 @@ int cna_ctx_destroy(cna_ctx* c) {
   prof_flush(c);
   comm_destroy(c);
   void* bufs[] = {c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
-                  c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr};
+                  c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->gram_done) (void)hipEventDestroy(c->gram_done);
+  if (c->null_done) (void)hipEventDestroy(c->null_done);
+  if (c->h_res) (void)hipHostFree(c->h_res);
   delete c;
   return 0;
 }
@@ -318,6 +326,21 @@ int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const doubl
   void* nm = c->nam;
   CNA_TRY(dev_reserve(c, &nm, &c->nam_cap, (int64_t)sizeof(double) * std::max<int64_t>(c->n_local, 1) * c->ld));
   c->nam = (double*)nm;
+  c->t_width = c->N;
+  c->t_ld = c->ld;
+  c->t_cur = 0;
+  c->steps_done = 0;
+  c->t_valid = false;
+  c->nam_valid = false;
+  c->x_valid = false;
+  return 0;
+}
+
+int cna_restart_nam(cna_ctx* c) {
+  CHECK_CTX(c);
+  if (!c->sid || !c->counts) CNA_FAIL(CNA_ESTATE, "cna_restart_nam needs cna_set_samples first");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  CNA_TRY(ensure_T(c, c->ld));
   c->t_width = c->N;
   c->t_ld = c->ld;
   c->t_cur = 0;
@@ -525,6 +548,45 @@ int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_
   return 0;
 }
 
+int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
+                            int64_t* n_zero_out) {
+  CHECK_CTX(c);
+  if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+  const int64_t nx = keep_idx ? n_keep : c->n_local;
+  const int Nx = colmap ? n_sel : c->N;
+  if (nx < 0 || nx > c->n_local || Nx < 2) CNA_FAIL(CNA_EINVAL, "cna_select_standardized: bad sizes");
+  c->nx = nx;
+  c->Nx = Nx;
+  c->ldx = round_up(Nx, 4);
+  void* xp = c->X;
+  CNA_TRY(dev_reserve(c, &xp, &c->x_cap, (int64_t)sizeof(double) * std::max<int64_t>(nx, 1) * c->ldx));
+  c->X = (double*)xp;
+  if (keep_idx) {
+    void* kp = c->keep_store;
+    CNA_TRY(dev_reserve(c, &kp, &c->keep_cap, 8 * std::max<int64_t>(nx, 1)));
+    c->keep_store = (int64_t*)kp;
+    HIP_TRY(hipMemcpyAsync(c->keep_store, keep_idx, 8 * nx, hipMemcpyHostToDevice, c->stream));
+    c->keep_idx = c->keep_store;
+  } else {
+    c->keep_idx = nullptr;
+  }
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({4 * (int64_t)Nx, 8})));
+  Carver cv(c->scratch);
+  int32_t* cm = cv.take<int32_t>(Nx);
+  unsigned long long* nz = cv.take<unsigned long long>(1);
+  if (colmap) HIP_TRY(hipMemcpyAsync(cm, colmap, 4 * Nx, hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(launch_select_std(c, colmap ? cm : nullptr, nz));
+  CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)nz, 1));
+  unsigned long long h = 0;
+  HIP_TRY(hipMemcpyAsync(&h, nz, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n_zero_out) *n_zero_out = (int64_t)h;
+  c->x_valid = true;
+  c->x_from_nam = true;
+  c->ncorrs_valid = false;
+  return 0;
+}
+
 int cna_upload_x(cna_ctx* c, const double* x_local, int64_t n_rows, int n_cols) {
   CHECK_CTX(c);
   if (n_rows < 0 || n_cols < 1 || n_cols > 512) CNA_FAIL(CNA_EINVAL, "cna_upload_x: bad shape");
@@ -571,17 +633,34 @@ int cna_standardize(cna_ctx* c, int center) {
   return 0;
 }
 
-int cna_gram(cna_ctx* c, double* G_out) {
+int cna_gram_launch(cna_ctx* c) {
   CHECK_CTX(c);
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
   const int Nx = c->Nx;
-  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, (int64_t)sizeof(double) * Nx * Nx));
-  double* G = (double*)c->scratch;
-  CNA_TRY(launch_gram(c, G));
-  CNA_TRY(comm_allreduce_f64_sum(c, G, (size_t)Nx * Nx));
-  HIP_TRY(hipMemcpyAsync(G_out, G, sizeof(double) * Nx * Nx, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  void* g = c->gram_buf;
+  CNA_TRY(dev_reserve(c, &g, &c->gram_cap, (int64_t)sizeof(double) * Nx * Nx));
+  c->gram_buf = (double*)g;
+  CNA_TRY(launch_gram(c, c->gram_buf));
+  CNA_TRY(comm_allreduce_f64_sum(c, c->gram_buf, (size_t)Nx * Nx));
+  HIP_TRY(hipEventRecord(c->gram_done, c->stream));
+  c->gram_n = Nx;
   return 0;
+}
+
+// Only touches the Gram buffer, the copy stream and the event: safe to call while another host
+// thread is blocked inside a long entry point of the same context (cna_null_local_resident).
+int cna_gram_fetch(cna_ctx* c, double* G_out) {
+  CHECK_CTX(c);
+  if (c->gram_n < 1) CNA_FAIL(CNA_ESTATE, "cna_gram_fetch before cna_gram_launch");
+  HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->gram_done, 0));
+  HIP_TRY(hipMemcpyAsync(G_out, c->gram_buf, sizeof(double) * c->gram_n * c->gram_n, hipMemcpyDeviceToHost, c->copy_stream));
+  HIP_TRY(hipStreamSynchronize(c->copy_stream));
+  return 0;
+}
+
+int cna_gram(cna_ctx* c, double* G_out) {
+  CNA_TRY(cna_gram_launch(c));
+  return cna_gram_fetch(c, G_out);
 }
 
 int cna_project(cna_ctx* c, const double* W, int n_w, double* out_local) {
@@ -696,9 +775,11 @@ static int ensure_zc(cna_ctx* c, int P) {
   return 0;
 }
 
-static int null_local_on_resident(cna_ctx* c, int col0, int P, const double* edges, int T, int64_t* tails_out,
-                                  int64_t* sums_out) {
+// queue everything of one local-null pass; results land in the pinned buffer h_res
+// ([T sums][P*T tails if requested]) and null_done fires when they are there
+static int null_local_queue(cna_ctx* c, int col0, int P, const double* edges, int T, int want_tails) {
   if (P < 1 || T < 1) CNA_FAIL(CNA_EINVAL, "cna_null_local: P and T must be positive");
+  if (c->null_pending) CNA_FAIL(CNA_ESTATE, "a local-null pass is still pending: fetch it first");
   for (int t = 1; t < T; ++t)
     if (!(edges[t] >= edges[t - 1])) CNA_FAIL(CNA_EINVAL, "cna_null_local: edges must ascend");
   if (!c->zc || col0 < 0 || col0 + P > c->zc_cols || c->zc_rows != c->Nx)
@@ -706,6 +787,13 @@ static int null_local_on_resident(cna_ctx* c, int col0, int P, const double* edg
   std::vector<double> cuts;
   double cut0, inv_step, eps;
   exact_cuts(edges, T, c->Nx, cuts, &cut0, &inv_step, &eps);
+  const int64_t hbytes = 8 * (int64_t)T + (want_tails ? 8 * (int64_t)P * T : 0);
+  if (hbytes > c->h_res_cap) {
+    if (c->h_res) HIP_TRY(hipHostFree(c->h_res));
+    c->h_res = nullptr;
+    HIP_TRY(hipHostMalloc(&c->h_res, (size_t)hbytes, hipHostMallocDefault));
+    c->h_res_cap = hbytes;
+  }
   CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({8 * (int64_t)T, 8 * (int64_t)P * T, 8 * (int64_t)P * T, 8 * (int64_t)T})));
   Carver cv(c->scratch);
   double* ed = cv.take<double>(T);
@@ -713,18 +801,51 @@ static int null_local_on_resident(cna_ctx* c, int col0, int P, const double* edg
   int64_t* tails = cv.take<int64_t>((int64_t)P * T);
   int64_t* sums = cv.take<int64_t>(T);
   HIP_TRY(hipMemcpyAsync(ed, cuts.data(), 8 * T, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));               // `cuts` is a local; the stream is idle here anyway
   // columns beyond col0+P inside the last 64-wide tile are other phenotypes: the kernel only
   // flushes counters of p < P, and reads stay inside the zero-padded leading dimension
   CNA_TRY(launch_null_local(c, c->zc + col0, c->zc_ld, P, ed, T, cut0, inv_step, eps, hist));
   CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)P * T));
   CNA_TRY(launch_suffix_sum(c, hist, P, T, tails));
-  if (tails_out) HIP_TRY(hipMemcpyAsync(tails_out, tails, 8 * (size_t)P * T, hipMemcpyDeviceToHost, c->stream));
-  if (sums_out) {
-    CNA_TRY(launch_tail_sums(c, tails, P, T, sums));
-    HIP_TRY(hipMemcpyAsync(sums_out, sums, 8 * (size_t)T, hipMemcpyDeviceToHost, c->stream));
-  }
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  CNA_TRY(launch_tail_sums(c, tails, P, T, sums));
+  HIP_TRY(hipMemcpyAsync(c->h_res, sums, 8 * (size_t)T, hipMemcpyDeviceToHost, c->stream));
+  if (want_tails)
+    HIP_TRY(hipMemcpyAsync((char*)c->h_res + 8 * (size_t)T, tails, 8 * (size_t)P * T, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipEventRecord(c->null_done, c->stream));
+  c->null_P = P;
+  c->null_T = T;
+  c->null_has_tails = want_tails;
+  c->null_pending = 1;
   return 0;
+}
+
+static int null_local_collect(cna_ctx* c, int64_t* tails_out, int64_t* sums_out) {
+  if (!c->null_pending) CNA_FAIL(CNA_ESTATE, "no local-null pass pending");
+  c->null_pending = 0;
+  HIP_TRY(hipEventSynchronize(c->null_done));
+  if (sums_out) std::memcpy(sums_out, c->h_res, 8 * (size_t)c->null_T);
+  if (tails_out) {
+    if (!c->null_has_tails) CNA_FAIL(CNA_EINVAL, "the pending pass was launched without want_tails");
+    std::memcpy(tails_out, (char*)c->h_res + 8 * (size_t)c->null_T, 8 * (size_t)c->null_P * c->null_T);
+  }
+  return 0;
+}
+
+static int null_local_on_resident(cna_ctx* c, int col0, int P, const double* edges, int T, int64_t* tails_out,
+                                  int64_t* sums_out) {
+  CNA_TRY(null_local_queue(c, col0, P, edges, T, tails_out != nullptr));
+  return null_local_collect(c, tails_out, sums_out);
+}
+
+int cna_null_local_launch(cna_ctx* c, int col0, int P, const double* edges, int T, int want_tails) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  return null_local_queue(c, col0, P, edges, T, want_tails);
+}
+
+int cna_null_local_fetch(cna_ctx* c, int64_t* tails_out, int64_t* tail_sums_out) {
+  CHECK_CTX(c);
+  return null_local_collect(c, tails_out, tail_sums_out);
 }
 
 int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int T, int64_t* tails_out) {
@@ -781,13 +902,16 @@ int cna_global_test(cna_ctx* c, const double* U, int kmax, const int32_t* ks, in
   double* mp = cv.take<double>(P);
   double* r2 = cv.take<double>(P);
   int32_t* ki = cv.take<int32_t>(P);
-  HIP_TRY(hipMemcpyAsync(Ud, U, 8 * (size_t)N * kmax, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(ksd, ks, 4 * (size_t)K, hipMemcpyHostToDevice, c->stream));
-  CNA_TRY(launch_global_test(c, c->zc, c->zc_ld, N, P, Ud, kmax, ksd, K, r, mp, r2, ki));
-  HIP_TRY(hipMemcpyAsync(minp_out, mp, 8 * (size_t)P, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(r2_out, r2, 8 * (size_t)P, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipMemcpyAsync(kidx_out, ki, 4 * (size_t)P, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  // Runs on the copy stream: Zc is complete (cna_condition_phenotypes synchronised) and only read, so
+  // these tiny kernels need not queue behind a local-null pass in flight on the main stream.
+  hipStream_t st = c->copy_stream;
+  HIP_TRY(hipMemcpyAsync(Ud, U, 8 * (size_t)N * kmax, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ksd, ks, 4 * (size_t)K, hipMemcpyHostToDevice, st));
+  CNA_TRY(launch_global_test(c, st, c->zc, c->zc_ld, N, P, Ud, kmax, ksd, K, r, mp, r2, ki));
+  HIP_TRY(hipMemcpyAsync(minp_out, mp, 8 * (size_t)P, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(r2_out, r2, 8 * (size_t)P, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(kidx_out, ki, 4 * (size_t)P, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return 0;
 }
 

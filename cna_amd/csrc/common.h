@@ -43,6 +43,15 @@ struct ProfSpan {
 struct cna_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;   // D2H of small results that must not queue behind long kernels
+  hipEvent_t gram_done = nullptr;
+  double* gram_buf = nullptr;          // Gram matrix of the last cna_gram_launch
+  hipEvent_t null_done = nullptr;      // results of the last local-null launch are in h_res
+  void* h_res = nullptr;               // pinned host staging for asynchronously fetched results
+  int64_t h_res_cap = 0;
+  int null_P = 0, null_T = 0, null_has_tails = 0, null_pending = 0;
+  int64_t gram_cap = 0;
+  int gram_n = 0;
   int64_t dev_bytes = 0;
 
   // ---- communicator
@@ -123,13 +132,16 @@ struct cna_ctx {
 };
 
 // profiling helpers (c_api.hip)
-void prof_begin(cna_ctx* c, int kid);
-void prof_end(cna_ctx* c, int kid);
+void prof_begin(cna_ctx* c, int kid, hipStream_t st);
+void prof_end(cna_ctx* c, int kid, hipStream_t st);
 struct ProfScope {
   cna_ctx* c;
   int kid;
-  ProfScope(cna_ctx* c_, int k) : c(c_), kid(k) { if (c->prof) prof_begin(c, kid); }
-  ~ProfScope() { if (c->prof) prof_end(c, kid); }
+  hipStream_t st;
+  ProfScope(cna_ctx* c_, int k, hipStream_t s = nullptr) : c(c_), kid(k), st(s ? s : c_->stream) {
+    if (c->prof) prof_begin(c, kid, st);
+  }
+  ~ProfScope() { if (c->prof) prof_end(c, kid, st); }
 };
 
 int dev_alloc(cna_ctx* c, void** p, size_t bytes);
@@ -155,6 +167,7 @@ int launch_batch_kurtosis(cna_ctx* c, const double* mat, int64_t rows, int ncols
 int launch_zero_variance(cna_ctx* c, const int32_t* colmap_dev, int n_sel, uint8_t* flags_dev,
                          unsigned long long* count_dev);
 int launch_select(cna_ctx* c, const int32_t* colmap_dev);
+int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev);
 int launch_standardize(cna_ctx* c, int center);
 int launch_ncorrs(cna_ctx* c, const double* y_dev, unsigned long long* maxbits_dev);
 int launch_obs_counts(cna_ctx* c, const double* edges_dev, const double* thr_dev, int T, double thr0,
@@ -172,8 +185,9 @@ int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const do
 
 // stats.hip
 int launch_condition(cna_ctx* c, const double* M_dev, const double* Y_dev, int N, int P, double* Zc_dev, int ldy);
-int launch_global_test(cna_ctx* c, const double* Zc_dev, int ldy, int N, int P, const double* U_dev, int kmax,
-                       const int32_t* ks_dev, int K, int r, double* minp_dev, double* r2_dev, int32_t* kidx_dev);
+int launch_global_test(cna_ctx* c, hipStream_t st, const double* Zc_dev, int ldy, int N, int P, const double* U_dev,
+                       int kmax, const int32_t* ks_dev, int K, int r, double* minp_dev, double* r2_dev,
+                       int32_t* kidx_dev);
 
 // ---- device helpers shared by the kernel files
 #ifdef __HIPCC__

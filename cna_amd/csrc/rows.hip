@@ -170,6 +170,78 @@ __global__ __launch_bounds__(256) void k_standardize(double* __restrict__ X, int
   }
 }
 
+// ---- fused fast path when no covariate / batch has to be regressed out (M = I):
+//   X[i', c'] = standardise_row( NAM[keep[i'], colmap[c']] )   with centring,
+// i.e. NAM.reindex(y.index)[filter] -> drop -> centre -> /std in one read of the NAM and one
+// write of X (_association.py:178-185, _nam.py:122,159).  Rows whose selected entries are all
+// equal (NAM.std(axis=0) == 0, _association.py:182) are counted; if there are any the caller
+// redoes the selection without them (rare).
+template <int NQ>
+__global__ __launch_bounds__(256) void k_select_std(const double* __restrict__ nam, int ld,
+                                                    const int64_t* __restrict__ keep,
+                                                    const int32_t* __restrict__ colmap, double* __restrict__ X,
+                                                    int64_t nx, int Nx, int ldx, unsigned long long* nzero) {
+  constexpr int RPW = 4;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+  const double n = (double)Nx;
+  int sc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int col = lane + 64 * q;
+    sc[q] = col < Nx ? (colmap ? colmap[col] : col) : 0;
+  }
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wv) * RPW; base < nx; base += stride) {
+    double x[RPW][NQ];
+    double sum[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      sum[r] = 0.0;
+      const bool live = base + r < nx;
+      const int64_t sr = live ? (keep ? keep[base + r] : base + r) : 0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        x[r][q] = (live && lane + 64 * q < Nx) ? nam[sr * ld + sc[q]] : 0.0;
+        sum[r] += x[r][q];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      if (base + r >= nx) break;                         // wave-uniform
+      // zero variance the way pandas sees it: avg = sum/N, every (avg - x) == 0
+      const double avg0 = wave_sum(sum[r]) / n;
+      bool flat = true;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (lane + 64 * q < Nx) flat = flat && (avg0 - x[r][q] == 0.0);
+      if (__all(flat) && lane == 0) atomicAdd(nzero, 1ull);
+      // centre (_nam.py:122), then std with ddof=1 of the centred values (_nam.py:159)
+      double s2 = 0.0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (lane + 64 * q < Nx) x[r][q] -= avg0;
+        s2 += x[r][q];
+      }
+      const double avg = wave_sum(s2) / n;
+      double ss = 0.0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (lane + 64 * q < Nx) {
+          const double d = avg - x[r][q];
+          ss += d * d;
+        }
+      }
+      const double sd = sqrt(wave_sum(ss) / (n - 1.0));
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int col = lane + 64 * q;
+        if (col < ldx) X[(base + r) * ldx + col] = col < Nx ? __ddiv_rn(x[r][q], sd) : 0.0;
+      }
+    }
+  }
+}
+
 // ---- ncorrs = (y[:,None]*NAMresid).mean(axis=0) (_association.py:77) -----------------------
 template <int NQ>
 __global__ __launch_bounds__(256) void k_ncorrs(const double* __restrict__ X, int64_t nx, int Nx, int ldx,
@@ -382,6 +454,22 @@ int launch_select(cna_ctx* c, const int32_t* colmap_dev) {
   ProfScope ps(c, CNA_K_SELECT);
   hipLaunchKernelGGL(k_select, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nam, c->ld,
                      c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev) {
+  HIP_TRY(hipMemsetAsync(nzero_dev, 0, sizeof(unsigned long long), c->stream));
+  if (c->nx == 0) return 0;
+  if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 512 samples are not supported");
+  ProfScope ps(c, CNA_K_SELECT);
+  const unsigned grid = wave_grid((c->nx + 3) / 4);
+  switch ((c->ldx + 63) / 64) {
+#define SS_CASE(Q) case Q: hipLaunchKernelGGL(k_select_std<Q>, dim3(grid), dim3(256), 0, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev); break
+    SS_CASE(1); SS_CASE(2); SS_CASE(3); SS_CASE(4);
+    default: hipLaunchKernelGGL(k_select_std<MAXQ>, dim3(grid), dim3(256), 0, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev);
+#undef SS_CASE
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }

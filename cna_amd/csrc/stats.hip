@@ -151,12 +151,13 @@ int launch_condition(cna_ctx* c, const double* M_dev, const double* Y_dev, int N
   return 0;
 }
 
-int launch_global_test(cna_ctx* c, const double* Zc_dev, int ldy, int N, int P, const double* U_dev, int kmax,
-                       const int32_t* ks_dev, int K, int r, double* minp_dev, double* r2_dev, int32_t* kidx_dev) {
+int launch_global_test(cna_ctx* c, hipStream_t st, const double* Zc_dev, int ldy, int N, int P, const double* U_dev,
+                       int kmax, const int32_t* ks_dev, int K, int r, double* minp_dev, double* r2_dev,
+                       int32_t* kidx_dev) {
   if (P == 0) return 0;
-  ProfScope ps(c, CNA_K_GLOBAL_TEST);
+  ProfScope ps(c, CNA_K_GLOBAL_TEST, st);
   const size_t sm = sizeof(double) * (N + kmax + 2 * K);
-  hipLaunchKernelGGL(k_global_test, dim3(P), dim3(64), sm, c->stream, Zc_dev, ldy, N, P, U_dev, kmax, ks_dev, K, r,
+  hipLaunchKernelGGL(k_global_test, dim3(P), dim3(64), sm, st, Zc_dev, ldy, N, P, U_dev, kmax, ks_dev, K, r,
                      minp_dev, r2_dev, kidx_dev);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -37,6 +37,7 @@ class Engine:
         self._graph_key = None
         self._graph_ref = None
         self._colsum_w = None
+        self._codes_token = self._codes_graph = None
         self.n = 0            # global cells
         self.row0 = 0
         self.n_local = 0
@@ -127,7 +128,14 @@ class Engine:
         return out
 
     # ---------------------------------------------------------------- NAM
-    def set_samples(self, codes, n_samples, counts):
+    def set_samples(self, codes, n_samples, counts, token=None):
+        """Sample code per cell + cells per sample.  ``token``: an opaque, hashable identity of
+        `codes` (see tools._nam.sample_codes_cached); when it equals the token of the codes already
+        on the device for this graph, the upload is skipped and only the walk is restarted."""
+        if token is not None and token == self._codes_token and self._codes_graph == self._graph_key:
+            check(self.lib.cna_restart_nam(self.h), 'cna_restart_nam')
+            self.nam_epoch += 1
+            return
         codes = np.ascontiguousarray(codes, dtype=np.int32)
         if len(codes) != self.n:
             raise ValueError('need one sample code per cell')
@@ -135,6 +143,7 @@ class Engine:
         check(self.lib.cna_set_samples(self.h, ptr(codes), int(n_samples), ptr(counts)), 'cna_set_samples')
         self.N = int(n_samples)
         self.nam_epoch += 1
+        self._codes_token, self._codes_graph = token, self._graph_key
 
     def nam_step(self, want_kurt, may_continue, may_stop):
         check(self.lib.cna_nam_step(self.h, int(bool(want_kurt)), int(bool(may_continue)), int(bool(may_stop))),
@@ -190,6 +199,24 @@ class Engine:
         check(self.lib.cna_select(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm)), 'cna_select')
         self.x_epoch += 1
 
+    def select_standardized(self, keep_global, colmap):
+        """select() + centre + divide by std in one pass (M = I); returns the number of selected
+        cells with zero variance (non-zero: redo with zero_variance()/select())."""
+        cm = None if colmap is None else np.ascontiguousarray(colmap, dtype=np.int32)
+        if keep_global is None:
+            idx, nk = None, 0
+            self.x_rows_total = self.n
+        else:
+            keep_global = np.asarray(keep_global, dtype=bool)
+            idx = np.ascontiguousarray(np.flatnonzero(keep_global[self.row0:self.row0 + self.n_local]), dtype=np.int64)
+            nk = len(idx)
+            self.x_rows_total = int(keep_global.sum())
+        nz = C.c_int64(0)
+        check(self.lib.cna_select_standardized(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm),
+                                               C.byref(nz)), 'cna_select_standardized')
+        self.x_epoch += 1
+        return nz.value
+
     def upload_x(self, x_local):
         x_local = _f64(x_local)
         check(self.lib.cna_upload_x(self.h, ptr(x_local), x_local.shape[0], x_local.shape[1]), 'cna_upload_x')
@@ -209,6 +236,15 @@ class Engine:
         rows, cols = self.matrix_shape(MAT_X)
         G = np.empty((cols, cols))
         check(self.lib.cna_gram(self.h, ptr(G)), 'cna_gram')
+        return G
+
+    def gram_launch(self):
+        check(self.lib.cna_gram_launch(self.h), 'cna_gram_launch')
+        self._gram_cols = self.matrix_shape(MAT_X)[1]
+
+    def gram_fetch(self):
+        G = np.empty((self._gram_cols, self._gram_cols))
+        check(self.lib.cna_gram_fetch(self.h, ptr(G)), 'cna_gram_fetch')
         return G
 
     def project(self, W):
@@ -251,6 +287,18 @@ class Engine:
         check(self.lib.cna_null_local_resident(self.h, int(col0), int(P), ptr(edges), T, ptr(tails), ptr(sums)),
               'cna_null_local_resident')
         return sums if sums_only else tails
+
+    def null_local_launch(self, col0, P, edges):
+        """Queue a local-null pass on resident columns; collect with null_local_fetch()."""
+        edges = _f64(edges)
+        check(self.lib.cna_null_local_launch(self.h, int(col0), int(P), ptr(edges), len(edges), 0),
+              'cna_null_local_launch')
+        self._null_T = len(edges)
+
+    def null_local_fetch(self):
+        sums = np.empty(self._null_T, dtype=np.int64)
+        check(self.lib.cna_null_local_fetch(self.h, None, ptr(sums)), 'cna_null_local_fetch')
+        return sums
 
     def global_test(self, U, ks, r):
         """min-p F-test of every resident phenotype column -> (index into ks, p, r2) arrays."""

@@ -19,7 +19,7 @@ import pandas as pd
 
 from .. import _ffi
 from ..engine import get_engine
-from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_device, _gather_rows, sample_codes,
+from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_plan, _resid_run, _gather_rows, sample_codes_cached,
                    _small_svd, _defer_pcs, host_blas_threads)
 from ._out import select_output
 from ._stats import conditional_permutation, grouplevel_permutation, default_ks, minp_stats
@@ -55,11 +55,11 @@ def _draw_null(y, batches, donorids, Nnull=1000, force_permute_all=False, seed=N
     return y, y_
 
 
-def _association(engine, G, res, y, y_, ks=None, Nnull=1000, local_test=True, show_progress=False,
+def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_progress=False,
                  npcs=None, n_cells=None):
     """Body of the reference's ``_association`` (_association.py:24-129) against the
-    residualised NAM held by ``engine`` (cells x samples).  ``G`` is its samples x samples Gram
-    matrix, ``res`` the namespace from the residualisation (M, r), ``y`` / ``y_`` the
+    residualised NAM held by ``engine`` (cells x samples), whose Gram-matrix kernels have been
+    queued.  ``res`` is the namespace from the residualisation (M, r), ``y`` / ``y_`` the
     standardised phenotype and its permutations.
 
     Ordering: the local-null kernel is started first and runs on the GPU while LAPACK's SVD of
@@ -84,7 +84,8 @@ def _association(engine, G, res, y, y_, ks=None, Nnull=1000, local_test=True, sh
     engine.condition(Mv, np.column_stack([y, y_]))
     # neighbourhood coefficients -> thresholds -> start the local null (device, asynchronous)
     _, maxabs = engine.ncorrs(y, fetch=False)
-    pending = thresholds = edges = None
+    pending = False
+    thresholds = edges = None
     if local_test:
         Nloc = min(1000, Nnull)
         maxcorr = max(maxabs, 0.001)
@@ -93,18 +94,19 @@ def _association(engine, G, res, y, y_, ks=None, Nnull=1000, local_test=True, sh
         edges = z2 - 1e-8 - 1e-5 * z2                        # tail_counts' bin edges (_stats.py:47)
         # tail counts from columns 1..Nloc of Zc, summed over permutations on the device; neither
         # cells x Nloc nor Nloc x T ever reaches the host
-        pending = _background().submit(engine.null_local_resident, 1, Nloc, edges, True)
+        engine.null_local_launch(1, Nloc, edges)                  # returns at once
+        pending = True
 
     tail_sums = None
     try:
-        # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105), under the local-null kernel
-        U, svs, _ = _small_svd(G)
+        # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105), and the global F-tests of the
+        # observed phenotype and every permutation (second stream), all under the local-null kernel
+        U, svs, _ = _small_svd(engine.gram_fetch())
+        best, pv, r2v = engine.global_test(U, ks_arr, r)
     finally:
-        if pending is not None:
-            tail_sums = pending.result()  # one device call at a time; also never leave it running
+        if pending:
+            tail_sums = engine.null_local_fetch()   # never leave a pass pending behind an exception
 
-    # global test of the observed phenotype and of every permutation (device F-tests)
-    best, pv, r2v = engine.global_test(U, ks_arr, r)
     if (best < 0).any():
         raise ValueError('All-NaN slice encountered')        # np.nanargmin in _minp_stats
     k, p, r2 = ks[best[0]], pv[0], r2v[0]
@@ -237,13 +239,21 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     covs = covs.reindex(y.index) if covs is not None else None
     donorids = donorids.reindex(y.index) if donorids is not None else None
     filter_samples = filter_samples.reindex(y.index)
-    extra = overlap(batches, donorids, filter_samples) if overlap is not None else None
+    sample_index = pd.Index(sample_index, name=sid_name)
+    extra = overlap(sample_index, batches, covs, donorids, filter_samples) if overlap is not None else None
 
-    zero_var, nzero = engine.zero_variance(colmap)
-    if nzero:
-        kept = kept & ~zero_var
-    engine.select(None if kept.all() else kept, colmap)
-    return (kept, pd.Index(sample_index, name=sid_name), colmap, batches, covs, donorids, filter_samples, extra)
+    plan = extra if hasattr(extra, 'kind') else None
+    nzero = -1
+    if plan is not None and plan.kind == 'identity':
+        # nothing to regress out: select + centre + /std in one pass over the NAM
+        nzero = engine.select_standardized(None if kept.all() else kept, colmap)
+        plan.standardized = nzero == 0
+    if nzero != 0:
+        zero_var, nzero = engine.zero_variance(colmap)
+        if nzero:
+            kept = kept & ~zero_var
+        engine.select(None if kept.all() else kept, colmap)
+    return (kept, sample_index, colmap, batches, covs, donorids, filter_samples, extra)
 
 
 def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=None, key_added='coef',
@@ -272,22 +282,35 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     Nnull = kwargs.get('Nnull', 1000)
 
     # factorise the per-cell sample ids once; validation and NAM construction share the result
-    codes, labels = sample_codes(data.obs[sid_name])
-    counts = np.bincount(codes if codes.min(initial=0) >= 0 else codes[codes >= 0], minlength=len(labels))
+    codes, labels, counts, token = sample_codes_cached(data.obs[sid_name])
     used = counts > 0
     batches, filter_samples = check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size,
                                            sids_present=labels[used] if isinstance(y, pd.Series) else None)
 
-    def draw(batches_, donorids_, filter_):
-        # host-only: runs while the diffusion kernels are executing
-        return _draw_null(y[filter_].values, batches_[filter_].values,
-                          donorids_[filter_].values if donorids_ is not None else None,
+    # the permutation draw (numpy RNG + argsort, both outside the GIL) needs only sample-level
+    # inputs: it starts on the helper thread right away and is collected just before the
+    # phenotypes go to the device.  Nothing else touches numpy's global RNG in between.
+    def null_job():
+        f = filter_samples.reindex(y.index)
+        b_ = batches.reindex(y.index)
+        d_ = donorids.reindex(y.index) if donorids is not None else None
+        return _draw_null(y[f].values, b_[f].values, d_[f].values if d_ is not None else None,
                           Nnull=Nnull, force_permute_all=kwargs.get('force_permute_all', False),
                           seed=kwargs.get('seed'))
+    null_future = _background().submit(null_job)
 
-    kept, sample_index, colmap, batches, covs, donorids, filter_samples, (y_std, y_null) = \
-        compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
-                                show_progress, codes_labels=(codes, labels, counts), overlap=draw)
+    def host_side(sample_index_, batches_, covs_, donorids_, filter_):
+        # host-only sample-space work: runs while the diffusion kernels are executing
+        return _resid_plan(sample_index_, covs_[filter_] if covs_ is not None else covs_,
+                           batches_[filter_] if batches_ is not None else batches_, ridges=ridges)
+
+    try:
+        kept, sample_index, colmap, batches, covs, donorids, filter_samples, plan = \
+            compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
+                                    show_progress, codes_labels=(codes, labels, counts, token), overlap=host_side)
+    except BaseException:
+        null_future.cancel() or null_future.exception()     # do not leave the helper thread running
+        raise
 
     def cell_index():
         # names of the kept cells: only needed for the frames of a full result
@@ -296,13 +319,13 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
 
     N = filter_samples.sum()
     npcs = min(N, max([10] + [int(max_frac_pcs * N)] + [ks if ks is not None else []][0]))
-    res, G = _resid_device(engine, sample_index, cell_index,
-                           covs[filter_samples] if covs is not None else covs,
-                           batches[filter_samples] if batches is not None else batches,
-                           ridges=ridges, show_progress=show_progress)
+    try:
+        res = _resid_run(engine, plan, cell_index, show_progress=show_progress)
+    finally:
+        y_std, y_null = null_future.result()
 
     print('performing association test', file=out)
-    coef_all, fdr_all, U, svs = _association(engine, G, res, y_std, y_null, ks=ks, Nnull=Nnull,
+    coef_all, fdr_all, U, svs = _association(engine, res, y_std, y_null, ks=ks, Nnull=Nnull,
                                              local_test=kwargs.get('local_test', True),
                                              show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_total)
     _defer_pcs(res, engine, U, svs, cell_index)

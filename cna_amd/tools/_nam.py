@@ -109,6 +109,47 @@ def sample_codes(col):
     return rank[codes], uniques[order]
 
 
+_codes_cache = {}
+
+
+def _fingerprint(arr):
+    """Identity + content check of a numeric per-cell id array: where it lives and two full-array
+    checksums (xor of the bit patterns and their wrapped sum) -- two passes at memory speed,
+    ~10x cheaper than hashing the column again."""
+    bits = arr.view({1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[arr.dtype.itemsize])
+    return (arr.__array_interface__['data'][0], arr.shape, arr.strides, arr.dtype.str,
+            int(np.bitwise_xor.reduce(bits)), int(bits.sum(dtype=np.uint64)))
+
+
+def sample_codes_cached(col):
+    """sample_codes() with a one-entry-per-column memo for numeric and categorical id columns.
+
+    Canonicalising the ids (hash 200k-2M values, rank the labels, count cells per sample) is pure
+    input preparation and identical for every phenotype tested on a dataset.  The memo is only
+    reused when the column's buffer is the same AND its full-content checksums match, so an
+    in-place edit of the ids is seen.  Returns (codes, labels, counts, token); the token lets the
+    engine keep the codes resident on the device."""
+    if isinstance(col.dtype, pd.CategoricalDtype):
+        arr = np.asarray(col.cat.codes)
+        extra = tuple(col.cat.categories)
+    else:
+        arr = col.values if isinstance(col.values, np.ndarray) else None
+        extra = ()
+    if arr is None or arr.dtype.kind not in 'iuf' or not arr.flags.c_contiguous or arr.dtype.itemsize not in (1, 2, 4, 8):
+        codes, labels = sample_codes(col)
+        counts = np.bincount(codes if codes.min(initial=0) >= 0 else codes[codes >= 0], minlength=len(labels))
+        return codes, labels, counts, None
+    fp = _fingerprint(arr) + (extra,)
+    hit = _codes_cache.get('last')
+    if hit is not None and hit[0] == fp:
+        return hit[1]
+    codes, labels = sample_codes(col)
+    counts = np.bincount(codes if codes.min(initial=0) >= 0 else codes[codes >= 0], minlength=len(labels))
+    out = (codes, labels, counts, fp)
+    _codes_cache['last'] = (fp, out)
+    return out
+
+
 def _column_r2(a, b):
     # R(A,B)**2 of _nam.py:47-49 (diagnostic print only).  The reference's operands are DataFrames,
     # so the covariance is a population moment but both std() calls are pandas' ddof=1.
@@ -165,14 +206,17 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
     engine holds NAM = (s/C) (cells x samples); returns (labels, steps taken)."""
     out = select_output(show_progress)
     _prepare_graph(engine, data, self_weight)
-    if codes_labels is not None and len(codes_labels) == 3:
+    token = None
+    if codes_labels is not None and len(codes_labels) == 4:
+        codes, labels, counts, token = codes_labels
+    elif codes_labels is not None and len(codes_labels) == 3:
         codes, labels, counts = codes_labels
     else:
         codes, labels = codes_labels if codes_labels is not None else sample_codes(data.obs[sid_name])
         counts = np.bincount(codes if codes.min(initial=0) >= 0 else codes[codes >= 0], minlength=len(labels))
     N = len(labels)
     C = counts.astype(np.float64)
-    engine.set_samples(codes, N, C)
+    engine.set_samples(codes, N, C, token=token)
     n = engine.n
 
     need_kurt = (nsteps is None) or show_progress
@@ -287,42 +331,64 @@ def _names(index_or_thunk):
     return index_or_thunk() if callable(index_or_thunk) else index_or_thunk
 
 
-def _resid_device(engine, sample_index, cell_index, covs, batches, ridges=None, show_progress=False):
-    """Reference ``_resid_nam`` (_nam.py:118-177) applied to the engine's working matrix X
-    (cells x samples, already restricted to ``sample_index`` / ``cell_index``)."""
-    out = select_output(show_progress)
+def _resid_plan(sample_index, covs, batches, ridges=None):
+    """Host-only half of the reference's ``_resid_nam`` (_nam.py:118-146): standardise the
+    covariates, one-hot the batches, and -- when no ridge schedule is involved -- form the
+    projector M.  Needs nothing from the device, so the caller runs it while the diffusion
+    kernels execute."""
     N = len(sample_index)
+    plan = Namespace(N=N, sample_index=sample_index, M=None, ridges=None, standardized=False)
     if covs is None:
         covs = pd.DataFrame(np.ones((N, 0)), index=sample_index)
     else:
         covs = (covs - covs.mean(axis=0)) / covs.std(axis=0)
-
     if batches is None or len(np.unique(batches)) == 1:
-        C = covs
-        if len(C.T) == 0:
-            M = pd.DataFrame(np.eye(N), columns=sample_index, index=sample_index)
-            # M = I: centring + division by the std is one row-local pass
-            engine.standardize(center=True)
+        plan.C = covs
+        if len(covs.T) == 0:
+            plan.kind = 'identity'
+            plan.M = pd.DataFrame(np.eye(N), columns=sample_index, index=sample_index)
         else:
-            M = np.eye(N) - C.dot(np.linalg.solve(C.T.dot(C), C.T))
+            plan.kind = 'single'
+            M = np.eye(N) - covs.dot(np.linalg.solve(covs.T.dot(covs), covs.T))
             M.columns = M.index
-            engine.resid_apply(M.values, center=True)
-            engine.standardize(center=False)
+            plan.M = M
     else:
+        plan.kind = 'ridge'
         B = pd.get_dummies(batches)
-        B = (B - B.mean(axis=0)) / B.std(axis=0)
-        C = pd.concat([B, covs], axis=1)
-        if ridges is None:
-            ridges = DEFAULT_RIDGES
-        bcodes, nb = _batch_codes(batches, sample_index)
+        plan.B = (B - B.mean(axis=0)) / B.std(axis=0)
+        plan.C = pd.concat([plan.B, covs], axis=1)
+        plan.ridges = DEFAULT_RIDGES if ridges is None else ridges
+        plan.bcodes, plan.nb = _batch_codes(batches, sample_index)
+    plan.r = len(plan.C.T)
+    return plan
+
+
+def _resid_run(engine, plan, cell_index, show_progress=False):
+    """Device half of ``_resid_nam`` (_nam.py:122,135,148-159,163): centre, apply M (or the ridge
+    schedule, which needs the batch kurtosis of the partially residualised matrix after every
+    ridge), divide by the per-cell std, and queue the Gram-matrix kernels.  The engine's working
+    matrix X is residualised in place; the Gram matrix is collected with engine.gram_fetch()."""
+    out = select_output(show_progress)
+    N, C, sample_index = plan.N, plan.C, plan.sample_index
+    if plan.kind == 'identity':
+        M = plan.M
+        if not plan.standardized:              # M = I: centring + division by the std is one row-local pass
+            engine.standardize(center=True)
+    elif plan.kind == 'single':
+        M = plan.M
+        engine.resid_apply(M.values, center=True)
+        engine.standardize(center=False)
+    else:
+        B = plan.B
         first = True
-        for ridge in ridges:
+        M = None
+        for ridge in plan.ridges:
             L = np.diag([1] * len(B.T) + [0] * (len(C.T) - len(B.T)))
             M = np.eye(N) - C.dot(np.linalg.solve(C.T.dot(C) + ridge * len(C) * L, C.T))
             M.columns = M.index
             engine.resid_apply(np.asarray(M.values, dtype=np.float64), center=first)
             first = False
-            engine.batch_kurtosis(_ffi.MAT_X, bcodes, nb)
+            engine.batch_kurtosis(_ffi.MAT_X, plan.bcodes, plan.nb)
             kurtoses = engine.cell_stat(engine.x_rows_total)
             med = np.median(kurtoses)
             print('\twith ridge', ridge, 'median batch kurtosis = ', med, file=out)
@@ -333,12 +399,11 @@ def _resid_device(engine, sample_index, cell_index, covs, batches, ridges=None, 
         engine.standardize(center=False)
 
     # svd_nam re-centres / re-standardises (_nam.py:103-104); X is already standardised, so
-    # that is an identity up to 1 ulp and the Gram matrix is taken of X directly.  The SVD of
-    # G itself is left to the caller, which overlaps it with device work.
-    G = engine.gram()
+    # that is an identity up to 1 ulp and the Gram matrix is taken of X directly.
+    engine.gram_launch()
     res = LazyNamespace()
     res.M = M
-    res.r = len(C.T)
+    res.r = plan.r
     epoch = engine.x_epoch
     n_cells = engine.x_rows_total
 
@@ -351,7 +416,7 @@ def _resid_device(engine, sample_index, cell_index, covs, batches, ridges=None, 
         return pd.DataFrame(full_t, index=sample_index, columns=_names(cell_index))
 
     res._defer('namresid', fetch_namresid)
-    return res, G
+    return res
 
 
 def _still_resident(engine, epoch):

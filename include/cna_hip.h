@@ -80,6 +80,9 @@ int  cna_fetch_colsums(cna_ctx* ctx, double* out_n_global);
 /* codes[i] = column of cell i in pd.get_dummies(obs[sid]) (_nam.py:51), for ALL n_global cells;
  * counts[c] = cells per sample C (_nam.py:54). */
 int  cna_set_samples(cna_ctx* ctx, const int32_t* codes, int n_samples, const double* counts);
+/* start a new walk from the one-hot state with the sample codes already on the device (same
+ * effect as calling cna_set_samples again with identical arguments, without the upload) */
+int  cna_restart_nam(cna_ctx* ctx);
 /* One diffusion step s <- A.(s/colsums) + w*s/colsums (_nam.py:31-34) of the sample indicators.
  * The first call after cna_set_samples starts from the one-hot matrix.
  *   want_kurt : also produce per-cell kurtosis over samples of s/C (_nam.py:59), readable with
@@ -110,6 +113,12 @@ int  cna_zero_variance(cna_ctx* ctx, const int32_t* colmap, int n_sel, uint8_t* 
  * _nam.py:99, _association.py:178-185).  keep_idx: local row indices, NULL = all rows. */
 int  cna_select(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_keep,
                 const int32_t* colmap, int n_sel);
+/* cna_select followed by centring and division by the per-cell std (ddof=1) in one pass, for the
+ * case M = I (_association.py:178-185 + _nam.py:122,159); n_zero_out = number of selected cells with
+ * zero variance over the selected samples, summed over ranks (if non-zero the caller drops them
+ * with cna_zero_variance + cna_select and standardises again). */
+int  cna_select_standardized(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_keep,
+                             const int32_t* colmap, int n_sel, int64_t* n_zero_out);
 /* upload a cells x samples matrix as X (cna.tl.svd_nam on a user NAM, _nam.py:102) */
 int  cna_upload_x(cna_ctx* ctx, const double* x_local, int64_t n_rows, int n_cols);
 
@@ -122,6 +131,10 @@ int  cna_resid_apply(cna_ctx* ctx, const double* M, int center);
 int  cna_standardize(cna_ctx* ctx, int center);
 /* G = X^T X over all cells of all ranks (NAM.dot(NAM.T), _nam.py:105), n_cols x n_cols row-major */
 int  cna_gram(cna_ctx* ctx, double* G_out);
+/* the same in two halves: queue the kernels, collect the matrix later (the copy does not wait
+ * for work queued after the launch, e.g. the local-null kernel) */
+int  cna_gram_launch(cna_ctx* ctx);
+int  cna_gram_fetch(cna_ctx* ctx, double* G_out);
 /* out = X . W  (V = NAM^T U / sqrt(svs), _nam.py:106; W = U/sqrt(svs), n_cols x n_w row-major),
  * local rows, row-major n_x_local x n_w */
 int  cna_project(cna_ctx* ctx, const double* W, int n_w, double* out_local);
@@ -152,6 +165,11 @@ int  cna_null_local(cna_ctx* ctx, const double* Yc, int P, const double* edges, 
 int  cna_condition_phenotypes(cna_ctx* ctx, const double* M, const double* Y, int P);
 int  cna_null_local_resident(cna_ctx* ctx, int col0, int P, const double* edges, int T, int64_t* tails_out,
                              int64_t* tail_sums_out);
+/* cna_null_local_resident in two halves: queue the pass (returns at once; at most one pending),
+ * collect its results later.  Between the two the host may call cna_gram_fetch and cna_global_test,
+ * which run beside the local-null kernel on a second stream. */
+int  cna_null_local_launch(cna_ctx* ctx, int col0, int P, const double* edges, int T, int want_tails);
+int  cna_null_local_fetch(cna_ctx* ctx, int64_t* tails_out, int64_t* tail_sums_out);
 int  cna_global_test(cna_ctx* ctx, const double* U, int kmax, const int32_t* ks, int K, int r,
                      double* minp_out, double* r2_out, int32_t* kidx_out);
 /* ranks[t] = #{i : ncorrs_i^2 >= edges[t]} (_stats.py:74) and

@@ -89,7 +89,7 @@ class FakeEngine:
         return self.colsum.copy()
 
     # -- NAM
-    def set_samples(self, codes, n_samples, counts):
+    def set_samples(self, codes, n_samples, counts, token=None):
         self.codes = np.asarray(codes)
         self.N = int(n_samples)
         self.counts = np.asarray(counts, dtype=np.float64)
@@ -156,6 +156,15 @@ class FakeEngine:
         self.x_rows_total = self.n if keep_global is None else int(np.sum(keep_global))
         self.x_epoch += 1
 
+    def select_standardized(self, keep_global, colmap):
+        self.select(keep_global, colmap)
+        with np.errstate(all='ignore'):
+            nz = int((self.X.std(axis=1, ddof=1) == 0).sum())
+        if self.coll:
+            nz = int(self.coll.allreduce_sum(np.array([nz]))[0])
+        self.standardize(center=True)
+        return nz
+
     def upload_x(self, x_local):
         self.X = np.array(x_local, dtype=np.float64)
         self.x_rows_total = self.X.shape[0]
@@ -176,6 +185,12 @@ class FakeEngine:
 
     def gram(self):
         return self._sum(self.X.T.dot(self.X))
+
+    def gram_launch(self):
+        self._G = self.gram()
+
+    def gram_fetch(self):
+        return self._G
 
     def project(self, W):
         return self.X.dot(np.asarray(W))
@@ -202,6 +217,13 @@ class FakeEngine:
     def null_local_resident(self, col0, P, edges, sums_only=False):
         tails = self.null_local(self.Zc[:, col0:col0 + P], edges)
         return tails.sum(axis=0) if sums_only else tails
+
+    def null_local_launch(self, col0, P, edges):
+        self._pending = self.null_local_resident(col0, P, edges, sums_only=True)
+
+    def null_local_fetch(self):
+        out, self._pending = self._pending, None
+        return out
 
     def global_test(self, U, ks, r):
         kix, p, r2 = orc.minp_stats(self._Y, self._M, np.asarray(U), np.asarray(ks), r)

@@ -157,3 +157,19 @@ def test_obs_to_sample():
     assert list(out.index) == [2, 1]
     assert out.loc[1, 'x'] == 3.0 and out.loc[2, 'age'] == 10.0
     assert cna.ut.obs_to_sample(d, 'x', 'id', aggregate='max').loc[1, 'x'] == 6.0
+
+
+def test_sample_code_memo_sees_in_place_edits():
+    from cna_amd.tools._nam import sample_codes_cached
+    ids = pd.Series(np.array([3, 1, 2, 1, 3, 3], dtype=np.int64))
+    c1, l1, n1, t1 = sample_codes_cached(ids)
+    c2, l2, n2, t2 = sample_codes_cached(ids)
+    assert t1 == t2 and c1 is c2 and list(l1) == [1, 2, 3] and list(n1) == [2, 1, 3]
+    ids.values[0] = 2                                   # same buffer, different content
+    c3, l3, n3, t3 = sample_codes_cached(ids)
+    assert t3 != t1 and list(c3) == [1, 0, 1, 0, 2, 2] and list(n3) == [2, 2, 2]
+    strs = pd.Series(['b', 'a', 'b'])
+    assert sample_codes_cached(strs)[3] is None         # object columns are never memoised
+    cat = pd.Series(pd.Categorical(['x', 'z', 'x'], categories=['x', 'y', 'z']))
+    cc, cl, cn, ct = sample_codes_cached(cat)
+    assert list(cl) == ['x', 'y', 'z'] and list(cn) == [2, 0, 1] and ct is not None
