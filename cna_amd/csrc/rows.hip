@@ -373,13 +373,23 @@ __global__ __launch_bounds__(512) void k_suffix_sum(const unsigned long long* __
   if (t < T) tails[(size_t)p * T + t] = buf[cur][t];
 }
 
-// sums[t] = sum_p tails[p][t]  (the FDR is mean_p(tails[p][t]/ranks[t]), _stats.py:79-80)
-__global__ void k_tail_sums(const int64_t* __restrict__ tails, int P, int T, int64_t* __restrict__ sums) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= T) return;
+// sums[t] = sum_p tails[p][t]  (the FDR is mean_p(tails[p][t]/ranks[t]), _stats.py:79-80).
+// block = 64 thresholds x 16 permutation groups: coalesced 512-byte reads, 16-way LDS fold
+__global__ __launch_bounds__(1024) void k_tail_sums(const int64_t* __restrict__ tails, int P, int T,
+                                                    int64_t* __restrict__ sums) {
+  __shared__ long long part[16][64];
+  const int t = blockIdx.x * 64 + threadIdx.x, g = threadIdx.y;
   long long s = 0;
-  for (int p = 0; p < P; ++p) s += tails[(size_t)p * T + t];
-  sums[t] = s;
+  if (t < T)
+    for (int p = g; p < P; p += 16) s += tails[(size_t)p * T + t];
+  part[g][threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && t < T) {
+    long long tot = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) tot += part[k][threadIdx.x];
+    sums[t] = tot;
+  }
 }
 
 __global__ void k_fill(double* v, int64_t n, double x) {
@@ -532,7 +542,7 @@ int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, 
 
 int launch_tail_sums(cna_ctx* c, const int64_t* tails, int P, int T, int64_t* sums) {
   if (T == 0) return 0;
-  hipLaunchKernelGGL(k_tail_sums, dim3((unsigned)((T + 63) / 64)), dim3(64), 0, c->stream, tails, P, T, sums);
+  hipLaunchKernelGGL(k_tail_sums, dim3((unsigned)((T + 63) / 64)), dim3(64, 16), 0, c->stream, tails, P, T, sums);
   HIP_TRY(hipGetLastError());
   return 0;
 }
