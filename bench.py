@@ -35,9 +35,9 @@ F64_MFMA_PEAK_TF = 78.6      # AMD MI355X datasheet: FP64 matrix 78.6 TFLOP/s (t
 # gfx950 correction, re-calibrated here on k_ncorrs (streams the 83.2 MB matrix once, FETCH_SIZE reads 41.6 MB).
 # Counted at the L2's fabric side, i.e. Infinity-Cache hits included.  Only valid for the profiled workload.
 PMC_TRAFFIC = {
-    ('C2', 'nam_step'): 2 * 513694e3 + 84650e3,
-    ('C2', 'nam_first'): 2 * 37894e3 + 81250e3,
-    ('C2', 'null_local'): 2 * 147138e3 + 52217e3,
+    ('C2', 'nam_step'): 2 * 513705e3 + 84700e3,
+    ('C2', 'nam_first'): 2 * 37898e3 + 81250e3,
+    ('C2', 'null_local'): 2 * 147889e3 + 52217e3,
 }
 
 WORKLOADS = {
