@@ -45,6 +45,7 @@ WORKLOADS = {
     'C2': (200_000, 50, 30, 3, 1000),
     'C3': (1_000_000, 100, 30, 3, 1000),
     'C4w': (250_000, 200, 30, 3, 1000),     # 8 GPUs x 250k = BASELINE config 4
+    'C4': (2_000_000, 200, 30, 3, 1000),    # BASELINE config 4 on ONE GPU (fits: ~14 GB of 288 GB)
 }
 
 

@@ -297,6 +297,7 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
   // measured (tools/kbench.py): one contiguous eighth per XCD is best at 200k x 50 (+4 % over
   // round-robin) and within 2 % of every chunk size at 1M x 100
   int64_t chunk = cpx;
+  if (const char* e = getenv("CNA_XCD_CHUNK")) { const int64_t v = atoll(e); if (v > 0 && v < cpx) chunk = v; }   // experiments
   cpx = (cpx + chunk - 1) / chunk * chunk;      // whole chunks per XCD
   a.xcd_chunk = (int)chunk;
   dim3 grid((unsigned)(cpx * 8));
