@@ -1,0 +1,126 @@
+"""Cell order on the device.
+
+The random walk gathers, for every cell, the state rows of its ~30 graph neighbours.  How many of
+those rows are already in L2 / Infinity Cache depends only on how the cells are numbered, and the
+caller's numbering is arbitrary (the reference never looks at it).  So the engine is free to keep
+the cells in a locality-preserving order of its own -- reverse Cuthill-McKee of the kNN graph,
+which turns the adjacency into a band -- as long as nothing order-dependent leaks out.
+
+Invariants that keep results bit-identical to the caller's order:
+  * only rows are renumbered; inside a row the neighbours stay in the caller's CSR order, so every
+    per-cell sum adds the same numbers in the same sequence;
+  * every per-cell quantity crossing the engine boundary is converted here (`CellOrder`), so
+    `cna_amd.tools` and the tests only ever see the caller's order.
+
+`perm[i]` is the caller's index of device row i.  Multi-GPU: every rank computes the same `perm`
+from the same graph (RCM is deterministic) and owns a contiguous block of *device* rows; with a
+banded adjacency most neighbours of a block live in the block itself.
+"""
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+
+def locality_order(A):
+    """Reverse Cuthill-McKee order of the (structurally symmetrised) graph, or None when the
+    reordering is switched off (CNA_REORDER=0) or pointless."""
+    if os.environ.get('CNA_REORDER', '1') in ('0', 'off', 'no') or A.shape[0] < 2:
+        return None
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+    perm = reverse_cuthill_mckee(sp.csr_matrix(A), symmetric_mode=False)
+    return np.ascontiguousarray(perm, dtype=np.int64)
+
+
+def inverse(perm):
+    inv = np.empty(len(perm), dtype=np.int64)
+    inv[perm] = np.arange(len(perm), dtype=np.int64)
+    return inv
+
+
+def permuted_rows(A, perm, r0, r1):
+    """CSR pieces (indptr int64, indices int32, data) of device rows [r0, r1) of P A P^T: row i
+    is the caller's row perm[i] with its columns relabelled and left in their original order."""
+    inv = inverse(perm)
+    rows = perm[r0:r1]
+    ptr = A.indptr.astype(np.int64, copy=False)
+    deg = ptr[rows + 1] - ptr[rows]
+    indptr = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.cumsum(deg, out=indptr[1:])
+    src = np.repeat(ptr[rows] - indptr[:-1], deg) + np.arange(indptr[-1], dtype=np.int64)
+    indices = inv[A.indices[src]].astype(np.int32)
+    return indptr, indices, np.ascontiguousarray(A.data[src])
+
+
+class CellOrder:
+    """Mixin for engines: conversions between the caller's cell order and the device's.
+
+    The engine provides: perm (or None), n, row0, n_local, nranks, block(), gather_rows_host(),
+    fetch_matrix(), project(), dense_load(), dense_fetch(), and records in `_keep_dev` the keep mask
+    (device order, None = all cells) of the last select and in `_x_is_selection` whether the
+    working matrix X came from the NAM (True) or from upload_x (False: already caller order)."""
+    perm = None
+    _keep_dev = None
+    _x_is_selection = False
+    _kept_order_cache = None
+
+    # per-cell vectors / row blocks over ALL cells
+    def cells_to_device(self, v):
+        return v if self.perm is None or v is None else np.asarray(v)[self.perm]
+
+    def cells_to_user(self, v):
+        if self.perm is None:
+            return v
+        out = np.empty_like(v)
+        out[self.perm] = v
+        return out
+
+    def local_keep(self, keep_global):
+        """Caller's keep mask -> indices of kept cells inside this rank's block (device order)."""
+        keep_dev = self.cells_to_device(np.asarray(keep_global, dtype=bool))
+        self._keep_dev = keep_dev
+        self._kept_order_cache = None
+        return np.ascontiguousarray(np.flatnonzero(keep_dev[self.row0:self.row0 + self.n_local]), dtype=np.int64)
+
+    # rows of X (kept cells of all ranks, device order) -> caller's order
+    def _kept_order(self):
+        if self._kept_order_cache is None:
+            ids = self.perm if self._keep_dev is None else self.perm[self._keep_dev]
+            self._kept_order_cache = np.argsort(ids, kind='stable')
+        return self._kept_order_cache
+
+    def kept_to_user(self, m):
+        if self.perm is None or not self._x_is_selection:
+            return m
+        return m[self._kept_order()]
+
+    def _all_rows(self, local, n_total):
+        return local if self.nranks == 1 else self.gather_rows_host(local, n_total)
+
+    # whole matrices in the caller's order
+    def nam_full(self):
+        """NAM of all cells (cells x samples)."""
+        from ._ffi import MAT_NAM
+        return self.cells_to_user(self._all_rows(self.fetch_matrix(MAT_NAM), self.n))
+
+    def x_full(self, transposed=False):
+        """Working matrix X over the kept cells (cells x samples, or its transpose)."""
+        from ._ffi import MAT_X
+        if self.nranks == 1 and (self.perm is None or not self._x_is_selection):
+            return self.fetch_matrix(MAT_X, transposed=transposed)
+        m = self.kept_to_user(self._all_rows(self.fetch_matrix(MAT_X), self.x_rows_total))
+        return np.ascontiguousarray(m.T) if transposed else m
+
+    def project_full(self, W):
+        return self.kept_to_user(self._all_rows(self.project(W), self.x_rows_total))
+
+    def x_stat(self):
+        """Per-row statistic of the last X-space kernel, caller's order of the kept cells."""
+        return self.kept_to_user(self.cell_stat(self.x_rows_total, nam_space=False))
+
+    def dense_begin(self, arr):
+        r0, r1 = self.block(arr.shape[0])
+        self.dense_load(arr[r0:r1] if self.perm is None else arr[self.perm[r0:r1]])
+
+    def dense_state(self):
+        return self.cells_to_user(self._all_rows(self.dense_fetch(), self.n))

@@ -189,7 +189,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_flush(c);
   comm_destroy(c);
-  void* bufs[] = {c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+  void* bufs[] = {c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
                   c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -234,7 +234,9 @@ int cna_graph_upload(cna_ctx* c, int64_t n_global, int64_t row0, int64_t n_local
   if (c->data) dev_free(c, c->data, (c->data_f64 ? 8 : 4) * c->nnz);
   if (c->colsum) dev_free(c, c->colsum, sizeof(double) * c->n_pad);
   if (c->stat) dev_free(c, c->stat, sizeof(double) * c->n_pad);
+  if (c->orig_idx) dev_free(c, c->orig_idx, sizeof(int64_t) * c->n_local);
   c->indptr = nullptr; c->indices = nullptr; c->data = nullptr; c->colsum = nullptr; c->stat = nullptr;
+  c->orig_idx = nullptr;
   c->n_global = n_global;
   c->row0 = (int64_t)c->rank * rpr;
   c->n_local = n_local;
@@ -261,6 +263,24 @@ int cna_graph_upload(cna_ctx* c, int64_t n_global, int64_t row0, int64_t n_local
   c->x_valid = false;
   c->ncorrs_valid = false;
   c->steps_done = 0;
+  return 0;
+}
+
+int cna_set_cell_order(cna_ctx* c, const int64_t* orig_index) {
+  CHECK_CTX(c);
+  if (!c->indptr) CNA_FAIL(CNA_ESTATE, "cna_set_cell_order before cna_graph_upload");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!orig_index) {
+    if (c->orig_idx) dev_free(c, c->orig_idx, sizeof(int64_t) * c->n_local);
+    c->orig_idx = nullptr;
+    return 0;
+  }
+  for (int64_t i = 0; i < c->n_local; ++i)
+    if (orig_index[i] < 0 || orig_index[i] >= c->n_global)
+      CNA_FAIL(CNA_EINVAL, "cna_set_cell_order: index out of range");
+  if (!c->orig_idx && c->n_local > 0) CNA_TRY(dev_alloc(c, (void**)&c->orig_idx, sizeof(int64_t) * c->n_local));
+  if (c->n_local > 0)
+    HIP_TRY(hipMemcpy(c->orig_idx, orig_index, sizeof(int64_t) * c->n_local, hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -949,18 +969,37 @@ int cna_percell_fdr(cna_ctx* c, const double* thr, const double* runmin_fdr, int
   double thr0 = 0, inv_step = 0;
   if (want_fdr) guess_from_thr(thr, T, &thr0, &inv_step);
   const int64_t Tn = want_fdr ? T : 1;
-  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({8 * Tn, 8 * Tn, 8 * c->n_pad, 8 * c->n_pad})));
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap,
+                      carve_bytes({8 * Tn, 8 * Tn, 8 * c->n_pad, 8 * c->n_pad, 8 * c->n_pad, 8 * c->n_pad})));
   Carver cv(c->scratch);
   double* td = cv.take<double>(Tn);
   double* rd = cv.take<double>(Tn);
   double* coef = cv.take<double>(c->n_pad);
   double* fdr = cv.take<double>(c->n_pad);
+  double* coef_u = cv.take<double>(c->n_pad);
+  double* fdr_u = cv.take<double>(c->n_pad);
   if (want_fdr) {
     HIP_TRY(hipMemcpyAsync(td, thr, 8 * T, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(rd, runmin_fdr, 8 * T, hipMemcpyHostToDevice, c->stream));
   }
   CNA_TRY(launch_percell_fdr(c, td, rd, want_fdr ? T : 0, thr0, inv_step, coef + c->row0, want_fdr ? fdr + c->row0 : nullptr));
-  if (c->nranks > 1) {
+  const bool sharded = c->nranks > 1 || c->comm;
+  if (c->orig_idx) {
+    // back to the caller's numbering: every rank scatters its rows into a zeroed vector, the sum
+    // over ranks (x + 0 keeps NaNs and bit patterns) is the full answer
+    if (sharded) {
+      HIP_TRY(hipMemsetAsync(coef_u, 0, 8 * c->n_pad, c->stream));
+      if (want_fdr) HIP_TRY(hipMemsetAsync(fdr_u, 0, 8 * c->n_pad, c->stream));
+    }
+    CNA_TRY(launch_unpermute2(c, coef + c->row0, want_fdr ? fdr + c->row0 : nullptr, c->orig_idx, c->n_local, coef_u,
+                              fdr_u));
+    if (sharded) {
+      CNA_TRY(comm_allreduce_f64_sum(c, coef_u, (size_t)c->n_global));
+      if (want_fdr) CNA_TRY(comm_allreduce_f64_sum(c, fdr_u, (size_t)c->n_global));
+    }
+    coef = coef_u;
+    fdr = fdr_u;
+  } else if (c->nranks > 1) {
     const size_t block = 8 * (size_t)c->rows_per_rank;
     CNA_TRY(comm_allgather_bytes(c, (char*)coef + block * c->rank, coef, block));
     if (want_fdr) CNA_TRY(comm_allgather_bytes(c, (char*)fdr + block * c->rank, fdr, block));

@@ -66,6 +66,7 @@ struct cna_ctx {
   int data_f64 = 0;
   double self_weight = 1.0;
   double* colsum = nullptr;  // n_pad, replicated
+  int64_t* orig_idx = nullptr;  // n_local: caller's cell index of local row i; null = identity
   bool have_colsum = false;
 
   // ---- samples
@@ -174,6 +175,8 @@ int launch_obs_counts(cna_ctx* c, const double* edges_dev, const double* thr_dev
                       double inv_step, unsigned long long* hist_dev /* 2*T */);
 int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, int64_t* tails);
 int launch_tail_sums(cna_ctx* c, const int64_t* tails, int P, int T, int64_t* sums);
+int launch_unpermute2(cna_ctx* c, const double* a, const double* b, const int64_t* idx, int64_t n, double* oa,
+                      double* ob);
 int launch_percell_fdr(cna_ctx* c, const double* thr_dev, const double* runmin_dev, int T, double thr0,
                        double inv_step, double* coef_local, double* fdr_local);
 int launch_transpose(cna_ctx* c, const double* in, int64_t rows, int cols, int ld, double* out);

@@ -401,6 +401,16 @@ __global__ void k_scatter(const double* __restrict__ src, const int64_t* __restr
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nx) dst[keep ? keep[i] : i] = src[i];
 }
+// out[idx[i]] = in[i] for up to two vectors at once (per-cell outputs back in the caller's numbering)
+__global__ void k_unpermute2(const double* __restrict__ a, const double* __restrict__ b,
+                             const int64_t* __restrict__ idx, int64_t n, double* __restrict__ oa,
+                             double* __restrict__ ob) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t j = idx[i];
+  oa[j] = a[i];
+  if (b) ob[j] = b[i];
+}
 // fdr_i = min{fdr_t : thr_t <= |coef_i|} else 1 (_association.py:234-237)
 __global__ void k_percell_fdr(const double* __restrict__ coef, int64_t n, const double* __restrict__ thr,
                               const double* __restrict__ runmin, int T, double thr0, double inv_step,
@@ -560,6 +570,14 @@ int launch_percell_fdr(cna_ctx* c, const double* thr_dev, const double* runmin_d
   if (fdr_local)
     hipLaunchKernelGGL(k_percell_fdr, dim3(g), dim3(256), 0, c->stream, coef_local, n, thr_dev, runmin_dev, T,
                        thr0, inv_step, fdr_local);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_unpermute2(cna_ctx* c, const double* a, const double* b, const int64_t* idx, int64_t n, double* oa,
+                      double* ob) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_unpermute2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a, b, idx, n, oa, ob);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -11,7 +11,7 @@ import weakref
 import numpy as np
 import scipy.sparse as sp
 
-from . import _ffi
+from . import _ffi, _order
 from ._ffi import check, ptr, MAT_NAM, MAT_X
 
 
@@ -19,7 +19,7 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-class Engine:
+class Engine(_order.CellOrder):
     def __init__(self, device=None, rank=0, nranks=1, unique_id=None):
         self.lib = _ffi.load()
         if device is None:
@@ -86,7 +86,9 @@ class Engine:
                 str(A.data.dtype))
 
     def ensure_graph(self, A):
-        """Upload the connectivities graph unless this very matrix is already resident."""
+        """Upload the connectivities graph unless this very matrix is already resident.  The cells
+        are kept on the device in a locality-preserving order (see _order.py); everything that
+        crosses this class's boundary is in the caller's order."""
         if not sp.issparse(A):
             raise TypeError('connectivities must be a scipy.sparse matrix')
         if not sp.isspmatrix_csr(A) and not isinstance(A, sp.csr_array):
@@ -98,15 +100,26 @@ class Engine:
             return False
         n = A.shape[0]
         r0, r1 = self.block(n)
-        lo, hi = int(A.indptr[r0]), int(A.indptr[r1])
-        indptr = np.ascontiguousarray(A.indptr[r0:r1 + 1].astype(np.int64) - lo)
-        indices = np.ascontiguousarray(A.indices[lo:hi], dtype=np.int32)
-        if A.data.dtype == np.float32:
-            data, f64 = np.ascontiguousarray(A.data[lo:hi]), 0
+        perm = _order.locality_order(A)
+        if perm is None:
+            lo, hi = int(A.indptr[r0]), int(A.indptr[r1])
+            indptr = np.ascontiguousarray(A.indptr[r0:r1 + 1].astype(np.int64) - lo)
+            indices = np.ascontiguousarray(A.indices[lo:hi], dtype=np.int32)
+            data = A.data[lo:hi]
         else:
-            data, f64 = np.ascontiguousarray(A.data[lo:hi], dtype=np.float64), 1
+            indptr, indices, data = _order.permuted_rows(A, perm, r0, r1)
+        if data.dtype == np.float32:
+            data, f64 = np.ascontiguousarray(data), 0
+        else:
+            data, f64 = np.ascontiguousarray(data, dtype=np.float64), 1
         check(self.lib.cna_graph_upload(self.h, n, r0, r1 - r0, ptr(indptr), ptr(indices), ptr(data), f64),
               'cna_graph_upload')
+        if perm is not None:
+            check(self.lib.cna_set_cell_order(self.h, ptr(np.ascontiguousarray(perm[r0:r1]))), 'cna_set_cell_order')
+        self.perm = perm
+        self._keep_dev = None
+        self._kept_order_cache = None
+        self._x_is_selection = False
         self.n, self.row0, self.n_local = n, r0, r1 - r0
         self._graph_key = key
         try:
@@ -125,7 +138,7 @@ class Engine:
     def fetch_colsums(self):
         out = np.empty(self.n)
         check(self.lib.cna_fetch_colsums(self.h, ptr(out)), 'cna_fetch_colsums')
-        return out
+        return self.cells_to_user(out)
 
     # ---------------------------------------------------------------- NAM
     def set_samples(self, codes, n_samples, counts, token=None):
@@ -136,9 +149,9 @@ class Engine:
             check(self.lib.cna_restart_nam(self.h), 'cna_restart_nam')
             self.nam_epoch += 1
             return
-        codes = np.ascontiguousarray(codes, dtype=np.int32)
         if len(codes) != self.n:
             raise ValueError('need one sample code per cell')
+        codes = np.ascontiguousarray(self.cells_to_device(np.asarray(codes)), dtype=np.int32)
         counts = _f64(counts)
         check(self.lib.cna_set_samples(self.h, ptr(codes), int(n_samples), ptr(counts)), 'cna_set_samples')
         self.N = int(n_samples)
@@ -149,10 +162,12 @@ class Engine:
         check(self.lib.cna_nam_step(self.h, int(bool(want_kurt)), int(bool(may_continue)), int(bool(may_stop))),
               'cna_nam_step')
 
-    def cell_stat(self, n_expected):
+    def cell_stat(self, n_expected, nam_space=True):
+        """Per-cell statistic of the last kernel that made one: over all cells in the caller's
+        order (nam_space) or over the rows of X in device order (see x_stat())."""
         out = np.empty(int(n_expected))
         check(self.lib.cna_fetch_cell_stat(self.h, ptr(out), int(n_expected)), 'cna_fetch_cell_stat')
-        return out
+        return self.cells_to_user(out) if nam_space else out
 
     # ---------------------------------------------------------------- dense diffusion
     def dense_load(self, s_local):
@@ -181,21 +196,23 @@ class Engine:
         nz = C.c_int64(0)
         check(self.lib.cna_zero_variance(self.h, ptr(cm), 0 if cm is None else len(cm), ptr(flags), C.byref(nz)),
               'cna_zero_variance')
-        return flags.astype(bool), nz.value
+        return self.cells_to_user(flags.astype(bool)), nz.value
+
+    def _selection(self, keep_global):
+        self._x_is_selection = True
+        if keep_global is None:
+            self._keep_dev = None
+            self._kept_order_cache = None
+            self.x_rows_total = self.n
+            return None, 0
+        idx = self.local_keep(keep_global)
+        self.x_rows_total = int(np.count_nonzero(self._keep_dev))
+        return idx, len(idx)
 
     def select(self, keep_global, colmap):
         """keep_global: bool mask over all cells (or None = all); colmap: NAM column per output column."""
         cm = None if colmap is None else np.ascontiguousarray(colmap, dtype=np.int32)
-        if keep_global is None:
-            idx, nk = None, 0
-            self.x_rows_total = self.n
-            self._x_local = self.n_local
-        else:
-            keep_global = np.asarray(keep_global, dtype=bool)
-            idx = np.ascontiguousarray(np.flatnonzero(keep_global[self.row0:self.row0 + self.n_local]), dtype=np.int64)
-            nk = len(idx)
-            self.x_rows_total = int(keep_global.sum())
-            self._x_local = nk
+        idx, nk = self._selection(keep_global)
         check(self.lib.cna_select(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm)), 'cna_select')
         self.x_epoch += 1
 
@@ -203,14 +220,7 @@ class Engine:
         """select() + centre + divide by std in one pass (M = I); returns the number of selected
         cells with zero variance (non-zero: redo with zero_variance()/select())."""
         cm = None if colmap is None else np.ascontiguousarray(colmap, dtype=np.int32)
-        if keep_global is None:
-            idx, nk = None, 0
-            self.x_rows_total = self.n
-        else:
-            keep_global = np.asarray(keep_global, dtype=bool)
-            idx = np.ascontiguousarray(np.flatnonzero(keep_global[self.row0:self.row0 + self.n_local]), dtype=np.int64)
-            nk = len(idx)
-            self.x_rows_total = int(keep_global.sum())
+        idx, nk = self._selection(keep_global)
         nz = C.c_int64(0)
         check(self.lib.cna_select_standardized(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm),
                                                C.byref(nz)), 'cna_select_standardized')
@@ -220,8 +230,8 @@ class Engine:
     def upload_x(self, x_local):
         x_local = _f64(x_local)
         check(self.lib.cna_upload_x(self.h, ptr(x_local), x_local.shape[0], x_local.shape[1]), 'cna_upload_x')
-        self._x_local = x_local.shape[0]
         self.x_rows_total = x_local.shape[0]   # single-rank use (cna.tl.svd_nam)
+        self._x_is_selection = False
         self.x_epoch += 1
 
     # ---------------------------------------------------------------- residualise + PCA
@@ -261,6 +271,8 @@ class Engine:
         out = np.empty(rows) if fetch else None
         m = C.c_double(0.0)
         check(self.lib.cna_ncorrs(self.h, ptr(y), ptr(out), C.byref(m)), 'cna_ncorrs')
+        if fetch and self.nranks == 1:
+            out = self.kept_to_user(out)     # one rank: kept cells in the caller's order
         return out, m.value
 
     def null_local(self, Yc, edges):

@@ -19,7 +19,7 @@ import pandas as pd
 
 from .. import _ffi
 from ..engine import get_engine
-from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_plan, _resid_run, _gather_rows, sample_codes_cached,
+from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_plan, _resid_run, sample_codes_cached,
                    _small_svd, _defer_pcs, host_blas_threads)
 from ._out import select_output
 from ._stats import conditional_permutation, grouplevel_permutation, default_ks, minp_stats
@@ -336,7 +336,7 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         if engine.nam_epoch != nam_epoch:
             raise RuntimeError('res.nam lives on the GPU and a later cna_amd call has replaced it; '
                                'read it (or call res.materialize()) before running the next analysis')
-        full = _gather_rows(engine, engine.fetch_matrix(_ffi.MAT_NAM), engine.n)
+        full = engine.nam_full()
         return pd.DataFrame(full[kept][:, colmap].T, index=sample_index, columns=cell_index())
 
     res._defer('nam', fetch_nam)

@@ -176,19 +176,12 @@ def diffuse_stepwise(data, s, maxnsteps=15, show_progress=False, self_weight=1, 
     arr = np.asarray(s, dtype=np.float64)
     if arr.ndim != 2:
         raise ValueError('s must be 2-dimensional (cells x columns)')
-    r0, r1 = engine.block(arr.shape[0])
-    engine.dense_load(arr[r0:r1])
+    engine.dense_begin(arr)
     for i in range(maxnsteps):
         print('\ttaking step', i + 1, file=out)
         engine.dense_step()
-        cur = _gather_rows(engine, engine.dense_fetch(), arr.shape[0])
+        cur = engine.dense_state()
         yield pd.DataFrame(cur, index=frame.index, columns=frame.columns) if frame is not None else cur
-
-
-def _gather_rows(engine, local, n):
-    if engine.nranks == 1:
-        return local
-    return engine.gather_rows_host(local, n)
 
 
 def diffuse(data, s, nsteps, show_progress=False, self_weight=1, engine=None):
@@ -233,8 +226,7 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
                 medkurt = np.median(engine.cell_stat(n))
             if show_progress:
                 # R2(t, t-1) is scale free per column, so NAM = s/C serves as s (_nam.py:60)
-                cur = engine.fetch_matrix(_ffi.MAT_NAM)
-                cur = _gather_rows(engine, cur, n)
+                cur = engine.nam_full()
                 R2 = _column_r2(cur, old if old is not None else np.zeros_like(cur))
                 old = cur
                 print('\tmedian kurtosis:', medkurt + 3, file=out)
@@ -296,7 +288,7 @@ def nam(data, sid_name, batches=None, nsteps=None, self_weight=1, max_frac_pcs=0
     labels, _ = _nam_device(engine, data, sid_name, nsteps=nsteps, self_weight=self_weight,
                             show_progress=show_progress)
     keep = _qc_device(engine, labels, batches, show_progress=show_progress)
-    full = _gather_rows(engine, engine.fetch_matrix(_ffi.MAT_NAM), engine.n)   # cells x samples
+    full = engine.nam_full()   # cells x samples
     index = pd.Index(labels, name=sid_name)
     frame = pd.DataFrame(full[keep].T, index=index, columns=data.obs.index[keep], dtype=float)
     return frame, keep
@@ -318,7 +310,7 @@ def svd_nam(NAM, engine=None):
     with host_blas_threads(1):
         U, svs, _ = _small_svd(G)
     with np.errstate(all='ignore'):
-        V = engine.project(U / np.sqrt(svs))
+        V = engine.project_full(U / np.sqrt(svs))
     names = _pc_names(U.shape[1])
     index = NAM.index if isinstance(NAM, pd.DataFrame) else None
     columns = NAM.columns if isinstance(NAM, pd.DataFrame) else None
@@ -389,7 +381,7 @@ def _resid_run(engine, plan, cell_index, show_progress=False):
             engine.resid_apply(np.asarray(M.values, dtype=np.float64), center=first)
             first = False
             engine.batch_kurtosis(_ffi.MAT_X, plan.bcodes, plan.nb)
-            kurtoses = engine.cell_stat(engine.x_rows_total)
+            kurtoses = engine.x_stat()
             med = np.median(kurtoses)
             print('\twith ridge', ridge, 'median batch kurtosis = ', med, file=out)
             if med <= 6:
@@ -409,10 +401,7 @@ def _resid_run(engine, plan, cell_index, show_progress=False):
 
     def fetch_namresid():
         _still_resident(engine, epoch)
-        if engine.nranks == 1:
-            full_t = engine.fetch_matrix(_ffi.MAT_X, transposed=True)           # samples x cells
-        else:
-            full_t = _gather_rows(engine, engine.fetch_matrix(_ffi.MAT_X), n_cells).T
+        full_t = engine.x_full(transposed=True)           # samples x cells
         return pd.DataFrame(full_t, index=sample_index, columns=_names(cell_index))
 
     res._defer('namresid', fetch_namresid)
@@ -434,8 +423,7 @@ def _defer_pcs(res, engine, U, svs, cell_index):
     def fetch_V():
         _still_resident(engine, epoch)
         with np.errstate(all='ignore'):
-            V = engine.project(U / np.sqrt(svs))
-        V = _gather_rows(engine, V, n_cells)
+            V = engine.project_full(U / np.sqrt(svs))
         return pd.DataFrame(V, index=_names(cell_index), columns=names)
 
     res._defer('namresid_nbhdXpc', fetch_V)

@@ -72,6 +72,13 @@ int  cna_comm_init(cna_ctx* ctx, int rank, int nranks, const void* id128);
 int  cna_graph_upload(cna_ctx* ctx, int64_t n_global, int64_t row0, int64_t n_local,
                       const int64_t* indptr, const int32_t* indices,
                       const void* data, int data_is_f64);
+/* Optional: the rows handed to cna_graph_upload are a renumbering of the caller's cells (the
+ * reference never depends on cell order, _nam.py:25-34; a banded numbering makes the walk's
+ * gathers cache-friendly).  orig_index[i] = caller's index of local row i (n_local entries, a
+ * slice of one global permutation).  Effect: cna_percell_fdr returns its per-cell outputs in the
+ * caller's numbering; every other per-cell array crosses the ABI in library row order.  NULL
+ * (and every cna_graph_upload) resets to the identity. */
+int  cna_set_cell_order(cna_ctx* ctx, const int64_t* orig_index);
 /* colsums = A.sum(axis=0) + self_weight (_nam.py:28), float64, all-reduced over ranks */
 int  cna_colsums(cna_ctx* ctx, double self_weight);
 int  cna_fetch_colsums(cna_ctx* ctx, double* out_n_global);

@@ -13,6 +13,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from oracle import cna_oracle as orc
+from cna_amd import _order
 
 MAT_NAM, MAT_X = 0, 1
 
@@ -43,9 +44,13 @@ class GlooColl:
         return np.concatenate(box, axis=0)
 
 
-class FakeEngine:
-    def __init__(self, coll=None):
+class FakeEngine(_order.CellOrder):
+    """order: None (caller's cell order on the "device"), 'rcm' (what the real engine does), 'random'
+    or an explicit permutation -- the last two exercise every order conversion of _order.CellOrder."""
+
+    def __init__(self, coll=None, order=None):
         self.coll = coll
+        self.order = order
         self.rank = coll.rank if coll else 0
         self.nranks = coll.nranks if coll else 1
         self.n = self.row0 = self.n_local = self.N = 0
@@ -61,7 +66,7 @@ class FakeEngine:
         return self.coll.allgather(a) if self.coll else a
 
     def gather_rows_host(self, local, n_total):
-        out = self._gather(local)
+        out = self._gather(np.asarray(local))
         assert out.shape[0] == n_total
         return out
 
@@ -76,7 +81,22 @@ class FakeEngine:
         self.n = A.shape[0]
         r0, r1 = self.block(self.n)
         self.row0, self.n_local = r0, r1 - r0
-        self.A_local = A[r0:r1].astype(np.float64)
+        if self.order is None:
+            self.perm = None
+        elif self.order == 'random':
+            self.perm = np.random.RandomState(7).permutation(self.n).astype(np.int64)
+        elif self.order == 'rcm':
+            self.perm = _order.locality_order(A)
+        else:
+            self.perm = np.asarray(self.order, dtype=np.int64)
+        if self.perm is None:
+            self.A_local = A[r0:r1].astype(np.float64)
+        else:
+            indptr, indices, data = _order.permuted_rows(A, self.perm, r0, r1)
+            self.A_local = sp.csr_matrix((data.astype(np.float64), indices, indptr), shape=(r1 - r0, self.n))
+        self._keep_dev = None
+        self._kept_order_cache = None
+        self._x_is_selection = False
         self._w = None
         return True
 
@@ -86,11 +106,11 @@ class FakeEngine:
         self.w = self_weight
 
     def fetch_colsums(self):
-        return self.colsum.copy()
+        return self.cells_to_user(self.colsum.copy())
 
     # -- NAM
     def set_samples(self, codes, n_samples, counts, token=None):
-        self.codes = np.asarray(codes)
+        self.codes = self.cells_to_device(np.asarray(codes))
         self.N = int(n_samples)
         self.counts = np.asarray(counts, dtype=np.float64)
         S = np.zeros((self.n, self.N))
@@ -117,9 +137,9 @@ class FakeEngine:
             if want_kurt:
                 self.stat = orc.row_kurtosis(self.S / self.counts)
 
-    def cell_stat(self, n_expected):
+    def cell_stat(self, n_expected, nam_space=True):
         assert len(self.stat) == n_expected
-        return self.stat.copy()
+        return self.cells_to_user(self.stat.copy()) if nam_space else self.stat.copy()
 
     # -- dense diffusion
     def dense_load(self, s_local):
@@ -145,14 +165,20 @@ class FakeEngine:
         with np.errstate(all='ignore'):
             flags = sub.std(axis=1, ddof=1) == 0
         flags = self._gather(flags.astype(np.uint8)).astype(bool)
-        return flags, int(flags.sum())
+        return self.cells_to_user(flags), int(flags.sum())
 
     def select(self, keep_global, colmap):
-        loc = slice(self.row0, self.row0 + self.n_local)
-        rows = self.nam if keep_global is None else self.nam[np.asarray(keep_global, dtype=bool)[loc]]
+        self._x_is_selection = True
+        if keep_global is None:
+            self._keep_dev, self._kept_order_cache = None, None
+            rows, self.keep_local = self.nam, None
+        else:
+            idx = self.local_keep(keep_global)
+            rows = self.nam[idx]
+            self.keep_local = np.zeros(self.n_local, dtype=bool)
+            self.keep_local[idx] = True
         self.X = rows if colmap is None else rows[:, np.asarray(colmap)]
         self.X = np.array(self.X)
-        self.keep_local = None if keep_global is None else np.asarray(keep_global, dtype=bool)[loc]
         self.x_rows_total = self.n if keep_global is None else int(np.sum(keep_global))
         self.x_epoch += 1
 
@@ -168,6 +194,7 @@ class FakeEngine:
     def upload_x(self, x_local):
         self.X = np.array(x_local, dtype=np.float64)
         self.x_rows_total = self.X.shape[0]
+        self._x_is_selection = False
         self.x_epoch += 1
 
     # -- residualise + PCA
@@ -201,7 +228,10 @@ class FakeEngine:
         m = np.abs(self.nc).max() if len(self.nc) else 0.0
         if self.coll:
             m = self.coll.allreduce_max(m)
-        return (self.nc.copy() if fetch else None), float(m)
+        out = None
+        if fetch:
+            out = self.kept_to_user(self.nc.copy()) if self.nranks == 1 else self.nc.copy()
+        return out, float(m)
 
     def null_local(self, Yc, edges):
         z2 = (np.abs(self.X.dot(Yc)) / self.X.shape[1]) ** 2
@@ -241,7 +271,7 @@ class FakeEngine:
             coef[:] = self.nc
         else:
             coef[self.keep_local] = self.nc
-        coef = self._gather(coef)
+        coef = self.cells_to_user(self._gather(coef))
         if thr is None:
             return coef, None
         idx = np.searchsorted(thr, np.abs(coef), side='right') - 1

@@ -69,7 +69,7 @@ def test_diffusion_steps_vs_oracle_and_golden(eng, orc, name):
     for i in range(nst):
         s = orc.diffusion_step(A, s, colsums, 1, first_onehot=(i == 0), mode='f64')
         eng.nam_step(True, i + 1 < nst, True)
-        got = eng.fetch_matrix(_ffi.MAT_NAM)
+        got = eng.nam_full()
         want = s / S.sum(axis=0)
         assert relerr(got, want) < 1e-13, (i, relerr(got, want))
         assert relerr(got, z['steps'][i] / S.sum(axis=0)) < 1e-5          # the reference itself
@@ -77,7 +77,7 @@ def test_diffusion_steps_vs_oracle_and_golden(eng, orc, name):
         np.testing.assert_allclose(kurt, orc.row_kurtosis(want), rtol=1e-9, atol=1e-12)
         assert np.median(kurt) == pytest.approx(z['steps_medkurt'][i], rel=1e-5)
     # the walk is column-stochastic: every sample's row of the (samples x cells) NAM sums to 1
-    got = eng.fetch_matrix(_ffi.MAT_NAM)
+    got = eng.nam_full()
     np.testing.assert_allclose(got.sum(axis=0), 1.0, rtol=1e-10)
 
 
@@ -155,7 +155,7 @@ def test_dense_row_kernels_vs_numpy(eng, orc, n, N):
     nb = min(7, N)
     bc = np.arange(N) % nb
     eng.batch_kurtosis(_ffi.MAT_X, bc, nb)
-    np.testing.assert_allclose(eng.cell_stat(n), orc.batch_kurtosis(want, bc, nb), rtol=1e-9)
+    np.testing.assert_allclose(eng.x_stat(), orc.batch_kurtosis(want, bc, nb), rtol=1e-9)
     # neighbourhood coefficients
     y = rs.randn(N)
     nc, m = eng.ncorrs(y, fetch=True)
@@ -380,3 +380,42 @@ def test_association_wide_sample_axis_vs_oracle(eng, orc, n, N, extra):
     from helpers import sign_align
     V, Vref = sign_align(res.namresid_nbhdXpc.values, ref['V'], int(res.k))
     assert relerr(V, Vref) < 1e-6
+
+
+def test_results_do_not_depend_on_device_cell_order(monkeypatch):
+    """The engine renumbers cells (reverse Cuthill-McKee) for gather locality; per-row neighbour
+    order is preserved, so every field must be bit-identical to a run in the caller's order --
+    here a deliberately scrambled one, with QC dropping cells and a non-trivial M."""
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.engine import Engine
+    data, meta = synth.make_dataset(20000, 30, k=15, seed=11, n_covs=1, n_batches=3, cluster_sorted=False)
+    out = {}
+    for flag in ('0', '1'):
+        monkeypatch.setenv('CNA_REORDER', flag)
+        e = Engine(device=0)
+        try:
+            res = cna.tl.association(data, meta['y'], 'id', covs=meta['covs'], batches=meta['batches'], Nnull=200,
+                                     seed=3, return_full=True, engine=e)
+            assert (e.perm is None) == (flag == '0')
+            if flag == '1':
+                assert not np.array_equal(e.perm, np.arange(len(e.perm)))
+            out[flag] = dict(p=res.p, k=res.k, kept=res.kept.copy(), ncorrs=res.ncorrs.values.copy(),
+                             nam=res.nam.values.copy(), namresid=res.namresid.values.copy(),
+                             V=res.namresid_nbhdXpc.values.copy(), U=res.namresid_sampleXpc.values.copy(),
+                             fdr=res.fdrs.values.copy(), coef=data.obs['coef'].values.copy(),
+                             coef_fdr=data.obs['coef_fdr'].values.copy())
+            sw = cna.tl.diffuse(data, np.random.RandomState(0).rand(20000, 3), 2, engine=e)
+            out[flag]['diffuse'] = sw
+        finally:
+            e.close()
+    a, b = out['0'], out['1']
+    assert a['p'] == b['p'] and a['k'] == b['k']
+    for key in ('kept', 'nam', 'diffuse'):
+        np.testing.assert_array_equal(a[key], b[key])
+    # past the Gram matrix the sum over cells runs in a different order: equal to rounding
+    for key in ('ncorrs', 'namresid', 'coef', 'coef_fdr', 'fdr'):
+        np.testing.assert_allclose(a[key], b[key], rtol=1e-9, atol=1e-12, equal_nan=True)
+    # leading PCs only: the trailing ones span the (numerically) null space left by residualisation
+    for key in ('U', 'V'):
+        np.testing.assert_allclose(a[key][:, :15], b[key][:, :15], rtol=1e-6, atol=1e-9)

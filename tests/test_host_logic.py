@@ -18,11 +18,17 @@ from helpers import golden_names, load_case, run_product, assert_matches_golden,
 NAMES = golden_names()
 
 
-@pytest.mark.parametrize('name', NAMES)
-def test_association_host_logic(name):
+ORDERS = [(n, None) for n in NAMES] + [(n, 'rcm') for n in NAMES] + \
+         [(n, 'random') for n in ('c01_plain_f32', 'c03_covs_batches', 'c12_batchy_qc', 'c13_zero_variance')]
+
+
+@pytest.mark.parametrize('name,order', ORDERS)
+def test_association_host_logic(name, order):
+    """order: how the engine numbers the cells internally (tests/fake_engine.py) -- results must not
+    depend on it."""
     case = load_case(name)
     z = case['z']
-    res, err, msgs = run_product(case, FakeEngine())
+    res, err, msgs = run_product(case, FakeEngine(order=order))
     if z['raised'].item():
         assert err is not None and type(err).__name__ == z['raised'].item().split(':')[0]
         assert str(err) == z['raised'].item().split(': ', 1)[1]

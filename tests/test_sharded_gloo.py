@@ -32,7 +32,7 @@ def _worker(rank, world, port, name, q):
     from fake_engine import FakeEngine, GlooColl
     from helpers import load_case
     case = load_case(name)
-    eng = FakeEngine(GlooColl())
+    eng = FakeEngine(GlooColl(), order='rcm' if name != 'c13_zero_variance' else None)
     res = cna.tl.association(case['data'], case['y'], case['sid_name'], batches=case['batches'], covs=case['covs'],
                              donorids=case['donorids'], return_full=True, engine=eng, **case['call'])
     out = dict(p=res.p, k=int(res.k), ncorrs=res.ncorrs.values, kept=res.kept, fdr=res.fdrs.fdr.values,
