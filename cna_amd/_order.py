@@ -52,6 +52,39 @@ def permuted_rows(A, perm, r0, r1):
     return indptr, indices, np.ascontiguousarray(A.data[src])
 
 
+def halo_plan(indices, row0, n_local, rows_per_rank, rank, nranks, allgather_i64, force_self=0):
+    """Which state rows must travel between diffusion steps when the cells are sharded by row blocks.
+
+    indices: global column ids of this rank's CSR block.  allgather_i64(a): concatenation, in rank
+    order, of every rank's int64 vector a (lengths may differ).  Returns None when exchanging whole
+    blocks (the all-gather) moves about as little, else
+      (send_rows, send_counts, recv_rows, recv_counts)
+    send_rows: local rows other ranks reference, grouped by destination; recv_rows: global rows
+    this rank references outside its block, grouped by owner.  Every rank takes the same decision.
+    force_self > 0 (tests on one GPU): also "exchange" that many of the rank's own rows with itself."""
+    cols = np.unique(indices)
+    remote = cols[(cols < row0) | (cols >= row0 + n_local)].astype(np.int64)
+    if force_self:
+        own = np.arange(row0, row0 + n_local, max(1, n_local // force_self), dtype=np.int64)
+        remote = np.sort(np.concatenate([remote, own]))
+    owner = remote // rows_per_rank
+    recv_counts = np.bincount(owner, minlength=nranks).astype(np.int64)
+    want = allgather_i64(recv_counts).reshape(nranks, nranks)        # want[r, p]: rows r needs from p
+    n_global_remote = want.sum() - np.trace(want)
+    full = float(nranks) * (nranks - 1) * rows_per_rank               # rows an all-gather delivers
+    if not force_self and n_global_remote > 0.6 * full:
+        return None
+    lists = allgather_i64(remote)
+    starts = np.concatenate([[0], np.cumsum(want.sum(axis=1))])
+    send, send_counts = [], np.zeros(nranks, dtype=np.int64)
+    for r in range(nranks):
+        off = starts[r] + want[r, :rank].sum()
+        send.append(lists[off:off + want[r, rank]] - row0)
+        send_counts[r] = want[r, rank]
+    send_rows = np.concatenate(send).astype(np.int64) if send else np.zeros(0, dtype=np.int64)
+    return (np.ascontiguousarray(send_rows), send_counts, np.ascontiguousarray(remote), recv_counts)
+
+
 class CellOrder:
     """Mixin for engines: conversions between the caller's cell order and the device's.
 

@@ -27,6 +27,8 @@ int dev_free(cna_ctx* c, void* p, size_t bytes) {
   }
   return 0;
 }
+static void halo_clear(cna_ctx* c);
+
 int dev_reserve(cna_ctx* c, void** p, int64_t* cap, int64_t need) {
   if (need <= *cap && *p) return 0;
   if (*p) {
@@ -189,7 +191,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_flush(c);
   comm_destroy(c);
-  void* bufs[] = {c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+  void* bufs[] = {c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
                   c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -237,6 +239,7 @@ int cna_graph_upload(cna_ctx* c, int64_t n_global, int64_t row0, int64_t n_local
   if (c->orig_idx) dev_free(c, c->orig_idx, sizeof(int64_t) * c->n_local);
   c->indptr = nullptr; c->indices = nullptr; c->data = nullptr; c->colsum = nullptr; c->stat = nullptr;
   c->orig_idx = nullptr;
+  halo_clear(c);
   c->n_global = n_global;
   c->row0 = (int64_t)c->rank * rpr;
   c->n_local = n_local;
@@ -337,7 +340,9 @@ int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const doubl
     c->sid_n = c->n_global;
   }
   c->N = n_samples;
-  c->ld = round_up(n_samples, 4);
+  int ld_align = 4;
+  if (const char* e = getenv("CNA_LD_ALIGN")) ld_align = std::max(4, atoi(e));   // experiments
+  c->ld = round_up(n_samples, ld_align);
   HIP_TRY(hipMemcpyAsync(c->sid, codes, sizeof(int32_t) * c->n_global, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->counts, counts, sizeof(double) * n_samples, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -371,7 +376,60 @@ int cna_restart_nam(cna_ctx* c) {
   return 0;
 }
 
+static void halo_clear(cna_ctx* c) {
+  if (c->halo_send_idx) dev_free(c, c->halo_send_idx, sizeof(int64_t) * std::max<int64_t>(c->halo_ns, 1));
+  if (c->halo_recv_idx) dev_free(c, c->halo_recv_idx, sizeof(int64_t) * std::max<int64_t>(c->halo_nr, 1));
+  c->halo_send_idx = c->halo_recv_idx = nullptr;
+  c->halo_ns = c->halo_nr = 0;
+  c->halo_on = false;
+}
+
+int cna_set_halo(cna_ctx* c, const int64_t* send_rows, const int64_t* send_counts, const int64_t* recv_rows,
+                 const int64_t* recv_counts) {
+  CHECK_CTX(c);
+  if (!c->indptr) CNA_FAIL(CNA_ESTATE, "cna_set_halo before cna_graph_upload");
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  halo_clear(c);
+  if (!send_counts || !recv_counts) return 0;
+  if (!c->comm) CNA_FAIL(CNA_ESTATE, "cna_set_halo needs cna_comm_init");
+  int64_t ns = 0, nr = 0;
+  for (int p = 0; p < c->nranks; ++p) {
+    if (send_counts[p] < 0 || recv_counts[p] < 0) CNA_FAIL(CNA_EINVAL, "cna_set_halo: negative count");
+    ns += send_counts[p];
+    nr += recv_counts[p];
+  }
+  if ((ns > 0 && !send_rows) || (nr > 0 && !recv_rows)) CNA_FAIL(CNA_EINVAL, "cna_set_halo: missing row list");
+  for (int64_t k = 0; k < ns; ++k)
+    if (send_rows[k] < 0 || send_rows[k] >= c->n_local) CNA_FAIL(CNA_EINVAL, "cna_set_halo: send row outside the local block");
+  for (int64_t k = 0; k < nr; ++k)
+    if (recv_rows[k] < 0 || recv_rows[k] >= c->n_global) CNA_FAIL(CNA_EINVAL, "cna_set_halo: recv row out of range");
+  CNA_TRY(dev_alloc(c, (void**)&c->halo_send_idx, sizeof(int64_t) * std::max<int64_t>(ns, 1)));
+  c->halo_ns = ns;
+  CNA_TRY(dev_alloc(c, (void**)&c->halo_recv_idx, sizeof(int64_t) * std::max<int64_t>(nr, 1)));
+  c->halo_nr = nr;
+  if (ns) HIP_TRY(hipMemcpy(c->halo_send_idx, send_rows, sizeof(int64_t) * ns, hipMemcpyHostToDevice));
+  if (nr) HIP_TRY(hipMemcpy(c->halo_recv_idx, recv_rows, sizeof(int64_t) * nr, hipMemcpyHostToDevice));
+  c->halo_send_cnt.assign(send_counts, send_counts + c->nranks);
+  c->halo_recv_cnt.assign(recv_counts, recv_counts + c->nranks);
+  c->halo_on = true;
+  return 0;
+}
+
+// Between diffusion steps every rank needs the state rows of its cells' neighbours.  Default: ring
+// all-gather of the row blocks (every rank ends up with everything).  With cna_set_halo: pack the
+// rows other ranks asked for, one grouped send/recv per peer, scatter what arrives -- with a banded
+// cell order that is a few per cent of the all-gather volume.
 static int exchange_state(cna_ctx* c, double* T) {
+  if (c->halo_on) {
+    const int ld = c->t_ld;
+    CNA_TRY(dev_reserve(c, &c->halo_sbuf, &c->halo_sbuf_cap, 8 * std::max<int64_t>(c->halo_ns, 1) * ld));
+    CNA_TRY(dev_reserve(c, &c->halo_rbuf, &c->halo_rbuf_cap, 8 * std::max<int64_t>(c->halo_nr, 1) * ld));
+    CNA_TRY(launch_pack_rows(c, T + c->row0 * ld, c->halo_send_idx, c->halo_ns, ld, (double*)c->halo_sbuf));
+    if (c->halo_ns + c->halo_nr > 0)
+      CNA_TRY(comm_halo_exchange(c, (const double*)c->halo_sbuf, (double*)c->halo_rbuf, ld));
+    CNA_TRY(launch_unpack_rows(c, (const double*)c->halo_rbuf, c->halo_recv_idx, c->halo_nr, ld, T));
+    return 0;
+  }
   if (c->nranks == 1) return 0;
   const size_t block = sizeof(double) * (size_t)c->rows_per_rank * c->t_ld;
   return comm_allgather_bytes(c, (char*)T + block * c->rank, T, block);

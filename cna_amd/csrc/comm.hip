@@ -17,6 +17,10 @@ struct Rccl {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -35,6 +39,10 @@ int rccl_load() {
   SYM(CommDestroy);
   SYM(AllReduce);
   SYM(AllGather);
+  SYM(Send);
+  SYM(Recv);
+  SYM(GroupStart);
+  SYM(GroupEnd);
   SYM(GetErrorString);
 #undef SYM
   g_rccl.h = h;
@@ -101,5 +109,30 @@ int comm_allgather_bytes(cna_ctx* c, const void* send, void* recv, size_t bytes_
   if (!c->comm) CNA_FAIL(CNA_ESTATE, "multi-rank context without cna_comm_init");
   ProfScope ps(c, CNA_K_ALLGATHER);
   NCCL_TRY(g_rccl.AllGather(send, recv, bytes_per_rank, ncclInt8, (ncclComm_t)c->comm, c->stream));
+  return 0;
+}
+
+// Point-to-point exchange of packed state rows: rank p receives halo_send_cnt[p] rows from us and
+// sends us halo_recv_cnt[p]; one grouped launch, so the xGMI links to all peers run concurrently.
+int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t doubles_per_row) {
+  if (!c->comm) CNA_FAIL(CNA_ESTATE, "halo exchange without cna_comm_init");
+  ProfScope ps(c, CNA_K_ALLGATHER);
+  NCCL_TRY(g_rccl.GroupStart());
+  int64_t so = 0, ro = 0;
+  ncclResult_t bad = ncclSuccess;
+  for (int p = 0; p < c->nranks; ++p) {
+    const int64_t ns = c->halo_send_cnt[p], nr = c->halo_recv_cnt[p];
+    if (ns > 0 && bad == ncclSuccess)
+      bad = g_rccl.Send(sendbuf + so * doubles_per_row, (size_t)(ns * doubles_per_row), ncclFloat64, p,
+                        (ncclComm_t)c->comm, c->stream);
+    if (nr > 0 && bad == ncclSuccess)
+      bad = g_rccl.Recv(recvbuf + ro * doubles_per_row, (size_t)(nr * doubles_per_row), ncclFloat64, p,
+                        (ncclComm_t)c->comm, c->stream);
+    so += ns;
+    ro += nr;
+  }
+  ncclResult_t end = g_rccl.GroupEnd();
+  if (bad != ncclSuccess) CNA_FAIL(CNA_ERCCL, std::string("ncclSend/ncclRecv: ") + g_rccl.GetErrorString(bad));
+  NCCL_TRY(end);
   return 0;
 }

@@ -57,6 +57,15 @@ struct cna_ctx {
   // ---- communicator
   int rank = 0, nranks = 1;
   void* comm = nullptr;  // ncclComm_t
+  // neighbour ("halo") exchange of the diffusion state, replacing the all-gather (cna_set_halo)
+  bool halo_on = false;
+  int64_t* halo_send_idx = nullptr;   // device: local rows to ship, grouped by destination rank
+  int64_t* halo_recv_idx = nullptr;   // device: global rows received, grouped by source rank
+  std::vector<int64_t> halo_send_cnt, halo_recv_cnt;
+  int64_t halo_ns = 0, halo_nr = 0;
+  void* halo_sbuf = nullptr;
+  void* halo_rbuf = nullptr;
+  int64_t halo_sbuf_cap = 0, halo_rbuf_cap = 0;
 
   // ---- graph (local row block)
   int64_t n_global = 0, row0 = 0, n_local = 0, rows_per_rank = 0, n_pad = 0, nnz = 0;
@@ -151,6 +160,9 @@ int dev_free(cna_ctx* c, void* p, size_t bytes);
 int dev_reserve(cna_ctx* c, void** p, int64_t* cap_bytes, int64_t need_bytes);
 
 // ---- collectives (comm.hip)
+int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t doubles_per_row);
+int launch_pack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst);
+int launch_unpack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst);
 int comm_allreduce_f64_sum(cna_ctx* c, double* buf, size_t count);
 int comm_allreduce_f64_max(cna_ctx* c, double* buf, size_t count);
 int comm_allreduce_i64_sum(cna_ctx* c, int64_t* buf, size_t count);

@@ -411,6 +411,23 @@ __global__ void k_unpermute2(const double* __restrict__ a, const double* __restr
   oa[j] = a[i];
   if (b) ob[j] = b[i];
 }
+// dst[k] = src[idx[k]] / dst[idx[k]] = src[k] for whole rows of ld doubles (16-byte lanes)
+__global__ void k_pack_rows(const double2* __restrict__ src, const int64_t* __restrict__ idx, int64_t nrows,
+                            int ld2, double2* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows * ld2) return;
+  const int64_t k = i / ld2;
+  const int col = (int)(i - k * ld2);
+  dst[i] = src[idx[k] * ld2 + col];
+}
+__global__ void k_unpack_rows(const double2* __restrict__ src, const int64_t* __restrict__ idx, int64_t nrows,
+                              int ld2, double2* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nrows * ld2) return;
+  const int64_t k = i / ld2;
+  const int col = (int)(i - k * ld2);
+  dst[idx[k] * ld2 + col] = src[i];
+}
 // fdr_i = min{fdr_t : thr_t <= |coef_i|} else 1 (_association.py:234-237)
 __global__ void k_percell_fdr(const double* __restrict__ coef, int64_t n, const double* __restrict__ thr,
                               const double* __restrict__ runmin, int T, double thr0, double inv_step,
@@ -578,6 +595,23 @@ int launch_unpermute2(cna_ctx* c, const double* a, const double* b, const int64_
                       double* ob) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_unpermute2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, a, b, idx, n, oa, ob);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_pack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst) {
+  if (nrows == 0) return 0;
+  const int64_t work = nrows * (ld / 2);
+  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, c->stream, (const double2*)src,
+                     idx, nrows, ld / 2, (double2*)dst);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int launch_unpack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst) {
+  if (nrows == 0) return 0;
+  const int64_t work = nrows * (ld / 2);
+  hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, c->stream,
+                     (const double2*)src, idx, nrows, ld / 2, (double2*)dst);
   HIP_TRY(hipGetLastError());
   return 0;
 }

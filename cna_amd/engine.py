@@ -31,6 +31,7 @@ class Engine(_order.CellOrder):
         self.rank, self.nranks = int(rank), int(nranks)
         if nranks > 1 and unique_id is None:
             raise ValueError('nranks > 1 needs the RCCL unique id created by rank 0')
+        self._has_comm = unique_id is not None
         if unique_id is not None:   # also with one rank: every collective then really goes through RCCL
             buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
             check(self.lib.cna_comm_init(self.h, self.rank, self.nranks, C.cast(buf, C.c_void_p)), 'cna_comm_init')
@@ -116,6 +117,17 @@ class Engine(_order.CellOrder):
               'cna_graph_upload')
         if perm is not None:
             check(self.lib.cna_set_cell_order(self.h, ptr(np.ascontiguousarray(perm[r0:r1]))), 'cna_set_cell_order')
+        self.halo = None
+        if self.nranks > 1 or (self._has_comm and os.environ.get('CNA_HALO_SELFTEST')):
+            self.n, self.row0, self.n_local = n, r0, r1 - r0
+            plan = _order.halo_plan(indices, r0, r1 - r0, -(-n // self.nranks), self.rank, self.nranks,
+                                    self._allgather_i64,
+                                    force_self=int(os.environ.get('CNA_HALO_SELFTEST', '0')))
+            if plan is not None and os.environ.get('CNA_HALO', '1') not in ('0', 'off'):
+                send_rows, send_counts, recv_rows, recv_counts = plan
+                check(self.lib.cna_set_halo(self.h, ptr(send_rows), ptr(send_counts), ptr(recv_rows),
+                                            ptr(recv_counts)), 'cna_set_halo')
+                self.halo = (int(send_counts.sum()), int(recv_counts.sum()))
         self.perm = perm
         self._keep_dev = None
         self._kept_order_cache = None
@@ -361,6 +373,18 @@ class Engine(_order.CellOrder):
         cols = local.shape[1] if local.ndim == 2 else 1
         out = np.empty((int(n_total), cols) if local.ndim == 2 else int(n_total))
         check(self.lib.cna_allgather_host(self.h, ptr(local), local.size, ptr(out), out.size), 'cna_allgather_host')
+        return out
+
+    def _allgather_i64(self, a):
+        """Concatenation over ranks of int64 vectors of differing lengths (graph preparation)."""
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        if self.nranks == 1:
+            return a.copy()
+        sizes = np.zeros(self.nranks)
+        check(self.lib.cna_allgather_host(self.h, ptr(np.array([float(len(a))])), 1, ptr(sizes), self.nranks),
+              'cna_allgather_host')
+        out = np.empty(int(sizes.sum()), dtype=np.int64)
+        check(self.lib.cna_allgather_host(self.h, ptr(a), len(a), ptr(out), len(out)), 'cna_allgather_host')
         return out
 
     # ---------------------------------------------------------------- measurement

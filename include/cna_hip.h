@@ -65,6 +65,15 @@ int  cna_ctx_device_bytes(cna_ctx* ctx, int64_t* bytes);
 int  cna_comm_unique_id(void* id128);
 int  cna_comm_init(cna_ctx* ctx, int rank, int nranks, const void* id128);
 
+/* Neighbour ("halo") exchange of the diffusion state between steps instead of the all-gather.
+ * After cna_graph_upload on every rank: send_rows = LOCAL row indices other ranks need, grouped by
+ * destination rank (send_counts[nranks]); recv_rows = GLOBAL row indices this rank's cells
+ * reference outside its block, grouped by owner rank (recv_counts[nranks]); the lists of two
+ * peers must mirror each other.  NULL counts (and every cna_graph_upload) switch back to the
+ * all-gather.  The walk itself is the reference's (_nam.py:31-34); only the data motion differs. */
+int  cna_set_halo(cna_ctx* ctx, const int64_t* send_rows, const int64_t* send_counts,
+                  const int64_t* recv_rows, const int64_t* recv_counts);
+
 /* ---- graph: data.obsp['connectivities'] (_nam.py:12-19,25) ---------------------------- */
 /* CSR rows [row0, row0+n_local) of the n_global x n_global kNN graph.  indptr has n_local+1
  * entries rebased so indptr[0]==0; column indices are global.  data is float32 (what scanpy

@@ -43,6 +43,11 @@ class GlooColl:
         self.td.all_gather_object(box, np.ascontiguousarray(a))
         return np.concatenate(box, axis=0)
 
+    def allgather_object(self, obj):
+        box = [None] * self.nranks
+        self.td.all_gather_object(box, obj)
+        return box
+
 
 class FakeEngine(_order.CellOrder):
     """order: None (caller's cell order on the "device"), 'rcm' (what the real engine does), 'random'
@@ -64,6 +69,23 @@ class FakeEngine(_order.CellOrder):
 
     def _gather(self, a):
         return self.coll.allgather(a) if self.coll else a
+
+    def _exchange(self, new_local):
+        """State rows after a step, as the next step sees them: everything (all-gather) or, with a
+        halo plan, only the own block and the rows the plan delivers -- the rest is NaN, so a plan
+        that misses a needed row poisons the result."""
+        if self.halo is None:
+            return self._gather(new_local)
+        send_rows, send_counts, recv_rows, recv_counts = self.halo
+        so = np.concatenate([[0], np.cumsum(send_counts)])
+        ro = np.concatenate([[0], np.cumsum(recv_counts)])
+        parcels = {p: new_local[send_rows[so[p]:so[p + 1]]] for p in range(self.nranks)}
+        box = self.coll.allgather_object(parcels)
+        out = np.full((self.n, new_local.shape[1]), np.nan)
+        out[self.row0:self.row0 + self.n_local] = new_local
+        for p in range(self.nranks):
+            out[recv_rows[ro[p]:ro[p + 1]]] = box[p][self.rank]
+        return out
 
     def gather_rows_host(self, local, n_total):
         out = self._gather(np.asarray(local))
@@ -97,6 +119,10 @@ class FakeEngine(_order.CellOrder):
         self._keep_dev = None
         self._kept_order_cache = None
         self._x_is_selection = False
+        self.halo = None
+        if self.coll:       # same plan the real engine hands to cna_set_halo
+            self.halo = _order.halo_plan(self.A_local.indices, r0, r1 - r0, -(-self.n // self.nranks), self.rank,
+                                         self.nranks, lambda a: self.coll.allgather(np.asarray(a, dtype=np.int64)))
         self._w = None
         return True
 
@@ -129,13 +155,13 @@ class FakeEngine(_order.CellOrder):
     def nam_step(self, want_kurt, may_continue, may_stop):
         self.calls.append(('nam_step', bool(want_kurt), bool(may_continue), bool(may_stop)))
         new_local = self._step(self.S)
-        self.S = self._gather(new_local)
+        self.S = self._exchange(new_local)
         self.steps += 1
         with np.errstate(all='ignore'):
             if may_stop:
                 self.nam = new_local / self.counts
             if want_kurt:
-                self.stat = orc.row_kurtosis(self.S / self.counts)
+                self.stat = self._gather(orc.row_kurtosis(new_local / self.counts))
 
     def cell_stat(self, n_expected, nam_space=True):
         assert len(self.stat) == n_expected
@@ -143,11 +169,11 @@ class FakeEngine(_order.CellOrder):
 
     # -- dense diffusion
     def dense_load(self, s_local):
-        self.D = self._gather(np.asarray(s_local, dtype=np.float64))
+        self.D = self._exchange(np.asarray(s_local, dtype=np.float64))
 
     def dense_step(self):
         self.D_local = self._step(self.D)
-        self.D = self._gather(self.D_local)
+        self.D = self._exchange(self.D_local)
 
     def dense_fetch(self):
         return self.D_local.copy()

@@ -302,15 +302,25 @@ def test_properties_at_scale(eng):
     assert 1 / 501 <= res.p <= 1 and len(res.nullminps) == 500
 
 
-def test_rccl_path_with_one_rank(orc):
+@pytest.mark.parametrize('selftest', [0, 40])
+def test_rccl_path_with_one_rank(orc, monkeypatch, selftest):
     """The collectives of the sharded path (all-reduce / all-gather through librccl.so) on a
-    one-rank communicator: same answers as without a communicator."""
+    one-rank communicator: same answers as without a communicator.  selftest > 0 additionally
+    routes the state exchange between diffusion steps through the halo path (pack kernel, grouped
+    ncclSend/ncclRecv -- here to the rank itself -- and unpack kernel) for that many rows."""
     from cna_amd.engine import Engine
     case = load_case('c12_batchy_qc')
+    if selftest:
+        monkeypatch.setenv('CNA_HALO_SELFTEST', str(selftest))
     e = Engine(device=0, rank=0, nranks=1, unique_id=Engine.new_unique_id())
     try:
         res, err, _ = run_product(case, e)
         assert err is None, repr(err)
+        assert (e.halo is not None and e.halo[0] == e.halo[1] >= selftest) if selftest else e.halo is None
+        import cna_amd as cna
+        A = sp.csr_matrix(case['data'].obsp['connectivities'])
+        s0 = np.random.RandomState(1).rand(A.shape[0], 5)
+        assert relerr(cna.tl.diffuse(case['data'], s0, 3, engine=e), orc.diffuse(A, s0, 3, mode='f64')) < 1e-14
         assert_matches_golden(res, case['data'], case['z'], tol=1e-5)
         prof_names = e.prof()
     finally:

@@ -38,30 +38,39 @@ def _worker(rank, world, port, name, q):
     out = dict(p=res.p, k=int(res.k), ncorrs=res.ncorrs.values, kept=res.kept, fdr=res.fdrs.fdr.values,
                num=res.fdrs.num_detected.values, coef=case['data'].obs['coef'].values,
                coef_fdr=case['data'].obs['coef_fdr'].values, nam=res.nam.values, namresid=res.namresid.values,
-               V=res.namresid_nbhdXpc.values, rows=(eng.row0, eng.n_local))
+               V=res.namresid_nbhdXpc.values, rows=(eng.row0, eng.n_local),
+               halo=None if eng.halo is None else (int(eng.halo[1].sum()), int(eng.halo[3].sum())))
     q.put((rank, out))
     td.barrier()
     td.destroy_process_group()
 
 
-@pytest.mark.parametrize('name', ['c01_plain_f32', 'c12_batchy_qc', 'c13_zero_variance'])
-def test_two_rank_sharded_equals_reference(name):
+@pytest.mark.parametrize('name,world', [('c01_plain_f32', 2), ('c12_batchy_qc', 2), ('c13_zero_variance', 2),
+                                        ('c03_covs_batches', 4)])
+def test_sharded_equals_reference(name, world):
     import torch.multiprocessing as mp
     from helpers import load_case, relerr
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, name, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=180) for _ in range(2))
+    got = dict(q.get(timeout=180) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     z = load_case(name)['z']
     a, b = got[0], got[1]
     n = len(z['kept'])
-    assert a['rows'] == (0, (n + 1) // 2) and b['rows'] == ((n + 1) // 2, n - (n + 1) // 2)
+    print('halo rows (sent, received):', [got[r]['halo'] for r in range(world)])
+    rpr = -(-n // world)
+    for r in range(world):
+        assert got[r]['rows'] == (min(r * rpr, n), max(0, min(rpr, n - r * rpr)))
+    if world > 2:   # several peers per rank: what is sent overall is what is received overall
+        assert sum(got[r]['halo'][0] for r in range(world)) == sum(got[r]['halo'][1] for r in range(world)) > 0
+    for r in range(2, world):
+        np.testing.assert_array_equal(got[r]['coef'], a['coef'])
     for key in ('p', 'k'):
         assert a[key] == b[key]
     for key in ('ncorrs', 'kept', 'fdr', 'num', 'coef', 'coef_fdr', 'nam', 'namresid'):
