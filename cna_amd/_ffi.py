@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libcna_hip.so')
+LIB_PATH = os.environ.get('CNA_HIP_LIB') or os.path.join(_HERE, 'libcna_hip.so')   # override: kernel experiments
 
 c_ctx = C.c_void_p
 c_i64p = C.POINTER(C.c_int64)
@@ -53,7 +53,7 @@ SIGNATURES = {
     'cna_project': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p]),
     'cna_ncorrs': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, c_f64p]),
     'cna_null_local': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
-    'cna_condition_phenotypes': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int]),
+    'cna_condition_phenotypes': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     'cna_null_local_resident': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'cna_null_local_launch': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     'cna_null_local_fetch': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),

@@ -841,15 +841,16 @@ static void exact_cuts(const double* edges, int T, int Nx, std::vector<double>& 
   }
 }
 
-static int ensure_zc(cna_ctx* c, int P) {
+static int ensure_zc(cna_ctx* c, int N, int P, hipStream_t st) {
   const int ldy = round_up(P, 64) + 64;   // one spare tile: a resident read may start at any column
+  const int rows = round_up(N, 4);        // = ldx of a working matrix with N samples
   void* p = c->zc;
-  CNA_TRY(dev_reserve(c, &p, &c->zc_cap, (int64_t)sizeof(double) * c->ldx * ldy));
+  CNA_TRY(dev_reserve(c, &p, &c->zc_cap, (int64_t)sizeof(double) * rows * ldy));
   c->zc = (double*)p;
-  HIP_TRY(hipMemsetAsync(c->zc, 0, sizeof(double) * c->ldx * ldy, c->stream));   // zero pads (rows >= Nx, cols >= P)
+  HIP_TRY(hipMemsetAsync(c->zc, 0, sizeof(double) * rows * ldy, st));   // zero pads (rows >= N, cols >= P)
   c->zc_ld = ldy;
   c->zc_cols = P;
-  c->zc_rows = c->Nx;
+  c->zc_rows = N;
   return 0;
 }
 
@@ -930,7 +931,7 @@ int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int
   CHECK_CTX(c);
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
   if (P < 1) CNA_FAIL(CNA_EINVAL, "cna_null_local: P must be positive");
-  CNA_TRY(ensure_zc(c, P));
+  CNA_TRY(ensure_zc(c, c->Nx, P, c->stream));
   HIP_TRY(hipMemcpy2DAsync(c->zc, sizeof(double) * c->zc_ld, Yc, sizeof(double) * P, sizeof(double) * P, c->Nx,
                            hipMemcpyHostToDevice, c->stream));
   return null_local_on_resident(c, 0, P, edges, T, tails_out, nullptr);
@@ -943,23 +944,26 @@ int cna_null_local_resident(cna_ctx* c, int col0, int P, const double* edges, in
   return null_local_on_resident(c, col0, P, edges, T, tails_out, tail_sums_out);
 }
 
-int cna_condition_phenotypes(cna_ctx* c, const double* M, const double* Y, int P) {
+int cna_condition_phenotypes(cna_ctx* c, const double* M, const double* Y, int N, int P) {
   CHECK_CTX(c);
-  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
   if (P < 1) CNA_FAIL(CNA_EINVAL, "P must be positive");
-  const int N = c->Nx;
   if (N < 2) CNA_FAIL(CNA_EINVAL, "need at least two samples");
-  CNA_TRY(ensure_zc(c, P));
+  if (c->null_pending) CNA_FAIL(CNA_ESTATE, "a local-null pass is still pending: fetch it first");
+  // Sample-space only, so it runs on the second stream: the caller may issue it while the diffusion
+  // kernels of the same analysis are still executing on the main stream.  Synchronised before
+  // returning, hence complete for every later consumer on either stream.
+  hipStream_t st = c->copy_stream;
+  CNA_TRY(ensure_zc(c, N, P, st));
   void* g = c->gt;
   CNA_TRY(dev_reserve(c, &g, &c->gt_cap, carve_bytes({8 * (int64_t)N * N, 8 * (int64_t)N * P})));
   c->gt = g;
   Carver cv(c->gt);
   double* Md = cv.take<double>((int64_t)N * N);
   double* Yd = cv.take<double>((int64_t)N * P);
-  HIP_TRY(hipMemcpyAsync(Md, M, 8 * (size_t)N * N, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipMemcpyAsync(Yd, Y, 8 * (size_t)N * P, hipMemcpyHostToDevice, c->stream));
-  CNA_TRY(launch_condition(c, Md, Yd, N, P, c->zc, c->zc_ld));
-  HIP_TRY(hipStreamSynchronize(c->stream));               // host buffers may be released
+  HIP_TRY(hipMemcpyAsync(Md, M, 8 * (size_t)N * N, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(Yd, Y, 8 * (size_t)N * P, hipMemcpyHostToDevice, st));
+  CNA_TRY(launch_condition(c, st, Md, Yd, N, P, c->zc, c->zc_ld));
+  HIP_TRY(hipStreamSynchronize(st));               // host buffers may be released
   return 0;
 }
 

@@ -199,7 +199,8 @@ int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const do
                       double cut0, double inv_step, double eps, unsigned long long* hist_dev);
 
 // stats.hip
-int launch_condition(cna_ctx* c, const double* M_dev, const double* Y_dev, int N, int P, double* Zc_dev, int ldy);
+int launch_condition(cna_ctx* c, hipStream_t st, const double* M_dev, const double* Y_dev, int N, int P,
+                     double* Zc_dev, int ldy);
 int launch_global_test(cna_ctx* c, hipStream_t st, const double* Zc_dev, int ldy, int N, int P, const double* U_dev,
                        int kmax, const int32_t* ks_dev, int K, int r, double* minp_dev, double* r2_dev,
                        int32_t* kidx_dev);

@@ -142,11 +142,12 @@ __global__ __launch_bounds__(64) void k_global_test(const double* __restrict__ Z
 
 }  // namespace
 
-int launch_condition(cna_ctx* c, const double* M_dev, const double* Y_dev, int N, int P, double* Zc_dev, int ldy) {
+int launch_condition(cna_ctx* c, hipStream_t st, const double* M_dev, const double* Y_dev, int N, int P,
+                     double* Zc_dev, int ldy) {
   if (P == 0) return 0;
   if (N > 512) CNA_FAIL(CNA_EINVAL, "more than 512 samples are not supported");
-  ProfScope ps(c, CNA_K_CONDITION);
-  hipLaunchKernelGGL(k_condition, dim3(P), dim3(64), sizeof(double) * N, c->stream, M_dev, Y_dev, N, P, Zc_dev, ldy);
+  ProfScope ps(c, CNA_K_CONDITION, st);
+  hipLaunchKernelGGL(k_condition, dim3(P), dim3(64), sizeof(double) * N, st, M_dev, Y_dev, N, P, Zc_dev, ldy);
   HIP_TRY(hipGetLastError());
   return 0;
 }

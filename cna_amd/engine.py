@@ -296,9 +296,13 @@ class Engine(_order.CellOrder):
         return tails
 
     def condition(self, M, Y):
-        """Zc = M.Y / std(M.Y, ddof=1) per column, kept on the device (column 0: observed phenotype)."""
+        """Zc = M.Y / std(M.Y, ddof=1) per column, kept on the device (column 0: observed phenotype).
+        Sample space only and on the second stream: may be issued while the diffusion is running."""
         M, Y = _f64(M), _f64(Y)
-        check(self.lib.cna_condition_phenotypes(self.h, ptr(M), ptr(Y), Y.shape[1]), 'cna_condition_phenotypes')
+        if M.shape != (Y.shape[0], Y.shape[0]):
+            raise ValueError('M must be square with one row per phenotype entry')
+        check(self.lib.cna_condition_phenotypes(self.h, ptr(M), ptr(Y), Y.shape[0], Y.shape[1]),
+              'cna_condition_phenotypes')
         self._zc_cols = Y.shape[1]
 
     def null_local_resident(self, col0, P, edges, sums_only=False):

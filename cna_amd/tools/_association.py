@@ -56,7 +56,7 @@ def _draw_null(y, batches, donorids, Nnull=1000, force_permute_all=False, seed=N
 
 
 def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_progress=False,
-                 npcs=None, n_cells=None):
+                 npcs=None, n_cells=None, conditioned=False):
     """Body of the reference's ``_association`` (_association.py:24-129) against the
     residualised NAM held by ``engine`` (cells x samples), whose Gram-matrix kernels have been
     queued.  ``res`` is the namespace from the residualisation (M, r), ``y`` / ``y_`` the
@@ -80,8 +80,10 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     ks_arr = np.asarray(ks)
     Mv = np.asarray(M, dtype=np.float64)
 
-    # phenotypes -> device: Zc = M.[y, y_] / std (ddof=1), resident for both tests
-    engine.condition(Mv, np.column_stack([y, y_]))
+    # phenotypes -> device: Zc = M.[y, y_] / std (ddof=1), resident for both tests (already there
+    # when the caller could issue it under the diffusion kernels)
+    if not conditioned:
+        engine.condition(Mv, np.column_stack([y, y_]))
     # neighbourhood coefficients -> thresholds -> start the local null (device, asynchronous)
     _, maxabs = engine.ncorrs(y, fetch=False)
     pending = False
@@ -214,18 +216,22 @@ def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_si
 
 
 def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
-                            show_progress, codes_labels=None, overlap=None, **kwargs):
+                            show_progress, codes_labels=None, overlap=None, nam_queued=None, **kwargs):
     """Reference compute_nam_and_reindex (_association.py:175-191) on the device: build the NAM,
     QC it, put the sample axis in ``y.index`` order restricted to ``filter_samples``, drop the
     cells whose remaining entries have zero variance.  Leaves the selected NAM in the engine's
     working matrix and returns the bookkeeping the caller needs.  ``overlap``: a host-only
     callable run after the diffusion kernels have been queued and before their first result is
-    needed; its return value is passed through."""
+    needed; its return value is passed through.  ``nam_queued``: result of a _nam_device() call the
+    caller has already issued for exactly these arguments (its kernels are in flight)."""
     out = select_output(show_progress)
     nam_kwargs = {k: v for k, v in kwargs.items() if k in ('self_weight',)}
     print('computing NAM', file=out)
-    labels, _ = _nam_device(engine, data, sid_name, nsteps=nsteps, show_progress=show_progress,
-                            codes_labels=codes_labels, **nam_kwargs)
+    if nam_queued is not None:
+        labels, _ = nam_queued
+    else:
+        labels, _ = _nam_device(engine, data, sid_name, nsteps=nsteps, show_progress=show_progress,
+                                codes_labels=codes_labels, **nam_kwargs)
     kept = _qc_device(engine, labels, batches, show_progress=show_progress)
 
     # NAM.reindex(y.index)[filter_samples]: boolean-Series indexing aligns on the index
@@ -283,6 +289,7 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
 
     # factorise the per-cell sample ids once; validation and NAM construction share the result
     codes, labels, counts, token = sample_codes_cached(data.obs[sid_name])
+    nam_queued = None
     used = counts > 0
     batches, filter_samples = check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size,
                                            sids_present=labels[used] if isinstance(y, pd.Series) else None)
@@ -299,15 +306,32 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                           seed=kwargs.get('seed'))
     null_future = _background().submit(null_job)
 
+    early = {}
+
     def host_side(sample_index_, batches_, covs_, donorids_, filter_):
         # host-only sample-space work: runs while the diffusion kernels are executing
-        return _resid_plan(sample_index_, covs_[filter_] if covs_ is not None else covs_,
+        plan = _resid_plan(sample_index_, covs_[filter_] if covs_ is not None else covs_,
                            batches_[filter_] if batches_ is not None else batches_, ridges=ridges)
+        if plan.M is not None and null_future.done():
+            # M does not depend on the device (no ridge schedule) and the permutations are drawn: the
+            # phenotypes can be conditioned and parked on the GPU now, on the second stream, while the
+            # diffusion still runs (large problems; on small ones the draw is the longer of the two and
+            # this happens later, in _association).  Errors are left to surface where the reference
+            # raises them.
+            try:
+                y_std, y_null = null_future.result()
+                if y_null is not None and len(y_std) == plan.N:
+                    engine.condition(np.asarray(plan.M, dtype=np.float64), np.column_stack([y_std, y_null]))
+                    early['conditioned'] = True
+            except Exception:
+                pass
+        return plan
 
     try:
         kept, sample_index, colmap, batches, covs, donorids, filter_samples, plan = \
             compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
-                                    show_progress, codes_labels=(codes, labels, counts, token), overlap=host_side)
+                                    show_progress, codes_labels=(codes, labels, counts, token), overlap=host_side,
+                                    nam_queued=nam_queued)
     except BaseException:
         null_future.cancel() or null_future.exception()     # do not leave the helper thread running
         raise
@@ -327,7 +351,8 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     print('performing association test', file=out)
     coef_all, fdr_all, U, svs = _association(engine, res, y_std, y_null, ks=ks, Nnull=Nnull,
                                              local_test=kwargs.get('local_test', True),
-                                             show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_total)
+                                             show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_total,
+                                             conditioned=early.get('conditioned', False))
     _defer_pcs(res, engine, U, svs, cell_index)
     res._defer('ncorrs', lambda: pd.Series(coef_all if kept.all() else coef_all[kept], index=cell_index()))
     res.kept = kept

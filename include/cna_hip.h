@@ -168,9 +168,11 @@ int  cna_ncorrs(cna_ctx* ctx, const double* y, double* out_local, double* max_ab
 int  cna_null_local(cna_ctx* ctx, const double* Yc, int P, const double* edges, int T,
                     int64_t* tails_out);
 /* ---- the permutation test with the phenotypes resident on the device -------------------
- * cna_condition_phenotypes: Y is n_cols x P row-major (observed phenotype in column 0, the
+ * cna_condition_phenotypes: M is N x N, Y is N x P row-major (observed phenotype in column 0, the
  * permuted ones after it, _association.py:80-83); computes, per column, zcond = M.z / std(M.z, ddof=1)
- * (_association.py:51-52,96-97) and keeps the result on the device.
+ * (_association.py:51-52,96-97) and keeps the result on the device.  Sample space only: it runs on
+ * the context's second stream and may be called before the working matrix exists (while the
+ * diffusion kernels execute); N must equal the matrix's column count when the tests run.
  * cna_null_local_resident: cna_null_local on columns [col0, col0+P) of that resident matrix;
  * tails_out (P x T) and tail_sums_out (T: sum over permutations, all the FDR needs) may each be NULL.
  * cna_global_test: _reg/_stats/_minp_stats (_association.py:35-61) for every resident column:
@@ -178,7 +180,7 @@ int  cna_null_local(cna_ctx* ctx, const double* Yc, int P, const double* edges, 
  * of conditioning columns; out: min over k of the F-test p-value (scipy.stats.f.sf semantics),
  * its r2 and the index of the chosen k (-1 when every p is NaN).  All three are replicated work
  * on every rank (sample space). */
-int  cna_condition_phenotypes(cna_ctx* ctx, const double* M, const double* Y, int P);
+int  cna_condition_phenotypes(cna_ctx* ctx, const double* M, const double* Y, int N, int P);
 int  cna_null_local_resident(cna_ctx* ctx, int col0, int P, const double* edges, int T, int64_t* tails_out,
                              int64_t* tail_sums_out);
 /* cna_null_local_resident in two halves: queue the pass (returns at once; at most one pending),

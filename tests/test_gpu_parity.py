@@ -317,11 +317,11 @@ def test_rccl_path_with_one_rank(orc, monkeypatch, selftest):
         res, err, _ = run_product(case, e)
         assert err is None, repr(err)
         assert (e.halo is not None and e.halo[0] == e.halo[1] >= selftest) if selftest else e.halo is None
+        assert_matches_golden(res, case['data'], case['z'], tol=1e-5)
         import cna_amd as cna
         A = sp.csr_matrix(case['data'].obsp['connectivities'])
         s0 = np.random.RandomState(1).rand(A.shape[0], 5)
         assert relerr(cna.tl.diffuse(case['data'], s0, 3, engine=e), orc.diffuse(A, s0, 3, mode='f64')) < 1e-14
-        assert_matches_golden(res, case['data'], case['z'], tol=1e-5)
         prof_names = e.prof()
     finally:
         e.close()
