@@ -35,9 +35,9 @@ F64_MFMA_PEAK_TF = 78.6      # AMD MI355X datasheet: FP64 matrix 78.6 TFLOP/s (t
 # gfx950 correction, re-calibrated here on k_ncorrs (streams the 83.2 MB matrix once, FETCH_SIZE reads 41.6 MB).
 # Counted at the L2's fabric side, i.e. Infinity-Cache hits included.  Only valid for the profiled workload.
 PMC_TRAFFIC = {
-    ('C2', 'nam_step'): 2 * 513705e3 + 84700e3,
-    ('C2', 'nam_first'): 2 * 37898e3 + 81250e3,
-    ('C2', 'null_local'): 2 * 147889e3 + 52217e3,
+    ('C2', 'nam_step'): 2 * 172400e3 + 82110e3,
+    ('C2', 'nam_first'): 2 * 37780e3 + 81250e3,
+    ('C2', 'null_local'): 2 * 147700e3 + 54410e3,
 }
 
 WORKLOADS = {
@@ -85,6 +85,29 @@ def algorithmic_work(kernel, n, nnz, N, P, T, wA):
     return 'hbm', 8 * n
 
 
+def load_or_make_dataset(synth, n, N, k, rank, world, td):
+    """One synthetic dataset for the whole job: rank 0 generates it (the kNN search is the slow,
+    CPU-only part) and the other ranks of this node read it from /dev/shm -- every rank holds the
+    full `data` object, as with a replicated AnnData."""
+    if world == 1:
+        return synth.make_dataset(n, N, k=k, seed=0)
+    import pickle
+    path = '/dev/shm/cna_bench_%s_%d_%d.pkl' % (os.environ.get('MASTER_PORT', '0'), n, N)
+    if rank == 0:
+        out = synth.make_dataset(n, N, k=k, seed=0)
+        with open(path + '.tmp', 'wb') as f:
+            pickle.dump(out, f, protocol=pickle.HIGHEST_PROTOCOL)
+        os.replace(path + '.tmp', path)
+    td.barrier()
+    if rank != 0:
+        with open(path, 'rb') as f:
+            out = pickle.load(f)
+    td.barrier()
+    if rank == 0:
+        os.remove(path)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -124,7 +147,7 @@ def main():
     cells_per_gpu, N, k, nsteps, Nnull = WORKLOADS[args.workload]
     n = cells_per_gpu * world
     t0 = time.time()
-    data, meta = synth.make_dataset(n, N, k=k, seed=0)
+    data, meta = load_or_make_dataset(synth, n, N, k, rank, world, td)
     t_gen = time.time() - t0
     A = get_connectivity(data)
     nnz = int(A.nnz)
@@ -190,7 +213,9 @@ def main():
     wA = A.data.dtype.itemsize
     T = 300
     n_loc = eng.n_local
-    nnz_loc = int(A.indptr[eng.row0 + n_loc] - A.indptr[eng.row0])
+    deg = np.diff(A.indptr)
+    rows_loc = slice(eng.row0, eng.row0 + n_loc)
+    nnz_loc = int(deg[eng.perm[rows_loc]].sum() if eng.perm is not None else deg[rows_loc].sum())
     kernels = {}
     for name, (ms, cnt) in prof.items():
         bound, work = algorithmic_work(name, n_loc, nnz_loc, N, min(1000, Nnull), T, wA)
