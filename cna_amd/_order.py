@@ -93,6 +93,7 @@ class CellOrder:
     (device order, None = all cells) of the last select and in `_x_is_selection` whether the
     working matrix X came from the NAM (True) or from upload_x (False: already caller order)."""
     perm = None
+    _nam_sig = None          # (inputs signature, nam_epoch, steps taken) of the NAM held by the device
     _keep_dev = None
     _x_is_selection = False
     _kept_order_cache = None
@@ -152,6 +153,8 @@ class CellOrder:
         return self.kept_to_user(self.cell_stat(self.x_rows_total, nam_space=False))
 
     def dense_begin(self, arr):
+        self._nam_sig = None                  # the dense walk reuses the state buffers of the NAM
+        self.nam_epoch += 1
         r0, r1 = self.block(arr.shape[0])
         self.dense_load(arr[r0:r1] if self.perm is None else arr[self.perm[r0:r1]])
 

@@ -46,6 +46,9 @@ class Engine(_order.CellOrder):
         self.x_rows_total = 0
         self.x_epoch = 0      # bumped whenever the working matrix X is replaced
         self.nam_epoch = 0    # bumped whenever a new NAM is started
+        # keep the NAM across analyses of one dataset (tools._nam._nam_device); CNA_NAM_CACHE=0 or
+        # engine.reuse_nam = False recomputes it every call (what bench.py measures)
+        self.reuse_nam = os.environ.get('CNA_NAM_CACHE', '1') not in ('0', 'off', 'no')
 
     # ---------------------------------------------------------------- lifetime
     def close(self):

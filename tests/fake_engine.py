@@ -56,6 +56,7 @@ class FakeEngine(_order.CellOrder):
     def __init__(self, coll=None, order=None):
         self.coll = coll
         self.order = order
+        self.reuse_nam = False
         self.rank = coll.rank if coll else 0
         self.nranks = coll.nranks if coll else 1
         self.n = self.row0 = self.n_local = self.N = 0
@@ -99,6 +100,9 @@ class FakeEngine(_order.CellOrder):
 
     # -- graph
     def ensure_graph(self, A):
+        if getattr(self, '_graph_obj', None) is A:
+            return False
+        self._graph_obj = A
         A = sp.csr_matrix(A)
         self.n = A.shape[0]
         r0, r1 = self.block(self.n)

@@ -429,3 +429,34 @@ def test_results_do_not_depend_on_device_cell_order(monkeypatch):
     # leading PCs only: the trailing ones span the (numerically) null space left by residualisation
     for key in ('U', 'V'):
         np.testing.assert_allclose(a[key][:, :15], b[key][:, :15], rtol=1e-6, atol=1e-9)
+
+
+def test_nam_cache_on_device(eng):
+    """A second phenotype on the same dataset reuses the resident NAM (no diffusion kernels) and gives
+    the results of a from-scratch run."""
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.engine import Engine
+    data, meta = synth.make_dataset(30000, 40, k=15, seed=2, n_covs=1)
+    y2 = pd.Series(np.random.RandomState(9).randn(40), index=meta['y'].index)
+    kw = dict(covs=meta['covs'], nsteps=3, Nnull=200, seed=4, return_full=True)
+    e = Engine(device=0)
+    try:
+        assert e.reuse_nam
+        cna.tl.association(data, meta['y'], 'id', engine=e, **kw)
+        e.prof_reset(); e.prof_enable(True)
+        r2 = cna.tl.association(data, y2, 'id', engine=e, **kw)
+        e.sync(); e.prof_enable(False)
+        assert not any(k.startswith('nam_') for k in e.prof()), e.prof().keys()
+        nam2 = r2.nam.values.copy()
+        e.reuse_nam = False
+        e.prof_reset(); e.prof_enable(True)
+        r3 = cna.tl.association(data, y2, 'id', engine=e, **kw)
+        e.sync(); e.prof_enable(False)
+        assert e.prof()['nam_step'][1] == 2 and e.prof()['nam_first'][1] == 1
+        assert r2.p == r3.p and r2.k == r3.k
+        np.testing.assert_array_equal(r2.ncorrs.values, r3.ncorrs.values)
+        np.testing.assert_array_equal(r2.fdrs.values, r3.fdrs.values)
+        np.testing.assert_array_equal(nam2, r3.nam.values)
+    finally:
+        e.close()

@@ -179,3 +179,47 @@ def test_sample_code_memo_sees_in_place_edits():
     cat = pd.Series(pd.Categorical(['x', 'z', 'x'], categories=['x', 'y', 'z']))
     cc, cl, cn, ct = sample_codes_cached(cat)
     assert list(cl) == ['x', 'y', 'z'] and list(cn) == [2, 0, 1] and ct is not None
+
+
+def test_nam_cache_skips_the_walk_for_a_second_phenotype():
+    """a second analysis of the same dataset (same graph object, same sample ids, same
+    step rule) reuses the NAM held by the engine; anything that changes the NAM's inputs, and any
+    progress printing, recomputes it."""
+    case = load_case('c01_plain_f32')
+    data, y = case['data'], case['y']
+    y2 = pd.Series(np.random.RandomState(5).randn(len(y)), index=y.index)
+    kw = dict(nsteps=3, Nnull=50, seed=1)
+
+    def steps(e):
+        return sum(1 for c in e.calls if c[0] == 'nam_step')
+
+    eng = FakeEngine()
+    eng.reuse_nam = True
+    r1 = cna.tl.association(data, y, 'id', return_full=True, engine=eng, **kw)
+    assert steps(eng) == 3
+    nam1 = r1.nam.values.copy()
+    r2 = cna.tl.association(data, y2, 'id', return_full=True, engine=eng, **kw)
+    assert steps(eng) == 3                                  # no further walk
+    np.testing.assert_array_equal(r1.nam.values, nam1)      # and the first result's NAM is still the resident one
+    fresh = cna.tl.association(data, y2, 'id', return_full=True, engine=FakeEngine(), **kw)
+    assert r2.p == fresh.p and r2.k == fresh.k
+    np.testing.assert_array_equal(r2.ncorrs.values, fresh.ncorrs.values)
+    np.testing.assert_array_equal(r2.nam.values, fresh.nam.values)
+    # a different step count, a dense diffusion in between, edited sample ids, progress output: recompute
+    cna.tl.association(data, y2, 'id', engine=eng, nsteps=2, Nnull=50, seed=1)
+    assert steps(eng) == 5
+    cna.tl.association(data, y2, 'id', engine=eng, nsteps=2, Nnull=50, seed=1)
+    assert steps(eng) == 5
+    cna.tl.diffuse(data, np.ones((len(data.obs), 1)), 1, engine=eng)
+    cna.tl.association(data, y2, 'id', engine=eng, nsteps=2, Nnull=50, seed=1)
+    assert steps(eng) == 7
+    with contextlib.redirect_stdout(io.StringIO()):
+        cna.tl.association(data, y2, 'id', engine=eng, nsteps=2, Nnull=50, seed=1, show_progress=True)
+    assert steps(eng) == 9
+    ids = data.obs['id'].values.copy()
+    a, b = ids[0], ids[ids != ids[0]][0]
+    ids[ids == a], ids[ids == b] = -1, a
+    ids[ids == -1] = b                                      # swap two samples' cells: same buffer size, new content
+    data.obs['id'] = ids
+    cna.tl.association(data, y2, 'id', engine=eng, nsteps=2, Nnull=50, seed=1)
+    assert steps(eng) == 11

@@ -12,7 +12,7 @@ from cna_amd.engine import get_engine, Engine
 
 n, N = int(sys.argv[1]) if len(sys.argv) > 1 else 200000, int(sys.argv[2]) if len(sys.argv) > 2 else 50
 data, meta = synth.make_dataset(n, N, k=30, seed=0)
-eng = get_engine()
+eng = get_engine(); eng.reuse_nam = False
 kw = dict(nsteps=3, Nnull=1000, seed=0)
 for _ in range(3):
     cna.tl.association(data, meta['y'], 'id', **kw)

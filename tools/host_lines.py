@@ -12,7 +12,7 @@ from cna_amd.tools import _association as A_, _nam as N_
 n, N = int(sys.argv[1]), int(sys.argv[2])
 print("tuned", cna.tune_host_allocator())
 data, meta = synth.make_dataset(n, N, k=30, seed=0)
-y = meta['y']; eng = get_engine(); kw = dict(nsteps=3, Nnull=1000, seed=0)
+y = meta['y']; eng = get_engine(); eng.reuse_nam = False; kw = dict(nsteps=3, Nnull=1000, seed=0)
 for _ in range(2): cna.tl.association(data, y, 'id', **kw)
 T = collections.OrderedDict()
 PER = collections.defaultdict(list)
