@@ -391,7 +391,7 @@ int cna_set_halo(cna_ctx* c, const int64_t* send_rows, const int64_t* send_count
   HIP_TRY(hipStreamSynchronize(c->stream));
   halo_clear(c);
   if (!send_counts || !recv_counts) return 0;
-  if (!c->comm) CNA_FAIL(CNA_ESTATE, "cna_set_halo needs cna_comm_init");
+  if (!comm_active(c)) CNA_FAIL(CNA_ESTATE, "cna_set_halo needs cna_comm_init");
   int64_t ns = 0, nr = 0;
   for (int p = 0; p < c->nranks; ++p) {
     if (send_counts[p] < 0 || recv_counts[p] < 0) CNA_FAIL(CNA_EINVAL, "cna_set_halo: negative count");
@@ -1045,7 +1045,7 @@ int cna_percell_fdr(cna_ctx* c, const double* thr, const double* runmin_fdr, int
     HIP_TRY(hipMemcpyAsync(rd, runmin_fdr, 8 * T, hipMemcpyHostToDevice, c->stream));
   }
   CNA_TRY(launch_percell_fdr(c, td, rd, want_fdr ? T : 0, thr0, inv_step, coef + c->row0, want_fdr ? fdr + c->row0 : nullptr));
-  const bool sharded = c->nranks > 1 || c->comm;
+  const bool sharded = c->nranks > 1 || comm_active(c);
   if (c->orig_idx) {
     // back to the caller's numbering: every rank scatters its rows into a zeroed vector, the sum
     // over ranks (x + 0 keeps NaNs and bit patterns) is the full answer

@@ -7,6 +7,11 @@
 #include <dlfcn.h>
 #include <cstring>
 #include <rccl/rccl.h>
+#include <atomic>
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 namespace {
 
@@ -55,7 +60,162 @@ int rccl_load() {
     if (_r != ncclSuccess) CNA_FAIL(CNA_ERCCL, std::string(#expr) + ": " + g_rccl.GetErrorString(_r)); \
   } while (0)
 
+
+// ---------------------------------------------------------------------------------------------
+// Host-staged communicator over POSIX shared memory.  RCCL refuses two ranks on one GPU, and the
+// development boxes have one; this backend lets several *processes* share a GPU so that every
+// multi-rank code path of the library (block offsets, ragged gathers, halo lists, the unpermuting
+// all-reduce, ...) runs for real in `pytest -m gpu`.  Same call sites, same semantics, no claim of
+// speed: every collective is D2H -> barrier -> H2D through one slot per rank.
+struct ShmHeader {
+  std::atomic<int> arrived;
+  std::atomic<int> generation;
+  std::atomic<int> ready;
+  int nranks;
+  int64_t slot_bytes;
+};
+struct ShmComm {
+  ShmHeader* hdr = nullptr;
+  char* slots = nullptr;
+  size_t map_bytes = 0;
+  int64_t slot_bytes = 0;
+  std::string name;
+  bool owner = false;
+  char* slot(int r) const { return slots + (size_t)r * slot_bytes; }
+};
+
+void shm_barrier(cna_ctx* c) {
+  ShmComm* s = (ShmComm*)c->shm;
+  const int gen = s->hdr->generation.load(std::memory_order_acquire);
+  if (s->hdr->arrived.fetch_add(1, std::memory_order_acq_rel) == c->nranks - 1) {
+    s->hdr->arrived.store(0, std::memory_order_relaxed);
+    s->hdr->generation.store(gen + 1, std::memory_order_release);
+  } else {
+    while (s->hdr->generation.load(std::memory_order_acquire) == gen) sched_yield();
+  }
+}
+
+template <typename T, typename Op>
+int shm_allreduce_t(cna_ctx* c, T* buf, size_t count, Op op) {
+  ShmComm* s = (ShmComm*)c->shm;
+  const size_t per = (size_t)s->slot_bytes / sizeof(T);
+  std::vector<T> acc;
+  for (size_t o = 0; o < count; o += per) {
+    const size_t m = std::min(per, count - o);
+    HIP_TRY(hipMemcpyAsync(s->slot(c->rank), buf + o, m * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    shm_barrier(c);
+    acc.assign((const T*)s->slot(0), (const T*)s->slot(0) + m);
+    for (int r = 1; r < c->nranks; ++r) {                  // fixed rank order: identical on every rank
+      const T* p = (const T*)s->slot(r);
+      for (size_t i = 0; i < m; ++i) acc[i] = op(acc[i], p[i]);
+    }
+    shm_barrier(c);                                        // everyone has read the slots
+    HIP_TRY(hipMemcpyAsync(buf + o, acc.data(), m * sizeof(T), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+
+int shm_allgather(cna_ctx* c, const void* send, void* recv, size_t bytes_per_rank) {
+  ShmComm* s = (ShmComm*)c->shm;
+  for (size_t o = 0; o < bytes_per_rank; o += (size_t)s->slot_bytes) {
+    const size_t m = std::min((size_t)s->slot_bytes, bytes_per_rank - o);
+    HIP_TRY(hipMemcpyAsync(s->slot(c->rank), (const char*)send + o, m, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    shm_barrier(c);
+    for (int r = 0; r < c->nranks; ++r)
+      HIP_TRY(hipMemcpyAsync((char*)recv + (size_t)r * bytes_per_rank + o, s->slot(r), m, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    shm_barrier(c);
+  }
+  return 0;
+}
+
+// slot of rank r: [nranks counts (int64, rows for each destination)] [rows for rank 0][rows for rank 1]...
+int shm_halo(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t dpr) {
+  ShmComm* s = (ShmComm*)c->shm;
+  const int64_t ns = c->halo_ns;
+  const size_t head = sizeof(int64_t) * c->nranks;
+  if ((int64_t)(head + (size_t)ns * dpr * 8) > s->slot_bytes) CNA_FAIL(CNA_EINVAL, "shm communicator: halo larger than a slot");
+  std::memcpy(s->slot(c->rank), c->halo_send_cnt.data(), head);
+  if (ns > 0) HIP_TRY(hipMemcpyAsync(s->slot(c->rank) + head, sendbuf, (size_t)ns * dpr * 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  shm_barrier(c);
+  int64_t ro = 0;
+  for (int p = 0; p < c->nranks; ++p) {
+    const int64_t* cnt = (const int64_t*)s->slot(p);
+    if (cnt[c->rank] != c->halo_recv_cnt[p]) CNA_FAIL(CNA_ESTATE, "halo lists of two ranks do not mirror each other");
+    int64_t so = 0;
+    for (int q = 0; q < c->rank; ++q) so += cnt[q];
+    if (cnt[c->rank] > 0)
+      HIP_TRY(hipMemcpyAsync(recvbuf + ro * dpr, s->slot(p) + head + (size_t)so * dpr * 8, (size_t)cnt[c->rank] * dpr * 8,
+                             hipMemcpyHostToDevice, c->stream));
+    ro += cnt[c->rank];
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  shm_barrier(c);
+  return 0;
+}
+
+void shm_destroy(cna_ctx* c) {
+  ShmComm* s = (ShmComm*)c->shm;
+  if (!s) return;
+  if (s->hdr) munmap((void*)s->hdr, s->map_bytes);
+  if (s->owner) shm_unlink(s->name.c_str());
+  delete s;
+  c->shm = nullptr;
+}
+
 }  // namespace
+
+extern "C" int cna_comm_init_shm(cna_ctx* c, int rank, int nranks, const char* name, int64_t slot_bytes) {
+  if (!c || nranks < 1 || rank < 0 || rank >= nranks || !name || slot_bytes < 4096)
+    CNA_FAIL(CNA_EINVAL, "cna_comm_init_shm: bad arguments");
+  if (c->comm || c->shm) CNA_FAIL(CNA_ESTATE, "context already has a communicator");
+  auto* s = new ShmComm;
+  s->name = std::string("/") + name;
+  s->slot_bytes = slot_bytes;
+  s->map_bytes = 4096 + (size_t)nranks * slot_bytes;
+  int fd = -1;
+  if (rank == 0) {
+    shm_unlink(s->name.c_str());
+    fd = shm_open(s->name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)s->map_bytes) != 0) { delete s; CNA_FAIL(CNA_ERCCL, "cna_comm_init_shm: cannot create the segment"); }
+    s->owner = true;
+  } else {
+    for (int tries = 0; tries < 60000 && fd < 0; ++tries) {       // rank 0 may not be there yet
+      fd = shm_open(s->name.c_str(), O_RDWR, 0600);
+      if (fd < 0) usleep(1000);
+    }
+    if (fd < 0) { delete s; CNA_FAIL(CNA_ERCCL, "cna_comm_init_shm: segment did not appear"); }
+    for (int tries = 0; tries < 60000; ++tries) {                  // ... or not sized yet
+      off_t len = lseek(fd, 0, SEEK_END);
+      if (len >= (off_t)s->map_bytes) break;
+      usleep(1000);
+    }
+  }
+  void* m = mmap(nullptr, s->map_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) { delete s; CNA_FAIL(CNA_ERCCL, "cna_comm_init_shm: mmap failed"); }
+  s->hdr = (ShmHeader*)m;
+  s->slots = (char*)m + 4096;
+  if (rank == 0) {
+    s->hdr->arrived.store(0);
+    s->hdr->generation.store(0);
+    s->hdr->nranks = nranks;
+    s->hdr->slot_bytes = slot_bytes;
+    s->hdr->ready.store(1, std::memory_order_release);
+  } else {
+    while (s->hdr->ready.load(std::memory_order_acquire) != 1) usleep(200);
+    if (s->hdr->nranks != nranks || s->hdr->slot_bytes != slot_bytes) { delete s; CNA_FAIL(CNA_EINVAL, "cna_comm_init_shm: ranks disagree on the geometry"); }
+  }
+  c->rank = rank;
+  c->nranks = nranks;
+  c->shm = s;
+  shm_barrier(c);
+  return 0;
+}
 
 extern "C" int cna_comm_unique_id(void* id128) {
   CNA_TRY(rccl_load());
@@ -81,6 +241,7 @@ extern "C" int cna_comm_init(cna_ctx* c, int rank, int nranks, const void* id128
 }
 
 int comm_destroy(cna_ctx* c) {
+  shm_destroy(c);
   if (c->comm) {
     g_rccl.CommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr;
@@ -89,6 +250,11 @@ int comm_destroy(cna_ctx* c) {
 }
 
 static int allreduce(cna_ctx* c, void* buf, size_t count, ncclDataType_t dt, ncclRedOp_t op) {
+  if (c->shm) {
+    if (dt == ncclInt64) return shm_allreduce_t<int64_t>(c, (int64_t*)buf, count, [](int64_t a, int64_t b) { return a + b; });
+    if (op == ncclMax) return shm_allreduce_t<double>(c, (double*)buf, count, [](double a, double b) { return a > b ? a : b; });
+    return shm_allreduce_t<double>(c, (double*)buf, count, [](double a, double b) { return a + b; });
+  }
   if (c->nranks == 1 && !c->comm) return 0;
   if (!c->comm) CNA_FAIL(CNA_ESTATE, "multi-rank context without cna_comm_init");
   ProfScope ps(c, CNA_K_ALLGATHER);
@@ -102,6 +268,7 @@ int comm_allreduce_i64_sum(cna_ctx* c, int64_t* buf, size_t count) { return allr
 
 // recv holds nranks blocks of bytes_per_rank; send may alias recv + rank*bytes_per_rank (in place)
 int comm_allgather_bytes(cna_ctx* c, const void* send, void* recv, size_t bytes_per_rank) {
+  if (c->shm) return shm_allgather(c, send, recv, bytes_per_rank);
   if (c->nranks == 1 && !c->comm) {
     if (send != recv) HIP_TRY(hipMemcpyAsync(recv, send, bytes_per_rank, hipMemcpyDeviceToDevice, c->stream));
     return 0;
@@ -115,6 +282,7 @@ int comm_allgather_bytes(cna_ctx* c, const void* send, void* recv, size_t bytes_
 // Point-to-point exchange of packed state rows: rank p receives halo_send_cnt[p] rows from us and
 // sends us halo_recv_cnt[p]; one grouped launch, so the xGMI links to all peers run concurrently.
 int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t doubles_per_row) {
+  if (c->shm) return shm_halo(c, sendbuf, recvbuf, doubles_per_row);
   if (!c->comm) CNA_FAIL(CNA_ESTATE, "halo exchange without cna_comm_init");
   ProfScope ps(c, CNA_K_ALLGATHER);
   NCCL_TRY(g_rccl.GroupStart());

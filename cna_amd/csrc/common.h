@@ -57,6 +57,7 @@ struct cna_ctx {
   // ---- communicator
   int rank = 0, nranks = 1;
   void* comm = nullptr;  // ncclComm_t
+  void* shm = nullptr;   // host-staged communicator of cna_comm_init_shm (several ranks on one GPU: tests)
   // neighbour ("halo") exchange of the diffusion state, replacing the all-gather (cna_set_halo)
   bool halo_on = false;
   int64_t* halo_send_idx = nullptr;   // device: local rows to ship, grouped by destination rank
@@ -160,6 +161,7 @@ int dev_free(cna_ctx* c, void* p, size_t bytes);
 int dev_reserve(cna_ctx* c, void** p, int64_t* cap_bytes, int64_t need_bytes);
 
 // ---- collectives (comm.hip)
+inline bool comm_active(const cna_ctx* c) { return c->comm != nullptr || c->shm != nullptr; }
 int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t doubles_per_row);
 int launch_pack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst);
 int launch_unpack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst);

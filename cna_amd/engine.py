@@ -20,7 +20,9 @@ def _f64(a):
 
 
 class Engine(_order.CellOrder):
-    def __init__(self, device=None, rank=0, nranks=1, unique_id=None):
+    def __init__(self, device=None, rank=0, nranks=1, unique_id=None, shm=None):
+        """unique_id: RCCL id from rank 0 (one GPU per rank).  shm: (segment name, slot bytes) selects
+        the host-staged test communicator instead, which lets several ranks share one GPU."""
         self.lib = _ffi.load()
         if device is None:
             device = int(os.environ.get('LOCAL_RANK', '0')) if nranks > 1 else 0
@@ -29,10 +31,13 @@ class Engine(_order.CellOrder):
         self.h = h
         self.device = int(device)
         self.rank, self.nranks = int(rank), int(nranks)
-        if nranks > 1 and unique_id is None:
+        if nranks > 1 and unique_id is None and shm is None:
             raise ValueError('nranks > 1 needs the RCCL unique id created by rank 0')
-        self._has_comm = unique_id is not None
-        if unique_id is not None:   # also with one rank: every collective then really goes through RCCL
+        self._has_comm = unique_id is not None or shm is not None
+        if shm is not None:
+            check(self.lib.cna_comm_init_shm(self.h, self.rank, self.nranks, str(shm[0]).encode(), int(shm[1])),
+                  'cna_comm_init_shm')
+        elif unique_id is not None:   # also with one rank: every collective then really goes through RCCL
             buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
             check(self.lib.cna_comm_init(self.h, self.rank, self.nranks, C.cast(buf, C.c_void_p)), 'cna_comm_init')
         self._graph_key = None

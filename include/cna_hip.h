@@ -64,6 +64,10 @@ int  cna_ctx_device_bytes(cna_ctx* ctx, int64_t* bytes);
 /* rank 0 creates a 128-byte id and ships it to the other ranks by any host channel */
 int  cna_comm_unique_id(void* id128);
 int  cna_comm_init(cna_ctx* ctx, int rank, int nranks, const void* id128);
+/* Test communicator: the same collectives staged through a POSIX shared-memory segment `name`
+ * (one slot of slot_bytes per rank), so that several ranks can share ONE GPU -- which RCCL refuses --
+ * and the multi-rank paths of this library run on a single-GPU box.  Not for production use. */
+int  cna_comm_init_shm(cna_ctx* ctx, int rank, int nranks, const char* name, int64_t slot_bytes);
 
 /* Neighbour ("halo") exchange of the diffusion state between steps instead of the all-gather.
  * After cna_graph_upload on every rank: send_rows = LOCAL row indices other ranks need, grouped by

@@ -1,0 +1,106 @@
+"""Multi-rank HIP path on ONE GPU (-m gpu): G processes, each with its own context on device 0,
+cells sharded by row blocks, the library's host-staged shared-memory communicator in place of RCCL
+(which refuses two ranks per GPU).  Everything else is the production path: the C ABI's block
+offsets, ragged gathers, halo pack / exchange / unpack, the unpermuting all-reduce, and the Python
+host code on every rank.  Results must equal the golden vectors of the reference and be identical
+on all ranks."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, seg, name, halo, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import warnings
+    warnings.simplefilter('ignore')
+    os.environ['CNA_HALO'] = '1' if halo else '0'
+    try:
+        import cna_amd as cna
+        from cna_amd.engine import Engine
+        from helpers import load_case
+        case = load_case(name)
+        eng = Engine(device=0, rank=rank, nranks=world, shm=(seg, 8 << 20))
+        res = cna.tl.association(case['data'], case['y'], case['sid_name'], batches=case['batches'],
+                                 covs=case['covs'], donorids=case['donorids'], return_full=True, engine=eng,
+                                 **case['call'])
+        out = dict(p=res.p, k=int(res.k), ncorrs=res.ncorrs.values, kept=res.kept, fdr=res.fdrs.fdr.values,
+                   num=res.fdrs.num_detected.values, coef=case['data'].obs['coef'].values,
+                   coef_fdr=case['data'].obs['coef_fdr'].values, nam=res.nam.values,
+                   namresid=res.namresid.values, V=res.namresid_nbhdXpc.values, rows=(eng.row0, eng.n_local),
+                   halo=eng.halo, perm=eng.perm is not None)
+        import scipy.sparse as sp
+        A = sp.csr_matrix(case['data'].obsp['connectivities'])
+        s0 = np.random.RandomState(1).rand(A.shape[0], 3)
+        out['diffuse'] = cna.tl.diffuse(case['data'], s0, 2, engine=eng)
+        NAM, keep = cna.tl.nam(case['data'], case['sid_name'], batches=case['batches'], engine=eng)
+        out['tlnam'] = NAM.values
+        out['tlkeep'] = keep
+        eng.close()
+        q.put((rank, out))
+    except BaseException as e:     # report instead of leaving the other ranks in a barrier forever
+        import traceback
+        q.put((rank, 'ERROR %r\n%s' % (e, traceback.format_exc())))
+        os._exit(1)
+
+
+@pytest.mark.parametrize('name,world,halo', [('c12_batchy_qc', 2, True), ('c03_covs_batches', 3, True),
+                                             ('c13_zero_variance', 2, False), ('c01_plain_f32', 4, True)])
+def test_sharded_hip_path_on_one_gpu(name, world, halo):
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import load_case, relerr
+    from oracle import cna_oracle as orc
+    import scipy.sparse as sp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    seg = 'cna_test_%d_%s' % (os.getpid(), name[:3])
+    procs = [ctx.Process(target=_worker, args=(r, world, seg, name, halo, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            r, out = q.get(timeout=240)
+            assert not isinstance(out, str), out
+            got[r] = out
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    case = load_case(name)
+    z = case['z']
+    n = len(z['kept'])
+    rpr = -(-n // world)
+    a = got[0]
+    assert a['perm']
+    for r in range(world):
+        assert got[r]['rows'] == (min(r * rpr, n), max(0, min(rpr, n - r * rpr)))
+        assert (got[r]['halo'] is not None) == halo
+        for key in ('ncorrs', 'kept', 'fdr', 'num', 'coef', 'coef_fdr', 'nam', 'namresid', 'diffuse', 'tlnam', 'tlkeep'):
+            np.testing.assert_array_equal(got[r][key], a[key])      # every rank holds the full result
+        assert got[r]['p'] == a['p'] and got[r]['k'] == a['k']
+    if halo:
+        assert sum(got[r]['halo'][0] for r in range(world)) == sum(got[r]['halo'][1] for r in range(world)) > 0
+    assert a['k'] == int(z['k']) and a['p'] == pytest.approx(float(z['p']), rel=1e-12)
+    assert np.array_equal(a['kept'], z['kept'])
+    assert relerr(a['ncorrs'], z['ncorrs']) < 1e-5
+    assert relerr(a['nam'], z['nam']) < 1e-5 and relerr(a['namresid'], z['namresid']) < 1e-5
+    T = min(len(a['fdr']), len(z['fdr_fdr']))
+    assert np.array_equal(a['num'][:T], z['fdr_num_detected'][:T])
+    assert relerr(a['fdr'][:T], z['fdr_fdr'][:T]) < 1e-4
+    assert np.array_equal(np.isnan(a['coef']), np.isnan(z['obs_coef']))
+    ok = ~np.isnan(a['coef'])
+    assert relerr(a['coef'][ok], z['obs_coef'][ok]) < 1e-5
+    np.testing.assert_allclose(a['coef_fdr'], z['obs_coef_fdr'], rtol=1e-4, atol=1e-12)
+    A = sp.csr_matrix(case['data'].obsp['connectivities'])
+    s0 = np.random.RandomState(1).rand(A.shape[0], 3)
+    assert relerr(a['diffuse'], orc.diffuse(A, s0, 2, mode='f64')) < 1e-13
+    # signs of the PCs are LAPACK's on every rank; V only has to be consistent with U there
+    assert a['V'].shape == z['V'].shape
