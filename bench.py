@@ -117,6 +117,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-cells', type=int, default=100_000)
     ap.add_argument('--profile-host', default=None, help='write a cProfile of 3 extra steps to this file')
+    ap.add_argument('--comm', default='rccl', choices=['rccl', 'shm'],
+                    help="shm: plumbing check of the N>1 path on ONE GPU (all ranks on device 0, gloo for the "
+                         "rendezvous, the library's shared-memory test communicator instead of RCCL); not a benchmark")
     ap.add_argument('--force-dist', action='store_true',
                     help='take the torch.distributed + RCCL code path even with one rank (plumbing check)')
     args = ap.parse_args()
@@ -128,7 +131,14 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit('bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)' % args.gpus)
     td = None
-    if world > 1 or args.force_dist:
+    if args.comm == 'shm' and world > 1:
+        import torch.distributed as td
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        td.init_process_group(backend='gloo', rank=rank, world_size=world)
+        from cna_amd import dist
+        dist.init(rank, world, device=0, shm=('cna_bench_%s' % os.environ['MASTER_PORT'], 64 << 20))
+    elif world > 1 or args.force_dist:
         import torch
         import torch.distributed as td
         torch.cuda.set_device(local_rank)
@@ -156,13 +166,17 @@ def main():
     eng.reuse_nam = False           # every timed step recomputes the NAM (no result caching across steps)
     kw = dict(nsteps=nsteps, Nnull=Nnull, seed=0)
 
+    on_gpu_group = td is not None and args.comm != 'shm'
+
     def sync():
         eng.sync()
-        if td is not None:
+        if on_gpu_group:
             import torch
             torch.cuda.synchronize()
             td.barrier()
             torch.cuda.synchronize()
+        elif td is not None:
+            td.barrier()
 
     # graph H2D + first call (also the PCIe-inclusive single-call time, reported separately)
     sync()
@@ -185,7 +199,7 @@ def main():
     prof = eng.prof()
     if td is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda' if on_gpu_group else 'cpu')
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = float(t[0])
     assert p_first == p_last
@@ -266,7 +280,9 @@ def main():
         'config': {'workload': '%s: %d cells (%d per GPU) x %d samples, k=%d kNN (%.1f nnz/row, float32 CSR), '
                                'nsteps=%d, Nnull=%d, local FDR pass on, NAM cache off' % (args.workload, n, cells_per_gpu, N, k,
                                                                           nnz / n, nsteps, Nnull),
-                   'parallelism': 'cells sharded in %d row block(s)' % world, 'p_value': p_last},
+                   'parallelism': 'cells sharded in %d row block(s)%s%s' % (
+                       world, '' if eng.halo is None else ', halo exchange %d/%d rows out/in on rank 0' % eng.halo,
+                       ' [--comm shm: ranks share one GPU, plumbing check only]' if args.comm == 'shm' and world > 1 else ''), 'p_value': p_last},
         'roofline': roofline,
         'cpu_baseline': cpu,
         'gpu_kernel_ms_per_step': round(gpu_ms_per_step, 3),

@@ -10,13 +10,14 @@ import os
 _cfg = {}
 
 
-def init(rank, nranks, unique_id=None, device=None):
-    """Describe this process' place in the job before the first engine is created."""
+def init(rank, nranks, unique_id=None, device=None, shm=None):
+    """Describe this process' place in the job before the first engine is created.  ``shm``:
+    (segment name, slot bytes) selects the host-staged test communicator (ranks may share a GPU)."""
     global _cfg
-    if nranks > 1 and unique_id is None:
+    if nranks > 1 and unique_id is None and shm is None:
         raise ValueError('unique_id required when nranks > 1 (create it on rank 0 with new_unique_id())')
     # with one rank a unique_id is optional: when given, collectives still go through RCCL
-    _cfg = dict(rank=int(rank), nranks=int(nranks), unique_id=unique_id,
+    _cfg = dict(rank=int(rank), nranks=int(nranks), unique_id=unique_id, shm=shm,
                 device=int(device) if device is not None else None)
     from . import engine
     engine.set_engine(None)

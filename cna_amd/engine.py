@@ -427,7 +427,7 @@ def get_engine():
         from . import dist
         cfg = dist.current()
         _default = Engine(device=cfg.get('device'), rank=cfg.get('rank', 0), nranks=cfg.get('nranks', 1),
-                          unique_id=cfg.get('unique_id'))
+                          unique_id=cfg.get('unique_id'), shm=cfg.get('shm'))
     return _default
 
 
