@@ -128,6 +128,8 @@ struct cna_ctx {
   // ---- scratch
   void* scratch = nullptr;
   int64_t scratch_cap = 0;
+  void* null_part = nullptr;      // per-block counter slabs of the local-null kernel
+  int64_t null_part_cap = 0;
   void* scratch2 = nullptr;
   int64_t scratch2_cap = 0;
   int gram_tiles_nt = -1;        // upper-triangular tile table of the Gram kernel (depends on nt only)

@@ -157,165 +157,176 @@ __global__ __launch_bounds__(1024) void k_gram_reduce(const double* __restrict__
 }
 
 // ======================================================================== local null
-// grid = (row chunks, ceil(P/64)); 8 waves.  Wave w owns permutations 64*pt + 16*(w&3) .. +15 and
-// keeps that 16-column strip of Yc in registers (KQ doubles per lane) for the whole kernel;
-// waves 0-3 take the first half of each slab of cells, waves 4-7 the second half, TS 16-cell
-// tiles each (independent accumulators, so the 64-cycle f64 MFMAs of one tile hide the
-// dependent-issue latency of the other).  Slabs of 32*TS cells stream through LDS with a
-// register prefetch of the next slab under the MFMAs.
+// Fused |X.Yc| -> threshold bin -> per-permutation histogram; the cells x permutations matrix of
+// _association.py:99 never exists.  grid = (row chunks, ceil(P/PT)), PT = 16*NS permutations.
+//
+// The block's strip of Yc (4*KQ x PT doubles) sits in LDS for the whole kernel; every wave walks
+// its own 16-cell tiles of the row chunk (stride = waves per block), loads the A operand straight
+// from global memory in MFMA layout (lane (i,k): X[r0+i][4q+k]; the tile of the next iteration is
+// prefetched into a second register set), runs NS independent accumulator chains over it
+// (v_mfma_f64_16x16x4_f64, 64 cycles each) and bins its own outputs.  There is no barrier in the
+// main loop: waves drift apart freely.  (A first version staged 64-cell slabs of X through LDS
+// between two barriers with Yc in registers; all eight waves then alternated between MFMA and
+// epilogue in lockstep.  Measured at 200k x 50 x 1000: 590 us -> 5xx us, see DESIGN.md.)
 //
 // Epilogue.  The reference bins z^2 = (|x.yc|/N)^2 against edges[t] (_stats.py:47-54).  Both
 // roundings are monotone in |x.yc|, so the host converts every edge into the smallest double
 // cut[t] with fl(fl(cut/N)^2) >= edges[t]; counting cut[t] <= |acc| is then *exactly* the
-// reference's count and costs one compare instead of a division and a square per element.
-// A linear guess + two exact compares finds the bin; counters are packed 16-bit pairs in LDS
-// (a chunk has < 65536 cells) and are flushed with integer global atomics -> bit-reproducible.
-template <int KQ, int TS, int MODE = 0>
-__global__ __launch_bounds__(512) void k_null(const double* __restrict__ X, int64_t nx, int64_t chunk_rows,
+// reference's count.  With c_s[k] = cuts[k-1] the count of an output is h = #{k in 1..T : c_s[k] <= x};
+// the cuts are an arithmetic progression to within `eps` steps (the host measures the worst
+// deviation), so g = (x - cut0)/step + OFF has h = floor(g) - OFF + 1 unless g lies within eps of an
+// integer.  u = trunc(g * 65536) (one fma, one saturating convert) gives both: h from u >> 16 and
+// the fraction u & 0xffff, whose distance from 0 / 65536 is compared with an integer margin
+// E >= eps * 65536 + 2; only outputs inside the margin (all of them when the progression test
+// failed: lim = 0) walk the exact table.  On this chip VALU work does not hide under f64 MFMAs
+// (ablation: arithmetic alone +130 us on a 366 us MFMA pipeline), so the epilogue is priced per
+// instruction: 32-bit LDS counters (address = one shift-add, increment = 1), nine VALU
+// instructions per output.  Each block stores its counters as one plain slab; k_hist_reduce sums
+// the slabs (integers: bit-reproducible) -- global atomics cost 60 us here.
+template <int KQ, int NS, bool PFETCH, int NW, int MODE = 0>
+__global__ __launch_bounds__(64 * NW) void k_null(const double* __restrict__ X, int64_t nx, int64_t chunk_rows,
                                               const double* __restrict__ Yc, int ldy, int P,
                                               const double* __restrict__ cuts, int T, double cut0,
-                                              double inv_step, double eps, unsigned long long* __restrict__ ghist) {
-  // KQ is the exact number of k-steps: the leading dimension of X is 4*KQ
+                                              double inv_step, double eps, unsigned int* __restrict__ partial) {
   extern __shared__ double sm[];
-  constexpr int ROWS = 32 * TS;
-  constexpr int LDX = 4 * KQ, LDP = LDX + 2;
-  constexpr int ND2 = ROWS * LDX / 2;                    // double2 elements per slab
-  constexpr int PF = (ND2 + 511) / 512;                  // double2 prefetch registers per thread
+  constexpr int PT = 16 * NS, LDB = PT + 16, LDX = 4 * KQ;   // LDB = 16 mod 32: the two k-rows of a 32-lane group hit disjoint banks
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int strip = wv & 3, half = wv >> 2;
-  const int ak = lane >> 4, ai = lane & 15;
-  const int HW = ((T + 1) >> 1) | 1;                     // odd row stride: the 16 strips' counters spread over all banks
-  const int TP = (T + 4) & ~1;                           // 0, cuts[0..T), +inf, +inf (even count)
+  const int ak = lane >> 4, aj = lane & 15;
+  const int TP = (T + 4) & ~1;                                // 0, cuts[0..T), +inf, +inf (even count)
+  const int TW = T + 1;                                       // counter row: [0] unused, [h] = bin h-1; odd/even either way fine
   double* c_s = sm;
-  double* xt = sm + TP;                                  // ROWS * LDP doubles
-  unsigned int* hist = (unsigned int*)(xt + ROWS * LDP);  // 64 * HW words
-  for (int i = tid; i < TP; i += 512) c_s[i] = i == 0 ? 0.0 : (i <= T ? cuts[i - 1] : __builtin_inf());
-  for (int i = tid; i < 64 * HW; i += 512) hist[i] = 0u;
-
+  double* bs = sm + TP;                                       // LDX x LDB
+  unsigned int* hist = (unsigned int*)(bs + LDX * LDB);       // PT x TW words
   const int pt = blockIdx.y;
-  double b[KQ];
-  {
-    const double* bp = Yc + (size_t)ak * ldy + pt * 64 + strip * 16 + ai;
-#pragma unroll
-    for (int q = 0; q < KQ; ++q) b[q] = bp[(size_t)4 * q * ldy];
+  for (int i = tid; i < TP; i += 64 * NW) c_s[i] = i == 0 ? 0.0 : (i <= T ? cuts[i - 1] : __builtin_inf());
+  for (int i = tid; i < PT * TW; i += 64 * NW) hist[i] = 0u;
+  for (int i = tid; i < LDX * PT; i += 64 * NW) {
+    const int k = i / PT, j = i - k * PT;
+    bs[k * LDB + j] = Yc[(size_t)k * ldy + pt * PT + j];
   }
-  // prefetch slots: slab-relative element offset (global) and padded offset (LDS) of each double2
-  unsigned goff[PF], loff[PF];
-#pragma unroll
-  for (int i = 0; i < PF; ++i) {
-    const unsigned f = tid + 512u * i;
-    const unsigned e = 2u * f;
-    const unsigned r = e / LDX;
-    goff[i] = (f < (unsigned)ND2) ? e : 0xffffffffu;
-    loff[i] = r * LDP + (e - r * LDX);
-  }
+  __syncthreads();
+
   const int64_t row_begin = (int64_t)blockIdx.x * chunk_rows;
   int64_t row_end = row_begin + chunk_rows;
   if (row_end > nx) row_end = nx;
+  const int64_t ntile = row_begin < row_end ? (row_end - row_begin + 15) / 16 : 0;
+  const double* bp = bs + ak * LDB + aj;
+  unsigned int* hrow = hist + aj * TW;                        // this lane's permutation within strip 0
 
-  // register prefetch two slabs ahead (pfA: even slabs, pfB: odd): one slab of MFMAs is shorter
-  // than an L2/Infinity-Cache round trip under load
-  double2 pfA[PF], pfB[PF];
-  auto prefetch = [&](double2 (&pf)[PF], int64_t r0) {
-    const double* __restrict__ slab = X + r0 * LDX;      // uniform base, 32-bit lane offsets
-    const int64_t left = r0 < row_end ? (row_end - r0) * LDX : 0;
-    const unsigned lim = left > (int64_t)(ROWS * LDX) ? (unsigned)(ROWS * LDX) : (unsigned)left;
+  auto load_a = [&](double (&a)[KQ], int64_t tile) {
+    const int64_t row = row_begin + 16 * tile + aj;
+    if (tile < ntile && row < row_end) {
+      const double* __restrict__ xp = X + row * LDX + ak;
 #pragma unroll
-    for (int i = 0; i < PF; ++i) {
-      pf[i] = make_double2(0.0, 0.0);
-      if (goff[i] < lim) pf[i] = *reinterpret_cast<const double2*>(slab + goff[i]);
+      for (int q = 0; q < KQ; ++q) a[q] = xp[4 * q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) a[q] = 0.0;               // zero rows never reach cut0 > 0
     }
   };
-  const unsigned hp = (unsigned)((strip * 16 + ai) * HW);   // this lane's counter row (word index)
-  // Output -> counter.  c_s[k] (k>=1) = cuts[k-1], c_s[0] = 0, c_s[T+1..] = +inf; the count of an
-  // output is h = #{k in 1..T : c_s[k] <= x}.  The cuts are an arithmetic progression to within
-  // `eps` steps (the host measures the worst deviation), so h = floor((x-cut0)/step) + 1 is exact
-  // unless x lies within eps of a cut -- only those outputs (and the last bin) consult the table.
-  // Rows past row_end were staged as zeros and cut0 > 0, so they never count.
-  auto count = [&](double v) {
-    const double x = fabs(v);
-    if (x >= cut0) {
-      const double f = (x - cut0) * inv_step;
-      const double fl = floor(f);
-      const double fr = f - fl;
-      int h = (fl < (double)(T - 1)) ? (int)fl + 1 : T;
-      if (!(fl < (double)(T - 1) && fr > eps && fr < 1.0 - eps)) {   // near a cut or in the top bin: exact walk
-        while (c_s[h + 1] <= x) ++h;                                  // c_s[T+1] = +inf
-        while (c_s[h] > x) --h;                                       // c_s[1] = cut0 <= x
+  unsigned sink = 0;
+  // g is offset by OFF >= cut0/step + 2 so that outputs below the first cut keep a meaningful
+  // fraction instead of saturating at 0: they are rejected on the fast path too.
+  const double ratio = cut0 * inv_step;
+  const bool linear = eps < 0.25 && ratio < 60000.0;
+  const int OFF = linear ? (int)ratio + 2 : 1;
+  const double K1 = inv_step * 65536.0, K0 = ((double)OFF - ratio) * 65536.0;
+  const unsigned E = linear ? (unsigned)(eps * 65536.0) + 3u : 65536u;
+  const unsigned lim = linear ? 65536u - 2u * E : 0u;
+  // one strip (4 outputs per lane) at a time: independent instructions for the scheduler without
+  // holding all NS*4 intermediate values in registers; the exact walk is one rarely taken region
+  auto count_strip = [&](const v4d& acc, unsigned int* row) {
+    unsigned u[4];
+    int h[4];
+    bool near = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = (unsigned)__builtin_fma(fabs(acc[i]), K1, K0);   // v_cvt_u32_f64 (saturating)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int hi = (int)(u[i] >> 16) - (OFF - 1);                  // floor((x - cut0)/step) + 1
+      h[i] = hi < T ? hi : T;
+      near |= !(((u[i] & 0xffffu) - E) < lim);
+    }
+    if (__builtin_expect(near, 0)) {                                  // some output within the margin of a cut
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!(((u[i] & 0xffffu) - E) < lim)) {
+          const double x = fabs(acc[i]);
+          int hh = h[i] > 0 ? h[i] : 0;
+          while (c_s[hh + 1] <= x) ++hh;                              // c_s[T+1] = +inf
+          while (c_s[hh] > x) --hh;                                   // c_s[0] = 0
+          h[i] = hh;
+        }
       }
-      const unsigned bin = (unsigned)(h - 1);
-      atomicAdd(&hist[hp + (bin >> 1)], (bin & 1u) ? 0x10000u : 1u);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (h[i] > 0) {
+        if (MODE == 2) sink += (unsigned)h[i];                        // experiment: arithmetic only
+        else atomicAdd(&row[h[i]], 1u);
+      }
     }
   };
-  auto count_all = [&](const v4d (&acc)[TS]) {
+  auto count_all = [&](const v4d (&acc)[NS]) {
 #pragma unroll
-    for (int t = 0; t < TS; ++t) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) count(acc[t][r]);
-    }
+    for (int s = 0; s < NS; ++s) count_strip(acc[s], hrow + 16 * s * TW);
   };
-  const double* ap = xt + (half * 16 * TS + ai) * LDP + ak;
-  auto stage = [&](double2 (&pf)[PF], int64_t r0) {
-    __syncthreads();                       // previous slab fully consumed
+  auto tile_body = [&](const double (&a)[KQ]) {
+    v4d acc[NS];
 #pragma unroll
-    for (int i = 0; i < PF; ++i)
-      if (goff[i] != 0xffffffffu) *reinterpret_cast<double2*>(xt + loff[i]) = pf[i];
-    __syncthreads();
-    prefetch(pf, r0 + 2 * ROWS);           // this register set is free again: fetch two slabs ahead
-  };
-  auto slab = [&]() {
-    v4d acc[TS];
-#pragma unroll
-    for (int t = 0; t < TS; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int s = 0; s < NS; ++s) acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
 #pragma unroll
-      for (int t = 0; t < TS; ++t) {
-        if (MODE == 2) {
-          if (q < 2) acc[t][q] += ap[t * 16 * LDP + 4 * q] * b[q];       // experiment: no matrix work
-        } else {
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[t * 16 * LDP + 4 * q], b[q], acc[t], 0, 0, 0);
-        }
-      }
+      for (int s = 0; s < NS; ++s)
+        acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bp[4 * q * LDB + 16 * s], acc[s], 0, 0, 0);
     }
     if (MODE == 1) {                                                     // experiment: no counting
       double z = 0.0;
 #pragma unroll
-      for (int t = 0; t < TS; ++t) z += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
-      if (z == 123.456) atomicAdd(&hist[hp], 1u);
-    } else {
-      count_all(acc);
+      for (int s = 0; s < NS; ++s) z += acc[s][0] + acc[s][1] + acc[s][2] + acc[s][3];
+      if (z == 123.456) atomicAdd(&hist[0], 1u);
+      return;
     }
+    count_all(acc);
   };
-  if (row_begin < row_end) {
-    prefetch(pfA, row_begin);
-    prefetch(pfB, row_begin + ROWS);
-    for (int64_t r0 = row_begin;;) {
-      stage(pfA, r0);
-      slab();
-      r0 += ROWS;
-      if (r0 >= row_end) break;
-      stage(pfB, r0);
-      slab();
-      r0 += ROWS;
-      if (r0 >= row_end) break;
+  if (PFETCH) {
+    double a0[KQ], a1[KQ];
+    load_a(a0, wv);
+    for (int64_t t = wv; t < ntile; t += 2 * NW) {
+      load_a(a1, t + NW);
+      tile_body(a0);
+      if (t + NW >= ntile) break;
+      load_a(a0, t + 2 * NW);
+      tile_body(a1);
+    }
+  } else {
+    double a0[KQ];
+    for (int64_t t = wv; t < ntile; t += NW) {
+      load_a(a0, t);
+      tile_body(a0);
     }
   }
+  if (MODE == 2 && sink == 0x12345u) hist[0] = 1u;
   __syncthreads();
-  for (int i = tid; i < 64 * HW; i += 512) {
-    const unsigned int w = hist[i];
-    if (w) {
-      const int pl = i / HW, hw = i - pl * HW;
-      const int p = pt * 64 + pl;
-      if (p < P) {
-        const unsigned int lo = w & 0xffffu, hi = w >> 16;
-        if (lo) atomicAdd(&ghist[(size_t)p * T + 2 * hw], (unsigned long long)lo);
-        if (hi && 2 * hw + 1 < T) atomicAdd(&ghist[(size_t)p * T + 2 * hw + 1], (unsigned long long)hi);
-      }
-    }
+  // slab of this block: partial[chunk][p][t], t contiguous
+  unsigned int* out = partial + ((size_t)blockIdx.x * P + (size_t)pt * PT) * T;
+  for (int i = tid; i < PT * T; i += 64 * NW) {
+    const int pl = i / T, t = i - pl * T;
+    if (pt * PT + pl < P) out[(size_t)pl * T + t] = hist[pl * TW + t + 1];
   }
+}
+
+// hist[p][t] = sum over row chunks of the per-block slabs (fixed order, integers)
+__global__ void k_hist_reduce(const unsigned int* __restrict__ partial, int nchunks, int64_t PT_total,
+                              unsigned long long* __restrict__ hist) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= PT_total) return;
+  unsigned long long s = 0;
+  for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * PT_total + i];
+  hist[i] = s;
 }
 
 template <int TPW>
@@ -328,29 +339,31 @@ int launch_gram_t(cna_ctx* c, int nt, int ldp, int ntri, const int32_t* tiles_de
   return 0;
 }
 
-template <int KQ, int TS>
+typedef int (*null_launch_fn)(cna_ctx*, dim3, size_t, int64_t, const double*, int, int, const double*, int, double,
+                              double, double, unsigned int*);
+template <int KQ, int NS>
 int launch_null_t(cna_ctx* c, dim3 grid, size_t smem, int64_t chunk_rows, const double* Yc, int ldy, int P,
-                  const double* cuts, int T, double cut0, double inv_step, double eps, unsigned long long* hist) {
+                  const double* cuts, int T, double cut0, double inv_step, double eps, unsigned int* partial) {
+  constexpr bool PF = KQ <= 32;                          // second A register set while it still fits
+  constexpr int NW = KQ <= 13 ? 16 : 8;                  // waves per block: 16 while 128 VGPRs are enough
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_null<KQ, TS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_null<KQ, NS, PF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_null<KQ, TS>), grid, dim3(512), smem, c->stream, c->X, c->nx, chunk_rows, Yc, ldy, P, cuts,
-                     T, cut0, inv_step, eps, hist);
+  hipLaunchKernelGGL((k_null<KQ, NS, PF, NW>), grid, dim3(64 * NW), smem, c->stream, c->X, c->nx, chunk_rows, Yc, ldy, P,
+                     cuts, T, cut0, inv_step, eps, partial);
   HIP_TRY(hipGetLastError());
   return 0;
 }
-
 // one instantiation per exact k-depth (ceil(N/4), N <= 256) so the MFMA loop has no guards
-typedef int (*null_launch_fn)(cna_ctx*, dim3, size_t, int64_t, const double*, int, int, const double*, int, double,
-                              double, double, unsigned long long*);
-template <int TS, int... KQ>
+template <int NS, int... KQ>
 constexpr std::array<null_launch_fn, sizeof...(KQ)> null_table(std::integer_sequence<int, KQ...>) {
-  return {{&launch_null_t<KQ + 1, TS>...}};
+  return {{&launch_null_t<KQ + 1, NS>...}};
 }
-const auto kNullTS2 = null_table<2>(std::make_integer_sequence<int, 54>{});   // KQ 1..54
-const auto kNullTS1 = null_table<1>(std::make_integer_sequence<int, 64>{});   // KQ 1..64
+const auto kNullNS4 = null_table<4>(std::make_integer_sequence<int, 40>{});   // KQ 1..40
+const auto kNullNS2 = null_table<2>(std::make_integer_sequence<int, 64>{});   // KQ 1..64
+const auto kNullNS1 = null_table<1>(std::make_integer_sequence<int, 64>{});   // KQ 1..64 (many thresholds)
 
 }  // namespace
 
@@ -420,39 +433,48 @@ int launch_gram(cna_ctx* c, double* G_dev) {
 
 int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* cuts_dev, int T,
                       double cut0, double inv_step, double eps, unsigned long long* hist_dev) {
-  HIP_TRY(hipMemsetAsync(hist_dev, 0, sizeof(unsigned long long) * (size_t)P * T, c->stream));
-  if (c->nx == 0 || P == 0 || T == 0) return 0;
+  if (c->nx == 0 || P == 0 || T == 0) {
+    HIP_TRY(hipMemsetAsync(hist_dev, 0, sizeof(unsigned long long) * (size_t)P * T, c->stream));
+    return 0;
+  }
   const int kq = c->ldx / 4;
   if (kq > 64) CNA_FAIL(CNA_EINVAL, "more than 256 samples are not supported by the local-null kernel yet");
   if (!(cut0 > 0.0)) CNA_FAIL(CNA_EINVAL, "local-null kernel needs strictly positive thresholds");
-  const int HW = ((T + 1) / 2) | 1;
-  const size_t fixed = sizeof(double) * ((T + 4) & ~1) + sizeof(unsigned int) * 64 * HW;
-  const size_t slab64 = sizeof(double) * 64 * (c->ldx + 2), slab32 = slab64 / 2;
-  const int TS = (kq <= 54 && fixed + slab64 <= 150 * 1024) ? 2 : 1;
-  const size_t smem = fixed + (TS == 2 ? slab64 : slab32);
-  if (smem > 160 * 1024) CNA_FAIL(CNA_EINVAL, "local-null kernel: thresholds/samples exceed LDS");
-  const int ROWS = 32 * TS;
-  const int nptile = (P + 63) / 64;
-  const int64_t nslab = (c->nx + ROWS - 1) / ROWS;
-  int64_t nchunks = (1024 + nptile - 1) / nptile;
-  if (nchunks > nslab) nchunks = nslab;
-  int64_t chunk_rows = ((nslab + nchunks - 1) / nchunks) * ROWS;
-  if (chunk_rows > 65472) chunk_rows = 65472;            // 16-bit packed counters; multiple of 64
+  // LDS: cuts, the Yc strip (4kq x (PT+16) doubles), PT x (T+1) 32-bit counters
+  auto lds = [&](int ns) {
+    return sizeof(double) * ((T + 4) & ~1) + sizeof(double) * (size_t)c->ldx * (16 * ns + 16) +
+           sizeof(unsigned int) * (size_t)16 * ns * (T + 1);
+  };
+  const size_t cap = 160 * 1024;
+  const int NS = (kq <= 40 && lds(4) <= cap) ? 4 : (lds(2) <= cap ? 2 : 1);
+  if (lds(NS) > cap) CNA_FAIL(CNA_EINVAL, "local-null kernel: thresholds/samples exceed LDS");
+  const int nptile = (P + 16 * NS - 1) / (16 * NS);
+  const int64_t ntile = (c->nx + 15) / 16;
+  // one block per CU fits (LDS); two rounds of blocks over the 256 CUs even out the tail
+  int64_t nchunks = (512 + nptile - 1) / nptile;
+  if (nchunks > (ntile + 15) / 16) nchunks = (ntile + 15) / 16;
+  if (nchunks < 1) nchunks = 1;
+  const int64_t chunk_rows = ((ntile + nchunks - 1) / nchunks) * 16;
   nchunks = (c->nx + chunk_rows - 1) / chunk_rows;
+  void* part = c->null_part;
+  CNA_TRY(dev_reserve(c, &part, &c->null_part_cap, (int64_t)sizeof(unsigned int) * nchunks * P * T));
+  c->null_part = part;
   dim3 grid((unsigned)nchunks, (unsigned)nptile);
   ProfScope ps(c, CNA_K_NULL_LOCAL);
-  null_launch_fn fn = TS == 2 ? kNullTS2[kq - 1] : kNullTS1[kq - 1];
-  if (const char* dbg = getenv("CNA_NULL_DEBUG")) {                      // experiments, N=50 only
-    if (kq == 13 && TS == 2 && atoi(dbg) == 1) {
-      hipLaunchKernelGGL((k_null<13, 2, 1>), grid, dim3(512), smem, c->stream, c->X, c->nx, chunk_rows, Yc_dev, ldy, P,
-                         cuts_dev, T, cut0, inv_step, eps, hist_dev);
-      return 0;
-    }
-    if (kq == 13 && TS == 2 && atoi(dbg) == 2) {
-      hipLaunchKernelGGL((k_null<13, 2, 2>), grid, dim3(512), smem, c->stream, c->X, c->nx, chunk_rows, Yc_dev, ldy, P,
-                         cuts_dev, T, cut0, inv_step, eps, hist_dev);
+  if (const char* dbg = getenv("CNA_NULL_DEBUG")) {                    // experiments, N=50 only
+    if (kq == 13 && NS == 4 && atoi(dbg) >= 1 && atoi(dbg) <= 2) {
+      auto kfn = atoi(dbg) == 1 ? k_null<13, 4, true, 16, 1> : k_null<13, 4, true, 16, 2>;
+      HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      hipLaunchKernelGGL(kfn, grid, dim3(1024), lds(NS), c->stream, c->X, c->nx, chunk_rows, Yc_dev, ldy, P, cuts_dev, T,
+                         cut0, inv_step, eps, (unsigned int*)c->null_part);
       return 0;
     }
   }
-  return fn(c, grid, smem, chunk_rows, Yc_dev, ldy, P, cuts_dev, T, cut0, inv_step, eps, hist_dev);
+  null_launch_fn fn = NS == 4 ? kNullNS4[kq - 1] : (NS == 2 ? kNullNS2[kq - 1] : kNullNS1[kq - 1]);
+  CNA_TRY(fn(c, grid, lds(NS), chunk_rows, Yc_dev, ldy, P, cuts_dev, T, cut0, inv_step, eps, (unsigned int*)c->null_part));
+  const int64_t tot = (int64_t)P * T;
+  hipLaunchKernelGGL(k_hist_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                     (const unsigned int*)c->null_part, (int)nchunks, tot, hist_dev);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
