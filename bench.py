@@ -37,7 +37,7 @@ F64_MFMA_PEAK_TF = 78.6      # AMD MI355X datasheet: FP64 matrix 78.6 TFLOP/s (t
 PMC_TRAFFIC = {
     ('C2', 'nam_step'): 2 * 172400e3 + 82110e3,
     ('C2', 'nam_first'): 2 * 37780e3 + 81250e3,
-    ('C2', 'null_local'): 2 * 147700e3 + 54410e3,
+    ('C2', 'null_local'): 2 * 83220e3 + 37500e3,
 }
 
 WORKLOADS = {
