@@ -201,6 +201,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   if (c->gram_done) (void)hipEventDestroy(c->gram_done);
   if (c->null_done) (void)hipEventDestroy(c->null_done);
   if (c->h_res) (void)hipHostFree(c->h_res);
+  if (c->h_cell) (void)hipHostFree(c->h_cell);
   delete c;
   return 0;
 }
@@ -458,6 +459,12 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
     c->stat_space = CNA_MAT_NAM;
     CNA_TRY(exchange_stat(c));
   }
+  return 0;
+}
+
+int cna_nam_steps(cna_ctx* c, int nsteps) {
+  if (nsteps < 1) CNA_FAIL(CNA_EINVAL, "nsteps < 1");
+  for (int i = 0; i < nsteps; ++i) CNA_TRY(cna_nam_step(c, 0, i + 1 < nsteps, i + 1 == nsteps));
   return 0;
 }
 
@@ -856,7 +863,8 @@ static int ensure_zc(cna_ctx* c, int N, int P, hipStream_t st) {
 
 // queue everything of one local-null pass; results land in the pinned buffer h_res
 // ([T sums][P*T tails if requested]) and null_done fires when they are there
-static int null_local_queue(cna_ctx* c, int col0, int P, const double* edges, int T, int want_tails) {
+static int null_local_queue(cna_ctx* c, int col0, int P, const double* edges, int T, int want_tails,
+                            const double* thr = nullptr) {
   if (P < 1 || T < 1) CNA_FAIL(CNA_EINVAL, "cna_null_local: P and T must be positive");
   if (c->null_pending) CNA_FAIL(CNA_ESTATE, "a local-null pass is still pending: fetch it first");
   for (int t = 1; t < T; ++t)
@@ -866,21 +874,44 @@ static int null_local_queue(cna_ctx* c, int col0, int P, const double* edges, in
   std::vector<double> cuts;
   double cut0, inv_step, eps;
   exact_cuts(edges, T, c->Nx, cuts, &cut0, &inv_step, &eps);
-  const int64_t hbytes = 8 * (int64_t)T + (want_tails ? 8 * (int64_t)P * T : 0);
+  const int64_t obs_off = 8 * (int64_t)T + (want_tails ? 8 * (int64_t)P * T : 0);
+  const int64_t hbytes = obs_off + 16 * (int64_t)T;
   if (hbytes > c->h_res_cap) {
     if (c->h_res) HIP_TRY(hipHostFree(c->h_res));
     c->h_res = nullptr;
     HIP_TRY(hipHostMalloc(&c->h_res, (size_t)hbytes, hipHostMallocDefault));
     c->h_res_cap = hbytes;
   }
-  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({8 * (int64_t)T, 8 * (int64_t)P * T, 8 * (int64_t)P * T, 8 * (int64_t)T})));
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap,
+                      carve_bytes({8 * (int64_t)T, 8 * (int64_t)P * T, 8 * (int64_t)P * T, 8 * (int64_t)T, 8 * (int64_t)T,
+                                   8 * (int64_t)T, 16 * (int64_t)T, 16 * (int64_t)T})));
   Carver cv(c->scratch);
   double* ed = cv.take<double>(T);
   unsigned long long* hist = cv.take<unsigned long long>((int64_t)P * T);
   int64_t* tails = cv.take<int64_t>((int64_t)P * T);
   int64_t* sums = cv.take<int64_t>(T);
+  double* oed = cv.take<double>(T);
+  double* otd = cv.take<double>(T);
+  unsigned long long* ohist = cv.take<unsigned long long>(2 * (int64_t)T);
+  int64_t* otails = cv.take<int64_t>(2 * (int64_t)T);
+  c->null_has_obs = 0;
+  if (thr) {
+    // threshold counts of the observed coefficients (cna_obs_counts) ride along: tiny kernels in front
+    // of the long one, results in the same pinned block
+    if (!c->ncorrs_valid) CNA_FAIL(CNA_ESTATE, "threshold counts need cna_ncorrs");
+    double thr0, ostep;
+    guess_from_thr(thr, T, &thr0, &ostep);
+    HIP_TRY(hipMemcpyAsync(oed, edges, 8 * T, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(otd, thr, 8 * T, hipMemcpyHostToDevice, c->stream));
+    CNA_TRY(launch_obs_counts(c, oed, otd, T, thr0, ostep, ohist));
+    CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)ohist, (size_t)2 * T));
+    CNA_TRY(launch_suffix_sum(c, ohist, 2, T, otails));
+    HIP_TRY(hipMemcpyAsync((char*)c->h_res + obs_off, otails, 16 * (size_t)T, hipMemcpyDeviceToHost, c->stream));
+    c->null_has_obs = 1;
+    c->null_obs_off = obs_off;
+  }
   HIP_TRY(hipMemcpyAsync(ed, cuts.data(), 8 * T, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));               // `cuts` is a local; the stream is idle here anyway
+  HIP_TRY(hipStreamSynchronize(c->stream));               // `cuts`, `edges`, `thr` are the caller's; the stream is nearly idle here
   // columns beyond col0+P inside the last 64-wide tile are other phenotypes: the kernel only
   // flushes counters of p < P, and reads stay inside the zero-padded leading dimension
   CNA_TRY(launch_null_local(c, c->zc + col0, c->zc_ld, P, ed, T, cut0, inv_step, eps, hist));
@@ -898,10 +929,17 @@ static int null_local_queue(cna_ctx* c, int col0, int P, const double* edges, in
   return 0;
 }
 
-static int null_local_collect(cna_ctx* c, int64_t* tails_out, int64_t* sums_out) {
+static int null_local_collect(cna_ctx* c, int64_t* tails_out, int64_t* sums_out, int64_t* ranks_out = nullptr,
+                              int64_t* numdet_out = nullptr) {
   if (!c->null_pending) CNA_FAIL(CNA_ESTATE, "no local-null pass pending");
   c->null_pending = 0;
   HIP_TRY(hipEventSynchronize(c->null_done));
+  if (ranks_out || numdet_out) {
+    if (!c->null_has_obs) CNA_FAIL(CNA_EINVAL, "the pending pass was launched without thresholds");
+    const char* o = (const char*)c->h_res + c->null_obs_off;
+    if (ranks_out) std::memcpy(ranks_out, o, 8 * (size_t)c->null_T);
+    if (numdet_out) std::memcpy(numdet_out, o + 8 * (size_t)c->null_T, 8 * (size_t)c->null_T);
+  }
   if (sums_out) std::memcpy(sums_out, c->h_res, 8 * (size_t)c->null_T);
   if (tails_out) {
     if (!c->null_has_tails) CNA_FAIL(CNA_EINVAL, "the pending pass was launched without want_tails");
@@ -916,15 +954,16 @@ static int null_local_on_resident(cna_ctx* c, int col0, int P, const double* edg
   return null_local_collect(c, tails_out, sums_out);
 }
 
-int cna_null_local_launch(cna_ctx* c, int col0, int P, const double* edges, int T, int want_tails) {
+int cna_null_local_launch(cna_ctx* c, int col0, int P, const double* edges, int T, int want_tails, const double* thr) {
   CHECK_CTX(c);
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
-  return null_local_queue(c, col0, P, edges, T, want_tails);
+  return null_local_queue(c, col0, P, edges, T, want_tails, thr);
 }
 
-int cna_null_local_fetch(cna_ctx* c, int64_t* tails_out, int64_t* tail_sums_out) {
+int cna_null_local_fetch(cna_ctx* c, int64_t* tails_out, int64_t* tail_sums_out, int64_t* ranks_out,
+                         int64_t* num_detected_out) {
   CHECK_CTX(c);
-  return null_local_collect(c, tails_out, tail_sums_out);
+  return null_local_collect(c, tails_out, tail_sums_out, ranks_out, num_detected_out);
 }
 
 int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int T, int64_t* tails_out) {
@@ -1020,6 +1059,25 @@ int cna_obs_counts(cna_ctx* c, const double* edges, const double* thr, int T, in
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (ranks_out) std::memcpy(ranks_out, h.data(), 8 * T);
   if (num_detected_out) std::memcpy(num_detected_out, h.data() + T, 8 * T);
+  return 0;
+}
+
+int cna_percell_fdr_pinned(cna_ctx* c, const double* thr, const double* runmin_fdr, int T, double** coef_ptr,
+                           double** fdr_ptr) {
+  CHECK_CTX(c);
+  if (!coef_ptr) CNA_FAIL(CNA_EINVAL, "cna_percell_fdr_pinned: coef_ptr is required");
+  const int64_t need = 16 * std::max<int64_t>(c->n_global, 1);
+  if (need > c->h_cell_cap) {
+    if (c->h_cell) HIP_TRY(hipHostFree(c->h_cell));
+    c->h_cell = nullptr;
+    HIP_TRY(hipHostMalloc(&c->h_cell, (size_t)need, hipHostMallocDefault));
+    c->h_cell_cap = need;
+  }
+  double* hc = (double*)c->h_cell;
+  const bool want_fdr = fdr_ptr && thr && runmin_fdr && T > 0;
+  CNA_TRY(cna_percell_fdr(c, thr, runmin_fdr, T, hc, want_fdr ? hc + c->n_global : nullptr));
+  *coef_ptr = hc;
+  if (fdr_ptr) *fdr_ptr = want_fdr ? hc + c->n_global : nullptr;
   return 0;
 }
 

@@ -128,6 +128,10 @@ struct cna_ctx {
   // ---- scratch
   void* scratch = nullptr;
   int64_t scratch_cap = 0;
+  int null_has_obs = 0;
+  int64_t null_obs_off = 0;
+  void* h_cell = nullptr;         // pinned: per-cell outputs of cna_percell_fdr_pinned (coef | fdr)
+  int64_t h_cell_cap = 0;
   void* null_part = nullptr;      // per-block counter slabs of the local-null kernel
   int64_t null_part_cap = 0;
   void* scratch2 = nullptr;

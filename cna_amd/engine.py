@@ -182,6 +182,10 @@ class Engine(_order.CellOrder):
         check(self.lib.cna_nam_step(self.h, int(bool(want_kurt)), int(bool(may_continue)), int(bool(may_stop))),
               'cna_nam_step')
 
+    def nam_steps(self, nsteps):
+        """nsteps walk steps in one call (fixed step count, nothing for the host to decide in between)."""
+        check(self.lib.cna_nam_steps(self.h, int(nsteps)), 'cna_nam_steps')
+
     def cell_stat(self, n_expected, nam_space=True):
         """Per-cell statistic of the last kernel that made one: over all cells in the caller's
         order (nam_space) or over the rows of X in device order (see x_stat())."""
@@ -324,17 +328,26 @@ class Engine(_order.CellOrder):
               'cna_null_local_resident')
         return sums if sums_only else tails
 
-    def null_local_launch(self, col0, P, edges):
-        """Queue a local-null pass on resident columns; collect with null_local_fetch()."""
+    def null_local_launch(self, col0, P, edges, thr=None):
+        """Queue a local-null pass on resident columns; collect with null_local_fetch().  With `thr`
+        the threshold counts of the observed coefficients (obs_counts) are queued in front of it."""
         edges = _f64(edges)
-        check(self.lib.cna_null_local_launch(self.h, int(col0), int(P), ptr(edges), len(edges), 0),
+        thr = None if thr is None else _f64(thr)
+        check(self.lib.cna_null_local_launch(self.h, int(col0), int(P), ptr(edges), len(edges), 0, ptr(thr)),
               'cna_null_local_launch')
         self._null_T = len(edges)
+        self._null_obs = thr is not None
 
     def null_local_fetch(self):
-        sums = np.empty(self._null_T, dtype=np.int64)
-        check(self.lib.cna_null_local_fetch(self.h, None, ptr(sums)), 'cna_null_local_fetch')
-        return sums
+        """Tail sums of the pending pass, or (tail sums, ranks, num_detected) when it was launched with thr."""
+        T = self._null_T
+        sums = np.empty(T, dtype=np.int64)
+        if not self._null_obs:
+            check(self.lib.cna_null_local_fetch(self.h, None, ptr(sums), None, None), 'cna_null_local_fetch')
+            return sums
+        ranks, numdet = np.empty(T, dtype=np.int64), np.empty(T, dtype=np.int64)
+        check(self.lib.cna_null_local_fetch(self.h, None, ptr(sums), ptr(ranks), ptr(numdet)), 'cna_null_local_fetch')
+        return sums, ranks, numdet
 
     def global_test(self, U, ks, r):
         """min-p F-test of every resident phenotype column -> (index into ks, p, r2) arrays."""
@@ -356,14 +369,20 @@ class Engine(_order.CellOrder):
         return ranks, numdet
 
     def percell(self, thr=None, runmin=None):
-        coef = np.empty(self.n)
+        """Per-cell coefficient (NaN for dropped cells) and FDR columns over all cells, caller's order.
+        The arrays are views of pinned buffers owned by the engine: valid until the next percell()
+        -- copy them (assigning to a DataFrame column does) before running another analysis."""
+        cp, fp = C.c_void_p(), C.c_void_p()
         if thr is None:
-            check(self.lib.cna_percell_fdr(self.h, None, None, 0, ptr(coef), None), 'cna_percell_fdr')
-            return coef, None
+            check(self.lib.cna_percell_fdr_pinned(self.h, None, None, 0, C.byref(cp), None), 'cna_percell_fdr_pinned')
+            return self._pinned_view(cp), None
         thr, runmin = _f64(thr), _f64(runmin)
-        fdr = np.empty(self.n)
-        check(self.lib.cna_percell_fdr(self.h, ptr(thr), ptr(runmin), len(thr), ptr(coef), ptr(fdr)), 'cna_percell_fdr')
-        return coef, fdr
+        check(self.lib.cna_percell_fdr_pinned(self.h, ptr(thr), ptr(runmin), len(thr), C.byref(cp), C.byref(fp)),
+              'cna_percell_fdr_pinned')
+        return self._pinned_view(cp), self._pinned_view(fp)
+
+    def _pinned_view(self, p):
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(self.n,))
 
     # ---------------------------------------------------------------- D2H
     def matrix_shape(self, which):

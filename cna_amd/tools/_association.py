@@ -38,6 +38,15 @@ def _background():
     return _pool
 
 
+_TRACE = None      # list of (label, perf_counter) when tools/host_trace.py switches tracing on
+
+
+def _mark(label):
+    if _TRACE is not None:
+        import time
+        _TRACE.append((label, time.perf_counter()))
+
+
 def _draw_null(y, batches, donorids, Nnull=1000, force_permute_all=False, seed=None):
     """Host-only head of the reference's ``_association`` (_association.py:15-22,79-83):
     seed numpy's global RNG, standardise y (ddof=0) and draw the permuted phenotypes.
@@ -96,10 +105,11 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         edges = z2 - 1e-8 - 1e-5 * z2                        # tail_counts' bin edges (_stats.py:47)
         # tail counts from columns 1..Nloc of Zc, summed over permutations on the device; neither
         # cells x Nloc nor Nloc x T ever reaches the host
-        engine.null_local_launch(1, Nloc, edges)                  # returns at once
+        # (the threshold counts of the observed coefficients ride along in front of it)
+        engine.null_local_launch(1, Nloc, edges, thresholds)      # returns at once
         pending = True
 
-    tail_sums = None
+    tail_sums = ranks = num_detected = None
     try:
         # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105), and the global F-tests of the
         # observed phenotype and every permutation (second stream), all under the local-null kernel
@@ -107,8 +117,9 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         best, pv, r2v = engine.global_test(U, ks_arr, r)
     finally:
         if pending:
-            tail_sums = engine.null_local_fetch()   # never leave a pass pending behind an exception
+            tail_sums, ranks, num_detected = engine.null_local_fetch()   # never leave a pass pending behind an exception
 
+    _mark('null fetched')
     if (best < 0).any():
         raise ValueError('All-NaN slice encountered')        # np.nanargmin in _minp_stats
     k, p, r2 = ks[best[0]], pv[0], r2v[0]
@@ -142,7 +153,6 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     fdr_5p_t = fdr_10p_t = None
     if local_test:
         print('computing neighborhood-level FDRs', file=out)
-        ranks, num_detected = engine.obs_counts(edges, thresholds)
         with np.errstate(all='ignore'):
             # mean over permutations of tails/ranks (_stats.py:79-80) from the per-threshold sums
             fdr_vals = tail_sums / ranks / Nloc
@@ -160,10 +170,12 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     if fdr_vals is not None:
         with np.errstate(invalid='ignore'):
             runmin = np.fmin.accumulate(fdr_vals)
+        _mark('pre percell')
         coef_all, fdr_all = engine.percell(thresholds, runmin)
     else:
         coef_all, fdr_all = engine.percell(None, None)
 
+    _mark('percell done')
     res.__dict__.update({'p': pfinal, 'nullminps': nullminps, 'k': k, 'fdr_5p_t': fdr_5p_t,
                          'fdr_10p_t': fdr_10p_t, 'yresid_hat': yhat, 'ks': ks, 'beta': beta,
                          'r2': r2, 'r2_perpc': r2_perpc, 'nullr2_mean': nullr2s.mean(),
@@ -182,11 +194,16 @@ def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_si
             raise TypeError(f"'{name}' must be a pandas {label}, but got {type(val)}")
     if sids_present is None:
         sids_present = pd.unique(data.obs[sid_name])
-    present = y.index.isin(sids_present)
-    if not present.all():
-        print("WARNING: index of 'y' contains values not present in 'data[sid_name]'. These samples will be ignored.")
-    if not pd.Index(sids_present).isin(y.index).all():
-        raise ValueError("'data[sid_name]' contains values not present in the index of 'y'.")
+    if isinstance(sids_present, pd.Index) and len(sids_present) == len(y.index) and sids_present.equals(y.index):
+        # the usual case -- y is indexed by exactly the samples of data, in canonical order -- needs
+        # neither of the two hash joins below (this runs on the critical path of small problems)
+        present = np.ones(len(y), dtype=bool)
+    else:
+        present = y.index.isin(sids_present)
+        if not present.all():
+            print("WARNING: index of 'y' contains values not present in 'data[sid_name]'. These samples will be ignored.")
+        if not pd.Index(sids_present).isin(y.index).all():
+            raise ValueError("'data[sid_name]' contains values not present in the index of 'y'.")
     if batches is not None and donorids is not None:
         raise ValueError('We do not currently support conditioning on batch ' +
                          'while also accounting for multiple samples per donor')
@@ -200,6 +217,8 @@ def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_si
                   'when conditioning on covariates. This conditioning may therefore account ' +
                   'only incompletely for the covariates of interest. We expect this to make ' +
                   'only minor differences in most cases, but we have not investigated it formally')
+    elif y.dtype.kind == 'f':
+        filter_samples = pd.Series(~np.isnan(y.values) & present, index=y.index, name=y.name)
     else:
         filter_samples = ~np.isnan(y) & present
 
@@ -288,7 +307,9 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     Nnull = kwargs.get('Nnull', 1000)
 
     # factorise the per-cell sample ids once; validation and NAM construction share the result
+    _mark('enter')
     codes, labels, counts, token = sample_codes_cached(data.obs[sid_name])
+    _mark('codes')
     nam_queued = None
     used = counts > 0
     batches, filter_samples = check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size,
@@ -298,13 +319,27 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     # inputs: it starts on the helper thread right away and is collected just before the
     # phenotypes go to the device.  Nothing else touches numpy's global RNG in between.
     def null_job():
-        f = filter_samples.reindex(y.index)
-        b_ = batches.reindex(y.index)
-        d_ = donorids.reindex(y.index) if donorids is not None else None
-        return _draw_null(y[f].values, b_[f].values, d_[f].values if d_ is not None else None,
+        _mark('draw starts')
+        # y[f] with f = filter.reindex(y.index), etc.; when the Series already share y's index
+        # object (check_inputs built them on it) that is plain numpy masking
+        if filter_samples.index is y.index and batches.index is y.index and donorids is None:
+            d_ = None
+            fv = filter_samples.values
+            yv, bv = y.values[fv], batches.values[fv]
+        else:
+            f = filter_samples.reindex(y.index)
+            b_ = batches.reindex(y.index)
+            d_ = donorids.reindex(y.index) if donorids is not None else None
+            yv, bv = y[f].values, b_[f].values
+        _mark('draw inputs ready')
+        out_ = _draw_null(yv, bv, d_[f].values if d_ is not None else None,
                           Nnull=Nnull, force_permute_all=kwargs.get('force_permute_all', False),
                           seed=kwargs.get('seed'))
+        _mark('draw done')
+        return out_
+    _mark('checked')
     null_future = _background().submit(null_job)
+    _mark('submitted')
 
     early = {}
 
@@ -348,13 +383,14 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     finally:
         y_std, y_null = null_future.result()
 
+    _mark('resid queued, null drawn')
     print('performing association test', file=out)
     coef_all, fdr_all, U, svs = _association(engine, res, y_std, y_null, ks=ks, Nnull=Nnull,
                                              local_test=kwargs.get('local_test', True),
                                              show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_total,
                                              conditioned=early.get('conditioned', False))
+    _mark('_association returned')
     _defer_pcs(res, engine, U, svs, cell_index)
-    res._defer('ncorrs', lambda: pd.Series(coef_all if kept.all() else coef_all[kept], index=cell_index()))
     res.kept = kept
 
     def fetch_nam():
@@ -365,14 +401,24 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         return pd.DataFrame(full[kept][:, colmap].T, index=sample_index, columns=cell_index())
 
     res._defer('nam', fetch_nam)
+    _mark('lazies set')
 
     if key_added in data.obs:
         warnings.warn(f"Key '{key_added}' already exists in data.obs. Overwriting.")
+    _mark('warned')
+    # coef_all / fdr_all may be views of the engine's pinned buffers: the DataFrame stores its own
+    # copy, and that copy (not the view) is what res.ncorrs is built from when somebody reads it
     data.obs[key_added] = coef_all
+    coef_kept = data.obs[key_added].values
+    if np.may_share_memory(coef_kept, coef_all):
+        coef_kept = np.array(coef_all)
+    res._defer('ncorrs', lambda: pd.Series(coef_kept if kept.all() else coef_kept[kept], index=cell_index()))
+    _mark('coef written')
     if fdr_all is None:
         # upstream dereferences res.fdrs here and dies when local_test=False (_association.py:235)
         raise AttributeError("'NoneType' object has no attribute 'loc'")
     data.obs[f'{key_added}_fdr'] = fdr_all
+    _mark('obs written')
 
     if return_full:
         # everything but the three cells x samples frames is materialised now, like upstream

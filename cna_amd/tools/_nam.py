@@ -228,6 +228,10 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
     prevmedkurt = np.inf
     old = None
     taken = 0
+    if not need_kurt and 1 <= nsteps <= maxnsteps:
+        engine.nam_steps(nsteps)                 # nothing to decide between steps: one call queues them all
+        engine._nam_sig = (sig, engine.nam_epoch, nsteps) if sig is not None else None
+        return labels, nsteps
     for i in range(maxnsteps):
         last_for_sure = (nsteps is not None and i + 1 == nsteps) or (i + 1 == maxnsteps)
         may_stop = last_for_sure or show_progress or (nsteps is None and i + 1 >= 3)

@@ -110,6 +110,9 @@ int  cna_restart_nam(cna_ctx* ctx);
  *   may_continue : keep the scaled state for another step (exchanged across ranks);
  *   may_stop  : also write NAM = s/C (_nam.py:73) so the walk can end here. */
 int  cna_nam_step(cna_ctx* ctx, int want_kurt, int may_continue, int may_stop);
+/* nsteps steps with a fixed step count and no per-step host decision (nsteps given, no progress
+ * output): cna_nam_step(0, more, last) x nsteps in one call */
+int  cna_nam_steps(cna_ctx* ctx, int nsteps);
 /* per-cell statistic of the last kernel that produced one (kurtosis / batch kurtosis),
  * gathered over ranks: out has n_global entries (CNA_MAT_NAM rows) or n_x_total (CNA_MAT_X) */
 int  cna_fetch_cell_stat(cna_ctx* ctx, double* out, int64_t n_expected);
@@ -190,8 +193,10 @@ int  cna_null_local_resident(cna_ctx* ctx, int col0, int P, const double* edges,
 /* cna_null_local_resident in two halves: queue the pass (returns at once; at most one pending),
  * collect its results later.  Between the two the host may call cna_gram_fetch and cna_global_test,
  * which run beside the local-null kernel on a second stream. */
-int  cna_null_local_launch(cna_ctx* ctx, int col0, int P, const double* edges, int T, int want_tails);
-int  cna_null_local_fetch(cna_ctx* ctx, int64_t* tails_out, int64_t* tail_sums_out);
+int  cna_null_local_launch(cna_ctx* ctx, int col0, int P, const double* edges, int T, int want_tails,
+                           const double* thr /* or NULL: also queue cna_obs_counts(edges, thr) */);
+int  cna_null_local_fetch(cna_ctx* ctx, int64_t* tails_out, int64_t* tail_sums_out,
+                          int64_t* ranks_out, int64_t* num_detected_out /* both NULL unless thr was given */);
 int  cna_global_test(cna_ctx* ctx, const double* U, int kmax, const int32_t* ks, int K, int r,
                      double* minp_out, double* r2_out, int32_t* kidx_out);
 /* ranks[t] = #{i : ncorrs_i^2 >= edges[t]} (_stats.py:74) and
@@ -203,6 +208,10 @@ int  cna_obs_counts(cna_ctx* ctx, const double* edges, const double* thr, int T,
  * runmin_fdr[t] = min(fdr[0..t]).  kept rows are the ones given to cna_select. */
 int  cna_percell_fdr(cna_ctx* ctx, const double* thr, const double* runmin_fdr, int T,
                      double* coef_out_global, double* fdr_out_global);
+/* same, into pinned host buffers owned by the context (n_global doubles each; valid until the next
+ * call on this context): the D2H copies run at PCIe speed and the caller copies or consumes them */
+int  cna_percell_fdr_pinned(cna_ctx* ctx, const double* thr, const double* runmin_fdr, int T,
+                            double** coef_ptr, double** fdr_ptr);
 
 /* ---- device -> host for the lazily materialised result fields (a20) -------------------- */
 int  cna_matrix_shape(cna_ctx* ctx, int which, int64_t* n_rows_local, int* n_cols);

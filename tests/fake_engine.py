@@ -167,6 +167,10 @@ class FakeEngine(_order.CellOrder):
             if want_kurt:
                 self.stat = self._gather(orc.row_kurtosis(new_local / self.counts))
 
+    def nam_steps(self, nsteps):
+        for i in range(nsteps):
+            self.nam_step(False, i + 1 < nsteps, i + 1 == nsteps)
+
     def cell_stat(self, n_expected, nam_space=True):
         assert len(self.stat) == n_expected
         return self.cells_to_user(self.stat.copy()) if nam_space else self.stat.copy()
@@ -278,8 +282,10 @@ class FakeEngine(_order.CellOrder):
         tails = self.null_local(self.Zc[:, col0:col0 + P], edges)
         return tails.sum(axis=0) if sums_only else tails
 
-    def null_local_launch(self, col0, P, edges):
+    def null_local_launch(self, col0, P, edges, thr=None):
         self._pending = self.null_local_resident(col0, P, edges, sums_only=True)
+        if thr is not None:
+            self._pending = (self._pending,) + tuple(self.obs_counts(edges, thr))
 
     def null_local_fetch(self):
         out, self._pending = self._pending, None

@@ -22,7 +22,10 @@ for name in dir(Engine):
             t0 = time.perf_counter(); r = fn(self, *a, **k); ev.append((t0, time.perf_counter(), name, threading.current_thread().name[:4])); return r
         return w
     setattr(Engine, name, mk(fn, name))
+from cna_amd.tools import _association as _A
+_A._TRACE = []
 t0 = time.perf_counter(); cna.tl.association(data, meta['y'], 'id', **kw); t1 = time.perf_counter()
+marks, _A._TRACE = _A._TRACE, None
 ev.sort()
 print('step %.3f ms' % ((t1 - t0) * 1e3))
 last = t0
@@ -30,3 +33,4 @@ for a, b, name, th in ev:
     print('%8.3f  +%6.3f gap  %-22s %6.3f ms  [%s]' % ((a - t0) * 1e3, (a - last) * 1e3, name, (b - a) * 1e3, th))
     if th == 'Main': last = b
 print('%8.3f  +%6.3f gap  end' % ((t1 - t0) * 1e3, (t1 - last) * 1e3))
+print('marks: ' + '  '.join('%s@%.3f' % (k, (v - t0) * 1e3) for k, v in marks))
