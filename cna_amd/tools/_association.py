@@ -65,11 +65,13 @@ def _draw_null(y, batches, donorids, Nnull=1000, force_permute_all=False, seed=N
 
 
 def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_progress=False,
-                 npcs=None, n_cells=None, conditioned=False):
+                 npcs=None, n_cells=None, conditioned=False, null_source=None):
     """Body of the reference's ``_association`` (_association.py:24-129) against the
     residualised NAM held by ``engine`` (cells x samples), whose Gram-matrix kernels have been
     queued.  ``res`` is the namespace from the residualisation (M, r), ``y`` / ``y_`` the
-    standardised phenotype and its permutations.
+    standardised phenotype and its permutations (``null_source``: a callable delivering ``y_``
+    when it is first needed, so that everything that only needs ``y`` runs while the permutations
+    are still being drawn).
 
     Ordering: the local-null kernel is started first and runs on the GPU while LAPACK's SVD of
     G and the global F-tests run here; the values, warnings and progress text are those of the
@@ -84,16 +86,10 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
             'Maximum number of PCs plus number of covariates must be less than n-1. ' +
             f'Currently it is {max(ks)+r} while n is {n}. Either reduce the number of covariates ' +
             'or reduce the number of PCs to consider using the optional argument ks=[...].')
-    if y_ is None:   # grouplevel_permutation refused (it printed why); upstream dies on y_.T
-        raise AttributeError("'NoneType' object has no attribute 'T'")
     ks_arr = np.asarray(ks)
     Mv = np.asarray(M, dtype=np.float64)
 
-    # phenotypes -> device: Zc = M.[y, y_] / std (ddof=1), resident for both tests (already there
-    # when the caller could issue it under the diffusion kernels)
-    if not conditioned:
-        engine.condition(Mv, np.column_stack([y, y_]))
-    # neighbourhood coefficients -> thresholds -> start the local null (device, asynchronous)
+    # neighbourhood coefficients -> thresholds (needs y only)
     _, maxabs = engine.ncorrs(y, fetch=False)
     pending = False
     thresholds = edges = None
@@ -103,9 +99,19 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         thresholds = np.arange(maxcorr / 4, maxcorr, maxcorr / 400)
         z2 = thresholds ** 2
         edges = z2 - 1e-8 - 1e-5 * z2                        # tail_counts' bin edges (_stats.py:47)
-        # tail counts from columns 1..Nloc of Zc, summed over permutations on the device; neither
-        # cells x Nloc nor Nloc x T ever reaches the host
-        # (the threshold counts of the observed coefficients ride along in front of it)
+
+    if null_source is not None:
+        y_ = null_source()
+    if y_ is None:   # grouplevel_permutation refused (it printed why); upstream dies on y_.T
+        raise AttributeError("'NoneType' object has no attribute 'T'")
+    # phenotypes -> device: Zc = M.[y, y_] / std (ddof=1), resident for both tests (already there
+    # when the caller could issue it under the diffusion kernels)
+    if not conditioned:
+        engine.condition(Mv, np.column_stack([y, y_]))
+    if local_test:
+        # start the local null (device, asynchronous): tail counts from columns 1..Nloc of Zc, summed
+        # over permutations on the device; neither cells x Nloc nor Nloc x T ever reaches the host.
+        # The threshold counts of the observed coefficients ride along in front of it.
         engine.null_local_launch(1, Nloc, edges, thresholds)      # returns at once
         pending = True
 
@@ -318,21 +324,20 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     # the permutation draw (numpy RNG + argsort, both outside the GIL) needs only sample-level
     # inputs: it starts on the helper thread right away and is collected just before the
     # phenotypes go to the device.  Nothing else touches numpy's global RNG in between.
+    # y[f] with f = filter.reindex(y.index), etc.; when the Series already share y's index object
+    # (check_inputs built them on it) that is plain numpy masking
+    if filter_samples.index is y.index and batches.index is y.index and donorids is None:
+        fv = filter_samples.values
+        yv, bv, dv = y.values[fv], batches.values[fv], None
+    else:
+        f = filter_samples.reindex(y.index)
+        b_ = batches.reindex(y.index)
+        d_ = donorids.reindex(y.index) if donorids is not None else None
+        yv, bv, dv = y[f].values, b_[f].values, (d_[f].values if d_ is not None else None)
+
     def null_job():
         _mark('draw starts')
-        # y[f] with f = filter.reindex(y.index), etc.; when the Series already share y's index
-        # object (check_inputs built them on it) that is plain numpy masking
-        if filter_samples.index is y.index and batches.index is y.index and donorids is None:
-            d_ = None
-            fv = filter_samples.values
-            yv, bv = y.values[fv], batches.values[fv]
-        else:
-            f = filter_samples.reindex(y.index)
-            b_ = batches.reindex(y.index)
-            d_ = donorids.reindex(y.index) if donorids is not None else None
-            yv, bv = y[f].values, b_[f].values
-        _mark('draw inputs ready')
-        out_ = _draw_null(yv, bv, d_[f].values if d_ is not None else None,
+        out_ = _draw_null(yv, bv, dv,
                           Nnull=Nnull, force_permute_all=kwargs.get('force_permute_all', False),
                           seed=kwargs.get('seed'))
         _mark('draw done')
@@ -380,15 +385,25 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     npcs = min(N, max([10] + [int(max_frac_pcs * N)] + [ks if ks is not None else []][0]))
     try:
         res = _resid_run(engine, plan, cell_index, show_progress=show_progress)
-    finally:
-        y_std, y_null = null_future.result()
+    except BaseException:
+        null_future.cancel() or null_future.exception()     # do not leave the helper thread running
+        raise
 
-    _mark('resid queued, null drawn')
+    _mark('resid queued')
     print('performing association test', file=out)
-    coef_all, fdr_all, U, svs = _association(engine, res, y_std, y_null, ks=ks, Nnull=Nnull,
+    # the standardised phenotype (numpy ddof=0, _association.py:22) does not need the draw; the
+    # permutations are collected inside _association, after everything that only needs y
+    with np.errstate(all='ignore'):
+        y_std = (yv - yv.mean()) / yv.std()
+
+    def drawn():
+        y_null = null_future.result()[1]
+        _mark('null drawn')
+        return y_null
+    coef_all, fdr_all, U, svs = _association(engine, res, y_std, None, ks=ks, Nnull=Nnull,
                                              local_test=kwargs.get('local_test', True),
                                              show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_total,
-                                             conditioned=early.get('conditioned', False))
+                                             conditioned=early.get('conditioned', False), null_source=drawn)
     _mark('_association returned')
     _defer_pcs(res, engine, U, svs, cell_index)
     res.kept = kept
