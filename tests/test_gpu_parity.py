@@ -460,3 +460,50 @@ def test_nam_cache_on_device(eng):
         np.testing.assert_array_equal(nam2, r3.nam.values)
     finally:
         e.close()
+
+
+def test_properties_at_baseline_config2_size(eng):
+    """BASELINE.json configs[1] (200k cells x 50 samples, k=30, nsteps=3, Nnull=1000) through
+    size-independent properties: oracle-free identities on the fetched matrices, the per-cell columns
+    recomputed on the host from the returned tables, and invariance under a random renumbering of the
+    cells (same graph, same samples, cells shuffled) -- the global p-value, the chosen k, the FDR
+    table and every cell's coefficient must not move."""
+    import cna_amd as cna
+    from cna_amd import synth
+    data, meta = synth.make_dataset(200000, 50, k=30, seed=0)
+    y = meta['y']
+    kw = dict(nsteps=3, Nnull=1000, seed=0, return_full=True)
+    res = cna.tl.association(data, y, 'id', **kw)
+    nam = res.nam.values                                               # samples x cells
+    np.testing.assert_allclose(nam.sum(axis=1), 1.0, rtol=1e-9)        # column-stochastic walk
+    X = res.namresid.values
+    assert np.abs(X.mean(axis=0)).max() < 1e-10
+    np.testing.assert_allclose(X.std(axis=0, ddof=1), 1.0, rtol=1e-10)
+    yz = (y.values - y.values.mean()) / y.values.std()
+    coef = data.obs['coef'].values.copy()
+    fdrcol = data.obs['coef_fdr'].values.copy()
+    np.testing.assert_allclose(coef, yz.dot(X) / 50, rtol=1e-9, atol=1e-12)
+    f = res.fdrs
+    thr, fdr, num = f.threshold.values, f.fdr.values, f.num_detected.values
+    assert np.array_equal(num, (np.abs(coef)[None, :] > thr[:, None]).sum(axis=1))
+    assert (np.diff(num) <= 0).all() and ((fdr >= 0) | np.isnan(fdr)).all()
+    runmin = np.fmin.accumulate(fdr)
+    idx = np.searchsorted(thr, np.abs(coef), side='right') - 1
+    want = np.where(idx >= 0, runmin[np.maximum(idx, 0)], 1.0)
+    np.testing.assert_allclose(fdrcol, want, rtol=1e-14)
+    assert 1 / 1001 <= res.p <= 1 and len(res.nullminps) == 1000 and res.kept.all()
+
+    # the same analysis with the cells renumbered at random
+    rs = np.random.RandomState(123)
+    perm = rs.permutation(200000)
+    A = sp.csr_matrix(data.obsp['connectivities'])
+    Ap = A[perm][:, perm].tocsr()
+    Ap.sort_indices()
+    obs2 = pd.DataFrame({'id': data.obs['id'].values[perm]}, index=data.obs.index[perm])
+    data2 = type('D', (), {'obs': obs2, 'obsp': {'connectivities': Ap}, 'uns': {}})()
+    res2 = cna.tl.association(data2, y, 'id', **kw)
+    assert res2.p == res.p and res2.k == res.k
+    # sums over neighbours run in a different order: equal to rounding, counts identical
+    np.testing.assert_allclose(data2.obs['coef'].values, coef[perm], rtol=1e-9, atol=1e-13)
+    assert np.array_equal(res2.fdrs.num_detected.values, num)
+    np.testing.assert_allclose(res2.fdrs.fdr.values, fdr, rtol=1e-9, equal_nan=True)
