@@ -115,7 +115,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-cells', type=int, default=100_000)
+    ap.add_argument('--cpu-sample-cells', type=int, default=200_000)
     ap.add_argument('--profile-host', default=None, help='write a cProfile of 3 extra steps to this file')
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'shm'],
                     help="shm: plumbing check of the N>1 path on ONE GPU (all ranks on device 0, gloo for the "
@@ -251,7 +251,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         from oracle import cna_oracle as orc
         ns = min(args.cpu_sample_cells, n)
-        sdata, smeta = synth.make_dataset(ns, N, k=k, seed=0)
+        sdata, smeta = (data, meta) if ns == n else synth.make_dataset(ns, N, k=k, seed=0)
         # give the CPU path the cores this container may actually use (cgroup quota), not the
         # host's core count: oversubscribed BLAS threads only get the process throttled
         threads = usable_cpus()
@@ -268,6 +268,7 @@ def main():
             t_cpu = time.perf_counter() - t0
         cpu = dict(value=round(ns * Nnull / t_cpu, 1), unit='cell*perm/s', cores=int(threads), kind='port',
                    seconds=round(t_cpu, 2), host_cpus=os.cpu_count(),
+                   p_value=float(ref['p']) if isinstance(ref, dict) and 'p' in ref else None,
                    sample='oracle/cna_oracle.py association(mode=reference) on %d cells x %d samples, k=%d, '
                           'nsteps=%d, Nnull=%d (same generator, seed 0); numpy/scipy vectorised port, '
                           'BLAS threads as listed' % (ns, N, k, nsteps, Nnull))
