@@ -191,7 +191,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_flush(c);
   comm_destroy(c);
-  void* bufs[] = {c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+  void* bufs[] = {c->sp_idx, c->sp_val, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
                   c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -326,6 +326,40 @@ static int ensure_T(cna_ctx* c, int ld) {
   return 0;
 }
 
+// The second walk step can gather a compressed copy of the state (diffuse.hip: k_nam_step_sparse).
+// Worth it when rows are mostly zeros after one step, i.e. many more samples than neighbours; kept
+// to the single-GPU path (the exchange between ranks carries dense rows).  CNA_SPARSE_MIN_N moves
+// the switch-over (0 = never).
+static int ensure_sparse_state(cna_ctx* c) {
+  int min_n = 96;
+  if (const char* e = getenv("CNA_SPARSE_MIN_N")) min_n = atoi(e);
+  const bool want = min_n > 0 && c->N >= min_n && c->nranks == 1 && !comm_active(c);
+  if (!want) {
+    if (c->sp_cnt) {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      dev_free(c, c->sp_idx, 2 * 64 * (size_t)c->sp_rows);
+      dev_free(c, c->sp_val, 8 * 64 * (size_t)c->sp_rows);
+      dev_free(c, c->sp_cnt, (size_t)c->sp_rows);
+      c->sp_idx = c->sp_val = c->sp_cnt = nullptr;
+      c->sp_rows = 0;
+    }
+    return 0;
+  }
+  if (c->sp_cnt && c->sp_rows == c->n_pad) return 0;
+  if (c->sp_cnt) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    dev_free(c, c->sp_idx, 2 * 64 * (size_t)c->sp_rows);
+    dev_free(c, c->sp_val, 8 * 64 * (size_t)c->sp_rows);
+    dev_free(c, c->sp_cnt, (size_t)c->sp_rows);
+    c->sp_idx = c->sp_val = c->sp_cnt = nullptr;
+  }
+  c->sp_rows = c->n_pad;
+  CNA_TRY(dev_alloc(c, &c->sp_idx, 2 * 64 * (size_t)c->sp_rows));
+  CNA_TRY(dev_alloc(c, &c->sp_val, 8 * 64 * (size_t)c->sp_rows));
+  CNA_TRY(dev_alloc(c, &c->sp_cnt, (size_t)c->sp_rows));
+  return 0;
+}
+
 // -------------------------------------------------------------------------------- NAM
 int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const double* counts) {
   CHECK_CTX(c);
@@ -359,6 +393,7 @@ int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const doubl
   c->t_valid = false;
   c->nam_valid = false;
   c->x_valid = false;
+  CNA_TRY(ensure_sparse_state(c));
   return 0;
 }
 

@@ -132,6 +132,11 @@ struct cna_ctx {
   int64_t null_obs_off = 0;
   void* h_cell = nullptr;         // pinned: per-cell outputs of cna_percell_fdr_pinned (coef | fdr)
   int64_t h_cell_cap = 0;
+  // compressed copy of the state after the first walk step (single GPU, wide sample axis)
+  void* sp_idx = nullptr;
+  void* sp_val = nullptr;
+  void* sp_cnt = nullptr;
+  int64_t sp_rows = 0;
   void* null_part = nullptr;      // per-block counter slabs of the local-null kernel
   int64_t null_part_cap = 0;
   void* scratch2 = nullptr;

@@ -39,7 +39,13 @@ struct StepArgs {
   double w;
   int want_kurt, write_t, write_nam;
   int xcd_chunk;
+  // compressed copy of the state after the first step (see k_nam_step_sparse); null = not kept
+  unsigned short* sp_idx;   // n x SP_CAP sample indices of the non-zeros of a row
+  double* sp_val;           // n x SP_CAP their values
+  unsigned char* sp_cnt;    // n: how many (SP_DENSE: more than SP_CAP, use the dense row)
 };
+constexpr int SP_CAP = 64;
+constexpr int SP_DENSE = 255;
 
 __device__ __forceinline__ double readlane_d(double v, int l) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -165,6 +171,25 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
 #pragma unroll
   for (int q = 0; q < NQ; ++q) s[q] = __dadd_rn(accl[lane + 64 * q], (lane + 64 * q == me.sid) ? self : 0.0);
   finish_row<NQ, ColStride1>(a, row, grow, lane, s);
+  if (a.sp_cnt) {
+    // after one step a row is non-zero only at the samples of the cell's neighbours: keep those
+    // (sample, value) pairs side by side so the second step gathers ~40 entries instead of N
+    const double cs = a.colsum[grow];
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int col = lane + 64 * q;
+      const double t = col < a.width ? __ddiv_rn(s[q], cs) : 0.0;        // what finish_row stored in T
+      const unsigned long long m = __ballot(t != 0.0);
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (t != 0.0 && pos < SP_CAP) {
+        a.sp_idx[grow * SP_CAP + pos] = (unsigned short)col;
+        a.sp_val[grow * SP_CAP + pos] = t;
+      }
+      base += __popcll(m);
+    }
+    if (lane == 0) a.sp_cnt[grow] = (unsigned char)(base <= SP_CAP ? base : SP_DENSE);
+  }
 }
 
 // Steps >= 2: gather-accumulate over neighbour rows of the scaled state T.  Each lane owns two
@@ -241,6 +266,95 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
   finish_row<2 * NQ2, ColPair>(a, row, grow, lane, s);
 }
 
+// Second step on the compressed state: the same sums in the same (CSR) order as k_nam_step -- the
+// zeros it skips contribute +0 there -- on a fraction of the bytes (~40 x 10 B instead of 8N B per
+// edge; at N = 200 a third of the cache lines).  Lane l of an edge adds weight x value_l into column
+// sample_l of the wave's LDS accumulator row with ds_add_f64: distinct columns inside one edge, and
+// the LDS serves one wave's instructions in program order, so the result is deterministic.
+// It is not bit-identical to k_nam_step, though: measured on this chip, the LDS f64 atomic does not
+// round like v_add_f64 (1-ulp differences, <= 6e-16 relative, in ~4 % of the outputs; an explicit
+// LDS read / v_add_f64 / LDS write variant reproduces k_nam_step to the bit but is latency bound
+// and slower than the dense kernel).  k_nam_first accumulates the same way.  Rows that overflowed
+// the compressed form (more than SP_CAP distinct samples) are taken dense.
+__device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+template <typename VT, int NQ2>
+__global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
+  constexpr int U = 8;
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* acc = sm + (size_t)wv * 128 * NQ2;
+#pragma unroll
+  for (int q = 0; q < 2 * NQ2; ++q) acc[lane + 64 * q] = 0.0;
+  const int64_t row = my_row(wv, a.xcd_chunk);
+  if (row >= a.n_local) return;
+  const int64_t grow = a.row0 + row;
+  const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
+  const double2* __restrict__ Tin = (const double2*)a.Tin;
+  const int ld2 = a.ld >> 1;
+  auto dense_edge = [&](int j, double av) {
+    const double2* __restrict__ rowp = Tin + (int64_t)j * ld2;
+#pragma unroll
+    for (int q = 0; q < NQ2; ++q) {
+      const int c2 = lane + 64 * q;
+      if (c2 < ld2) {
+        const double2 t = rowp[c2];
+        lds_add(&acc[2 * c2], __dmul_rn(av, t.x));
+        lds_add(&acc[2 * c2 + 1], __dmul_rn(av, t.y));
+      }
+    }
+  };
+  for (int64_t base = start; base < end; base += 64) {
+    int jl;
+    double al;
+    load_edges<VT>(a, base, end, lane, jl, al);
+    const int cl = (base + lane < end) ? (int)a.sp_cnt[jl] : 0;
+    const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+    int l = 0;
+    for (; l + U <= cnt; l += U) {
+      int si[U], cc[U];
+      double sv[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = __builtin_amdgcn_readlane(jl, l + u);
+        cc[u] = __builtin_amdgcn_readlane(cl, l + u);
+        si[u] = 0;
+        sv[u] = 0.0;
+        if (cc[u] != SP_DENSE && lane < cc[u]) {
+          si[u] = a.sp_idx[(int64_t)j * SP_CAP + lane];
+          sv[u] = a.sp_val[(int64_t)j * SP_CAP + lane];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double av = readlane_d(al, l + u);
+        if (cc[u] == SP_DENSE) dense_edge(__builtin_amdgcn_readlane(jl, l + u), av);
+        else if (lane < cc[u]) lds_add(&acc[si[u]], __dmul_rn(av, sv[u]));
+      }
+    }
+    for (; l < cnt; ++l) {                       // ragged tail
+      const int j = __builtin_amdgcn_readlane(jl, l);
+      const int c = __builtin_amdgcn_readlane(cl, l);
+      const double av = readlane_d(al, l);
+      if (c == SP_DENSE) dense_edge(j, av);
+      else if (lane < c)
+        lds_add(&acc[a.sp_idx[(int64_t)j * SP_CAP + lane]], __dmul_rn(av, a.sp_val[(int64_t)j * SP_CAP + lane]));
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  double s[2 * NQ2];
+#pragma unroll
+  for (int q = 0; q < NQ2; ++q) {
+    const int c2 = lane + 64 * q;
+    const bool act = c2 < ld2;
+    const double2 own = act ? Tin[grow * ld2 + c2] : make_double2(0.0, 0.0);
+    s[2 * q] = __dadd_rn(act ? acc[2 * c2] : 0.0, __dmul_rn(a.w, own.x));          // + w*s/colsums
+    s[2 * q + 1] = __dadd_rn(act ? acc[2 * c2 + 1] : 0.0, __dmul_rn(a.w, own.y));
+  }
+  finish_row<2 * NQ2, ColPair>(a, row, grow, lane, s);
+}
+
 __global__ void k_cellinfo(const double* __restrict__ colsum, const int32_t* __restrict__ sid, int64_t n,
                            CellInfo* __restrict__ info) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -289,6 +403,12 @@ int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
   return 0;
 }
 
+template <typename VT, int NQ2>
+int launch_step_sparse_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
+  hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2>), grid, dim3(256), sizeof(double) * 4 * 128 * NQ2, c->stream, a);
+  return 0;
+}
+
 template <typename VT>
 int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
   const int64_t nblk = (c->n_local + 3) / 4;
@@ -310,6 +430,13 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
       case 4: launch_first_t<VT, 4>(c, a, grid); break;
       case 5: case 6: launch_first_t<VT, 6>(c, a, grid); break;
       default: launch_first_t<VT, 8>(c, a, grid); break;
+    }
+  } else if (a.sp_cnt) {
+    switch ((a.ld / 2 + 63) / 64) {
+      case 1: launch_step_sparse_t<VT, 1>(c, a, grid); break;
+      case 2: launch_step_sparse_t<VT, 2>(c, a, grid); break;
+      case 3: launch_step_sparse_t<VT, 3>(c, a, grid); break;
+      default: launch_step_sparse_t<VT, 4>(c, a, grid); break;
     }
   } else {
     switch ((a.ld / 2 + 63) / 64) {
@@ -381,6 +508,11 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
   a.want_kurt = want_kurt;
   a.write_t = write_t;
   a.write_nam = write_nam;
+  // compressed state: written by the first step, read by the second (sample indicators only)
+  const bool sp = c->sp_cnt && !dense && (first || c->steps_done == 1);
+  a.sp_idx = sp ? (unsigned short*)c->sp_idx : nullptr;
+  a.sp_val = sp ? (double*)c->sp_val : nullptr;
+  a.sp_cnt = sp ? (unsigned char*)c->sp_cnt : nullptr;
   return c->data_f64 ? launch_step_q<double>(c, first, a) : launch_step_q<float>(c, first, a);
 }
 

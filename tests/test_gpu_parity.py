@@ -507,3 +507,49 @@ def test_properties_at_baseline_config2_size(eng):
     np.testing.assert_allclose(data2.obs['coef'].values, coef[perm], rtol=1e-9, atol=1e-13)
     assert np.array_equal(res2.fdrs.num_detected.values, num)
     np.testing.assert_allclose(res2.fdrs.fdr.values, fdr, rtol=1e-9, equal_nan=True)
+
+
+@pytest.mark.parametrize('N', [7, 50, 100, 130, 200])
+def test_compressed_second_step_matches_dense(monkeypatch, N):
+    """The second walk step may gather a compressed copy of the state (k_nam_step_sparse): same sums
+    in the same order as the dense kernel, accumulated with LDS f64 atomics, whose rounding differs
+    from v_add_f64 by at most an ulp per add on this chip -- so: equal to a few ulps, zeros exactly
+    where the dense kernel has zeros, and bit-reproducible from run to run.  Covers rows with more
+    distinct samples than the compressed form holds (a hub cell with 300 neighbours), isolated
+    cells and every later step."""
+    import cna_amd as cna
+    from cna_amd.engine import Engine
+    rs = np.random.RandomState(N)
+    n = 3000
+    A = sp.random(n, n, density=12.0 / n, random_state=rs, format='lil', dtype=np.float64)
+    A[17, :] = 0
+    A[:, 17] = 0                                   # isolated cell
+    hub = rs.choice(n, 300, replace=False)
+    A[5, hub] = rs.rand(300)                       # far more than 64 distinct samples when N is large
+    A[hub[:40], 5] = rs.rand(40)                   # ... and cells that gather the hub's (dense) row
+    A = sp.csr_matrix(A)
+    A.setdiag(0)
+    A.eliminate_zeros()
+    A = A.astype(np.float32)
+    obs = pd.DataFrame({'id': rs.randint(0, N, n)})
+    obs.loc[:N - 1, 'id'] = np.arange(N)           # every sample present
+    data = type('D', (), {'obs': obs, 'obsp': {'connectivities': A}, 'uns': {}})()
+    out = {}
+    for flag in ('0', '1'):
+        monkeypatch.setenv('CNA_SPARSE_MIN_N', flag)
+        e = Engine(device=0)
+        try:
+            for nsteps in (2, 3):
+                NAM, keep = cna.tl.nam(data, 'id', nsteps=nsteps, engine=e)
+                out[flag, nsteps] = NAM.values.copy()
+            e.prof_reset(); e.prof_enable(True)
+            NAM, _ = cna.tl.nam(data, 'id', nsteps=None, engine=e)          # auto-stop path, with kurtosis
+            e.sync(); e.prof_enable(False)
+            out[flag, 'auto'] = NAM.values.copy()
+            again, _ = cna.tl.nam(data, 'id', nsteps=3, engine=e)
+            np.testing.assert_array_equal(again.values, out[flag, 3])       # deterministic
+        finally:
+            e.close()
+    for key in (2, 3, 'auto'):
+        np.testing.assert_allclose(out['1', key], out['0', key], rtol=4e-15, atol=0)
+        assert np.array_equal(out['1', key] == 0, out['0', key] == 0)
