@@ -111,8 +111,8 @@ def load_or_make_dataset(synth, n, N, k, rank, world, td):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='C2', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-cells', type=int, default=200_000)
@@ -148,6 +148,10 @@ def main():
         from cna_amd import dist
         dist.init_from_torch(device=local_rank, always_comm=args.force_dist)
 
+    import warnings
+    # every repeated call warns that data.obs['coef'] exists (as the reference does); keep the
+    # formatting and the stderr write of that message out of the timed loop
+    warnings.filterwarnings('ignore', message="Key '.*' already exists in data.obs")
     import cna_amd as cna
     from cna_amd import synth
     cna.tune_host_allocator()       # host-side: no mmap/munmap churn for per-cell numpy temporaries

@@ -48,13 +48,27 @@ def mixture_points(n, dim=8, n_clusters=20, seed=0, spread=4.0, cluster_sorted=T
     return X.astype(np.float32), cl
 
 
-def fuzzy_knn_graph(X, k=30, dtype=np.float32, workers=-1, n_iter=40):
+def _usable_cpus():
+    """CPUs this process may really use: the cgroup v2 quota if there is one, else the affinity mask
+    (a 256-thread kd-tree query under a 16-CPU quota only earns throttling)."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
+def fuzzy_knn_graph(X, k=30, dtype=np.float32, workers=None, n_iter=40):
     """UMAP-style connectivities for points X with ``k`` neighbours (self included,
     as scanpy counts them), symmetrised by fuzzy union A + A^T - A*A^T."""
     n = X.shape[0]
     kk = min(k, n)
     tree = cKDTree(X)
-    dist, idx = tree.query(X, k=kk, workers=workers)
+    dist, idx = tree.query(X, k=kk, workers=workers or _usable_cpus())
     dist = dist[:, 1:].astype(np.float64)      # drop self
     idx = idx[:, 1:]
     m = dist.shape[1]
