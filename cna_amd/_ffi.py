@@ -44,7 +44,8 @@ SIGNATURES = {
     'cna_batch_kurtosis': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int]),
     'cna_zero_variance': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, c_i64p]),
     'cna_select': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
-    'cna_select_standardized': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, c_i64p]),
+    'cna_select_standardized': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_int64),
+                                          C.c_void_p, C.POINTER(C.c_double)]),
     'cna_upload_x': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_int]),
     'cna_resid_apply': (C.c_int, [c_ctx, C.c_void_p, C.c_int]),
     'cna_standardize': (C.c_int, [c_ctx, C.c_int]),
@@ -57,6 +58,7 @@ SIGNATURES = {
     'cna_condition_phenotypes': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     'cna_null_local_resident': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'cna_null_local_launch': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'cna_null_local_prepare': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'cna_null_local_fetch': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cna_percell_fdr_pinned': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     'cna_nam_steps': (C.c_int, [c_ctx, C.c_int]),

@@ -669,7 +669,7 @@ int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_
 }
 
 int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
-                            int64_t* n_zero_out) {
+                            int64_t* n_zero_out, const double* y, double* max_abs_out) {
   CHECK_CTX(c);
   if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
   const int64_t nx = keep_idx ? n_keep : c->n_local;
@@ -690,20 +690,32 @@ int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep,
   } else {
     c->keep_idx = nullptr;
   }
-  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({4 * (int64_t)Nx, 8})));
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({4 * (int64_t)Nx, 8, 8 * (int64_t)Nx, 8 * 4098})));
   Carver cv(c->scratch);
   int32_t* cm = cv.take<int32_t>(Nx);
   unsigned long long* nz = cv.take<unsigned long long>(1);
+  double* yd = cv.take<double>(Nx);
+  unsigned long long* mb = cv.take<unsigned long long>(4098);
   if (colmap) HIP_TRY(hipMemcpyAsync(cm, colmap, 4 * Nx, hipMemcpyHostToDevice, c->stream));
-  CNA_TRY(launch_select_std(c, colmap ? cm : nullptr, nz));
+  if (y) {
+    void* np = c->ncorrs;
+    CNA_TRY(dev_reserve(c, &np, &c->ncorrs_cap, 8 * std::max<int64_t>(nx, 1)));
+    c->ncorrs = (double*)np;
+    HIP_TRY(hipMemcpyAsync(yd, y, 8 * Nx, hipMemcpyHostToDevice, c->stream));
+  }
+  CNA_TRY(launch_select_std(c, colmap ? cm : nullptr, nz, y ? yd : nullptr, y ? mb : nullptr));
   CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)nz, 1));
+  if (y) CNA_TRY(comm_allreduce_f64_max(c, (double*)mb, 1));
   unsigned long long h = 0;
+  double m = 0.0;
   HIP_TRY(hipMemcpyAsync(&h, nz, 8, hipMemcpyDeviceToHost, c->stream));
+  if (y) HIP_TRY(hipMemcpyAsync(&m, mb, 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (n_zero_out) *n_zero_out = (int64_t)h;
+  if (max_abs_out) *max_abs_out = m;
   c->x_valid = true;
   c->x_from_nam = true;
-  c->ncorrs_valid = false;
+  c->ncorrs_valid = y != nullptr;     // meaningful only when no cell had zero variance (the caller checks)
   return 0;
 }
 
@@ -896,19 +908,19 @@ static int ensure_zc(cna_ctx* c, int N, int P, hipStream_t st) {
   return 0;
 }
 
-// queue everything of one local-null pass; results land in the pinned buffer h_res
-// ([T sums][P*T tails if requested]) and null_done fires when they are there
-static int null_local_queue(cna_ctx* c, int col0, int P, const double* edges, int T, int want_tails,
-                            const double* thr = nullptr) {
+// One local-null pass in two halves.  prepare: everything that needs only the thresholds (exact cuts,
+// their upload, the threshold counts of the observed coefficients) -- the caller can issue it while
+// the permuted phenotypes are still on their way.  go: the kernel and its reductions; results land in
+// the pinned buffer h_res ([T sums][P*T tails if requested][2T observed counts]) and null_done fires
+// when they are there.  Nothing else may use c->scratch between the two.
+static int null_local_prepare(cna_ctx* c, int P, const double* edges, int T, int want_tails, const double* thr) {
   if (P < 1 || T < 1) CNA_FAIL(CNA_EINVAL, "cna_null_local: P and T must be positive");
   if (c->null_pending) CNA_FAIL(CNA_ESTATE, "a local-null pass is still pending: fetch it first");
   for (int t = 1; t < T; ++t)
     if (!(edges[t] >= edges[t - 1])) CNA_FAIL(CNA_EINVAL, "cna_null_local: edges must ascend");
-  if (!c->zc || col0 < 0 || col0 + P > c->zc_cols || c->zc_rows != c->Nx)
-    CNA_FAIL(CNA_ESTATE, "no conditioned phenotypes resident for these columns");
+  c->null_prepared = 0;
   std::vector<double> cuts;
-  double cut0, inv_step, eps;
-  exact_cuts(edges, T, c->Nx, cuts, &cut0, &inv_step, &eps);
+  exact_cuts(edges, T, c->Nx, cuts, &c->null_cut0, &c->null_inv_step, &c->null_eps);
   const int64_t obs_off = 8 * (int64_t)T + (want_tails ? 8 * (int64_t)P * T : 0);
   const int64_t hbytes = obs_off + 16 * (int64_t)T;
   if (hbytes > c->h_res_cap) {
@@ -922,9 +934,9 @@ static int null_local_queue(cna_ctx* c, int col0, int P, const double* edges, in
                                    8 * (int64_t)T, 16 * (int64_t)T, 16 * (int64_t)T})));
   Carver cv(c->scratch);
   double* ed = cv.take<double>(T);
-  unsigned long long* hist = cv.take<unsigned long long>((int64_t)P * T);
-  int64_t* tails = cv.take<int64_t>((int64_t)P * T);
-  int64_t* sums = cv.take<int64_t>(T);
+  cv.take<unsigned long long>((int64_t)P * T);
+  cv.take<int64_t>((int64_t)P * T);
+  cv.take<int64_t>(T);
   double* oed = cv.take<double>(T);
   double* otd = cv.take<double>(T);
   unsigned long long* ohist = cv.take<unsigned long long>(2 * (int64_t)T);
@@ -947,21 +959,42 @@ static int null_local_queue(cna_ctx* c, int col0, int P, const double* edges, in
   }
   HIP_TRY(hipMemcpyAsync(ed, cuts.data(), 8 * T, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));               // `cuts`, `edges`, `thr` are the caller's; the stream is nearly idle here
+  c->null_P = P;
+  c->null_T = T;
+  c->null_has_tails = want_tails;
+  c->null_prepared = 1;
+  return 0;
+}
+
+static int null_local_go(cna_ctx* c, int col0) {
+  if (!c->null_prepared) CNA_FAIL(CNA_ESTATE, "local-null pass not prepared");
+  c->null_prepared = 0;
+  const int P = c->null_P, T = c->null_T;
+  if (!c->zc || col0 < 0 || col0 + P > c->zc_cols || c->zc_rows != c->Nx)
+    CNA_FAIL(CNA_ESTATE, "no conditioned phenotypes resident for these columns");
+  Carver cv(c->scratch);                                   // same carve as in null_local_prepare
+  double* ed = cv.take<double>(T);
+  unsigned long long* hist = cv.take<unsigned long long>((int64_t)P * T);
+  int64_t* tails = cv.take<int64_t>((int64_t)P * T);
+  int64_t* sums = cv.take<int64_t>(T);
   // columns beyond col0+P inside the last 64-wide tile are other phenotypes: the kernel only
   // flushes counters of p < P, and reads stay inside the zero-padded leading dimension
-  CNA_TRY(launch_null_local(c, c->zc + col0, c->zc_ld, P, ed, T, cut0, inv_step, eps, hist));
+  CNA_TRY(launch_null_local(c, c->zc + col0, c->zc_ld, P, ed, T, c->null_cut0, c->null_inv_step, c->null_eps, hist));
   CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)P * T));
   CNA_TRY(launch_suffix_sum(c, hist, P, T, tails));
   CNA_TRY(launch_tail_sums(c, tails, P, T, sums));
   HIP_TRY(hipMemcpyAsync(c->h_res, sums, 8 * (size_t)T, hipMemcpyDeviceToHost, c->stream));
-  if (want_tails)
+  if (c->null_has_tails)
     HIP_TRY(hipMemcpyAsync((char*)c->h_res + 8 * (size_t)T, tails, 8 * (size_t)P * T, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipEventRecord(c->null_done, c->stream));
-  c->null_P = P;
-  c->null_T = T;
-  c->null_has_tails = want_tails;
   c->null_pending = 1;
   return 0;
+}
+
+static int null_local_queue(cna_ctx* c, int col0, int P, const double* edges, int T, int want_tails,
+                            const double* thr = nullptr) {
+  CNA_TRY(null_local_prepare(c, P, edges, T, want_tails, thr));
+  return null_local_go(c, col0);
 }
 
 static int null_local_collect(cna_ctx* c, int64_t* tails_out, int64_t* sums_out, int64_t* ranks_out = nullptr,
@@ -989,9 +1022,21 @@ static int null_local_on_resident(cna_ctx* c, int col0, int P, const double* edg
   return null_local_collect(c, tails_out, sums_out);
 }
 
+int cna_null_local_prepare(cna_ctx* c, int P, const double* edges, int T, int want_tails, const double* thr) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  if (!edges) CNA_FAIL(CNA_EINVAL, "cna_null_local_prepare: edges required");
+  return null_local_prepare(c, P, edges, T, want_tails, thr);
+}
+
 int cna_null_local_launch(cna_ctx* c, int col0, int P, const double* edges, int T, int want_tails, const double* thr) {
   CHECK_CTX(c);
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  if (!edges) {                                            // second half of a prepared pass
+    if (!c->null_prepared || P != c->null_P || T != c->null_T)
+      CNA_FAIL(CNA_ESTATE, "cna_null_local_launch without edges needs a matching cna_null_local_prepare");
+    return null_local_go(c, col0);
+  }
   return null_local_queue(c, col0, P, edges, T, want_tails, thr);
 }
 

@@ -128,6 +128,8 @@ struct cna_ctx {
   // ---- scratch
   void* scratch = nullptr;
   int64_t scratch_cap = 0;
+  int null_prepared = 0;          // cna_null_local_prepare done, launch still to come
+  double null_cut0 = 0, null_inv_step = 0, null_eps = 0;
   int null_has_obs = 0;
   int64_t null_obs_off = 0;
   void* h_cell = nullptr;         // pinned: per-cell outputs of cna_percell_fdr_pinned (coef | fdr)
@@ -193,7 +195,8 @@ int launch_batch_kurtosis(cna_ctx* c, const double* mat, int64_t rows, int ncols
 int launch_zero_variance(cna_ctx* c, const int32_t* colmap_dev, int n_sel, uint8_t* flags_dev,
                          unsigned long long* count_dev);
 int launch_select(cna_ctx* c, const int32_t* colmap_dev);
-int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev);
+int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev, const double* y_dev,
+                      unsigned long long* maxbits_dev);
 int launch_standardize(cna_ctx* c, int center);
 int launch_ncorrs(cna_ctx* c, const double* y_dev, unsigned long long* maxbits_dev);
 int launch_obs_counts(cna_ctx* c, const double* edges_dev, const double* thr_dev, int T, double thr0,

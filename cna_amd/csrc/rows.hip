@@ -180,18 +180,27 @@ template <int NQ>
 __global__ __launch_bounds__(256) void k_select_std(const double* __restrict__ nam, int ld,
                                                     const int64_t* __restrict__ keep,
                                                     const int32_t* __restrict__ colmap, double* __restrict__ X,
-                                                    int64_t nx, int Nx, int ldx, unsigned long long* nzero) {
+                                                    int64_t nx, int Nx, int ldx, unsigned long long* nzero,
+                                                    const double* __restrict__ y, double* __restrict__ nc,
+                                                    unsigned long long* __restrict__ blockmax) {
+  // y != null: the rows leave this kernel final (M = I), so the neighbourhood coefficients
+  // ncorrs = X.y/N (_association.py:77) and their max |.| are taken on the way out, as k_ncorrs would
   constexpr int RPW = 4;
+  __shared__ unsigned long long wmax[4];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
   const double n = (double)Nx;
   int sc[NQ];
+  double yv[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int col = lane + 64 * q;
     sc[q] = col < Nx ? (colmap ? colmap[col] : col) : 0;
+    yv[q] = (y && col < Nx) ? y[col] : 0.0;
   }
+  double vmax = 0.0;
+  bool any_nan = false;
   for (int64_t base = ((int64_t)blockIdx.x * 4 + wv) * RPW; base < nx; base += stride) {
     double x[RPW][NQ];
     double sum[RPW];
@@ -233,11 +242,31 @@ __global__ __launch_bounds__(256) void k_select_std(const double* __restrict__ n
         }
       }
       const double sd = sqrt(wave_sum(ss) / (n - 1.0));
+      double dot = 0.0;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int col = lane + 64 * q;
-        if (col < ldx) X[(base + r) * ldx + col] = col < Nx ? __ddiv_rn(x[r][q], sd) : 0.0;
+        const double xs = col < Nx ? __ddiv_rn(x[r][q], sd) : 0.0;
+        if (col < ldx) X[(base + r) * ldx + col] = xs;
+        dot += yv[q] * xs;
       }
+      if (y) {
+        const double v = wave_sum(dot) / n;
+        if (lane == 0) nc[base + r] = v;
+        const double av = fabs(v);
+        if (av > vmax) vmax = av;
+        any_nan = any_nan || (v != v);
+      }
+    }
+  }
+  if (y) {                                   // one slot per workgroup, folded by k_max_fold (see k_ncorrs)
+    if (lane == 0)
+      wmax[wv] = any_nan ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(vmax);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long m = wmax[0];
+      for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
+      blockmax[blockIdx.x] = m;
     }
   }
 }
@@ -495,18 +524,22 @@ int launch_select(cna_ctx* c, const int32_t* colmap_dev) {
   return 0;
 }
 
-int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev) {
+int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev, const double* y_dev,
+                      unsigned long long* maxbits_dev) {
+  // maxbits_dev (with y_dev): [0] = max |ncorrs| bits, [1 ..] per-workgroup partials (4097 words)
   HIP_TRY(hipMemsetAsync(nzero_dev, 0, sizeof(unsigned long long), c->stream));
+  if (maxbits_dev) HIP_TRY(hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned long long), c->stream));
   if (c->nx == 0) return 0;
   if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 512 samples are not supported");
   ProfScope ps(c, CNA_K_SELECT);
   const unsigned grid = wave_grid((c->nx + 3) / 4);
   switch ((c->ldx + 63) / 64) {
-#define SS_CASE(Q) case Q: hipLaunchKernelGGL(k_select_std<Q>, dim3(grid), dim3(256), 0, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev); break
+#define SS_CASE(Q) case Q: hipLaunchKernelGGL(k_select_std<Q>, dim3(grid), dim3(256), 0, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev, y_dev, c->ncorrs, maxbits_dev ? maxbits_dev + 1 : nullptr); break
     SS_CASE(1); SS_CASE(2); SS_CASE(3); SS_CASE(4);
-    default: hipLaunchKernelGGL(k_select_std<MAXQ>, dim3(grid), dim3(256), 0, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev);
+    default: hipLaunchKernelGGL(k_select_std<MAXQ>, dim3(grid), dim3(256), 0, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev, y_dev, c->ncorrs, maxbits_dev ? maxbits_dev + 1 : nullptr);
 #undef SS_CASE
   }
+  if (y_dev) hipLaunchKernelGGL(k_max_fold, dim3(1), dim3(256), 0, c->stream, maxbits_dev + 1, (int)grid, maxbits_dev);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -240,16 +240,20 @@ class Engine(_order.CellOrder):
         check(self.lib.cna_select(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm)), 'cna_select')
         self.x_epoch += 1
 
-    def select_standardized(self, keep_global, colmap):
+    def select_standardized(self, keep_global, colmap, y=None):
         """select() + centre + divide by std in one pass (M = I); returns the number of selected
-        cells with zero variance (non-zero: redo with zero_variance()/select())."""
+        cells with zero variance (non-zero: redo with zero_variance()/select()).  With ``y`` (the
+        standardised phenotype in the selected samples' order) the neighbourhood coefficients are
+        taken in the same pass and (n_zero, max |ncorrs|) is returned -- ncorrs(y) is then done."""
         cm = None if colmap is None else np.ascontiguousarray(colmap, dtype=np.int32)
         idx, nk = self._selection(keep_global)
         nz = C.c_int64(0)
+        m = C.c_double(0.0)
+        yv = None if y is None else _f64(y)
         check(self.lib.cna_select_standardized(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm),
-                                               C.byref(nz)), 'cna_select_standardized')
+                                               C.byref(nz), ptr(yv), C.byref(m)), 'cna_select_standardized')
         self.x_epoch += 1
-        return nz.value
+        return nz.value if y is None else (nz.value, m.value)
 
     def upload_x(self, x_local):
         x_local = _f64(x_local)
@@ -328,9 +332,23 @@ class Engine(_order.CellOrder):
               'cna_null_local_resident')
         return sums if sums_only else tails
 
+    def null_local_prepare(self, P, edges, thr=None):
+        """First half of null_local_launch: needs the thresholds only (exact cuts, observed counts);
+        finish with null_local_launch(col0, P, None)."""
+        edges = _f64(edges)
+        thr = None if thr is None else _f64(thr)
+        check(self.lib.cna_null_local_prepare(self.h, int(P), ptr(edges), len(edges), 0, ptr(thr)),
+              'cna_null_local_prepare')
+        self._null_T = len(edges)
+        self._null_obs = thr is not None
+
     def null_local_launch(self, col0, P, edges, thr=None):
         """Queue a local-null pass on resident columns; collect with null_local_fetch().  With `thr`
         the threshold counts of the observed coefficients (obs_counts) are queued in front of it."""
+        if edges is None:                       # prepared pass
+            check(self.lib.cna_null_local_launch(self.h, int(col0), int(P), None, self._null_T, 0, None),
+                  'cna_null_local_launch')
+            return
         edges = _f64(edges)
         thr = None if thr is None else _f64(thr)
         check(self.lib.cna_null_local_launch(self.h, int(col0), int(P), ptr(edges), len(edges), 0, ptr(thr)),

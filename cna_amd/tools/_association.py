@@ -65,7 +65,7 @@ def _draw_null(y, batches, donorids, Nnull=1000, force_permute_all=False, seed=N
 
 
 def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_progress=False,
-                 npcs=None, n_cells=None, conditioned=False, null_source=None):
+                 npcs=None, n_cells=None, conditioned=False, null_source=None, maxabs=None):
     """Body of the reference's ``_association`` (_association.py:24-129) against the
     residualised NAM held by ``engine`` (cells x samples), whose Gram-matrix kernels have been
     queued.  ``res`` is the namespace from the residualisation (M, r), ``y`` / ``y_`` the
@@ -89,8 +89,10 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     ks_arr = np.asarray(ks)
     Mv = np.asarray(M, dtype=np.float64)
 
-    # neighbourhood coefficients -> thresholds (needs y only)
-    _, maxabs = engine.ncorrs(y, fetch=False)
+    # neighbourhood coefficients -> thresholds (needs y only; already taken with the selection pass
+    # when nothing had to be regressed out)
+    if maxabs is None:
+        _, maxabs = engine.ncorrs(y, fetch=False)
     pending = False
     thresholds = edges = None
     if local_test:
@@ -99,9 +101,12 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         thresholds = np.arange(maxcorr / 4, maxcorr, maxcorr / 400)
         z2 = thresholds ** 2
         edges = z2 - 1e-8 - 1e-5 * z2                        # tail_counts' bin edges (_stats.py:47)
+        # the half of the local-null launch that needs the thresholds only (exact cuts, the threshold
+        # counts of the observed coefficients) goes out now
+        engine.null_local_prepare(Nloc, edges, thresholds)
 
     if null_source is not None:
-        y_ = null_source()
+        y_, conditioned = null_source()
     if y_ is None:   # grouplevel_permutation refused (it printed why); upstream dies on y_.T
         raise AttributeError("'NoneType' object has no attribute 'T'")
     # phenotypes -> device: Zc = M.[y, y_] / std (ddof=1), resident for both tests (already there
@@ -111,8 +116,7 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     if local_test:
         # start the local null (device, asynchronous): tail counts from columns 1..Nloc of Zc, summed
         # over permutations on the device; neither cells x Nloc nor Nloc x T ever reaches the host.
-        # The threshold counts of the observed coefficients ride along in front of it.
-        engine.null_local_launch(1, Nloc, edges, thresholds)      # returns at once
+        engine.null_local_launch(1, Nloc, None)                   # returns at once
         pending = True
 
     tail_sums = ranks = num_detected = None
@@ -241,14 +245,17 @@ def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_si
 
 
 def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
-                            show_progress, codes_labels=None, overlap=None, nam_queued=None, **kwargs):
+                            show_progress, codes_labels=None, overlap=None, nam_queued=None, y_std=None,
+                            **kwargs):
     """Reference compute_nam_and_reindex (_association.py:175-191) on the device: build the NAM,
     QC it, put the sample axis in ``y.index`` order restricted to ``filter_samples``, drop the
     cells whose remaining entries have zero variance.  Leaves the selected NAM in the engine's
     working matrix and returns the bookkeeping the caller needs.  ``overlap``: a host-only
     callable run after the diffusion kernels have been queued and before their first result is
     needed; its return value is passed through.  ``nam_queued``: result of a _nam_device() call the
-    caller has already issued for exactly these arguments (its kernels are in flight)."""
+    caller has already issued for exactly these arguments (its kernels are in flight).  ``y_std``:
+    the standardised phenotype of the filtered samples; when nothing has to be regressed out the
+    neighbourhood coefficients are then taken in the selection pass (plan.maxabs)."""
     out = select_output(show_progress)
     nam_kwargs = {k: v for k, v in kwargs.items() if k in ('self_weight',)}
     print('computing NAM', file=out)
@@ -277,7 +284,11 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     nzero = -1
     if plan is not None and plan.kind == 'identity':
         # nothing to regress out: select + centre + /std in one pass over the NAM
-        nzero = engine.select_standardized(None if kept.all() else kept, colmap)
+        if y_std is not None and len(y_std) == len(colmap):
+            nzero, maxabs = engine.select_standardized(None if kept.all() else kept, colmap, y=y_std)
+            plan.maxabs = maxabs if nzero == 0 else None
+        else:
+            nzero = engine.select_standardized(None if kept.all() else kept, colmap)
         plan.standardized = nzero == 0
     if nzero != 0:
         zero_var, nzero = engine.zero_variance(colmap)
@@ -335,43 +346,48 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         d_ = donorids.reindex(y.index) if donorids is not None else None
         yv, bv, dv = y[f].values, b_[f].values, (d_[f].values if d_ is not None else None)
 
+    # the standardised phenotype (numpy ddof=0, _association.py:22) needs neither the device nor the draw
+    with np.errstate(all='ignore'):
+        y_std = (yv - yv.mean()) / yv.std() if len(yv) else yv
+
+    early = {}
+
     def null_job():
         _mark('draw starts')
         out_ = _draw_null(yv, bv, dv,
                           Nnull=Nnull, force_permute_all=kwargs.get('force_permute_all', False),
                           seed=kwargs.get('seed'))
         _mark('draw done')
+        # If the projector is already known (no ridge schedule; the main thread builds it under the
+        # diffusion kernels), condition the phenotypes from here: sample space only, second stream,
+        # its own buffers -- the main thread is busy with the selection meanwhile.  Anything unusual
+        # is left to the main thread, which does it (and reports errors) where the reference would.
+        M_ = early.get('M')
+        if M_ is not None and out_[1] is not None and len(out_[0]) == len(M_):
+            try:
+                engine.condition(M_, np.column_stack([out_[0], out_[1]]))
+                early['conditioned'] = True
+                _mark('conditioned (helper)')
+            except Exception:
+                pass
         return out_
     _mark('checked')
     null_future = _background().submit(null_job)
     _mark('submitted')
 
-    early = {}
-
     def host_side(sample_index_, batches_, covs_, donorids_, filter_):
         # host-only sample-space work: runs while the diffusion kernels are executing
         plan = _resid_plan(sample_index_, covs_[filter_] if covs_ is not None else covs_,
                            batches_[filter_] if batches_ is not None else batches_, ridges=ridges)
-        if plan.M is not None and null_future.done():
-            # M does not depend on the device (no ridge schedule) and the permutations are drawn: the
-            # phenotypes can be conditioned and parked on the GPU now, on the second stream, while the
-            # diffusion still runs (large problems; on small ones the draw is the longer of the two and
-            # this happens later, in _association).  Errors are left to surface where the reference
-            # raises them.
-            try:
-                y_std, y_null = null_future.result()
-                if y_null is not None and len(y_std) == plan.N:
-                    engine.condition(np.asarray(plan.M, dtype=np.float64), np.column_stack([y_std, y_null]))
-                    early['conditioned'] = True
-            except Exception:
-                pass
+        if plan.M is not None:
+            early['M'] = np.asarray(plan.M, dtype=np.float64)     # the helper conditions with it after the draw
         return plan
 
     try:
         kept, sample_index, colmap, batches, covs, donorids, filter_samples, plan = \
             compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
                                     show_progress, codes_labels=(codes, labels, counts, token), overlap=host_side,
-                                    nam_queued=nam_queued)
+                                    nam_queued=nam_queued, y_std=y_std)
     except BaseException:
         null_future.cancel() or null_future.exception()     # do not leave the helper thread running
         raise
@@ -391,19 +407,16 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
 
     _mark('resid queued')
     print('performing association test', file=out)
-    # the standardised phenotype (numpy ddof=0, _association.py:22) does not need the draw; the
-    # permutations are collected inside _association, after everything that only needs y
-    with np.errstate(all='ignore'):
-        y_std = (yv - yv.mean()) / yv.std()
-
+    # the permutations are collected inside _association, after everything that only needs y
     def drawn():
         y_null = null_future.result()[1]
         _mark('null drawn')
-        return y_null
+        return y_null, early.get('conditioned', False)
     coef_all, fdr_all, U, svs = _association(engine, res, y_std, None, ks=ks, Nnull=Nnull,
                                              local_test=kwargs.get('local_test', True),
                                              show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_total,
-                                             conditioned=early.get('conditioned', False), null_source=drawn)
+                                             null_source=drawn,
+                                             maxabs=getattr(plan, 'maxabs', None))
     _mark('_association returned')
     _defer_pcs(res, engine, U, svs, cell_index)
     res.kept = kept

@@ -139,9 +139,12 @@ int  cna_select(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_keep,
 /* cna_select followed by centring and division by the per-cell std (ddof=1) in one pass, for the
  * case M = I (_association.py:178-185 + _nam.py:122,159); n_zero_out = number of selected cells with
  * zero variance over the selected samples, summed over ranks (if non-zero the caller drops them
- * with cna_zero_variance + cna_select and standardises again). */
+ * with cna_zero_variance + cna_select and standardises again).  With y (n_sel doubles, the
+ * standardised phenotype in X's column order) the rows are final when they leave the kernel, so
+ * cna_ncorrs(y) is taken in the same pass: max_abs_out = max |ncorrs| over all ranks. */
 int  cna_select_standardized(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_keep,
-                             const int32_t* colmap, int n_sel, int64_t* n_zero_out);
+                             const int32_t* colmap, int n_sel, int64_t* n_zero_out,
+                             const double* y /* or NULL */, double* max_abs_out /* or NULL */);
 /* upload a cells x samples matrix as X (cna.tl.svd_nam on a user NAM, _nam.py:102) */
 int  cna_upload_x(cna_ctx* ctx, const double* x_local, int64_t n_rows, int n_cols);
 
@@ -195,6 +198,11 @@ int  cna_null_local_resident(cna_ctx* ctx, int col0, int P, const double* edges,
  * which run beside the local-null kernel on a second stream. */
 int  cna_null_local_launch(cna_ctx* ctx, int col0, int P, const double* edges, int T, int want_tails,
                            const double* thr /* or NULL: also queue cna_obs_counts(edges, thr) */);
+/* the part of a launch that needs only the thresholds (exact cuts, their upload, the observed
+ * counts), for callers that know them before the phenotypes are conditioned; follow it with
+ * cna_null_local_launch(ctx, col0, P, NULL, T, want_tails, NULL).  No other entry point that uses the
+ * context's main scratch (selection, ncorrs, percell) may run in between. */
+int  cna_null_local_prepare(cna_ctx* ctx, int P, const double* edges, int T, int want_tails, const double* thr);
 int  cna_null_local_fetch(cna_ctx* ctx, int64_t* tails_out, int64_t* tail_sums_out,
                           int64_t* ranks_out, int64_t* num_detected_out /* both NULL unless thr was given */);
 int  cna_global_test(cna_ctx* ctx, const double* U, int kmax, const int32_t* ks, int K, int r,

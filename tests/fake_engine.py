@@ -216,14 +216,17 @@ class FakeEngine(_order.CellOrder):
         self.x_rows_total = self.n if keep_global is None else int(np.sum(keep_global))
         self.x_epoch += 1
 
-    def select_standardized(self, keep_global, colmap):
+    def select_standardized(self, keep_global, colmap, y=None):
         self.select(keep_global, colmap)
         with np.errstate(all='ignore'):
             nz = int((self.X.std(axis=1, ddof=1) == 0).sum())
         if self.coll:
             nz = int(self.coll.allreduce_sum(np.array([nz]))[0])
         self.standardize(center=True)
-        return nz
+        if y is None:
+            return nz
+        with np.errstate(all='ignore'):
+            return nz, self.ncorrs(y)[1]
 
     def upload_x(self, x_local):
         self.X = np.array(x_local, dtype=np.float64)
@@ -282,7 +285,12 @@ class FakeEngine(_order.CellOrder):
         tails = self.null_local(self.Zc[:, col0:col0 + P], edges)
         return tails.sum(axis=0) if sums_only else tails
 
+    def null_local_prepare(self, P, edges, thr=None):
+        self._prepared = (np.asarray(edges), None if thr is None else np.asarray(thr))
+
     def null_local_launch(self, col0, P, edges, thr=None):
+        if edges is None:
+            edges, thr = self._prepared
         self._pending = self.null_local_resident(col0, P, edges, sums_only=True)
         if thr is not None:
             self._pending = (self._pending,) + tuple(self.obs_counts(edges, thr))
