@@ -553,3 +553,38 @@ def test_compressed_second_step_matches_dense(monkeypatch, N):
     for key in (2, 3, 'auto'):
         np.testing.assert_allclose(out['1', key], out['0', key], rtol=4e-15, atol=0)
         assert np.array_equal(out['1', key] == 0, out['0', key] == 0)
+
+
+def test_prepared_null_launch_and_misuse(eng):
+    """cna_null_local_prepare + launch(edges=None) equals the one-call launch; launching without a
+    prepared pass, or with a shape that does not match it, is an error and leaves nothing pending."""
+    from cna_amd._ffi import CnaHipError
+    rs = np.random.RandomState(4)
+    n, N, P = 4000, 30, 90
+    X = _random_x(rs, n, N)
+    eng.upload_x(X)
+    eng.standardize(center=True)
+    y = rs.randn(N)
+    _, m = eng.ncorrs(y)
+    Y = rs.randn(N, P + 1)
+    eng.condition(np.eye(N), Y)
+    thr = np.arange(m / 4, m, m / 400)
+    edges = thr ** 2 - 1e-8 - 1e-5 * thr ** 2
+    eng.null_local_launch(1, P, edges, thr)
+    a = eng.null_local_fetch()
+    eng.null_local_prepare(P, edges, thr)
+    eng.null_local_launch(1, P, None)
+    b = eng.null_local_fetch()
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+    ranks, numdet = eng.obs_counts(edges, thr)
+    np.testing.assert_array_equal(a[1], ranks)
+    np.testing.assert_array_equal(a[2], numdet)
+    with pytest.raises(CnaHipError, match='prepare'):
+        eng.null_local_launch(1, P, None)                  # nothing prepared any more
+    eng.null_local_prepare(P, edges, thr)
+    with pytest.raises(CnaHipError, match='prepare'):
+        eng.null_local_launch(1, P - 1, None)              # shape differs from the prepared pass
+    eng.null_local_launch(1, P, None)
+    c = eng.null_local_fetch()
+    np.testing.assert_array_equal(c[0], a[0])
