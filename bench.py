@@ -95,15 +95,21 @@ def load_or_make_dataset(synth, n, N, k, rank, world, td):
     path = '/dev/shm/cna_bench_%s_%d_%d.pkl' % (os.environ.get('MASTER_PORT', '0'), n, N)
     if rank == 0:
         out = synth.make_dataset(n, N, k=k, seed=0)
-        with open(path + '.tmp', 'wb') as f:
-            pickle.dump(out, f, protocol=pickle.HIGHEST_PROTOCOL)
-        os.replace(path + '.tmp', path)
+        try:
+            with open(path + '.tmp', 'wb') as f:
+                pickle.dump(out, f, protocol=pickle.HIGHEST_PROTOCOL)
+            os.replace(path + '.tmp', path)
+        except OSError:                      # no room in /dev/shm: the other ranks generate their own copy
+            pass
     td.barrier()
     if rank != 0:
-        with open(path, 'rb') as f:
-            out = pickle.load(f)
+        if os.path.exists(path):
+            with open(path, 'rb') as f:
+                out = pickle.load(f)
+        else:
+            out = synth.make_dataset(n, N, k=k, seed=0)
     td.barrier()
-    if rank == 0:
+    if rank == 0 and os.path.exists(path):
         os.remove(path)
     return out
 
