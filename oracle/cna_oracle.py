@@ -386,7 +386,8 @@ def nam(data, sid_name, batches=None, nsteps=None, self_weight=1, mode='referenc
 
 
 def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=None,
-                max_frac_pcs=0.15, nsteps=None, ridges=None, mode='reference', **kwargs):
+                max_frac_pcs=0.15, nsteps=None, ridges=None, mode='reference', allow_low_sample_size=False,
+                **kwargs):
     """cna.tl.association (_association.py:193-242) on pandas inputs; returns a dict of arrays
     (cells x samples orientation for nam / namresid)."""
     obs_sid = data.obs[sid_name]
@@ -401,6 +402,8 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
         filt = ~(y.isna() | covs.isna().any(axis=1)) & present
     else:
         filt = ~np.isnan(y) & present
+    if filt.sum() < 10 and not allow_low_sample_size:       # _association.py:163-172
+        raise ValueError('You are supplying phenotype information on fewer than 10 samples.')
     nm = nam(data, sid_name, batches=batches, nsteps=nsteps, mode=mode)
     labels, kept = nm['labels'], nm['keep'].copy()
     # NAM.reindex(y.index)[filter_samples]: sample axis follows y.index order

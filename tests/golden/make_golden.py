@@ -132,6 +132,11 @@ def build_cases():
          call=dict(nsteps=3, Nnull=100, seed=14, ridges=[10.0, 1.0, 0.0]), mutate='batchy', extras=('progress',))
     base('c16_ridge_loop', seed=15, N=30, gen=dict(n_batches=10), call=dict(nsteps=3, Nnull=100, seed=15),
          mutate='batchy_all', extras=('progress',))
+    # fewer than 10 samples (allowed explicitly), so few permutations that the p-value hits its floor
+    base('c17_low_sample_size', seed=16, N=8, n=800, call=dict(nsteps=3, Nnull=20, seed=16, allow_low_sample_size=True))
+    # covariates with a missing row, wider PC budget, auto-stopped walk, sample ids handed over unsorted
+    base('c18_covs_nan_maxfrac', seed=17, N=28, gen=dict(n_covs=3, cluster_sorted=False),
+         call=dict(Nnull=100, seed=17, max_frac_pcs=0.3), mutate='covs_nan', extras=('progress',))
     return cases
 
 
@@ -163,6 +168,10 @@ def run_case(case):
         perm = np.random.RandomState(5).permutation(len(y))
         y = y.iloc[perm]
         covs = covs.iloc[perm]   # same order as y: the reference mis-aligns its sample filter otherwise
+    elif mut == 'covs_nan':
+        covs = covs.copy()
+        covs.iloc[5, 1] = np.nan
+        covs.iloc[11, 2] = np.nan
     elif mut == 'batchy':
         # make one cluster's cells come only from batch-0 samples so that batch
         # kurtosis of those neighbourhoods is extreme (_nam.py:85-99)
