@@ -173,7 +173,13 @@ int cna_ctx_create(int device, cna_ctx** out) {
   cna_ctx* c = new cna_ctx();
   c->device = device;
   hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    // the second stream carries short sample-space kernels (F-tests, conditioning) that should slip in
+    // between the workgroup rounds of a long kernel on the main stream: highest priority
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    e = hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, hi);
+  }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->gram_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->null_done, hipEventDisableTiming);
   if (e != hipSuccess) {

@@ -187,7 +187,8 @@ template <int KQ, int NS, bool PFETCH, int NW, int MODE = 0>
 __global__ __launch_bounds__(64 * NW) void k_null(const double* __restrict__ X, int64_t nx, int64_t chunk_rows,
                                               const double* __restrict__ Yc, int ldy, int P,
                                               const double* __restrict__ cuts, int T, double cut0,
-                                              double inv_step, double eps, unsigned int* __restrict__ partial) {
+                                              double inv_step, double eps, unsigned int* __restrict__ partial,
+                                              int pt0) {
   extern __shared__ double sm[];
   constexpr int PT = 16 * NS, LDB = PT + 16, LDX = 4 * KQ;   // LDB = 16 mod 32: the two k-rows of a 32-lane group hit disjoint banks
   const int tid = threadIdx.x;
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(64 * NW) void k_null(const double* __restrict__ X, 
   double* c_s = sm;
   double* bs = sm + TP;                                       // LDX x LDB
   unsigned int* hist = (unsigned int*)(bs + LDX * LDB);       // PT x TW words
-  const int pt = blockIdx.y;
+  const int pt = pt0 + blockIdx.y;
   for (int i = tid; i < TP; i += 64 * NW) c_s[i] = i == 0 ? 0.0 : (i <= T ? cuts[i - 1] : __builtin_inf());
   for (int i = tid; i < PT * TW; i += 64 * NW) hist[i] = 0u;
   for (int i = tid; i < LDX * PT; i += 64 * NW) {
@@ -351,8 +352,15 @@ int launch_null_t(cna_ctx* c, dim3 grid, size_t smem, int64_t chunk_rows, const 
     HIP_TRY(hipFuncSetAttribute((const void*)k_null<KQ, NS, PF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_null<KQ, NS, PF, NW>), grid, dim3(64 * NW), smem, c->stream, c->X, c->nx, chunk_rows, Yc, ldy, P,
-                     cuts, T, cut0, inv_step, eps, partial);
+  // two launches over the permutation tiles: with ~2 workgroup rounds in total, the boundary lets the
+  // short high-priority kernels of the second stream (global F-tests) in half-way instead of after
+  // the whole kernel
+  const unsigned half = (grid.y + 1) / 2;
+  for (unsigned y0 = 0; y0 < grid.y; y0 += half) {
+    const unsigned ny = grid.y - y0 < half ? grid.y - y0 : half;
+    hipLaunchKernelGGL((k_null<KQ, NS, PF, NW>), dim3(grid.x, ny), dim3(64 * NW), smem, c->stream, c->X, c->nx, chunk_rows,
+                       Yc, ldy, P, cuts, T, cut0, inv_step, eps, partial, (int)y0);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -466,7 +474,7 @@ int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const do
       auto kfn = atoi(dbg) == 1 ? k_null<13, 4, true, 16, 1> : k_null<13, 4, true, 16, 2>;
       HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       hipLaunchKernelGGL(kfn, grid, dim3(1024), lds(NS), c->stream, c->X, c->nx, chunk_rows, Yc_dev, ldy, P, cuts_dev, T,
-                         cut0, inv_step, eps, (unsigned int*)c->null_part);
+                         cut0, inv_step, eps, (unsigned int*)c->null_part, 0);
       return 0;
     }
   }
