@@ -174,6 +174,9 @@ def test_sample_code_memo_sees_in_place_edits():
     ids.values[0] = 2                                   # same buffer, different content
     c3, l3, n3, t3 = sample_codes_cached(ids)
     assert t3 != t1 and list(c3) == [1, 0, 1, 0, 2, 2] and list(n3) == [2, 2, 2]
+    ids.values[[0, 1]] = ids.values[[1, 0]]             # same buffer, same multiset of values, other order
+    c4, l4, n4, t4 = sample_codes_cached(ids)
+    assert t4 != t3 and list(c4) == [0, 1, 1, 0, 2, 2] and list(n4) == [2, 2, 2]
     strs = pd.Series(['b', 'a', 'b'])
     assert sample_codes_cached(strs)[3] is None         # object columns are never memoised
     cat = pd.Series(pd.Categorical(['x', 'z', 'x'], categories=['x', 'y', 'z']))
