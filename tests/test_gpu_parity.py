@@ -588,3 +588,22 @@ def test_prepared_null_launch_and_misuse(eng):
     eng.null_local_launch(1, P, None)
     c = eng.null_local_fetch()
     np.testing.assert_array_equal(c[0], a[0])
+
+
+def test_resident_graph_notices_bulk_in_place_edits(eng, orc):
+    """The graph stays on the device while the same scipy object is passed; an in-place rescaling of
+    its values must be seen (window hash in Engine._key) and the graph uploaded again."""
+    import cna_amd as cna
+    case = load_case('c01_plain_f32')
+    data = case['data']
+    A = data.obsp['connectivities']
+    s0 = np.random.RandomState(2).rand(A.shape[0], 2)
+    a = cna.tl.diffuse(data, s0, 2, engine=eng)
+    assert eng.ensure_graph(A) is False                      # resident
+    A.data *= 0.5                                            # same object, same buffers, other values
+    try:
+        b = cna.tl.diffuse(data, s0, 2, engine=eng)
+        assert relerr(b, orc.diffuse(sp.csr_matrix(A), s0, 2, mode='f64')) < 1e-13
+        assert relerr(a, b) > 1e-3
+    finally:
+        A.data *= 2.0
