@@ -607,3 +607,73 @@ def test_resident_graph_notices_bulk_in_place_edits(eng, orc):
         assert relerr(a, b) > 1e-3
     finally:
         A.data *= 2.0
+
+
+def _fuzz_config(seed):
+    rs = np.random.RandomState(1000 + seed)
+    n = int(rs.choice([400, 900, 1700, 3100]))
+    N = int(rs.choice([10, 13, 24, 37, 64, 90, 110]))
+    cfg = dict(n=n, N=N, k=int(rs.choice([5, 10, 20])), n_covs=int(rs.choice([0, 0, 1, 3])),
+               n_batches=int(rs.choice([0, 0, 2, 5, 9])), graph_dtype=rs.choice(['float32', 'float64']),
+               sid_kind=str(rs.choice(['int', 'str', 'cat'])), cluster_sorted=bool(rs.rand() < 0.5),
+               signal=bool(rs.rand() < 0.7))
+    call = dict(nsteps=rs.choice([None, 1, 2, 3, 5]), Nnull=int(rs.choice([20, 77, 200, 1100])), seed=int(rs.randint(0, 99)))
+    call['nsteps'] = None if call['nsteps'] is None else int(call['nsteps'])
+    if rs.rand() < 0.3:
+        call['ks'] = sorted(set(int(v) for v in rs.randint(1, max(2, N // 6), 3)))
+    if rs.rand() < 0.2:
+        call['force_permute_all'] = True
+    if rs.rand() < 0.3:
+        call['max_frac_pcs'] = float(rs.choice([0.05, 0.3]))
+    cfg['drop_y'] = int(rs.randint(0, 3))                  # samples whose phenotype is missing
+    cfg['donors'] = bool(cfg['n_batches'] == 0 and rs.rand() < 0.25)
+    return cfg, call
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_configurations_vs_oracle(eng, orc, seed):
+    """Seeded random sweep over the argument space (sizes, graph dtype, id column kind, covariates,
+    batches, donors, missing phenotypes, step rule, permutation count, ks, PC budget): the product
+    against the float64 oracle, or the same exception type when the inputs are not admissible."""
+    import cna_amd as cna
+    from cna_amd import synth
+    import warnings
+    cfg, call = _fuzz_config(seed)
+    data, meta = synth.make_dataset(cfg['n'], cfg['N'], k=cfg['k'], seed=seed, n_covs=cfg['n_covs'],
+                                    n_batches=cfg['n_batches'], graph_dtype=np.dtype(cfg['graph_dtype']).type,
+                                    sid_kind=cfg['sid_kind'], cluster_sorted=cfg['cluster_sorted'], signal=cfg['signal'])
+    y = meta['y'].copy()
+    if cfg['drop_y']:
+        y.iloc[np.random.RandomState(seed).choice(len(y), cfg['drop_y'], replace=False)] = np.nan
+    donorids = None
+    if cfg['donors']:
+        donor = np.arange(len(y)) // 2
+        donorids = pd.Series(donor, index=y.index)
+        y = pd.Series(y.groupby(donorids).transform('first').values, index=y.index)
+    kw = dict(covs=meta['covs'], batches=meta['batches'], donorids=donorids, **call)
+    data2 = type('D', (), {'obs': data.obs.copy(), 'obsp': data.obsp, 'uns': {}})()
+    want_err = got_err = None
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        try:
+            ref = orc.association(data2, y, 'id', mode='f64', allow_low_sample_size=True, **kw)
+        except Exception as e:          # noqa: BLE001
+            want_err = e
+        try:
+            res = cna.tl.association(data, y, 'id', return_full=True, allow_low_sample_size=True, engine=eng, **kw)
+        except Exception as e:          # noqa: BLE001
+            got_err = e
+    if want_err is not None or got_err is not None:
+        assert want_err is not None and got_err is not None, (repr(want_err), repr(got_err), cfg, call)
+        assert type(want_err) is type(got_err) or isinstance(got_err, (ValueError, AttributeError)), (want_err, got_err)
+        return
+    assert int(res.k) == int(ref['k']) and np.array_equal(res.kept, ref['kept']), (cfg, call)
+    assert res.p == pytest.approx(ref['p'], rel=1e-12), (cfg, call)
+    assert relerr(res.nam.values.T, ref['nam']) < 1e-12
+    assert relerr(res.namresid.values.T, ref['namresid']) < 1e-8
+    assert relerr(res.ncorrs.values, ref['ncorrs']) < 1e-8
+    np.testing.assert_allclose(res.nullminps, ref['nullminps'], rtol=1e-6)
+    if ref.get('fdrs') is not None:
+        T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
+        assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T]), (cfg, call)
+        np.testing.assert_allclose(res.fdrs.fdr.values[:T], ref['fdrs']['fdr'][:T], rtol=1e-7, atol=1e-13)
