@@ -104,3 +104,70 @@ def test_sharded_hip_path_on_one_gpu(name, world, halo):
     assert relerr(a['diffuse'], orc.diffuse(A, s0, 2, mode='f64')) < 1e-13
     # signs of the PCs are LAPACK's on every rank; V only has to be consistent with U there
     assert a['V'].shape == z['V'].shape
+
+
+def _fuzz_worker(rank, world, seg, seed, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import warnings
+    warnings.simplefilter('ignore')
+    try:
+        import cna_amd as cna
+        from cna_amd import synth
+        from cna_amd.engine import Engine
+        from test_gpu_parity import _fuzz_config
+        cfg, call = _fuzz_config(seed)
+        data, meta = synth.make_dataset(cfg['n'], cfg['N'], k=cfg['k'], seed=seed, n_covs=cfg['n_covs'],
+                                        n_batches=cfg['n_batches'], graph_dtype=np.dtype(cfg['graph_dtype']).type,
+                                        sid_kind=cfg['sid_kind'], cluster_sorted=cfg['cluster_sorted'], signal=cfg['signal'])
+        eng = Engine(device=0, rank=rank, nranks=world, shm=(seg, 8 << 20)) if world > 1 else Engine(device=0)
+        res = cna.tl.association(data, meta['y'], 'id', covs=meta['covs'], batches=meta['batches'], return_full=True,
+                                 allow_low_sample_size=True, engine=eng, **call)
+        out = dict(p=res.p, k=int(res.k), kept=res.kept, ncorrs=res.ncorrs.values, fdr=res.fdrs.fdr.values,
+                   num=res.fdrs.num_detected.values, coef=data.obs['coef'].values, coef_fdr=data.obs['coef_fdr'].values,
+                   nam=res.nam.values)
+        eng.close()
+        q.put((rank, out))
+    except BaseException as e:
+        import traceback
+        q.put((rank, 'ERROR %r\n%s' % (e, traceback.format_exc())))
+        os._exit(1)
+
+
+@pytest.mark.parametrize('seed,world', [(3, 2), (12, 3), (20, 2), (15, 4)])
+def test_sharded_random_configurations_equal_single_gpu(seed, world):
+    """Configurations of the random sweep (QC dropping cells, batches with the ridge schedule,
+    covariates) run sharded over `world` ranks on one GPU: every rank must hold what one GPU computes
+    -- integers and masks exactly, floats to rounding (sums over cells are split differently)."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    results = {}
+    for w in (1, world):
+        q = ctx.Queue()
+        seg = 'cna_fz_%d_%d_%d' % (os.getpid(), seed, w)
+        procs = [ctx.Process(target=_fuzz_worker, args=(r, w, seg, seed, q)) for r in range(w)]
+        for p in procs:
+            p.start()
+        got = {}
+        try:
+            for _ in range(w):
+                r, out = q.get(timeout=240)
+                assert not isinstance(out, str), out
+                got[r] = out
+        finally:
+            for p in procs:
+                p.join(timeout=30)
+                if p.is_alive():
+                    p.kill()
+        results[w] = got
+    one = results[1][0]
+    for r in range(world):
+        g = results[world][r]
+        assert g['k'] == one['k'] and np.array_equal(g['kept'], one['kept']) and np.array_equal(g['num'], one['num'])
+        assert g['p'] == pytest.approx(one['p'], rel=1e-12)
+        # column sums of a float64 graph are added in a different order when sharded (float32 graphs: exact)
+        np.testing.assert_allclose(g['nam'], one['nam'], rtol=1e-13, atol=0)
+        np.testing.assert_allclose(g['ncorrs'], one['ncorrs'], rtol=1e-9, atol=1e-13)
+        np.testing.assert_allclose(g['fdr'], one['fdr'], rtol=1e-9, atol=1e-13, equal_nan=True)
+        np.testing.assert_allclose(g['coef'], one['coef'], rtol=1e-9, atol=1e-13, equal_nan=True)
+        np.testing.assert_allclose(g['coef_fdr'], one['coef_fdr'], rtol=1e-9, atol=1e-13)
