@@ -302,9 +302,23 @@ def main():
         'dataset_gen_s': round(t_gen, 1),
         'kernels': kernels,
     }
-    print(json.dumps(out))
+    # the JSON line is the last thing this process writes: tear the communicators down first and
+    # push out whatever the libraries (RCCL prints a version banner) still hold in C stdio buffers
+    try:
+        eng.close()
+    except Exception:
+        pass
     if td is not None:
         td.destroy_process_group()
+    sys.stderr.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(out) + '\n')
+    sys.stdout.flush()
+    os._exit(0)                     # nothing may print after the line (atexit banners of the runtime libraries)
 
 
 if __name__ == '__main__':
