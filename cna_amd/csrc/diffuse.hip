@@ -14,6 +14,15 @@
 #include "common.h"
 #include <cstdlib>
 
+// The walk's products and sums are meant to round like scipy's csr_matvecs (a multiply, then an add).
+// hipcc contracts a*b+c into an fma by default -- also through __dmul_rn / __dadd_rn, which are plain
+// operators carrying the header's contract flag (the gather loop compiled to v_fmac_f64) -- so
+// contraction is switched off for this file and the walk uses its own mul_rn / add_rn, defined below
+// the pragma.  The division sequences use explicit fma builtins and are not affected.
+#pragma clang fp contract(off)
+__device__ __forceinline__ double mul_rn(double a, double b) { return a * b; }
+__device__ __forceinline__ double add_rn(double a, double b) { return a + b; }
+
 namespace {
 
 struct CellInfo {      // one gather per edge in the first step
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
     load_edges<VT>(a, base, end, lane, jl, al);
     if (base + lane < end) {
       const CellInfo ci = info[jl];
-      if (ci.sid >= 0) unsafeAtomicAdd(&accl[ci.sid], __dmul_rn(al, ci.inv_colsum));
+      if (ci.sid >= 0) unsafeAtomicAdd(&accl[ci.sid], mul_rn(al, ci.inv_colsum));
     }
   }
   const CellInfo me = info[grow];
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   double s[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) s[q] = __dadd_rn(accl[lane + 64 * q], (lane + 64 * q == me.sid) ? self : 0.0);
+  for (int q = 0; q < NQ; ++q) s[q] = add_rn(accl[lane + 64 * q], (lane + 64 * q == me.sid) ? self : 0.0);
   finish_row<NQ, ColStride1>(a, row, grow, lane, s);
   if (a.sp_cnt) {
     // after one step a row is non-zero only at the samples of the cell's neighbours: keep those
@@ -239,8 +248,8 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
         const double av = readlane_d(al, l + u);
 #pragma unroll
         for (int q = 0; q < NQ2; ++q) {
-          acc[q].x = __dadd_rn(acc[q].x, __dmul_rn(av, t[u][q].x));
-          acc[q].y = __dadd_rn(acc[q].y, __dmul_rn(av, t[u][q].y));
+          acc[q].x = add_rn(acc[q].x, mul_rn(av, t[u][q].x));
+          acc[q].y = add_rn(acc[q].y, mul_rn(av, t[u][q].y));
         }
       }
     }
@@ -251,8 +260,8 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
 #pragma unroll
       for (int q = 0; q < NQ2; ++q) {
         const double2 t = act[q] ? rowp[off[q]] : make_double2(0.0, 0.0);
-        acc[q].x = __dadd_rn(acc[q].x, __dmul_rn(av, t.x));
-        acc[q].y = __dadd_rn(acc[q].y, __dmul_rn(av, t.y));
+        acc[q].x = add_rn(acc[q].x, mul_rn(av, t.x));
+        acc[q].y = add_rn(acc[q].y, mul_rn(av, t.y));
       }
     }
   }
@@ -260,8 +269,8 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
 #pragma unroll
   for (int q = 0; q < NQ2; ++q) {
     const double2 own = act[q] ? Tin[grow * ld2 + off[q]] : make_double2(0.0, 0.0);
-    s[2 * q] = __dadd_rn(acc[q].x, __dmul_rn(a.w, own.x));          // + w*s/colsums  (exact for w=1)
-    s[2 * q + 1] = __dadd_rn(acc[q].y, __dmul_rn(a.w, own.y));
+    s[2 * q] = add_rn(acc[q].x, mul_rn(a.w, own.x));          // + w*s/colsums  (exact for w=1)
+    s[2 * q + 1] = add_rn(acc[q].y, mul_rn(a.w, own.y));
   }
   finish_row<2 * NQ2, ColPair>(a, row, grow, lane, s);
 }
@@ -269,13 +278,11 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
 // Second step on the compressed state: the same sums in the same (CSR) order as k_nam_step -- the
 // zeros it skips contribute +0 there -- on a fraction of the bytes (~40 x 10 B instead of 8N B per
 // edge; at N = 200 a third of the cache lines).  Lane l of an edge adds weight x value_l into column
-// sample_l of the wave's LDS accumulator row with ds_add_f64: distinct columns inside one edge, and
-// the LDS serves one wave's instructions in program order, so the result is deterministic.
-// It is not bit-identical to k_nam_step, though: measured on this chip, the LDS f64 atomic does not
-// round like v_add_f64 (1-ulp differences, <= 6e-16 relative, in ~4 % of the outputs; an explicit
-// LDS read / v_add_f64 / LDS write variant reproduces k_nam_step to the bit but is latency bound
-// and slower than the dense kernel).  k_nam_first accumulates the same way.  Rows that overflowed
-// the compressed form (more than SP_CAP distinct samples) are taken dense.
+// sample_l of the wave's LDS accumulator row with ds_add_f64: distinct columns inside one edge, the
+// LDS serves one wave's instructions in program order, and the LDS f64 add rounds like v_add_f64
+// (tools/micro/lds_add_rounding.hip: 4M single adds and 260k chains of 40, no difference), so the
+// result is bit-identical to k_nam_step.  Rows that overflowed the compressed form (more than SP_CAP
+// distinct samples) are taken dense.
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 template <typename VT, int NQ2>
@@ -300,8 +307,8 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
       const int c2 = lane + 64 * q;
       if (c2 < ld2) {
         const double2 t = rowp[c2];
-        lds_add(&acc[2 * c2], __dmul_rn(av, t.x));
-        lds_add(&acc[2 * c2 + 1], __dmul_rn(av, t.y));
+        lds_add(&acc[2 * c2], mul_rn(av, t.x));
+        lds_add(&acc[2 * c2 + 1], mul_rn(av, t.y));
       }
     }
   };
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
       for (int u = 0; u < U; ++u) {
         const double av = readlane_d(al, l + u);
         if (cc[u] == SP_DENSE) dense_edge(__builtin_amdgcn_readlane(jl, l + u), av);
-        else if (lane < cc[u]) lds_add(&acc[si[u]], __dmul_rn(av, sv[u]));
+        else if (lane < cc[u]) lds_add(&acc[si[u]], mul_rn(av, sv[u]));
       }
     }
     for (; l < cnt; ++l) {                       // ragged tail
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
       const double av = readlane_d(al, l);
       if (c == SP_DENSE) dense_edge(j, av);
       else if (lane < c)
-        lds_add(&acc[a.sp_idx[(int64_t)j * SP_CAP + lane]], __dmul_rn(av, a.sp_val[(int64_t)j * SP_CAP + lane]));
+        lds_add(&acc[a.sp_idx[(int64_t)j * SP_CAP + lane]], mul_rn(av, a.sp_val[(int64_t)j * SP_CAP + lane]));
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -349,8 +356,8 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
     const int c2 = lane + 64 * q;
     const bool act = c2 < ld2;
     const double2 own = act ? Tin[grow * ld2 + c2] : make_double2(0.0, 0.0);
-    s[2 * q] = __dadd_rn(act ? acc[2 * c2] : 0.0, __dmul_rn(a.w, own.x));          // + w*s/colsums
-    s[2 * q + 1] = __dadd_rn(act ? acc[2 * c2 + 1] : 0.0, __dmul_rn(a.w, own.y));
+    s[2 * q] = add_rn(act ? acc[2 * c2] : 0.0, mul_rn(a.w, own.x));          // + w*s/colsums
+    s[2 * q + 1] = add_rn(act ? acc[2 * c2 + 1] : 0.0, mul_rn(a.w, own.y));
   }
   finish_row<2 * NQ2, ColPair>(a, row, grow, lane, s);
 }
