@@ -72,6 +72,10 @@ def test_diffusion_steps_vs_oracle_and_golden(eng, orc, name):
         got = eng.nam_full()
         want = s / S.sum(axis=0)
         assert relerr(got, want) < 1e-13, (i, relerr(got, want))
+        if A.dtype == np.float32:
+            # float32 graphs (what scanpy emits): column sums are exact in float64 whatever the order, and
+            # the kernels round like scipy's csr_matvecs (unfused multiply and add, CSR order) -- bit-identical
+            np.testing.assert_array_equal(got, want)
         assert relerr(got, z['steps'][i] / S.sum(axis=0)) < 1e-5          # the reference itself
         kurt = eng.cell_stat(A.shape[0])
         np.testing.assert_allclose(kurt, orc.row_kurtosis(want), rtol=1e-9, atol=1e-12)
