@@ -35,9 +35,9 @@ F64_MFMA_PEAK_TF = 78.6      # AMD MI355X datasheet: FP64 matrix 78.6 TFLOP/s (t
 # gfx950 correction, re-calibrated here on k_ncorrs (streams the 83.2 MB matrix once, FETCH_SIZE reads 41.6 MB).
 # Counted at the L2's fabric side, i.e. Infinity-Cache hits included.  Only valid for the profiled workload.
 PMC_TRAFFIC = {
-    ('C2', 'nam_step'): 2 * 172400e3 + 82110e3,
-    ('C2', 'nam_first'): 2 * 37780e3 + 81250e3,
-    ('C2', 'null_local'): 2 * 83220e3 + 37500e3,
+    ('C2', 'nam_step'): 2 * 172600e3 + 82070e3,
+    ('C2', 'nam_first'): 2 * 37770e3 + 81250e3,
+    ('C2', 'null_local'): 2 * (2 * 41670e3 + 18750e3),     # two launches per pass
 }
 
 WORKLOADS = {
@@ -317,8 +317,7 @@ def main():
     except Exception:
         pass
     sys.stdout.write(json.dumps(out) + '\n')
-    sys.stdout.flush()
-    os._exit(0)                     # nothing may print after the line (atexit banners of the runtime libraries)
+    sys.stdout.flush()              # (a normal exit follows: profilers attached to this process write at exit)
 
 
 if __name__ == '__main__':
