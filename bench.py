@@ -228,6 +228,17 @@ def main():
         with open(args.profile_host, 'w') as f:
             f.write(buf.getvalue())
 
+    if td is not None:
+        # every rank pushes out what its runtime libraries buffered (RCCL's version banner) before
+        # rank 0 goes on to print the result line: nothing from another rank can land after it
+        sys.stderr.flush()
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        td.barrier()
     if rank != 0:
         if td is not None:
             td.destroy_process_group()
