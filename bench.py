@@ -46,6 +46,7 @@ WORKLOADS = {
     'C3': (1_000_000, 100, 30, 3, 1000),
     'C4w': (250_000, 200, 30, 3, 1000),     # 8 GPUs x 250k = BASELINE config 4
     'C4': (2_000_000, 200, 30, 3, 1000),    # BASELINE config 4 on ONE GPU (fits: ~14 GB of 288 GB)
+    'C5': (2_000_000, 200, 30, 3, 10000),   # BASELINE config 5 on ONE GPU: + 5 covariates, Nnull = 10000
 }
 
 
@@ -85,16 +86,16 @@ def algorithmic_work(kernel, n, nnz, N, P, T, wA):
     return 'hbm', 8 * n
 
 
-def load_or_make_dataset(synth, n, N, k, rank, world, td):
+def load_or_make_dataset(synth, n, N, k, rank, world, td, n_covs=0):
     """One synthetic dataset for the whole job: rank 0 generates it (the kNN search is the slow,
     CPU-only part) and the other ranks of this node read it from /dev/shm -- every rank holds the
     full `data` object, as with a replicated AnnData."""
     if world == 1:
-        return synth.make_dataset(n, N, k=k, seed=0)
+        return synth.make_dataset(n, N, k=k, seed=0, n_covs=n_covs)
     import pickle
     path = '/dev/shm/cna_bench_%s_%d_%d.pkl' % (os.environ.get('MASTER_PORT', '0'), n, N)
     if rank == 0:
-        out = synth.make_dataset(n, N, k=k, seed=0)
+        out = synth.make_dataset(n, N, k=k, seed=0, n_covs=n_covs)
         try:
             with open(path + '.tmp', 'wb') as f:
                 pickle.dump(out, f, protocol=pickle.HIGHEST_PROTOCOL)
@@ -107,7 +108,7 @@ def load_or_make_dataset(synth, n, N, k, rank, world, td):
             with open(path, 'rb') as f:
                 out = pickle.load(f)
         else:
-            out = synth.make_dataset(n, N, k=k, seed=0)
+            out = synth.make_dataset(n, N, k=k, seed=0, n_covs=n_covs)
     td.barrier()
     if rank == 0 and os.path.exists(path):
         os.remove(path)
@@ -165,9 +166,10 @@ def main():
     from cna_amd.tools._nam import get_connectivity
 
     cells_per_gpu, N, k, nsteps, Nnull = WORKLOADS[args.workload]
+    n_covs = 5 if args.workload == 'C5' else 0
     n = cells_per_gpu * world
     t0 = time.time()
-    data, meta = load_or_make_dataset(synth, n, N, k, rank, world, td)
+    data, meta = load_or_make_dataset(synth, n, N, k, rank, world, td, n_covs=n_covs)
     t_gen = time.time() - t0
     A = get_connectivity(data)
     nnz = int(A.nnz)
@@ -175,6 +177,8 @@ def main():
     eng = get_engine()
     eng.reuse_nam = False           # every timed step recomputes the NAM (no result caching across steps)
     kw = dict(nsteps=nsteps, Nnull=Nnull, seed=0)
+    if meta.get('covs') is not None:
+        kw['covs'] = meta['covs']
 
     on_gpu_group = td is not None and args.comm != 'shm'
 
