@@ -118,9 +118,17 @@ class CellOrder:
 
     # rows of X (kept cells of all ranks, device order) -> caller's order
     def _kept_order(self):
+        """X row (device order, kept cells of all ranks) of every kept cell in the caller's order --
+        two gathers through the inverse permutation instead of a sort."""
         if self._kept_order_cache is None:
-            ids = self.perm if self._keep_dev is None else self.perm[self._keep_dev]
-            self._kept_order_cache = np.argsort(ids, kind='stable')
+            inv = inverse(self.perm)
+            if self._keep_dev is None:
+                self._kept_order_cache = inv
+            else:
+                pos = np.cumsum(self._keep_dev) - 1                 # device row -> X row
+                kept_user = np.zeros(len(self.perm), dtype=bool)
+                kept_user[self.perm[self._keep_dev]] = True
+                self._kept_order_cache = pos[inv[np.flatnonzero(kept_user)]]
         return self._kept_order_cache
 
     def kept_to_user(self, m):
@@ -148,9 +156,11 @@ class CellOrder:
     def project_full(self, W):
         return self.kept_to_user(self._all_rows(self.project(W), self.x_rows_total))
 
-    def x_stat(self):
-        """Per-row statistic of the last X-space kernel, caller's order of the kept cells."""
-        return self.kept_to_user(self.cell_stat(self.x_rows_total, nam_space=False))
+    def x_stat(self, ordered=True):
+        """Per-row statistic of the last X-space kernel over the kept cells: in the caller's order,
+        or (ordered=False, e.g. for a median) in whatever order the device holds them."""
+        v = self.cell_stat(self.x_rows_total, nam_space=False)
+        return self.kept_to_user(v) if ordered else v
 
     def dense_begin(self, arr):
         self._nam_sig = None                  # the dense walk reuses the state buffers of the NAM

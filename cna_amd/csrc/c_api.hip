@@ -527,6 +527,63 @@ int cna_fetch_cell_stat(cna_ctx* c, double* out, int64_t n_expected) {
   return ragged_gather(c, c->stat, c->nx, out, n_expected);
 }
 
+// Exact median of the per-cell statistic (np.median semantics: NaN if any entry is NaN, mean of the
+// two middle values for an even count) by radix select on the device: 8 passes of an 8-bit digit
+// histogram per order statistic, a 2 KB read-back each -- ~0.3 ms instead of the 1-6 ms numpy's
+// partition takes on 200k-1M values, and no cells-sized transfer.  NAM-space statistics are
+// replicated on every rank (all n_global values); X-space ones are the local rows, so the
+// histograms are summed over ranks.
+static int stat_select(cna_ctx* c, const double* v, int64_t n_loc, bool sharded, int64_t k, unsigned long long* hist_dev,
+                       double* value, int64_t* n_nan, int64_t* n_total) {
+  unsigned long long prefix = 0;
+  std::vector<unsigned long long> h(257);
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 56 - 8 * pass;
+    CNA_TRY(launch_digit_hist(c, v, n_loc, prefix, shift, hist_dev));
+    if (sharded) CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist_dev, 257));
+    HIP_TRY(hipMemcpyAsync(h.data(), hist_dev, 8 * 257, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (pass == 0) {
+      int64_t tot = 0;
+      for (int d = 0; d < 256; ++d) tot += (int64_t)h[d];
+      *n_nan = (int64_t)h[256];
+      *n_total = tot + *n_nan;
+      if (*n_nan > 0 || tot == 0) return 0;
+      if (k < 0) k = (tot - 1) / 2;                        // caller asked for the lower middle
+      if (k >= tot) k = tot - 1;
+    }
+    int d = 0;
+    int64_t before = 0;
+    while (d < 255 && before + (int64_t)h[d] <= k) before += (int64_t)h[d++];
+    k -= before;
+    prefix = (prefix << 8) | (unsigned long long)d;
+  }
+  const unsigned long long bits = (prefix >> 63) ? (prefix & 0x7fffffffffffffffull) : ~prefix;
+  std::memcpy(value, &bits, 8);
+  return 0;
+}
+
+int cna_stat_median(cna_ctx* c, double* median_out) {
+  CHECK_CTX(c);
+  if (!median_out) CNA_FAIL(CNA_EINVAL, "cna_stat_median: null output");
+  const double* v = c->stat;
+  int64_t n_loc;
+  bool sharded;
+  if (c->stat_space == CNA_MAT_NAM) { n_loc = c->n_global; sharded = false; }
+  else if (c->stat_space == CNA_MAT_X) { n_loc = c->nx; sharded = c->nranks > 1 || comm_active(c); }
+  else CNA_FAIL(CNA_ESTATE, "no per-cell statistic available");
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, 8 * 257 + 64));   // main-stream scratch (not c->gt:
+  unsigned long long* hist = (unsigned long long*)c->scratch;            // the helper thread may be conditioning)
+  double lo = 0.0, hi = 0.0;
+  int64_t n_nan = 0, n_tot = 0;
+  CNA_TRY(stat_select(c, v, n_loc, sharded, -1, hist, &lo, &n_nan, &n_tot));
+  if (n_tot == 0 || n_nan > 0) { *median_out = __builtin_nan(""); return 0; }
+  if (n_tot & 1) { *median_out = lo; return 0; }
+  CNA_TRY(stat_select(c, v, n_loc, sharded, n_tot / 2, hist, &hi, &n_nan, &n_tot));
+  *median_out = (lo + hi) / 2.0;
+  return 0;
+}
+
 // --------------------------------------------------------------------- dense diffusion
 int cna_dense_load(cna_ctx* c, const double* s_local, int m) {
   CHECK_CTX(c);

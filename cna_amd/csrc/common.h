@@ -195,6 +195,8 @@ int launch_batch_kurtosis(cna_ctx* c, const double* mat, int64_t rows, int ncols
 int launch_zero_variance(cna_ctx* c, const int32_t* colmap_dev, int n_sel, uint8_t* flags_dev,
                          unsigned long long* count_dev);
 int launch_select(cna_ctx* c, const int32_t* colmap_dev);
+int launch_digit_hist(cna_ctx* c, const double* v, int64_t n, unsigned long long prefix, int shift,
+                      unsigned long long* hist_dev);
 int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev, const double* y_dev,
                       unsigned long long* maxbits_dev);
 int launch_standardize(cna_ctx* c, int center);

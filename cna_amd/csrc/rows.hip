@@ -320,6 +320,31 @@ __global__ __launch_bounds__(256) void k_ncorrs(const double* __restrict__ X, in
   }
 }
 
+// One pass of an exact radix select over doubles: histogram of the 8-bit digit at `shift` among the
+// values whose order-preserving 64-bit key matches `prefix` above that digit; hist[256] counts NaNs.
+__device__ __forceinline__ unsigned long long order_key(double x) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);       // negatives reversed, positives above them
+}
+__global__ __launch_bounds__(256) void k_digit_hist(const double* __restrict__ v, int64_t n, unsigned long long prefix,
+                                                    int shift, unsigned long long* __restrict__ hist) {
+  __shared__ unsigned int h[257];
+  for (int i = threadIdx.x; i < 257; i += 256) h[i] = 0u;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double x = v[i];
+    if (x != x) {
+      if (shift == 56) atomicAdd(&h[256], 1u);               // NaNs are counted once, in the first pass
+      continue;
+    }
+    const unsigned long long k = order_key(x);
+    if (shift == 56 || (k >> (shift + 8)) == prefix) atomicAdd(&h[(unsigned)(k >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 257; i += 256)
+    if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
 __global__ __launch_bounds__(256) void k_max_fold(const unsigned long long* __restrict__ blockmax, int nblocks,
                                                   unsigned long long* __restrict__ out) {
   __shared__ unsigned long long sm[256];
@@ -541,6 +566,18 @@ int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long*
   }
   if (y_dev) hipLaunchKernelGGL(k_max_fold, dim3(1), dim3(256), 0, c->stream, maxbits_dev + 1, (int)grid, maxbits_dev);
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_digit_hist(cna_ctx* c, const double* v, int64_t n, unsigned long long prefix, int shift,
+                      unsigned long long* hist_dev) {
+  HIP_TRY(hipMemsetAsync(hist_dev, 0, sizeof(unsigned long long) * 257, c->stream));
+  if (n > 0) {
+    const int64_t want = (n + 1023) / 1024;
+    const unsigned grid = (unsigned)(want < 1024 ? want : 1024);
+    hipLaunchKernelGGL(k_digit_hist, dim3(grid), dim3(256), 0, c->stream, v, n, prefix, shift, hist_dev);
+    HIP_TRY(hipGetLastError());
+  }
   return 0;
 }
 

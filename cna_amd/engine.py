@@ -199,6 +199,13 @@ class Engine(_order.CellOrder):
         """nsteps walk steps in one call (fixed step count, nothing for the host to decide in between)."""
         check(self.lib.cna_nam_steps(self.h, int(nsteps)), 'cna_nam_steps')
 
+    def stat_median(self):
+        """np.median of the per-cell statistic of the last kernel that made one, over all cells (or all
+        kept cells, all ranks): exact radix select on the device, no cells-sized transfer."""
+        m = C.c_double(0.0)
+        check(self.lib.cna_stat_median(self.h, C.byref(m)), 'cna_stat_median')
+        return m.value
+
     def cell_stat(self, n_expected, nam_space=True):
         """Per-cell statistic of the last kernel that made one: over all cells in the caller's
         order (nam_space) or over the rows of X in device order (see x_stat())."""

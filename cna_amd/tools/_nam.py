@@ -247,8 +247,7 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
         engine.nam_step(need_kurt, not last_for_sure, may_stop)
         taken = i + 1
         if need_kurt:
-            with np.errstate(all='ignore'):
-                medkurt = np.median(engine.cell_stat(n))
+            medkurt = engine.stat_median()
             if show_progress:
                 # R2(t, t-1) is scale free per column, so NAM = s/C serves as s (_nam.py:60)
                 cur = engine.nam_full()
@@ -290,8 +289,8 @@ def _qc_device(engine, labels, batches, show_progress=False):
         return np.repeat(True, engine.n)
     codes, nb = _batch_codes(batches, labels)
     engine.batch_kurtosis(_ffi.MAT_NAM, codes, nb)
+    threshold = max(6, 2 * engine.stat_median())
     kurtoses = engine.cell_stat(engine.n)
-    threshold = max(6, 2 * np.median(kurtoses))
     print('throwing out neighborhoods with batch kurtosis >=', threshold, file=out)
     with np.errstate(invalid='ignore'):
         keep = kurtoses < threshold
@@ -407,8 +406,7 @@ def _resid_run(engine, plan, cell_index, show_progress=False):
             engine.resid_apply(np.asarray(M.values, dtype=np.float64), center=first)
             first = False
             engine.batch_kurtosis(_ffi.MAT_X, plan.bcodes, plan.nb)
-            kurtoses = engine.x_stat()
-            med = np.median(kurtoses)
+            med = engine.stat_median()
             print('\twith ridge', ridge, 'median batch kurtosis = ', med, file=out)
             if med <= 6:
                 break

@@ -116,6 +116,10 @@ int  cna_nam_steps(cna_ctx* ctx, int nsteps);
 /* per-cell statistic of the last kernel that produced one (kurtosis / batch kurtosis),
  * gathered over ranks: out has n_global entries (CNA_MAT_NAM rows) or n_x_total (CNA_MAT_X) */
 int  cna_fetch_cell_stat(cna_ctx* ctx, double* out, int64_t n_expected);
+/* np.median of that statistic over all cells (or all kept cells, all ranks), computed on the device
+ * by an exact radix select: NaN if any entry is NaN, mean of the two middle values for an even count
+ * (medians of _nam.py:59,94,150) */
+int  cna_stat_median(cna_ctx* ctx, double* median_out);
 
 /* cna.tl.diffuse / diffuse_stepwise on an arbitrary dense cells x m state (_nam.py:21-41):
  * load the local rows, step, fetch the local rows (unscaled state s). */

@@ -171,6 +171,10 @@ class FakeEngine(_order.CellOrder):
         for i in range(nsteps):
             self.nam_step(False, i + 1 < nsteps, i + 1 == nsteps)
 
+    def stat_median(self):
+        with np.errstate(all='ignore'):
+            return float(np.median(self.stat))
+
     def cell_stat(self, n_expected, nam_space=True):
         assert len(self.stat) == n_expected
         return self.cells_to_user(self.stat.copy()) if nam_space else self.stat.copy()

@@ -679,3 +679,38 @@ def test_random_configurations_vs_oracle(eng, orc, seed):
         T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
         assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T]), (cfg, call)
         np.testing.assert_allclose(res.fdrs.fdr.values[:T], ref['fdrs']['fdr'][:T], rtol=1e-7, atol=1e-13)
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 64, 257, 999, 1000])
+def test_device_median_equals_numpy(eng, n):
+    """cna_stat_median (radix select on the device) against np.median: odd and even counts, duplicates,
+    negative values, NaNs (-> NaN), in both statistic spaces."""
+    from cna_amd import _ffi
+    eng.ensure_graph(load_case('c01_plain_f32')['data'].obsp['connectivities'])   # sizes the statistic buffer (1000 cells)
+    rs = np.random.RandomState(n)
+    N = 12
+    X = np.round(rs.randn(n, N), 1)                     # coarse values: plenty of exact duplicates downstream
+    eng.upload_x(X)
+    bc = np.arange(N) % 4
+    eng.batch_kurtosis(_ffi.MAT_X, bc, 4)
+    with np.errstate(all='ignore'):
+        v = eng.x_stat(ordered=False)
+        want = np.median(v)
+    got = eng.stat_median()
+    assert (np.isnan(want) and np.isnan(got)) or got == want, (got, want)
+    if n >= 3:
+        X[n // 2] = 1.0                                 # a constant row: its batch kurtosis is NaN
+        eng.upload_x(X)
+        eng.batch_kurtosis(_ffi.MAT_X, bc, 4)
+        assert np.isnan(eng.x_stat(ordered=False)).any() and np.isnan(eng.stat_median())
+
+
+def test_device_median_of_walk_kurtosis(eng, orc):
+    """... and on the NAM-space statistic (Fisher kurtosis per cell: negative values occur)."""
+    case = load_case('c02_covs_autostop')
+    A, codes, N = _setup_nam(eng, orc, case)
+    for i in range(4):
+        eng.nam_step(True, True, True)
+        v = eng.cell_stat(A.shape[0])
+        assert (v < 0).any()
+        assert eng.stat_median() == np.median(v)
