@@ -4,7 +4,7 @@ set -u
 R=$GRAFT_REPO_ROOT; TAG=${1:-r01}; OUT=$R/gpurun_out/prof_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench_C2.json 2> $OUT/bench_C2.err
-python $R/bench.py --workload C3 --no-cpu-baseline > $OUT/bench_C3.json 2> $OUT/bench_C3.err
+python $R/bench.py --workload C3 --no-cpu-baseline --steps 20 --warmup 5 > $OUT/bench_C3.json 2> $OUT/bench_C3.err
 python $R/bench.py --workload C4 --no-cpu-baseline --steps 3 --warmup 2 > $OUT/bench_C4.json 2> $OUT/bench_C4.err
 timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o stats -- python $R/bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
 pass() { n=$1; shift; timeout -k 5 200 rocprofv3 --kernel-trace --output-format csv -d $OUT -o $n --pmc "$@" -- python $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $OUT/$n.log 2>&1 || echo "pass $n failed"; }
