@@ -62,6 +62,8 @@ SIGNATURES = {
     'cna_null_local_fetch': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cna_percell_fdr_pinned': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     'cna_nam_steps': (C.c_int, [c_ctx, C.c_int]),
+    'cna_fetch_rows': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    'cna_project_keep': (C.c_int, [c_ctx, C.c_void_p, C.c_int]),
     'cna_stat_median': (C.c_int, [c_ctx, C.POINTER(C.c_double)]),
     'cna_global_test': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
@@ -76,7 +78,7 @@ SIGNATURES = {
     'cna_kernel_name': (C.c_char_p, [C.c_int]),
 }
 
-MAT_NAM, MAT_X = 0, 1
+MAT_NAM, MAT_X, MAT_PROJ = 0, 1, 2
 KERNELS = ['colsum', 'nam_first', 'nam_step', 'batch_kurtosis', 'zero_variance', 'select', 'resid_xb',
            'standardize', 'gram', 'gram_reduce', 'ncorrs', 'null_local', 'obs_counts', 'percell_fdr',
            'project_xb', 'transpose', 'rccl', 'condition', 'global_test']

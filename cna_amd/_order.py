@@ -139,21 +139,49 @@ class CellOrder:
     def _all_rows(self, local, n_total):
         return local if self.nranks == 1 else self.gather_rows_host(local, n_total)
 
-    # whole matrices in the caller's order
-    def nam_full(self):
-        """NAM of all cells (cells x samples)."""
+    # whole matrices in the caller's order.  On one GPU the rows (and columns) are picked, ordered and
+    # -- if asked -- transposed by a gather kernel before the copy (engine.fetch_rows); sharded runs
+    # gather the row blocks on the host and reorder there.
+    def _on_device(self):
+        return self.nranks == 1 and hasattr(self, 'fetch_rows')
+
+    def _nam_rows(self, keep):
+        """device row of every (kept) cell in the caller's order, or None for "all, in order" """
+        if keep is not None and np.all(keep):
+            keep = None
+        if self.perm is None:
+            return None if keep is None else np.flatnonzero(keep).astype(np.int64)
+        inv = inverse(self.perm)
+        return inv if keep is None else inv[np.flatnonzero(keep)]
+
+    def nam_full(self, keep=None, cols=None, transposed=False):
+        """NAM (cells x samples) of all cells, or of the cells of a boolean mask `keep` and the samples
+        `cols`, in the caller's order; transposed=True gives samples x cells."""
         from ._ffi import MAT_NAM
-        return self.cells_to_user(self._all_rows(self.fetch_matrix(MAT_NAM), self.n))
+        if self._on_device():
+            return self.fetch_rows(MAT_NAM, self._nam_rows(keep), cols, transposed)
+        m = self.cells_to_user(self._all_rows(self.fetch_matrix(MAT_NAM), self.n))
+        if keep is not None and not np.all(keep):
+            m = m[np.asarray(keep, dtype=bool)]
+        if cols is not None:
+            m = m[:, np.asarray(cols)]
+        return np.ascontiguousarray(m.T) if transposed else m
 
     def x_full(self, transposed=False):
         """Working matrix X over the kept cells (cells x samples, or its transpose)."""
         from ._ffi import MAT_X
-        if self.nranks == 1 and (self.perm is None or not self._x_is_selection):
-            return self.fetch_matrix(MAT_X, transposed=transposed)
+        if self._on_device():
+            rows = self._kept_order() if (self.perm is not None and self._x_is_selection) else None
+            return self.fetch_rows(MAT_X, rows, None, transposed)
         m = self.kept_to_user(self._all_rows(self.fetch_matrix(MAT_X), self.x_rows_total))
         return np.ascontiguousarray(m.T) if transposed else m
 
     def project_full(self, W):
+        from ._ffi import MAT_PROJ
+        if self._on_device() and hasattr(self, 'project_keep'):
+            self.project_keep(W)
+            rows = self._kept_order() if (self.perm is not None and self._x_is_selection) else None
+            return self.fetch_rows(MAT_PROJ, rows, None, False)
         return self.kept_to_user(self._all_rows(self.project(W), self.x_rows_total))
 
     def x_stat(self, ordered=True):

@@ -197,7 +197,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_flush(c);
   comm_destroy(c);
-  void* bufs[] = {c->sp_idx, c->sp_val, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+  void* bufs[] = {c->proj, c->sp_idx, c->sp_val, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
                   c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -879,6 +879,29 @@ int cna_project(cna_ctx* c, const double* W, int n_w, double* out_local) {
   return 0;
 }
 
+// cna_project with the result left on the device (rows of X x n_w), to be read with
+// cna_fetch_rows(CNA_MAT_PROJ, ...) in whatever row order the caller wants
+int cna_project_keep(cna_ctx* c, const double* W, int n_w) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  if (n_w < 1) CNA_FAIL(CNA_EINVAL, "n_w < 1");
+  const int Nx = c->Nx, ldx = c->ldx;
+  const int ldb = round_up(n_w, 16);
+  std::vector<double> B((size_t)ldx * ldb, 0.0);
+  for (int k = 0; k < Nx; ++k)
+    for (int j = 0; j < n_w; ++j) B[(size_t)k * ldb + j] = W[(size_t)k * n_w + j];
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, (int64_t)sizeof(double) * ldx * ldb));
+  HIP_TRY(hipMemcpyAsync(c->scratch, B.data(), sizeof(double) * ldx * ldb, hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(dev_reserve(c, &c->proj, &c->proj_cap, (int64_t)sizeof(double) * std::max<int64_t>(c->nx, 1) * ldb));
+  CNA_TRY(launch_xb(c, (const double*)c->scratch, ldb, n_w, false, (double*)c->proj, ldb));
+  HIP_TRY(hipStreamSynchronize(c->stream));               // B is a local
+  c->proj_ld = ldb;
+  c->proj_cols = n_w;
+  c->proj_rows = c->nx;
+  c->proj_valid = true;
+  return 0;
+}
+
 // ------------------------------------------------------------------------- association
 int cna_ncorrs(cna_ctx* c, const double* y, double* out_local, double* max_abs) {
   CHECK_CTX(c);
@@ -1304,6 +1327,49 @@ int cna_fetch_matrix(cna_ctx* c, int which, double* out, int transposed) {
     HIP_TRY(hipMemcpy2DAsync(out, 8 * (size_t)cols, src, 8 * (size_t)ld, 8 * (size_t)cols, rows,
                              hipMemcpyDeviceToHost, c->stream));
   }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// cna_fetch_matrix with the rows (and columns) picked and ordered on the device: out[i][j] =
+// matrix[rows[i]][cols[j]], or its transpose.  which = CNA_MAT_NAM / CNA_MAT_X, or CNA_MAT_PROJ for the
+// result of the last cna_project_keep.  One gather kernel and one contiguous copy instead of a
+// strided copy plus cells x samples sized reshuffles on the host.
+int cna_fetch_rows(cna_ctx* c, int which, const int64_t* rows, int64_t n_out, const int32_t* cols, int n_cols,
+                   double* out, int transposed) {
+  CHECK_CTX(c);
+  const double* src;
+  int ld, width;
+  int64_t have;
+  if (which == CNA_MAT_PROJ) {
+    if (!c->proj_valid) CNA_FAIL(CNA_ESTATE, "no projection resident (cna_project_keep)");
+    src = (const double*)c->proj; ld = c->proj_ld; width = c->proj_cols; have = c->proj_rows;
+  } else {
+    int cc;
+    CNA_TRY(cna_matrix_shape(c, which, &have, &cc));
+    width = cc;
+    src = which == CNA_MAT_NAM ? c->nam : c->X;
+    ld = which == CNA_MAT_NAM ? c->ld : c->ldx;
+  }
+  if (!rows) n_out = have;
+  if (!cols) n_cols = width;
+  if (n_out < 0 || n_cols < 0) CNA_FAIL(CNA_EINVAL, "cna_fetch_rows: bad sizes");
+  if (n_out == 0 || n_cols == 0) return 0;
+  if (rows)
+    for (int64_t i = 0; i < n_out; ++i)
+      if (rows[i] < 0 || rows[i] >= have) CNA_FAIL(CNA_EINVAL, "cna_fetch_rows: row index out of range");
+  if (cols)
+    for (int j = 0; j < n_cols; ++j)
+      if (cols[j] < 0 || cols[j] >= width) CNA_FAIL(CNA_EINVAL, "cna_fetch_rows: column index out of range");
+  CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, carve_bytes({8 * n_out * (int64_t)n_cols, 8 * n_out, 4 * (int64_t)n_cols})));
+  Carver cv(c->scratch2);
+  double* dst = cv.take<double>(n_out * (int64_t)n_cols);
+  int64_t* rd = cv.take<int64_t>(n_out);
+  int32_t* cd = cv.take<int32_t>(n_cols);
+  if (rows) HIP_TRY(hipMemcpyAsync(rd, rows, 8 * n_out, hipMemcpyHostToDevice, c->stream));
+  if (cols) HIP_TRY(hipMemcpyAsync(cd, cols, 4 * (size_t)n_cols, hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(launch_gather_rows(c, src, ld, rows ? rd : nullptr, n_out, cols ? cd : nullptr, n_cols, dst, transposed));
+  HIP_TRY(hipMemcpyAsync(out, dst, 8 * (size_t)n_out * n_cols, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }

@@ -128,6 +128,10 @@ struct cna_ctx {
   // ---- scratch
   void* scratch = nullptr;
   int64_t scratch_cap = 0;
+  void* proj = nullptr;           // result of cna_project_keep (rows of X x proj_cols, leading dimension proj_ld)
+  int64_t proj_cap = 0, proj_rows = 0;
+  int proj_ld = 0, proj_cols = 0;
+  bool proj_valid = false;
   int null_prepared = 0;          // cna_null_local_prepare done, launch still to come
   double null_cut0 = 0, null_inv_step = 0, null_eps = 0;
   int null_has_obs = 0;
@@ -195,6 +199,8 @@ int launch_batch_kurtosis(cna_ctx* c, const double* mat, int64_t rows, int ncols
 int launch_zero_variance(cna_ctx* c, const int32_t* colmap_dev, int n_sel, uint8_t* flags_dev,
                          unsigned long long* count_dev);
 int launch_select(cna_ctx* c, const int32_t* colmap_dev);
+int launch_gather_rows(cna_ctx* c, const double* src, int ld, const int64_t* rows_dev, int64_t n_out,
+                       const int32_t* cols_dev, int n_cols, double* dst, int transposed);
 int launch_digit_hist(cna_ctx* c, const double* v, int64_t n, unsigned long long prefix, int shift,
                       unsigned long long* hist_dev);
 int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev, const double* y_dev,

@@ -493,6 +493,39 @@ __global__ void k_percell_fdr(const double* __restrict__ coef, int64_t n, const 
   fdr[i] = h > 0 ? runmin[h - 1] : 1.0;
 }
 
+// dst[i][j] = src[rows[i]][cols[j]] (rows / cols null = identity), written row-major (n_out x n_cols)
+// or transposed (n_cols x n_out): the matrices handed back to the caller leave the device already in
+// the caller's cell order and orientation.
+__global__ __launch_bounds__(256) void k_gather_rows(const double* __restrict__ src, int ld,
+                                                     const int64_t* __restrict__ rows, int64_t n_out,
+                                                     const int32_t* __restrict__ cols, int n_cols,
+                                                     double* __restrict__ dst, int transposed) {
+  __shared__ double tile[32][33];
+  const int64_t i0 = (int64_t)blockIdx.x * 32;
+  const int j0 = blockIdx.y * 32;
+  for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+    const int64_t i = i0 + k;
+    const int j = j0 + threadIdx.x;
+    double v = 0.0;
+    if (i < n_out && j < n_cols) v = src[(rows ? rows[i] : i) * ld + (cols ? cols[j] : j)];
+    tile[k][threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (!transposed) {
+    for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+      const int64_t i = i0 + k;
+      const int j = j0 + threadIdx.x;
+      if (i < n_out && j < n_cols) dst[i * n_cols + j] = tile[k][threadIdx.x];
+    }
+  } else {
+    for (int k = threadIdx.y; k < 32; k += blockDim.y) {
+      const int j = j0 + k;
+      const int64_t i = i0 + threadIdx.x;
+      if (j < n_cols && i < n_out) dst[(int64_t)j * n_out + i] = tile[threadIdx.x][k];
+    }
+  }
+}
+
 __global__ void k_transpose(const double* __restrict__ in, int64_t rows, int cols, int ld,
                             double* __restrict__ out) {
   __shared__ double tile[32][33];
@@ -682,6 +715,16 @@ int launch_unpack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_
   const int64_t work = nrows * (ld / 2);
   hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, c->stream,
                      (const double2*)src, idx, nrows, ld / 2, (double2*)dst);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_gather_rows(cna_ctx* c, const double* src, int ld, const int64_t* rows_dev, int64_t n_out,
+                       const int32_t* cols_dev, int n_cols, double* dst, int transposed) {
+  if (n_out == 0 || n_cols == 0) return 0;
+  ProfScope ps(c, CNA_K_TRANSPOSE);
+  dim3 grid((unsigned)((n_out + 31) / 32), (unsigned)((n_cols + 31) / 32)), block(32, 8);
+  hipLaunchKernelGGL(k_gather_rows, grid, block, 0, c->stream, src, ld, rows_dev, n_out, cols_dev, n_cols, dst, transposed);
   HIP_TRY(hipGetLastError());
   return 0;
 }

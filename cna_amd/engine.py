@@ -434,6 +434,28 @@ class Engine(_order.CellOrder):
         check(self.lib.cna_fetch_matrix(self.h, which, ptr(out), int(bool(transposed))), 'cna_fetch_matrix')
         return out
 
+    def fetch_rows(self, which, rows=None, cols=None, transposed=False):
+        """out[i, j] = M[rows[i], cols[j]] (None = all, in order) picked and ordered on the device;
+        transposed=True returns the (columns x rows) layout.  which: MAT_NAM, MAT_X or MAT_PROJ."""
+        if which == _ffi.MAT_PROJ:
+            have, width = self._proj_shape
+        else:
+            have, width = self.matrix_shape(which)
+        r = None if rows is None else np.ascontiguousarray(rows, dtype=np.int64)
+        cm = None if cols is None else np.ascontiguousarray(cols, dtype=np.int32)
+        n_out = have if r is None else len(r)
+        n_cols = width if cm is None else len(cm)
+        out = np.empty((n_cols, n_out) if transposed else (n_out, n_cols))
+        check(self.lib.cna_fetch_rows(self.h, which, ptr(r), n_out, ptr(cm), n_cols, ptr(out), int(bool(transposed))),
+              'cna_fetch_rows')
+        return out
+
+    def project_keep(self, W):
+        """X.W left on the device; read it with fetch_rows(MAT_PROJ, ...)."""
+        W = _f64(W)
+        check(self.lib.cna_project_keep(self.h, ptr(W), W.shape[1]), 'cna_project_keep')
+        self._proj_shape = (self.matrix_shape(MAT_X)[0], W.shape[1])
+
     def gather_rows_host(self, local, n_total):
         """Row blocks of every rank, concatenated in rank order (no-op on one GPU)."""
         local = _f64(local)

@@ -425,8 +425,8 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         if engine.nam_epoch != nam_epoch:
             raise RuntimeError('res.nam lives on the GPU and a later cna_amd call has replaced it; '
                                'read it (or call res.materialize()) before running the next analysis')
-        full = engine.nam_full()
-        return pd.DataFrame(full[kept][:, colmap].T, index=sample_index, columns=cell_index())
+        return pd.DataFrame(engine.nam_full(keep=kept, cols=colmap, transposed=True), index=sample_index,
+                            columns=cell_index(), copy=False)
 
     res._defer('nam', fetch_nam)
     _mark('lazies set')

@@ -313,9 +313,9 @@ def nam(data, sid_name, batches=None, nsteps=None, self_weight=1, max_frac_pcs=0
     labels, _ = _nam_device(engine, data, sid_name, nsteps=nsteps, self_weight=self_weight,
                             show_progress=show_progress)
     keep = _qc_device(engine, labels, batches, show_progress=show_progress)
-    full = engine.nam_full()   # cells x samples
+    kept_t = engine.nam_full(keep=keep, transposed=True)       # samples x kept cells, caller's cell order
     index = pd.Index(labels, name=sid_name)
-    frame = pd.DataFrame(full[keep].T, index=index, columns=data.obs.index[keep], dtype=float)
+    frame = pd.DataFrame(kept_t, index=index, columns=data.obs.index[keep], dtype=float, copy=False)
     return frame, keep
 
 

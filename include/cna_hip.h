@@ -41,6 +41,7 @@ typedef struct cna_ctx cna_ctx;
 /* matrix selectors for cna_matrix_shape / cna_fetch_matrix */
 #define CNA_MAT_NAM   0    /* NAM after diffusion, all local cells x all samples           */
 #define CNA_MAT_X     1    /* working matrix: selected NAM, then residualised NAM in place */
+#define CNA_MAT_PROJ  2    /* result of cna_project_keep (cna_fetch_rows only)             */
 
 /* kernel ids for the profiling counters (cna_prof_get) */
 enum {
@@ -168,6 +169,8 @@ int  cna_gram_fetch(cna_ctx* ctx, double* G_out);
 /* out = X . W  (V = NAM^T U / sqrt(svs), _nam.py:106; W = U/sqrt(svs), n_cols x n_w row-major),
  * local rows, row-major n_x_local x n_w */
 int  cna_project(cna_ctx* ctx, const double* W, int n_w, double* out_local);
+/* cna_project with the result left on the device: read it with cna_fetch_rows(CNA_MAT_PROJ, ...) */
+int  cna_project_keep(cna_ctx* ctx, const double* W, int n_w);
 
 /* ---- association (_association.py:77-120, _stats.py:34-83) ----------------------------- */
 /* ncorrs = (y[:,None]*NAMresid).mean(axis=0) (_association.py:77); kept on the device and
@@ -229,6 +232,12 @@ int  cna_percell_fdr_pinned(cna_ctx* ctx, const double* thr, const double* runmi
 int  cna_matrix_shape(cna_ctx* ctx, int which, int64_t* n_rows_local, int* n_cols);
 /* transposed!=0 writes samples x cells (the reference's orientation), else cells x samples */
 int  cna_fetch_matrix(cna_ctx* ctx, int which, double* out, int transposed);
+/* the same with rows and columns picked and ordered on the device: out[i][j] = M[rows[i]][cols[j]]
+ * (n_out x n_cols, or its transpose); rows / cols NULL = all, in order.  rows are local row indices
+ * of the matrix.  One gather kernel + one contiguous copy: the caller's cell order and orientation
+ * (res.nam, res.namresid, cna.tl.nam: _nam.py:73,193) cost no cells x samples reshuffle on the host. */
+int  cna_fetch_rows(cna_ctx* ctx, int which, const int64_t* rows, int64_t n_out,
+                    const int32_t* cols, int n_cols, double* out, int transposed);
 
 /* concatenate count_local doubles from every rank, in rank order, into out_all on every rank
  * (row blocks of the lazily fetched matrices when the job spans several GPUs) */

@@ -435,6 +435,51 @@ def test_results_do_not_depend_on_device_cell_order(monkeypatch):
         np.testing.assert_allclose(a[key][:, :15], b[key][:, :15], rtol=1e-6, atol=1e-9)
 
 
+def test_ordered_fetch_on_device_equals_host_reorder(monkeypatch):
+    """nam / namresid / V leave the device already restricted to the kept cells and samples, in the
+    caller's order and layout (cna_fetch_rows); the sharded path reorders on the host instead.  Both
+    must hand back the very same arrays, and bad row / column indices are refused."""
+    import cna_amd as cna
+    from cna_amd import synth, _order, _ffi
+    from cna_amd.engine import Engine
+    data, meta = synth.make_dataset(20000, 30, k=15, seed=11, n_covs=1, n_batches=10, cluster_sorted=False)
+    # one cluster is populated by batch-0 samples only: its neighbourhoods fail the batch-kurtosis QC
+    sid = np.asarray(data.obs['id']).copy()
+    target = np.flatnonzero(meta['cluster'] == np.bincount(meta['cluster']).argmax())
+    sid[target] = np.random.RandomState(3).choice(np.flatnonzero(meta['batches'].values == 0), size=len(target))
+    data.obs['id'] = sid
+    y = meta['y'].copy()
+    y.iloc[[3, 17]] = np.nan                                # drops two samples: a real column map
+    kw = dict(covs=meta['covs'], batches=meta['batches'], Nnull=100, seed=2, return_full=True)
+    out = []
+    for device_side in (True, False):
+        if not device_side:
+            monkeypatch.setattr(_order.CellOrder, '_on_device', lambda self: False)
+        e = Engine(device=0)
+        try:
+            res = cna.tl.association(data, y, 'id', engine=e, **kw)
+            assert e.perm is not None and not res.kept.all()
+            out.append((res.nam.values.copy(), res.namresid.values.copy(), res.namresid_nbhdXpc.values.copy()))
+            frame, keep = cna.tl.nam(data, 'id', batches=meta['batches'], engine=e)
+            assert frame.shape == (30, keep.sum()) and (frame.columns == data.obs.index[keep]).all()
+            out[-1] += (frame.values.copy(),)
+            if device_side:
+                n = e.matrix_shape(_ffi.MAT_NAM)[0]
+                for rows, cols in ((np.array([0, n]), None), (np.array([-1]), None), (None, np.array([0, 30]))):
+                    with pytest.raises(RuntimeError):
+                        e.fetch_rows(_ffi.MAT_NAM, rows, cols)
+                full = e.fetch_matrix(_ffi.MAT_NAM)
+                pick = np.array([5, 0, n - 1, 5])
+                np.testing.assert_array_equal(e.fetch_rows(_ffi.MAT_NAM, pick, np.array([2, 1])), full[pick][:, [2, 1]])
+                np.testing.assert_array_equal(e.fetch_rows(_ffi.MAT_NAM, None, None, True), full.T)
+        finally:
+            e.close()
+    assert out[0][0].shape[0] == 28
+    for a, b in zip(*out):
+        assert a.shape == b.shape
+        np.testing.assert_array_equal(a, b)
+
+
 def test_nam_cache_on_device(eng):
     """A second phenotype on the same dataset reuses the resident NAM (no diffusion kernels) and gives
     the results of a from-scratch run."""
