@@ -275,6 +275,136 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
   finish_row<2 * NQ2, ColPair>(a, row, grow, lane, s);
 }
 
+// Narrow states (ld <= 64 columns, i.e. at most 32 column pairs): TWO destination rows per wave, one
+// per half-wave.  The vector-memory path spends ~16 clk per wave instruction whatever its width or
+// exec mask (tools/micro/gather_pair.hip: 8.5 -> 12.6 TB/s on 400-byte rows), so a row that fills
+// only 25 lanes wastes most of it; here one load instruction fetches a neighbour row for each of the
+// two destination rows.  The neighbour (index, weight) records of both rows sit in LDS, 16 bytes
+// each, and a half-wave reads its row's record with one broadcast ds_read_b128.  Every row still
+// adds its own products one by one in CSR order: same bits as k_nam_step.
+struct alignas(16) EdgeRec {
+  double a;
+  unsigned byte_off;    // j * row bytes
+  int pad;
+};
+
+__device__ __forceinline__ double half_sum(double v, int h) {
+  v = dpp_add(v, 0);
+  v = dpp_add(v, 1);
+  v = dpp_add(v, 2);
+  v = dpp_add(v, 3);
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return h ? (r2 + r3) : (r0 + r1);           // what wave_sum gives when the other half holds zeros
+}
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_nam_step_pair(StepArgs a) {
+  constexpr int U = 8;                          // neighbour rows in flight per half-wave (4: same, 16: -14 %)
+  __shared__ EdgeRec recs[4][2][32];
+  const int lane = threadIdx.x & 63, hl = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row_a = my_row(wv, a.xcd_chunk) * 2;          // this wave: rows row_a, row_a + 1
+  if (row_a >= a.n_local) return;
+  const bool have = row_a + h < a.n_local;                    // odd n_local: the last wave's upper half idles
+  const int64_t row = have ? row_a + h : row_a;
+  const int64_t grow = a.row0 + row;
+  const int64_t start = a.indptr[row];
+  const int deg = have ? (int)(a.indptr[row + 1] - start) : 0;
+  const int d0 = __builtin_amdgcn_readlane(deg, 0), d1 = __builtin_amdgcn_readlane(deg, 32);
+  const int degmax = d0 > d1 ? d0 : d1;
+  const int ld2 = a.ld >> 1;
+  const unsigned rowbytes = (unsigned)a.ld * 8u;
+  const char* __restrict__ Tb = (const char*)a.Tin;
+  const bool act = hl < ld2;
+  const unsigned off = act ? (unsigned)hl * 16u : 0u;
+  EdgeRec* mine = recs[wv][h];
+  const unsigned own_off = (unsigned)grow * rowbytes;         // < 4 GiB (checked by the launcher)
+  double2 acc = make_double2(0.0, 0.0);
+  for (int base = 0; base < degmax; base += 32) {
+    {
+      const bool ok = base + hl < deg;
+      const int64_t e = start + base + hl;
+      EdgeRec r;
+      // past the end of the row: weight 0 on the row's own (finite, soon needed) state row, so the
+      // gather below needs no per-edge branch
+      r.a = ok ? (double)((const VT*)a.val)[e] : 0.0;
+      r.byte_off = ok ? (unsigned)a.idx[e] * rowbytes : own_off;
+      r.pad = 0;
+      *(uint4*)&mine[hl] = *(const uint4*)&r;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const int left = degmax - base;
+    const int cnt = left < 32 ? left : 32;                    // scalar: edges of the longer row in this batch
+    for (int l = 0; l < cnt; l += U) {
+      double2 t[U];
+      double w[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint4 r = *(const uint4*)&mine[l + u];
+        w[u] = __hiloint2double((int)r.y, (int)r.x);
+        t[u] = *(const double2*)(Tb + (r.z + off));           // idle column lanes re-read column pair 0
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {                           // past a row's end: acc + 0 * finite = acc
+        acc.x = add_rn(acc.x, mul_rn(w[u], t[u].x));
+        acc.y = add_rn(acc.y, mul_rn(w[u], t[u].y));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  if (!have) return;
+  const double2 own = act ? *(const double2*)(Tb + ((uint64_t)grow * rowbytes + off)) : make_double2(0.0, 0.0);
+  double s[2];
+  s[0] = add_rn(acc.x, mul_rn(a.w, own.x));
+  s[1] = add_rn(acc.y, mul_rn(a.w, own.y));
+  // write-out: finish_row for a half-wave (columns 2*hl, 2*hl + 1)
+  const double cs = a.colsum[grow];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int col = 2 * hl + k;
+    if (col < a.ld) {
+      const bool in = col < a.width;
+      if (a.write_t) a.Tout[grow * a.ld + col] = in ? __ddiv_rn(s[k], cs) : 0.0;
+      if (a.dense_out) a.dense_out[row * a.ld + col] = in ? s[k] : 0.0;
+    }
+  }
+  if (a.write_nam || a.want_kurt) {
+    double x[2];
+    double sum = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int col = 2 * hl + k;
+      const bool in = col < a.width;
+      x[k] = in ? __ddiv_rn(s[k], a.counts[in ? col : 0]) : 0.0;
+      if (a.write_nam && col < a.ld) a.nam[row * a.ld + col] = x[k];
+      sum += x[k];
+    }
+    if (a.want_kurt) {
+      const double n = (double)a.width;
+      const double mean = half_sum(sum, h) / n;
+      double d2s = 0.0, d4s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        if (2 * hl + k < a.width) {
+          const double d = x[k] - mean;
+          const double d2 = d * d;
+          d2s += d2;
+          d4s += d2 * d2;
+        }
+      }
+      const double m2 = half_sum(d2s, h) / n;
+      const double m4 = half_sum(d4s, h) / n;
+      const double em = 2.220446049250313e-16 * mean;
+      const double k4 = (m2 <= em * em) ? __builtin_nan("") : m4 / (m2 * m2);
+      if (hl == 0) a.stat[grow] = k4 - 3.0;
+    }
+  }
+}
+
 // Second step on the compressed state: the same sums in the same (CSR) order as k_nam_step -- the
 // zeros it skips contribute +0 there -- on a fraction of the bytes (~40 x 10 B instead of 8N B per
 // edge; at N = 200 a third of the cache lines).  Lane l of an edge adds weight x value_l into column
@@ -418,9 +548,12 @@ int launch_step_sparse_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
 
 template <typename VT>
 int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
-  const int64_t nblk = (c->n_local + 3) / 4;
-  int64_t cpx = (nblk + 7) / 8;
   StepArgs a = a_in;
+  // two rows per wave when a row fits a half-wave and byte offsets into the state fit 32 bits
+  const bool pair = !first && !a.sp_cnt && a.ld <= 64 && c->n_pad * (int64_t)a.ld * 8 < (int64_t)4 << 30 &&
+                    !getenv("CNA_STEP_WIDE");
+  const int64_t nblk = pair ? (c->n_local + 7) / 8 : (c->n_local + 3) / 4;
+  int64_t cpx = (nblk + 7) / 8;
   // measured (tools/kbench.py): one contiguous eighth per XCD is best at 200k x 50 (+4 % over
   // round-robin) and within 2 % of every chunk size at 1M x 100
   int64_t chunk = cpx;
@@ -445,6 +578,8 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
       case 3: launch_step_sparse_t<VT, 3>(c, a, grid); break;
       default: launch_step_sparse_t<VT, 4>(c, a, grid); break;
     }
+  } else if (pair) {
+    hipLaunchKernelGGL((k_nam_step_pair<VT>), grid, dim3(256), 0, c->stream, a);
   } else {
     switch ((a.ld / 2 + 63) / 64) {
       case 1: launch_step_t<VT, 1>(c, a, grid); break;

@@ -602,6 +602,57 @@ def test_compressed_second_step_matches_dense(monkeypatch, N):
         np.testing.assert_array_equal(out['1', key], out['0', key])
 
 
+@pytest.mark.parametrize('N,n', [(50, 3001), (64, 3000), (33, 2999), (7, 500)])
+def test_two_rows_per_wave_step_matches_wave_per_row(monkeypatch, N, n):
+    """States of at most 64 columns are walked two destination rows per wave (k_nam_step_pair, one
+    load instruction gathers a neighbour row for each).  Each row still adds its products in CSR
+    order, so NAM, kurtosis-driven auto-stop and the dense walk are bit-identical to the
+    wave-per-row kernel (CNA_STEP_WIDE=1).  Odd row counts, an isolated cell, a 300-neighbour hub
+    next to a 1-neighbour row, and a run of empty rows exercise the ragged pairing."""
+    import cna_amd as cna
+    from cna_amd.engine import Engine
+    rs = np.random.RandomState(N)
+    A = sp.random(n, n, density=12.0 / n, random_state=rs, format='lil', dtype=np.float64)
+    A[17, :] = 0
+    A[:, 17] = 0
+    for r in range(40, 47):
+        A[r, :] = 0                                # empty rows (their columns stay referenced)
+    hub = rs.choice(n, min(300, n // 2), replace=False)
+    A[4, hub] = rs.rand(len(hub))                  # rows 4 and 5 share a wave when no reordering happens
+    A[5, :] = 0
+    A[5, 9] = 0.5
+    A = sp.csr_matrix(A)
+    A.setdiag(0)
+    A.eliminate_zeros()
+    A = A.astype(np.float32)
+    obs = pd.DataFrame({'id': rs.randint(0, N, n)})
+    obs.loc[:N - 1, 'id'] = np.arange(N)
+    data = type('D', (), {'obs': obs, 'obsp': {'connectivities': A}, 'uns': {}})()
+    dense0 = rs.randn(n, 3)
+    out = {}
+    for wide in ('', '1'):
+        if wide:
+            monkeypatch.setenv('CNA_STEP_WIDE', '1')
+        for reorder in ('0', '1'):
+            monkeypatch.setenv('CNA_REORDER', reorder)
+            e = Engine(device=0)
+            try:
+                NAM, _ = cna.tl.nam(data, 'id', nsteps=3, engine=e)
+                e.prof_reset(); e.prof_enable(True)
+                auto, _ = cna.tl.nam(data, 'id', nsteps=None, engine=e)
+                e.sync(); e.prof_enable(False)
+                out[wide, reorder] = (NAM.values.copy(), auto.values.copy(), e.prof()['nam_step'][1],
+                                      cna.tl.diffuse(data, dense0, 3, engine=e))
+            finally:
+                e.close()
+    for reorder in ('0', '1'):
+        a, b = out['', reorder], out['1', reorder]
+        assert a[2] == b[2]                        # auto-stop took the same number of steps
+        for u, v in zip((a[0], a[1], a[3]), (b[0], b[1], b[3])):
+            np.testing.assert_array_equal(u, v)
+    np.testing.assert_array_equal(out['', '0'][0], out['', '1'][0])
+
+
 def test_prepared_null_launch_and_misuse(eng):
     """cna_null_local_prepare + launch(edges=None) equals the one-call launch; launching without a
     prepared pass, or with a shape that does not match it, is an error and leaves nothing pending."""
