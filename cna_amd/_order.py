@@ -38,10 +38,12 @@ def inverse(perm):
     return inv
 
 
-def permuted_rows(A, perm, r0, r1):
+def permuted_rows(A, perm, r0, r1, col_map=None):
     """CSR pieces (indptr int64, indices int32, data) of device rows [r0, r1) of P A P^T: row i
-    is the caller's row perm[i] with its columns relabelled and left in their original order."""
-    inv = inverse(perm)
+    is the caller's row perm[i] with its columns relabelled and left in their original order.
+    col_map (sharded callers, whose A holds the rows of one block only): device column of every
+    global caller column, instead of the inverse of `perm`."""
+    inv = inverse(perm) if col_map is None else col_map
     rows = perm[r0:r1]
     ptr = A.indptr.astype(np.int64, copy=False)
     deg = ptr[rows + 1] - ptr[rows]
@@ -91,8 +93,14 @@ class CellOrder:
     The engine provides: perm (or None), n, row0, n_local, nranks, block(), gather_rows_host(),
     fetch_matrix(), project(), dense_load(), dense_fetch(), and records in `_keep_dev` the keep mask
     (device order, None = all cells) of the last select and in `_x_is_selection` whether the
-    working matrix X came from the NAM (True) or from upload_x (False: already caller order)."""
+    working matrix X came from the NAM (True) or from upload_x (False: already caller order).
+
+    Two views.  Replicated (default): the caller holds all n cells on every rank, per-cell vectors
+    are global and `perm` is a global permutation.  Local (`view_local`, sharded callers): the
+    caller holds the cells of this rank's row block only; n == n_local, per-cell vectors and `perm`
+    are local to the block and nothing cells-sized is gathered."""
     perm = None
+    view_local = False
     _nam_sig = None          # (inputs signature, nam_epoch, steps taken) of the NAM held by the device
     _keep_dev = None
     _x_is_selection = False
@@ -114,7 +122,8 @@ class CellOrder:
         keep_dev = self.cells_to_device(np.asarray(keep_global, dtype=bool))
         self._keep_dev = keep_dev
         self._kept_order_cache = None
-        return np.ascontiguousarray(np.flatnonzero(keep_dev[self.row0:self.row0 + self.n_local]), dtype=np.int64)
+        mine = keep_dev if self.view_local else keep_dev[self.row0:self.row0 + self.n_local]
+        return np.ascontiguousarray(np.flatnonzero(mine), dtype=np.int64)
 
     # rows of X (kept cells of all ranks, device order) -> caller's order
     def _kept_order(self):
@@ -137,13 +146,13 @@ class CellOrder:
         return m[self._kept_order()]
 
     def _all_rows(self, local, n_total):
-        return local if self.nranks == 1 else self.gather_rows_host(local, n_total)
+        return local if self.nranks == 1 or self.view_local else self.gather_rows_host(local, n_total)
 
     # whole matrices in the caller's order.  On one GPU the rows (and columns) are picked, ordered and
     # -- if asked -- transposed by a gather kernel before the copy (engine.fetch_rows); sharded runs
     # gather the row blocks on the host and reorder there.
     def _on_device(self):
-        return self.nranks == 1 and hasattr(self, 'fetch_rows')
+        return (self.nranks == 1 or self.view_local) and hasattr(self, 'fetch_rows')
 
     def _nam_rows(self, keep):
         """device row of every (kept) cell in the caller's order, or None for "all, in order" """
@@ -193,7 +202,7 @@ class CellOrder:
     def dense_begin(self, arr):
         self._nam_sig = None                  # the dense walk reuses the state buffers of the NAM
         self.nam_epoch += 1
-        r0, r1 = self.block(arr.shape[0])
+        r0, r1 = (0, arr.shape[0]) if self.view_local else self.block(arr.shape[0])
         self.dense_load(arr[r0:r1] if self.perm is None else arr[self.perm[r0:r1]])
 
     def dense_state(self):

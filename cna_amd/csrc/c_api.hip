@@ -285,12 +285,24 @@ int cna_set_cell_order(cna_ctx* c, const int64_t* orig_index) {
     c->orig_idx = nullptr;
     return 0;
   }
+  const int64_t lim = c->local_view ? c->n_local : c->n_global;
   for (int64_t i = 0; i < c->n_local; ++i)
-    if (orig_index[i] < 0 || orig_index[i] >= c->n_global)
+    if (orig_index[i] < 0 || orig_index[i] >= lim)
       CNA_FAIL(CNA_EINVAL, "cna_set_cell_order: index out of range");
   if (!c->orig_idx && c->n_local > 0) CNA_TRY(dev_alloc(c, (void**)&c->orig_idx, sizeof(int64_t) * c->n_local));
   if (c->n_local > 0)
     HIP_TRY(hipMemcpy(c->orig_idx, orig_index, sizeof(int64_t) * c->n_local, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int cna_set_local_view(cna_ctx* c, int on) {
+  CHECK_CTX(c);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if ((on != 0) != c->local_view && c->orig_idx) {      // a cell order belongs to the view it was given in
+    dev_free(c, c->orig_idx, sizeof(int64_t) * c->n_local);
+    c->orig_idx = nullptr;
+  }
+  c->local_view = on != 0;
   return 0;
 }
 
@@ -511,6 +523,12 @@ int cna_nam_steps(cna_ctx* c, int nsteps) {
 
 int cna_fetch_cell_stat(cna_ctx* c, double* out, int64_t n_expected) {
   CHECK_CTX(c);
+  if (c->stat_space == CNA_MAT_NAM && c->local_view) {
+    if (n_expected != c->n_local) CNA_FAIL(CNA_EINVAL, "cna_fetch_cell_stat: expected n_local entries");
+    HIP_TRY(hipMemcpyAsync(out, c->stat + c->row0, sizeof(double) * c->n_local, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+  }
   if (c->stat_space == CNA_MAT_NAM) {
     if (n_expected != c->n_global) CNA_FAIL(CNA_EINVAL, "cna_fetch_cell_stat: expected n_global entries");
     HIP_TRY(hipMemcpyAsync(out, c->stat, sizeof(double) * c->n_global, hipMemcpyDeviceToHost, c->stream));
@@ -518,7 +536,7 @@ int cna_fetch_cell_stat(cna_ctx* c, double* out, int64_t n_expected) {
     return 0;
   }
   if (c->stat_space != CNA_MAT_X) CNA_FAIL(CNA_ESTATE, "no per-cell statistic available");
-  if (c->nranks == 1) {
+  if (c->nranks == 1 || c->local_view) {
     if (n_expected != c->nx) CNA_FAIL(CNA_EINVAL, "cna_fetch_cell_stat: expected nx entries");
     HIP_TRY(hipMemcpyAsync(out, c->stat, sizeof(double) * c->nx, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -686,7 +704,10 @@ int cna_zero_variance(cna_ctx* c, const int32_t* colmap, int n_sel, uint8_t* fla
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (n_zero_out) *n_zero_out = (int64_t)h;
   if (flags_out) {
-    if (h == 0) {
+    if (c->local_view) {
+      HIP_TRY(hipMemcpyAsync(flags_out, flags + c->row0, c->n_local, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    } else if (h == 0) {
       std::memset(flags_out, 0, c->n_global);
     } else {
       if (c->nranks > 1)
@@ -1232,7 +1253,8 @@ int cna_percell_fdr_pinned(cna_ctx* c, const double* thr, const double* runmin_f
                            double** fdr_ptr) {
   CHECK_CTX(c);
   if (!coef_ptr) CNA_FAIL(CNA_EINVAL, "cna_percell_fdr_pinned: coef_ptr is required");
-  const int64_t need = 16 * std::max<int64_t>(c->n_global, 1);
+  const int64_t n_out = c->local_view ? c->n_local : c->n_global;
+  const int64_t need = 16 * std::max<int64_t>(n_out, 1);
   if (need > c->h_cell_cap) {
     if (c->h_cell) HIP_TRY(hipHostFree(c->h_cell));
     c->h_cell = nullptr;
@@ -1241,9 +1263,9 @@ int cna_percell_fdr_pinned(cna_ctx* c, const double* thr, const double* runmin_f
   }
   double* hc = (double*)c->h_cell;
   const bool want_fdr = fdr_ptr && thr && runmin_fdr && T > 0;
-  CNA_TRY(cna_percell_fdr(c, thr, runmin_fdr, T, hc, want_fdr ? hc + c->n_global : nullptr));
+  CNA_TRY(cna_percell_fdr(c, thr, runmin_fdr, T, hc, want_fdr ? hc + n_out : nullptr));
   *coef_ptr = hc;
-  if (fdr_ptr) *fdr_ptr = want_fdr ? hc + c->n_global : nullptr;
+  if (fdr_ptr) *fdr_ptr = want_fdr ? hc + n_out : nullptr;
   return 0;
 }
 
@@ -1269,8 +1291,21 @@ int cna_percell_fdr(cna_ctx* c, const double* thr, const double* runmin_fdr, int
     HIP_TRY(hipMemcpyAsync(rd, runmin_fdr, 8 * T, hipMemcpyHostToDevice, c->stream));
   }
   CNA_TRY(launch_percell_fdr(c, td, rd, want_fdr ? T : 0, thr0, inv_step, coef + c->row0, want_fdr ? fdr + c->row0 : nullptr));
-  const bool sharded = c->nranks > 1 || comm_active(c);
-  if (c->orig_idx) {
+  const bool sharded = (c->nranks > 1 || comm_active(c)) && !c->local_view;
+  int64_t n_out = c->n_global;
+  if (c->local_view) {
+    // this rank's rows only, in the caller's (local) order: nothing crosses the fabric
+    n_out = c->n_local;
+    if (c->orig_idx) {
+      CNA_TRY(launch_unpermute2(c, coef + c->row0, want_fdr ? fdr + c->row0 : nullptr, c->orig_idx, c->n_local, coef_u,
+                                fdr_u));
+      coef = coef_u;
+      fdr = fdr_u;
+    } else {
+      coef += c->row0;
+      fdr += c->row0;
+    }
+  } else if (c->orig_idx) {
     // back to the caller's numbering: every rank scatters its rows into a zeroed vector, the sum
     // over ranks (x + 0 keeps NaNs and bit patterns) is the full answer
     if (sharded) {
@@ -1290,8 +1325,8 @@ int cna_percell_fdr(cna_ctx* c, const double* thr, const double* runmin_fdr, int
     CNA_TRY(comm_allgather_bytes(c, (char*)coef + block * c->rank, coef, block));
     if (want_fdr) CNA_TRY(comm_allgather_bytes(c, (char*)fdr + block * c->rank, fdr, block));
   }
-  if (coef_out) HIP_TRY(hipMemcpyAsync(coef_out, coef, 8 * c->n_global, hipMemcpyDeviceToHost, c->stream));
-  if (want_fdr) HIP_TRY(hipMemcpyAsync(fdr_out, fdr, 8 * c->n_global, hipMemcpyDeviceToHost, c->stream));
+  if (coef_out && n_out > 0) HIP_TRY(hipMemcpyAsync(coef_out, coef, 8 * n_out, hipMemcpyDeviceToHost, c->stream));
+  if (want_fdr && n_out > 0) HIP_TRY(hipMemcpyAsync(fdr_out, fdr, 8 * n_out, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }

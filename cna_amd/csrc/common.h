@@ -77,6 +77,7 @@ struct cna_ctx {
   double self_weight = 1.0;
   double* colsum = nullptr;  // n_pad, replicated
   int64_t* orig_idx = nullptr;  // n_local: caller's cell index of local row i; null = identity
+  bool local_view = false;      // per-cell outputs cover this rank's rows only (cna_set_local_view)
   bool have_colsum = false;
 
   // ---- samples

@@ -47,3 +47,34 @@ def init_from_torch(device=None, always_comm=False):
         uid = box[0]
     init(rank, nranks, uid, device)
     return rank, nranks
+
+
+def block(n_cells, rank, nranks):
+    """Rows [r0, r1) of an n_cells problem that rank `rank` of `nranks` owns (ceil split; the same
+    rule as Engine.block and cna_graph_upload)."""
+    rpr = -(-int(n_cells) // int(nranks))
+    r0 = min(int(rank) * rpr, int(n_cells))
+    return r0, min(r0 + rpr, int(n_cells))
+
+
+def shard(data, rank=None, nranks=None):
+    """This rank's block of an AnnData-like dataset, for sharded runs: the rows [r0, r1) of
+    ``data.obs`` and of the connectivities graph (all columns, global ids).  Pass the result to
+    ``cna.tl.association`` / ``cna.tl.nam`` / ``cna.tl.diffuse`` on every rank: per-cell inputs and
+    outputs (``obs`` columns, ``res.ncorrs``, ``res.kept``, NAM columns) then cover this rank's
+    cells only and no cells-sized vector is gathered; sample-level results (p-value, PCs, FDR
+    thresholds) are global and identical on all ranks.  A loader that never materialises the whole
+    dataset can build the same object itself: ``obs`` of the block, an (r1 - r0) x n_cells CSR under
+    ``obsp['connectivities']`` and ``uns['cna_shard'] = {'row0': r0, 'n_global': n_cells}``."""
+    import scipy.sparse as sp
+    from .synth import CellData
+    from .tools._nam import get_connectivity
+    cfg = current()
+    rank = cfg.get('rank', 0) if rank is None else rank
+    nranks = cfg.get('nranks', 1) if nranks is None else nranks
+    A = sp.csr_matrix(get_connectivity(data))
+    n = A.shape[0]
+    r0, r1 = block(n, rank, nranks)
+    part = CellData(data.obs.iloc[r0:r1].copy(), A[r0:r1])
+    part.uns['cna_shard'] = {'row0': r0, 'n_global': n}
+    return part

@@ -44,7 +44,8 @@ class Engine(_order.CellOrder):
         self._graph_ref = None
         self._colsum_w = None
         self._codes_token = self._codes_graph = None
-        self.n = 0            # global cells
+        self.n = 0            # cells in the caller's view: all of them, or (view_local) this rank's block
+        self.n_global = 0
         self.row0 = 0
         self.n_local = 0
         self.N = 0
@@ -107,40 +108,61 @@ class Engine(_order.CellOrder):
         return (id(A), A.shape, A.nnz, A.data.ctypes.data, A.indices.ctypes.data, A.indptr.ctypes.data,
                 str(A.data.dtype), probe)
 
-    def ensure_graph(self, A):
+    def ensure_graph(self, A, shard=None):
         """Upload the connectivities graph unless this very matrix is already resident.  The cells
         are kept on the device in a locality-preserving order (see _order.py); everything that
-        crosses this class's boundary is in the caller's order."""
+        crosses this class's boundary is in the caller's order.
+
+        shard=None: A is the whole n x n graph (on every rank; each keeps its row block).
+        shard=(row0, n_global): A holds only the rows [row0, row0 + A.shape[0]) of the graph, with
+        global column ids -- the block engine.block(n_global) assigns to this rank.  The engine then
+        works in the local view: every per-cell input and output covers this rank's cells only."""
         if not sp.issparse(A):
             raise TypeError('connectivities must be a scipy.sparse matrix')
         if not sp.isspmatrix_csr(A) and not isinstance(A, sp.csr_array):
             A = sp.csr_matrix(A)
-        if A.shape[0] != A.shape[1]:
+        if shard is None and A.shape[0] != A.shape[1]:
             raise ValueError('connectivities must be square')
-        key = self._key(A)
+        key = self._key(A) + (None if shard is None else tuple(int(v) for v in shard),)
         if self._graph_key == key and self._graph_ref is not None and self._graph_ref() is A:
             return False
-        n = A.shape[0]
-        r0, r1 = self.block(n)
-        perm = _order.locality_order(A)
-        if perm is None:
-            lo, hi = int(A.indptr[r0]), int(A.indptr[r1])
-            indptr = np.ascontiguousarray(A.indptr[r0:r1 + 1].astype(np.int64) - lo)
-            indices = np.ascontiguousarray(A.indices[lo:hi], dtype=np.int32)
-            data = A.data[lo:hi]
+        if shard is None:
+            n = A.shape[0]
+            r0, r1 = self.block(n)
+            perm = _order.locality_order(A)
+            if perm is None:
+                lo, hi = int(A.indptr[r0]), int(A.indptr[r1])
+                indptr = np.ascontiguousarray(A.indptr[r0:r1 + 1].astype(np.int64) - lo)
+                indices = np.ascontiguousarray(A.indices[lo:hi], dtype=np.int32)
+                data = A.data[lo:hi]
+            else:
+                indptr, indices, data = _order.permuted_rows(A, perm, r0, r1)
+            order = None if perm is None else perm[r0:r1]
         else:
-            indptr, indices, data = _order.permuted_rows(A, perm, r0, r1)
+            r0, n = int(shard[0]), int(shard[1])
+            r1 = r0 + A.shape[0]
+            if A.shape[1] != n or (r0, r1) != self.block(n):
+                raise ValueError('rank %d of %d owns rows [%d, %d) of %d cells (engine.block); got rows [%d, %d) '
+                                 'of a %d-column graph' % ((self.rank, self.nranks) + self.block(n) + (n, r0, r1, A.shape[1])))
+            # locality order inside the block (RCM of its diagonal part); the ranks exchange their
+            # orders once, so that each can relabel the columns that point into other blocks
+            perm = _order.locality_order(A[:, r0:r1]) if r1 > r0 else None
+            if perm is None:
+                perm = np.arange(r1 - r0, dtype=np.int64)
+            col_map = _order.inverse(self._allgather_i64(perm + r0))
+            indptr, indices, data = _order.permuted_rows(A, perm, 0, r1 - r0, col_map=col_map)
+            order = perm
         if data.dtype == np.float32:
             data, f64 = np.ascontiguousarray(data), 0
         else:
             data, f64 = np.ascontiguousarray(data, dtype=np.float64), 1
+        check(self.lib.cna_set_local_view(self.h, int(shard is not None)), 'cna_set_local_view')
         check(self.lib.cna_graph_upload(self.h, n, r0, r1 - r0, ptr(indptr), ptr(indices), ptr(data), f64),
               'cna_graph_upload')
-        if perm is not None:
-            check(self.lib.cna_set_cell_order(self.h, ptr(np.ascontiguousarray(perm[r0:r1]))), 'cna_set_cell_order')
+        if order is not None:
+            check(self.lib.cna_set_cell_order(self.h, ptr(np.ascontiguousarray(order))), 'cna_set_cell_order')
         self.halo = None
         if self.nranks > 1 or (self._has_comm and os.environ.get('CNA_HALO_SELFTEST')):
-            self.n, self.row0, self.n_local = n, r0, r1 - r0
             plan = _order.halo_plan(indices, r0, r1 - r0, -(-n // self.nranks), self.rank, self.nranks,
                                     self._allgather_i64,
                                     force_self=int(os.environ.get('CNA_HALO_SELFTEST', '0')))
@@ -150,16 +172,19 @@ class Engine(_order.CellOrder):
                                             ptr(recv_counts)), 'cna_set_halo')
                 self.halo = (int(send_counts.sum()), int(recv_counts.sum()))
         self.perm = perm
+        self.view_local = shard is not None
         self._keep_dev = None
         self._kept_order_cache = None
         self._x_is_selection = False
-        self.n, self.row0, self.n_local = n, r0, r1 - r0
+        self.n_global, self.row0, self.n_local = n, r0, r1 - r0
+        self.n = self.n_local if self.view_local else n
         self._graph_key = key
         try:
             self._graph_ref = weakref.ref(A)
         except TypeError:
             self._graph_ref = None
         self._colsum_w = None
+        self._codes_token = self._codes_graph = None
         return True
 
     def colsums(self, self_weight=1):
@@ -169,9 +194,9 @@ class Engine(_order.CellOrder):
             self._colsum_w = w
 
     def fetch_colsums(self):
-        out = np.empty(self.n)
+        out = np.empty(self.n_global)
         check(self.lib.cna_fetch_colsums(self.h, ptr(out)), 'cna_fetch_colsums')
-        return self.cells_to_user(out)
+        return self.cells_to_user(out[self.row0:self.row0 + self.n_local] if self.view_local else out)
 
     # ---------------------------------------------------------------- NAM
     def set_samples(self, codes, n_samples, counts, token=None):
@@ -184,7 +209,10 @@ class Engine(_order.CellOrder):
             return
         if len(codes) != self.n:
             raise ValueError('need one sample code per cell')
-        codes = np.ascontiguousarray(self.cells_to_device(np.asarray(codes)), dtype=np.int32)
+        codes = self.cells_to_device(np.asarray(codes))
+        if self.view_local:      # every rank needs the sample of every cell (first walk step): blocks in rank order
+            codes = self._allgather_i64(codes)
+        codes = np.ascontiguousarray(codes, dtype=np.int32)
         counts = _f64(counts)
         check(self.lib.cna_set_samples(self.h, ptr(codes), int(n_samples), ptr(counts)), 'cna_set_samples')
         self.N = int(n_samples)
@@ -319,8 +347,8 @@ class Engine(_order.CellOrder):
         out = np.empty(rows) if fetch else None
         m = C.c_double(0.0)
         check(self.lib.cna_ncorrs(self.h, ptr(y), ptr(out), C.byref(m)), 'cna_ncorrs')
-        if fetch and self.nranks == 1:
-            out = self.kept_to_user(out)     # one rank: kept cells in the caller's order
+        if fetch and (self.nranks == 1 or self.view_local):
+            out = self.kept_to_user(out)     # kept cells (of the caller's view) in the caller's order
         return out, m.value
 
     def null_local(self, Yc, edges):
@@ -455,6 +483,37 @@ class Engine(_order.CellOrder):
         W = _f64(W)
         check(self.lib.cna_project_keep(self.h, ptr(W), W.shape[1]), 'cna_project_keep')
         self._proj_shape = (self.matrix_shape(MAT_X)[0], W.shape[1])
+
+    def x_rows_global(self):
+        """Rows of the working matrix over all ranks (a collective in the local view)."""
+        if not self.view_local or self.nranks == 1:
+            return self.x_rows_total
+        return int(self.allgather_fixed([self.x_rows_total]).sum())
+
+    def allgather_fixed(self, values):
+        """(nranks x len(values)) int64: the same-length vector of every rank, one collective."""
+        a = np.ascontiguousarray(values, dtype=np.int64)
+        if self.nranks == 1:
+            return a.reshape(1, -1).copy()
+        out = np.empty(self.nranks * len(a), dtype=np.int64)
+        check(self.lib.cna_allgather_host(self.h, ptr(a), len(a), ptr(out), len(out)), 'cna_allgather_host')
+        return out.reshape(self.nranks, len(a))
+
+    def allgather_objects(self, obj):
+        """[obj of rank 0, obj of rank 1, ...] for small picklable host objects (sample labels)."""
+        import pickle
+        if self.nranks == 1:
+            return [obj]
+        blob = pickle.dumps(obj, protocol=4)
+        pad = (-len(blob)) % 8
+        words = np.frombuffer(blob + b'\0' * pad, dtype=np.int64)
+        sizes = self.allgather_fixed([len(blob), len(words)])
+        flat = self._allgather_i64(words)
+        out, off = [], 0
+        for nbytes, nwords in sizes:
+            out.append(pickle.loads(flat[off:off + nwords].tobytes()[:nbytes]))
+            off += nwords
+        return out
 
     def gather_rows_host(self, local, n_total):
         """Row blocks of every rank, concatenated in rank order (no-op on one GPU)."""

@@ -20,6 +20,7 @@ import pandas as pd
 from .. import _ffi
 from ..engine import get_engine
 from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_plan, _resid_run, sample_codes_cached,
+                   shard_of, global_samples,
                    _small_svd, _defer_pcs, host_blas_threads)
 from ._out import select_output
 from ._stats import conditional_permutation, grouplevel_permutation, default_ks, minp_stats
@@ -149,7 +150,7 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         return ['PC' + str(i) for i in range(1, len(U) + 1)]
     res._defer('namresid_sampleXpc', lambda: pd.DataFrame(U, index=M.index, columns=_names()))
     res._defer('namresid_svs', lambda: pd.Series(svs, index=_names())[:npcs if npcs is not None else len(U)])
-    res._defer('namresid_varexp', lambda: pd.Series(svs, index=_names()) / len(U) / n_cells)
+    res._defer('namresid_varexp', lambda: pd.Series(svs, index=_names()) / len(U) / (n_cells() if callable(n_cells) else n_cells))
     res._defer('yresid', lambda: pd.Series(ycond_v, index=getattr(M, 'index', None)))
 
     nullminps, nullr2s = pv[1:], r2v[1:]
@@ -326,11 +327,14 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     # factorise the per-cell sample ids once; validation and NAM construction share the result
     _mark('enter')
     codes, labels, counts, token = sample_codes_cached(data.obs[sid_name])
+    sharded = shard_of(data) is not None
+    if sharded:      # this rank's cells only: agree with the other ranks on the samples and their sizes
+        codes, labels, counts, token = global_samples(engine, codes, labels, counts, token)
     _mark('codes')
     nam_queued = None
     used = counts > 0
     batches, filter_samples = check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size,
-                                           sids_present=labels[used] if isinstance(y, pd.Series) else None)
+                                           sids_present=labels[used] if isinstance(y, pd.Series) or sharded else None)
 
     # the permutation draw (numpy RNG + argsort, both outside the GIL) needs only sample-level
     # inputs: it starts on the helper thread right away and is collected just before the
@@ -414,7 +418,7 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         return y_null, early.get('conditioned', False)
     coef_all, fdr_all, U, svs = _association(engine, res, y_std, None, ks=ks, Nnull=Nnull,
                                              local_test=kwargs.get('local_test', True),
-                                             show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_total,
+                                             show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_global,
                                              null_source=drawn,
                                              maxabs=getattr(plan, 'maxabs', None))
     _mark('_association returned')

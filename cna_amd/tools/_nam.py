@@ -167,9 +167,49 @@ def _column_r2(a, b):
     return r ** 2
 
 
+def shard_of(data):
+    """(row0, n_global) when `data` holds one rank's block of cells (cna_amd.dist.shard), else None."""
+    info = getattr(data, 'uns', None)
+    info = info.get('cna_shard') if hasattr(info, 'get') else None
+    return None if info is None else (int(info['row0']), int(info['n_global']))
+
+
+_global_codes_cache = {}
+
+
+def global_samples(engine, codes, labels, counts, token):
+    """Sharded callers: a rank sees the sample ids of its own cells only.  Returns what
+    sample_codes_cached() would have returned on the whole dataset, restricted to this rank's cells:
+    codes into the sorted union of every rank's labels, the union, cells per sample over all ranks,
+    and a token all ranks agree on (None as soon as one rank cannot vouch for its ids)."""
+    local = -1 if token is None else (hash(token) & 0x3fffffffffffffff)
+    sigs = engine.allgather_fixed([local])[:, 0]
+    gtoken = None if (sigs < 0).any() else ('sharded',) + tuple(int(v) for v in sigs)
+    hit = _global_codes_cache.get('last')
+    if gtoken is not None and hit is not None and hit[0] == gtoken:
+        return hit[1]
+    everyone = engine.allgather_objects(np.asarray(labels))
+    if all(len(l) == len(everyone[0]) and np.array_equal(l, everyone[0]) for l in everyone):
+        glabels, gcodes = labels, np.asarray(codes)          # e.g. one categorical dtype shared by all ranks
+    else:
+        glabels = pd.Index(np.unique(np.concatenate([np.asarray(l, dtype=object) for l in everyone])))
+        try:
+            glabels = pd.Index(np.asarray(glabels, dtype=np.result_type(*[l.dtype for l in everyone])))
+        except TypeError:
+            pass
+        remap = np.append(glabels.get_indexer(pd.Index(labels)), -1).astype(np.int32)
+        gcodes = remap[np.asarray(codes)]
+    own = np.bincount(gcodes[gcodes >= 0], minlength=len(glabels)).astype(np.int64)
+    gcounts = engine.allgather_fixed(own).sum(axis=0)
+    out = (gcodes, glabels, gcounts, gtoken)
+    if gtoken is not None:
+        _global_codes_cache['last'] = (gtoken, out)
+    return out
+
+
 def _prepare_graph(engine, data, self_weight):
     A = _as_csr(get_connectivity(data))
-    if engine.ensure_graph(A):
+    if engine.ensure_graph(A, shard=shard_of(data)):
         engine._nam_sig = None          # new graph: whatever NAM the device holds is stale
     engine.colsums(self_weight)
     return A
@@ -217,6 +257,8 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
     else:
         codes, labels = codes_labels if codes_labels is not None else sample_codes(data.obs[sid_name])
         counts = np.bincount(codes if codes.min(initial=0) >= 0 else codes[codes >= 0], minlength=len(labels))
+        if codes_labels is None and engine.view_local:
+            codes, labels, counts, token = global_samples(engine, codes, labels, counts, None)
     N = len(labels)
     # NAM cache: the NAM is a function of the graph, the per-cell sample ids, the
     # step rule and the self weight only -- not of the phenotype.  When the device still holds the
@@ -307,7 +349,7 @@ def nam(data, sid_name, batches=None, nsteps=None, self_weight=1, max_frac_pcs=0
     out = select_output(show_progress)
     engine = engine or get_engine()
     if batches is None:
-        u = data.obs[sid_name].unique()
+        u = data.obs[sid_name].unique()          # (a shard's own samples: one batch either way)
         batches = pd.Series(np.ones(len(u)), index=u)
     print('computing NAM', file=out)
     labels, _ = _nam_device(engine, data, sid_name, nsteps=nsteps, self_weight=self_weight,

@@ -93,6 +93,13 @@ int  cna_graph_upload(cna_ctx* ctx, int64_t n_global, int64_t row0, int64_t n_lo
  * caller's numbering; every other per-cell array crosses the ABI in library row order.  NULL
  * (and every cna_graph_upload) resets to the identity. */
 int  cna_set_cell_order(cna_ctx* ctx, const int64_t* orig_index);
+/* Sharded callers (one process per GPU, each holding only the cells of its row block -- the layout
+ * SURVEY.md 8(e) asks for; the reference has no counterpart, its AnnData is whole): with the local
+ * view on, every per-cell array that leaves the library covers this rank's n_local rows only --
+ * cna_percell_fdr / _pinned (no all-reduce of cells-sized vectors), the flags of cna_zero_variance,
+ * cna_fetch_cell_stat -- and cna_set_cell_order takes indices into the local block.  Sample-space
+ * results (Gram, histograms, p-values, medians) stay global.  Call before cna_set_cell_order. */
+int  cna_set_local_view(cna_ctx* ctx, int on);
 /* colsums = A.sum(axis=0) + self_weight (_nam.py:28), float64, all-reduced over ranks */
 int  cna_colsums(cna_ctx* ctx, double self_weight);
 int  cna_fetch_colsums(cna_ctx* ctx, double* out_n_global);

@@ -59,7 +59,7 @@ class FakeEngine(_order.CellOrder):
         self.reuse_nam = False
         self.rank = coll.rank if coll else 0
         self.nranks = coll.nranks if coll else 1
-        self.n = self.row0 = self.n_local = self.N = 0
+        self.n = self.n_global = self.row0 = self.n_local = self.N = 0
         self.x_rows_total = 0
         self.x_epoch = self.nam_epoch = 0
         self.calls = []
@@ -82,11 +82,26 @@ class FakeEngine(_order.CellOrder):
         ro = np.concatenate([[0], np.cumsum(recv_counts)])
         parcels = {p: new_local[send_rows[so[p]:so[p + 1]]] for p in range(self.nranks)}
         box = self.coll.allgather_object(parcels)
-        out = np.full((self.n, new_local.shape[1]), np.nan)
+        out = np.full((self.n_global, new_local.shape[1]), np.nan)
         out[self.row0:self.row0 + self.n_local] = new_local
         for p in range(self.nranks):
             out[recv_rows[ro[p]:ro[p + 1]]] = box[p][self.rank]
         return out
+
+    def _allgather_i64(self, a):
+        return self._gather(np.asarray(a, dtype=np.int64))
+
+    def allgather_fixed(self, values):
+        a = np.asarray(values, dtype=np.int64)
+        return self._gather(a.reshape(1, -1)) if self.coll else a.reshape(1, -1)
+
+    def allgather_objects(self, obj):
+        return self.coll.allgather_object(obj) if self.coll else [obj]
+
+    def x_rows_global(self):
+        if not self.view_local or not self.coll:
+            return self.x_rows_total
+        return int(self.allgather_fixed([self.x_rows_total]).sum())
 
     def gather_rows_host(self, local, n_total):
         out = self._gather(np.asarray(local))
@@ -99,33 +114,48 @@ class FakeEngine(_order.CellOrder):
         return r0, min(r0 + rpr, n)
 
     # -- graph
-    def ensure_graph(self, A):
+    def ensure_graph(self, A, shard=None):
         if getattr(self, '_graph_obj', None) is A:
             return False
         self._graph_obj = A
         A = sp.csr_matrix(A)
-        self.n = A.shape[0]
-        r0, r1 = self.block(self.n)
+        if shard is None:
+            self.n_global = A.shape[0]
+            r0, r1 = self.block(self.n_global)
+            n_order, diag = self.n_global, A
+        else:
+            r0, self.n_global = int(shard[0]), int(shard[1])
+            r1 = r0 + A.shape[0]
+            assert (r0, r1) == self.block(self.n_global) and A.shape[1] == self.n_global
+            n_order, diag = r1 - r0, A[:, r0:r1]
         self.row0, self.n_local = r0, r1 - r0
         if self.order is None:
             self.perm = None
         elif self.order == 'random':
-            self.perm = np.random.RandomState(7).permutation(self.n).astype(np.int64)
+            self.perm = np.random.RandomState(7 + (self.rank if shard is not None else 0)).permutation(n_order).astype(np.int64)
         elif self.order == 'rcm':
-            self.perm = _order.locality_order(A)
+            self.perm = _order.locality_order(diag)
         else:
             self.perm = np.asarray(self.order, dtype=np.int64)
-        if self.perm is None:
+        if shard is not None:
+            if self.perm is None:
+                self.perm = np.arange(n_order, dtype=np.int64)
+            col_map = _order.inverse(self._allgather_i64(self.perm + r0))
+            indptr, indices, data = _order.permuted_rows(A, self.perm, 0, r1 - r0, col_map=col_map)
+            self.A_local = sp.csr_matrix((data.astype(np.float64), indices, indptr), shape=(r1 - r0, self.n_global))
+        elif self.perm is None:
             self.A_local = A[r0:r1].astype(np.float64)
         else:
             indptr, indices, data = _order.permuted_rows(A, self.perm, r0, r1)
-            self.A_local = sp.csr_matrix((data.astype(np.float64), indices, indptr), shape=(r1 - r0, self.n))
+            self.A_local = sp.csr_matrix((data.astype(np.float64), indices, indptr), shape=(r1 - r0, self.n_global))
+        self.view_local = shard is not None
+        self.n = self.n_local if self.view_local else self.n_global
         self._keep_dev = None
         self._kept_order_cache = None
         self._x_is_selection = False
         self.halo = None
         if self.coll:       # same plan the real engine hands to cna_set_halo
-            self.halo = _order.halo_plan(self.A_local.indices, r0, r1 - r0, -(-self.n // self.nranks), self.rank,
+            self.halo = _order.halo_plan(self.A_local.indices, r0, r1 - r0, -(-self.n_global // self.nranks), self.rank,
                                          self.nranks, lambda a: self.coll.allgather(np.asarray(a, dtype=np.int64)))
         self._w = None
         return True
@@ -136,15 +166,18 @@ class FakeEngine(_order.CellOrder):
         self.w = self_weight
 
     def fetch_colsums(self):
-        return self.cells_to_user(self.colsum.copy())
+        own = self.colsum[self.row0:self.row0 + self.n_local] if self.view_local else self.colsum
+        return self.cells_to_user(own.copy())
 
     # -- NAM
     def set_samples(self, codes, n_samples, counts, token=None):
         self.codes = self.cells_to_device(np.asarray(codes))
+        if self.view_local:
+            self.codes = self._gather(self.codes)
         self.N = int(n_samples)
         self.counts = np.asarray(counts, dtype=np.float64)
-        S = np.zeros((self.n, self.N))
-        S[np.arange(self.n), self.codes] = 1.0
+        S = np.zeros((self.n_global, self.N))
+        S[np.arange(self.n_global), self.codes] = 1.0
         self.S = S
         self.steps = 0
         self.nam_epoch += 1
@@ -165,7 +198,8 @@ class FakeEngine(_order.CellOrder):
             if may_stop:
                 self.nam = new_local / self.counts
             if want_kurt:
-                self.stat = self._gather(orc.row_kurtosis(new_local / self.counts))
+                self.stat_local = orc.row_kurtosis(new_local / self.counts)
+                self.stat = self._gather(self.stat_local)
 
     def nam_steps(self, nsteps):
         for i in range(nsteps):
@@ -176,8 +210,9 @@ class FakeEngine(_order.CellOrder):
             return float(np.median(self.stat))
 
     def cell_stat(self, n_expected, nam_space=True):
-        assert len(self.stat) == n_expected
-        return self.cells_to_user(self.stat.copy()) if nam_space else self.stat.copy()
+        stat = self.stat_local if self.view_local else self.stat
+        assert len(stat) == n_expected
+        return self.cells_to_user(stat.copy()) if nam_space else stat.copy()
 
     # -- dense diffusion
     def dense_load(self, s_local):
@@ -196,12 +231,16 @@ class FakeEngine(_order.CellOrder):
         bc = np.asarray(batch_codes)
         with np.errstate(all='ignore'):
             local = orc.batch_kurtosis(mat, bc, n_batches)
+        self.stat_local = local
         self.stat = self._gather(local)
 
     def zero_variance(self, colmap):
         sub = self.nam if colmap is None else self.nam[:, np.asarray(colmap)]
         with np.errstate(all='ignore'):
             flags = sub.std(axis=1, ddof=1) == 0
+        if self.view_local:
+            total = int(self.coll.allreduce_sum(np.array([int(flags.sum())]))[0]) if self.coll else int(flags.sum())
+            return self.cells_to_user(flags), total
         flags = self._gather(flags.astype(np.uint8)).astype(bool)
         return self.cells_to_user(flags), int(flags.sum())
 
@@ -271,7 +310,7 @@ class FakeEngine(_order.CellOrder):
             m = self.coll.allreduce_max(m)
         out = None
         if fetch:
-            out = self.kept_to_user(self.nc.copy()) if self.nranks == 1 else self.nc.copy()
+            out = self.kept_to_user(self.nc.copy()) if self.nranks == 1 or self.view_local else self.nc.copy()
         return out, float(m)
 
     def null_local(self, Yc, edges):
@@ -319,7 +358,7 @@ class FakeEngine(_order.CellOrder):
             coef[:] = self.nc
         else:
             coef[self.keep_local] = self.nc
-        coef = self.cells_to_user(self._gather(coef))
+        coef = self.cells_to_user(coef if self.view_local else self._gather(coef))
         if thr is None:
             return coef, None
         idx = np.searchsorted(thr, np.abs(coef), side='right') - 1

@@ -171,3 +171,125 @@ def test_sharded_random_configurations_equal_single_gpu(seed, world):
         np.testing.assert_allclose(g['fdr'], one['fdr'], rtol=1e-9, atol=1e-13, equal_nan=True)
         np.testing.assert_allclose(g['coef'], one['coef'], rtol=1e-9, atol=1e-13, equal_nan=True)
         np.testing.assert_allclose(g['coef_fdr'], one['coef_fdr'], rtol=1e-9, atol=1e-13)
+
+
+def _shard_worker(rank, world, seg, name, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import warnings
+    warnings.simplefilter('ignore')
+    try:
+        import cna_amd as cna
+        from cna_amd import dist
+        from cna_amd.engine import Engine
+        from helpers import load_case
+        case = load_case(name)
+        part = dist.shard(case['data'], rank, world)       # this rank's cells only
+        eng = Engine(device=0, rank=rank, nranks=world, shm=(seg, 8 << 20))
+        res = cna.tl.association(part, case['y'], case['sid_name'], batches=case['batches'], covs=case['covs'],
+                                 donorids=case['donorids'], return_full=True, engine=eng, **case['call'])
+        out = dict(p=res.p, k=int(res.k), ncorrs=res.ncorrs.values, kept=res.kept, fdr=res.fdrs.fdr.values,
+                   num=res.fdrs.num_detected.values, coef=part.obs['coef'].values, coef_fdr=part.obs['coef_fdr'].values,
+                   nam=res.nam.values, namresid=res.namresid.values, V=res.namresid_nbhdXpc.values,
+                   varexp=res.namresid_varexp.values, n_obs=len(part.obs), view=eng.view_local, halo=eng.halo)
+        # a second phenotype on the resident shard (sample memo + NAM cache agreed on by all ranks)
+        y2 = case['y'].copy()
+        y2[:] = np.random.RandomState(5).randn(len(y2))
+        res2 = cna.tl.association(part, y2, case['sid_name'], batches=case['batches'], covs=case['covs'],
+                                  donorids=case['donorids'], return_full=True, engine=eng, **case['call'])
+        out['p2'], out['ncorrs2'] = res2.p, res2.ncorrs.values
+        s0 = np.random.RandomState(1).rand(case['data'].obsp['connectivities'].shape[0], 3)
+        r0 = part.uns['cna_shard']['row0']
+        out['diffuse'] = cna.tl.diffuse(part, s0[r0:r0 + len(part.obs)], 2, engine=eng)
+        NAM, keep = cna.tl.nam(part, case['sid_name'], batches=case['batches'], engine=eng)
+        out['tlnam'], out['tlkeep'] = NAM.values, keep
+        eng.close()
+        q.put((rank, out))
+    except BaseException as e:
+        import traceback
+        q.put((rank, 'ERROR %r\n%s' % (e, traceback.format_exc())))
+        os._exit(1)
+
+
+def _one_gpu_worker(name, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import warnings
+    warnings.simplefilter('ignore')
+    import cna_amd as cna
+    from cna_amd.engine import Engine
+    from helpers import load_case
+    case = load_case(name)
+    eng = Engine(device=0)
+    y2 = case['y'].copy()
+    y2[:] = np.random.RandomState(5).randn(len(y2))
+    res2 = cna.tl.association(case['data'], y2, case['sid_name'], batches=case['batches'], covs=case['covs'],
+                              donorids=case['donorids'], return_full=True, engine=eng, **case['call'])
+    q.put((0, dict(p2=res2.p, ncorrs2=res2.ncorrs.values)))
+    eng.close()
+
+
+@pytest.mark.parametrize('name,world', [('c01_plain_f32', 2), ('c12_batchy_qc', 3), ('c13_zero_variance', 2),
+                                        ('c03_covs_batches', 4), ('c11_string_ids_null_y', 2)])
+def test_sharded_inputs_on_one_gpu(name, world):
+    """Sharded callers (cna_amd.dist.shard): each rank is handed its own block of cells and nothing
+    else -- obs rows, graph rows with global column ids -- and gets per-cell results for that block;
+    no cells-sized vector crosses ranks (cna_set_local_view).  Stitched in rank order the pieces are
+    the reference's results; sample-level results agree on every rank."""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import load_case, relerr
+    from oracle import cna_oracle as orc
+    import scipy.sparse as sp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    seg = 'cna_sh_%d_%s' % (os.getpid(), name[:3])
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, seg, name, q)) for r in range(world)]
+    procs.append(ctx.Process(target=_one_gpu_worker, args=(name, q)))
+    for p in procs[:-1]:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            r, out = q.get(timeout=240)
+            assert not isinstance(out, str), out
+            got[r] = out
+        procs[-1].start()
+        one = q.get(timeout=240)[1]
+    finally:
+        for p in procs:
+            if p.pid is not None:
+                p.join(timeout=30)
+                if p.is_alive():
+                    p.kill()
+    case = load_case(name)
+    z = case['z']
+    n = len(z['kept'])
+    rpr = -(-n // world)
+    parts = [got[r] for r in range(world)]
+    a = parts[0]
+    for r, g in enumerate(parts):
+        assert g['view'] and g['n_obs'] == max(0, min(rpr, n - r * rpr)) == len(g['kept']) == len(g['coef'])
+        assert g['p'] == a['p'] and g['k'] == a['k'] and g['p2'] == a['p2']
+        for key in ('fdr', 'num', 'varexp'):
+            np.testing.assert_array_equal(g[key], a[key])
+    cat = lambda key, axis=0: np.concatenate([g[key] for g in parts], axis=axis)
+    assert a['k'] == int(z['k']) and a['p'] == pytest.approx(float(z['p']), rel=1e-12)
+    assert np.array_equal(cat('kept'), z['kept'])
+    assert relerr(cat('ncorrs'), z['ncorrs']) < 1e-5
+    assert relerr(cat('nam', 1), z['nam']) < 1e-5 and relerr(cat('namresid', 1), z['namresid']) < 1e-5
+    assert cat('V').shape == z['V'].shape
+    T = min(len(a['fdr']), len(z['fdr_fdr']))
+    assert np.array_equal(a['num'][:T], z['fdr_num_detected'][:T])
+    assert relerr(a['fdr'][:T], z['fdr_fdr'][:T]) < 1e-4
+    coef = cat('coef')
+    assert np.array_equal(np.isnan(coef), np.isnan(z['obs_coef']))
+    assert relerr(coef[~np.isnan(coef)], z['obs_coef'][~np.isnan(coef)]) < 1e-5
+    np.testing.assert_allclose(cat('coef_fdr'), z['obs_coef_fdr'], rtol=1e-4, atol=1e-12)
+    A = sp.csr_matrix(case['data'].obsp['connectivities'])
+    s0 = np.random.RandomState(1).rand(A.shape[0], 3)
+    assert relerr(cat('diffuse'), orc.diffuse(A, s0, 2, mode='f64')) < 1e-13
+    assert cat('tlkeep').shape == (n,) and cat('tlnam', 1).shape[0] == a['tlnam'].shape[0]
+    # second phenotype: equal to what one GPU holding everything computes
+    assert a['p2'] == pytest.approx(one['p2'], rel=1e-12)
+    np.testing.assert_allclose(cat('ncorrs2'), one['ncorrs2'], rtol=1e-9, atol=1e-13)

@@ -84,3 +84,89 @@ def test_sharded_equals_reference(name, world):
     assert relerr(a['fdr'][:T], z['fdr_fdr'][:T]) < 1e-4
     np.testing.assert_allclose(a['coef_fdr'], z['obs_coef_fdr'], rtol=1e-4, atol=1e-12)
     assert a['V'].shape == z['V'].shape
+
+
+def _shard_worker(rank, world, port, name, order, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import warnings
+    warnings.simplefilter('ignore')
+    import torch.distributed as td
+    td.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    import cna_amd as cna
+    from cna_amd import dist
+    from fake_engine import FakeEngine, GlooColl
+    from helpers import load_case
+    case = load_case(name)
+    part = dist.shard(case['data'], rank, world)          # this rank's cells only
+    eng = FakeEngine(GlooColl(), order=order)
+    res = cna.tl.association(part, case['y'], case['sid_name'], batches=case['batches'], covs=case['covs'],
+                             donorids=case['donorids'], return_full=True, engine=eng, **case['call'])
+    out = dict(p=res.p, k=int(res.k), ncorrs=res.ncorrs.values, kept=res.kept, fdr=res.fdrs.fdr.values,
+               num=res.fdrs.num_detected.values, coef=part.obs['coef'].values, coef_fdr=part.obs['coef_fdr'].values,
+               nam=res.nam.values, namresid=res.namresid.values, V=res.namresid_nbhdXpc.values,
+               varexp=res.namresid_varexp.values, cells=list(res.nam.columns), n_obs=len(part.obs), view=eng.view_local)
+    s0 = np.random.RandomState(1).rand(case['data'].obsp['connectivities'].shape[0], 3)
+    r0 = part.uns['cna_shard']['row0']
+    out['diffuse'] = cna.tl.diffuse(part, s0[r0:r0 + len(part.obs)], 2, engine=eng)
+    NAM, keep = cna.tl.nam(part, case['sid_name'], batches=case['batches'], engine=eng)
+    out['tlnam'], out['tlkeep'] = NAM.values, keep
+    q.put((rank, out))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize('name,world,order', [('c01_plain_f32', 2, 'rcm'), ('c12_batchy_qc', 3, 'random'),
+                                              ('c13_zero_variance', 2, None), ('c10_categorical_ids', 2, 'rcm'),
+                                              ('c11_string_ids_null_y', 2, 'random')])
+def test_sharded_inputs_local_view(name, world, order):
+    """Every rank is handed ONLY its block of cells (cna_amd.dist.shard): obs rows, graph rows.  The
+    per-cell results it gets back cover that block; stitched together in rank order they are the
+    reference's, and the sample-level results are the reference's on every rank."""
+    import torch.multiprocessing as mp
+    import scipy.sparse as sp
+    from helpers import load_case, relerr
+    from oracle import cna_oracle as orc
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, name, order, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    case = load_case(name)
+    z = case['z']
+    n = len(z['kept'])
+    rpr = -(-n // world)
+    parts = [got[r] for r in range(world)]
+    for r, g in enumerate(parts):
+        assert g['view'] and g['n_obs'] == max(0, min(rpr, n - r * rpr)) == len(g['kept']) == len(g['coef'])
+        assert g['p'] == parts[0]['p'] and g['k'] == parts[0]['k']
+        np.testing.assert_array_equal(g['fdr'], parts[0]['fdr'])
+        np.testing.assert_array_equal(g['num'], parts[0]['num'])
+        np.testing.assert_array_equal(g['varexp'], parts[0]['varexp'])
+    cat = lambda key, axis=0: np.concatenate([g[key] for g in parts], axis=axis)
+    a = parts[0]
+    assert a['k'] == int(z['k']) and a['p'] == pytest.approx(float(z['p']), rel=1e-12)
+    assert np.array_equal(cat('kept'), z['kept'])
+    assert relerr(cat('ncorrs'), z['ncorrs']) < 1e-5
+    assert relerr(cat('nam', 1), z['nam']) < 1e-5 and relerr(cat('namresid', 1), z['namresid']) < 1e-5
+    assert cat('V').shape == z['V'].shape
+    kept_names = np.asarray(case['data'].obs.index)[z['kept']]
+    assert [c for g in parts for c in g['cells']] == list(kept_names)
+    T = min(len(a['fdr']), len(z['fdr_fdr']))
+    assert np.array_equal(a['num'][:T], z['fdr_num_detected'][:T])
+    assert relerr(a['fdr'][:T], z['fdr_fdr'][:T]) < 1e-4
+    coef = cat('coef')
+    assert np.array_equal(np.isnan(coef), np.isnan(z['obs_coef']))
+    assert relerr(coef[~np.isnan(coef)], z['obs_coef'][~np.isnan(coef)]) < 1e-5
+    np.testing.assert_allclose(cat('coef_fdr'), z['obs_coef_fdr'], rtol=1e-4, atol=1e-12)
+    A = sp.csr_matrix(case['data'].obsp['connectivities'])
+    s0 = np.random.RandomState(1).rand(A.shape[0], 3)
+    assert relerr(cat('diffuse'), orc.diffuse(A, s0, 2, mode='f64')) < 1e-12
+    if 'tlnam' in z.files if hasattr(z, 'files') else 'tlnam' in z:
+        assert relerr(cat('tlnam', 1), z['tlnam']) < 1e-5
+    assert cat('tlkeep').shape == (n,)
