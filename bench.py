@@ -35,9 +35,9 @@ F64_MFMA_PEAK_TF = 78.6      # AMD MI355X datasheet: FP64 matrix 78.6 TFLOP/s (t
 # gfx950 correction, re-calibrated here on k_ncorrs (streams the 83.2 MB matrix once, FETCH_SIZE reads 41.6 MB).
 # Counted at the L2's fabric side, i.e. Infinity-Cache hits included.  Only valid for the profiled workload.
 PMC_TRAFFIC = {
-    ('C2', 'nam_step'): 2 * 172600e3 + 82070e3,
-    ('C2', 'nam_first'): 2 * 37770e3 + 81250e3,
-    ('C2', 'null_local'): 2 * (2 * 41670e3 + 18750e3),     # two launches per pass
+    ('C2', 'nam_step'): 2 * 184100e3 + 83530e3,
+    ('C2', 'nam_first'): 2 * 37780e3 + 81250e3,
+    ('C2', 'null_local'): 2 * (2 * 41630e3 + 18750e3),     # two launches per pass
 }
 
 WORKLOADS = {
@@ -127,6 +127,10 @@ def main():
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'shm'],
                     help="shm: plumbing check of the N>1 path on ONE GPU (all ranks on device 0, gloo for the "
                          "rendezvous, the library's shared-memory test communicator instead of RCCL); not a benchmark")
+    ap.add_argument('--inputs', default='sharded', choices=['sharded', 'replicated'],
+                    help='N>1 only.  sharded (default): every rank is handed its own block of cells '
+                         '(cna_amd.dist.shard) and gets per-cell results for that block; replicated: every rank '
+                         'holds the whole dataset and the whole result, like a replicated AnnData')
     ap.add_argument('--force-dist', action='store_true',
                     help='take the torch.distributed + RCCL code path even with one rank (plumbing check)')
     args = ap.parse_args()
@@ -173,6 +177,12 @@ def main():
     t_gen = time.time() - t0
     A = get_connectivity(data)
     nnz = int(A.nnz)
+    deg_full = np.diff(A.indptr)
+    sharded_inputs = world > 1 and args.inputs == 'sharded'
+    if sharded_inputs:
+        from cna_amd import dist
+        data = dist.shard(data, rank, world)     # from here on this rank knows its own cells only
+        del A
     y = meta['y']
     eng = get_engine()
     eng.reuse_nam = False           # every timed step recomputes the NAM (no result caching across steps)
@@ -250,12 +260,15 @@ def main():
 
     ms_per_step = dt / args.steps * 1e3
     value = n * Nnull * args.steps / dt
-    wA = A.data.dtype.itemsize
+    wA = get_connectivity(data).data.dtype.itemsize
     T = 300
     n_loc = eng.n_local
-    deg = np.diff(A.indptr)
+    deg = deg_full
     rows_loc = slice(eng.row0, eng.row0 + n_loc)
-    nnz_loc = int(deg[eng.perm[rows_loc]].sum() if eng.perm is not None else deg[rows_loc].sum())
+    if sharded_inputs:
+        nnz_loc = int(deg[rows_loc].sum())
+    else:
+        nnz_loc = int(deg[eng.perm[rows_loc]].sum() if eng.perm is not None else deg[rows_loc].sum())
     kernels = {}
     for name, (ms, cnt) in prof.items():
         bound, work = algorithmic_work(name, n_loc, nnz_loc, N, min(1000, Nnull), T, wA)
@@ -306,8 +319,10 @@ def main():
         'config': {'workload': '%s: %d cells (%d per GPU) x %d samples, k=%d kNN (%.1f nnz/row, float32 CSR), '
                                'nsteps=%d, Nnull=%d, local FDR pass on, NAM cache off' % (args.workload, n, cells_per_gpu, N, k,
                                                                           nnz / n, nsteps, Nnull),
-                   'parallelism': 'cells sharded in %d row block(s)%s%s' % (
-                       world, '' if eng.halo is None else ', halo exchange %d/%d rows out/in on rank 0' % eng.halo,
+                   'parallelism': 'cells sharded in %d row block(s)%s%s%s' % (
+                       world, '' if world == 1 else (', every rank holds its block of cells only' if sharded_inputs
+                                                     else ', dataset and per-cell results replicated on every rank'),
+                       '' if eng.halo is None else ', halo exchange %d/%d rows out/in on rank 0' % eng.halo,
                        ' [--comm shm: ranks share one GPU, plumbing check only]' if args.comm == 'shm' and world > 1 else ''), 'p_value': p_last},
         'roofline': roofline,
         'cpu_baseline': cpu,

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
 struct alignas(16) EdgeRec {
   double a;
   unsigned byte_off;    // j * row bytes
-  int pad;
+  unsigned lane_mask;   // ~0 for an edge, 0 for padding past the end of the row
 };
 
 __device__ __forceinline__ double half_sum(double v, int h) {
@@ -303,7 +303,7 @@ __device__ __forceinline__ double half_sum(double v, int h) {
 
 template <typename VT>
 __global__ __launch_bounds__(256) void k_nam_step_pair(StepArgs a) {
-  constexpr int U = 8;                          // neighbour rows in flight per half-wave (4: same, 16: -14 %)
+  constexpr int U = 4;                          // neighbour rows in flight per half-wave (8: +2 % time, 16: +16 %)
   __shared__ EdgeRec recs[4][2][32];
   const int lane = threadIdx.x & 63, hl = lane & 31, h = lane >> 5;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -329,11 +329,12 @@ __global__ __launch_bounds__(256) void k_nam_step_pair(StepArgs a) {
       const bool ok = base + hl < deg;
       const int64_t e = start + base + hl;
       EdgeRec r;
-      // past the end of the row: weight 0 on the row's own (finite, soon needed) state row, so the
-      // gather below needs no per-edge branch
+      // past the end of the row: weight 0 on the first 16 bytes of the row's own (finite) state row
+      // -- all lanes of the half on one address, a single L1 access -- so the gather below needs no
+      // per-edge branch and padding costs next to nothing in the vector-memory pipeline
       r.a = ok ? (double)((const VT*)a.val)[e] : 0.0;
       r.byte_off = ok ? (unsigned)a.idx[e] * rowbytes : own_off;
-      r.pad = 0;
+      r.lane_mask = ok ? ~0u : 0u;
       *(uint4*)&mine[hl] = *(const uint4*)&r;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void k_nam_step_pair(StepArgs a) {
       for (int u = 0; u < U; ++u) {
         const uint4 r = *(const uint4*)&mine[l + u];
         w[u] = __hiloint2double((int)r.y, (int)r.x);
-        t[u] = *(const double2*)(Tb + (r.z + off));           // idle column lanes re-read column pair 0
+        t[u] = *(const double2*)(Tb + (r.z + (off & r.w)));   // idle column lanes re-read column pair 0
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {                           // past a row's end: acc + 0 * finite = acc
