@@ -55,13 +55,14 @@ def _draw_null(y, batches, donorids, Nnull=1000, force_permute_all=False, seed=N
     execute; the RNG is consumed by nothing else in between, so the draws are the same."""
     if seed is not None:
         np.random.seed(seed)
+    clean = seed is not None           # freshly seeded: no cached normal pending (RandomState._reset_gauss)
     if force_permute_all:
         batches = np.ones(len(y))
     y = (y - y.mean()) / y.std()
     if donorids is not None:
-        y_ = grouplevel_permutation(donorids, y, Nnull)
+        y_ = grouplevel_permutation(donorids, y, Nnull, clean=clean)
     else:
-        y_ = conditional_permutation(batches, y, Nnull)
+        y_ = conditional_permutation(batches, y, Nnull, clean=clean)
     return y, y_
 
 

@@ -251,6 +251,13 @@ int  cna_fetch_rows(cna_ctx* ctx, int which, const int64_t* rows, int64_t n_out,
 int  cna_allgather_host(cna_ctx* ctx, const double* local, int64_t count_local, double* out_all,
                         int64_t count_total);
 
+/* ---- host-side helper: the permutation draw's random stream (_stats.py:10) ----------------- */
+/* n values of np.random.randn from numpy's legacy generator, bit for bit, vectorised (host code
+ * only, no device involved; csrc/host_rng.c).  key[624] / *pos / *has_gauss / *gauss: the state as
+ * np.random.get_state() reports it, advanced in place to where numpy's own draw would leave it.
+ * No context: callable from any thread. */
+int  cna_host_legacy_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss, int64_t n, double* out);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 /* HIP-event timing of every kernel launch on the context's stream (bench.py roofline) */
 int  cna_prof_enable(cna_ctx* ctx, int on);

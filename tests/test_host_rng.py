@@ -1,0 +1,68 @@
+"""The library's restatement of numpy's legacy normal stream (csrc/host_rng.c) against numpy itself:
+values and generator state bit for bit.  Host code only -- runs without a GPU."""
+import numpy as np
+import pytest
+
+from cna_amd.tools import _stats
+
+
+def _same_state(a, b):
+    return a[2] == b[2] and a[3] == b[3] and a[4] == b[4] and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize('seed', [0, 1, 12345])
+def test_legacy_randn_is_numpys_stream(seed):
+    for m, num in ((1, 1), (1, 2), (3, 1), (7, 3), (50, 20), (13, 24), (156, 1), (157, 1), (312, 2), (50, 1000), (3, 16667)):
+        for pre in (0, 1, 2, 3, 5, 623, 624, 625):
+            np.random.seed(seed)
+            if pre:
+                np.random.random_sample(pre)
+            if pre == 5:
+                np.random.randn(1)                       # leaves a cached second value behind
+            start = np.random.get_state()
+            ref = np.random.randn(m, num)
+            ref_state = np.random.get_state()
+            ref_next = np.random.randn(3), np.random.randint(0, 1000, 4), np.random.permutation(5)
+            np.random.set_state(start)
+            got = _stats.legacy_randn(m, num).copy()
+            assert got.shape == ref.shape and np.array_equal(got.view(np.uint64), ref.view(np.uint64)), (m, num, pre)
+            assert _same_state(np.random.get_state(), ref_state), (m, num, pre)
+            nxt = np.random.randn(3), np.random.randint(0, 1000, 4), np.random.permutation(5)
+            assert all(np.array_equal(u, v) for u, v in zip(nxt, ref_next))
+
+
+def test_permutation_draws_match_plain_numpy(monkeypatch):
+    """conditional_permutation / grouplevel_permutation through the fast stream == through np.random.randn."""
+    rs = np.random.RandomState(3)
+    Y = rs.randn(37)
+    B = rs.randint(0, 4, 37)
+    G = np.repeat(np.arange(13), 3)[:37]
+    Yg = rs.randn(13)[G]
+    np.random.seed(11)
+    a = _stats.conditional_permutation(B, Y, 101)
+    ag = _stats.grouplevel_permutation(G, Yg, 55)
+    a_next = np.random.rand(2)
+    for num in (100, 101):             # freshly seeded: even blocks run on numpy's own state memory
+        np.random.seed(11)
+        c = _stats.conditional_permutation(B, Y, num, clean=True)
+        c_next = np.random.randn(3)
+        np.random.seed(11)
+        d = _stats.conditional_permutation(B, Y, num)
+        assert np.array_equal(c, d) and np.array_equal(c_next, np.random.randn(3))
+    np.random.seed(11)
+    _stats.conditional_permutation(B, Y, 101)
+    assert np.array_equal(_stats.grouplevel_permutation(G, Yg, 55, clean=False), ag)
+    monkeypatch.setattr(_stats, 'legacy_randn', lambda m, num, clean=False: np.random.randn(m, num))
+    np.random.seed(11)
+    b = _stats.conditional_permutation(B, Y, 101)
+    bg = _stats.grouplevel_permutation(G, Yg, 55)
+    b_next = np.random.rand(2)
+    assert np.array_equal(a, b) and np.array_equal(ag, bg) and np.array_equal(a_next, b_next)
+
+
+def test_other_global_generators_are_left_to_numpy(monkeypatch):
+    class Odd:
+        _bit_generator = object()
+    monkeypatch.setattr(np.random.mtrand, '_rand', Odd(), raising=False)
+    out = _stats.legacy_randn(4, 5)
+    assert out.shape == (4, 5)
