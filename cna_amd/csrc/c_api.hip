@@ -181,6 +181,8 @@ int cna_ctx_create(int device, cna_ctx** out) {
     e = hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, hi);
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->gram_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->coef_ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->coef_copied, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->null_done, hipEventDisableTiming);
   if (e != hipSuccess) {
     delete c;
@@ -197,7 +199,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_flush(c);
   comm_destroy(c);
-  void* bufs[] = {c->proj, c->sp_idx, c->sp_val, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+  void* bufs[] = {c->coef_dev, c->proj, c->sp_idx, c->sp_val, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
                   c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -205,6 +207,8 @@ int cna_ctx_destroy(cna_ctx* c) {
   (void)hipStreamDestroy(c->stream);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->gram_done) (void)hipEventDestroy(c->gram_done);
+  if (c->coef_ready) (void)hipEventDestroy(c->coef_ready);
+  if (c->coef_copied) (void)hipEventDestroy(c->coef_copied);
   if (c->null_done) (void)hipEventDestroy(c->null_done);
   if (c->h_res) (void)hipHostFree(c->h_res);
   if (c->h_cell) (void)hipHostFree(c->h_cell);
@@ -272,6 +276,7 @@ int cna_graph_upload(cna_ctx* c, int64_t n_global, int64_t row0, int64_t n_local
   c->nam_valid = false;
   c->x_valid = false;
   c->ncorrs_valid = false;
+  c->coef_early = false;
   c->steps_done = 0;
   return 0;
 }
@@ -749,6 +754,7 @@ int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_
   c->x_valid = true;
   c->x_from_nam = true;
   c->ncorrs_valid = false;
+  c->coef_early = false;
   return 0;
 }
 
@@ -800,6 +806,7 @@ int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep,
   c->x_valid = true;
   c->x_from_nam = true;
   c->ncorrs_valid = y != nullptr;     // meaningful only when no cell had zero variance (the caller checks)
+  c->coef_early = false;
   return 0;
 }
 
@@ -821,6 +828,7 @@ int cna_upload_x(cna_ctx* c, const double* x_local, int64_t n_rows, int n_cols) 
   c->x_valid = true;
   c->x_from_nam = false;
   c->ncorrs_valid = false;
+  c->coef_early = false;
   return 0;
 }
 
@@ -838,6 +846,7 @@ int cna_resid_apply(cna_ctx* c, const double* M, int center) {
   CNA_TRY(launch_xb(c, (const double*)c->scratch, ldb, Nx, center != 0, c->X, ldx));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->ncorrs_valid = false;
+  c->coef_early = false;
   return 0;
 }
 
@@ -846,6 +855,7 @@ int cna_standardize(cna_ctx* c, int center) {
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
   CNA_TRY(launch_standardize(c, center));
   c->ncorrs_valid = false;
+  c->coef_early = false;
   return 0;
 }
 
@@ -944,6 +954,7 @@ int cna_ncorrs(cna_ctx* c, const double* y, double* out_local, double* max_abs) 
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (max_abs) *max_abs = m;
   c->ncorrs_valid = true;
+  c->coef_early = false;
   return 0;
 }
 
@@ -1249,21 +1260,67 @@ int cna_obs_counts(cna_ctx* c, const double* edges, const double* thr, int T, in
   return 0;
 }
 
+static int ensure_cell_pinned(cna_ctx* c, int64_t n_out) {
+  const int64_t need = 16 * std::max<int64_t>(n_out, 1);
+  if (need > c->h_cell_cap) {
+    if (c->h_cell) HIP_TRY(hipHostFree(c->h_cell));
+    c->h_cell = nullptr;
+    c->coef_early = false;
+    HIP_TRY(hipHostMalloc(&c->h_cell, (size_t)need, hipHostMallocDefault));
+    c->h_cell_cap = need;
+  }
+  return 0;
+}
+
+// The coefficient column of the result (data.obs[key_added], _association.py:230-233) depends on
+// the observed phenotype only, not on the permutation null: queued here -- ahead of the local-null
+// kernel in stream order, copied out on the second stream -- it reaches the host while that kernel
+// runs, and the caller can write the column before the null is even finished.
+int cna_percell_coef_launch(cna_ctx* c) {
+  CHECK_CTX(c);
+  if (!c->ncorrs_valid || !c->x_from_nam) CNA_FAIL(CNA_ESTATE, "cna_percell_coef_launch needs cna_select + cna_ncorrs");
+  if ((c->nranks > 1 || comm_active(c)) && !c->local_view)
+    CNA_FAIL(CNA_ESTATE, "cna_percell_coef_launch: replicated multi-rank outputs are assembled by cna_percell_fdr");
+  const int64_t n_out = c->local_view ? c->n_local : c->n_global;
+  CNA_TRY(ensure_cell_pinned(c, n_out));
+  void* p = c->coef_dev;
+  CNA_TRY(dev_reserve(c, &p, &c->coef_dev_cap, 16 * std::max<int64_t>(c->n_pad, 1)));
+  c->coef_dev = (double*)p;
+  double* tmp = c->coef_dev;
+  double* out = tmp;
+  CNA_TRY(launch_percell_fdr(c, nullptr, nullptr, 0, 0.0, 0.0, tmp, nullptr));
+  if (c->orig_idx) {
+    out = c->coef_dev + c->n_pad;
+    CNA_TRY(launch_unpermute2(c, tmp, nullptr, c->orig_idx, c->n_local, out, nullptr));
+  }
+  HIP_TRY(hipEventRecord(c->coef_ready, c->stream));
+  HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->coef_ready, 0));
+  if (n_out > 0)
+    HIP_TRY(hipMemcpyAsync(c->h_cell, out, 8 * n_out, hipMemcpyDeviceToHost, c->copy_stream));
+  HIP_TRY(hipEventRecord(c->coef_copied, c->copy_stream));
+  c->coef_early = true;
+  return 0;
+}
+
+int cna_percell_coef_wait(cna_ctx* c, double** coef_ptr) {
+  CHECK_CTX(c);
+  if (!coef_ptr) CNA_FAIL(CNA_EINVAL, "cna_percell_coef_wait: coef_ptr is required");
+  if (!c->coef_early) CNA_FAIL(CNA_ESTATE, "cna_percell_coef_wait without cna_percell_coef_launch");
+  HIP_TRY(hipEventSynchronize(c->coef_copied));
+  *coef_ptr = (double*)c->h_cell;
+  return 0;
+}
+
 int cna_percell_fdr_pinned(cna_ctx* c, const double* thr, const double* runmin_fdr, int T, double** coef_ptr,
                            double** fdr_ptr) {
   CHECK_CTX(c);
   if (!coef_ptr) CNA_FAIL(CNA_EINVAL, "cna_percell_fdr_pinned: coef_ptr is required");
   const int64_t n_out = c->local_view ? c->n_local : c->n_global;
-  const int64_t need = 16 * std::max<int64_t>(n_out, 1);
-  if (need > c->h_cell_cap) {
-    if (c->h_cell) HIP_TRY(hipHostFree(c->h_cell));
-    c->h_cell = nullptr;
-    HIP_TRY(hipHostMalloc(&c->h_cell, (size_t)need, hipHostMallocDefault));
-    c->h_cell_cap = need;
-  }
+  CNA_TRY(ensure_cell_pinned(c, n_out));
   double* hc = (double*)c->h_cell;
   const bool want_fdr = fdr_ptr && thr && runmin_fdr && T > 0;
-  CNA_TRY(cna_percell_fdr(c, thr, runmin_fdr, T, hc, want_fdr ? hc + n_out : nullptr));
+  if (c->coef_early) HIP_TRY(hipEventSynchronize(c->coef_copied));     // coefficients already on the host
+  CNA_TRY(cna_percell_fdr(c, thr, runmin_fdr, T, c->coef_early ? nullptr : hc, want_fdr ? hc + n_out : nullptr));
   *coef_ptr = hc;
   if (fdr_ptr) *fdr_ptr = want_fdr ? hc + n_out : nullptr;
   return 0;

@@ -137,6 +137,10 @@ struct cna_ctx {
   double null_cut0 = 0, null_inv_step = 0, null_eps = 0;
   int null_has_obs = 0;
   int64_t null_obs_off = 0;
+  double* coef_dev = nullptr;     // early copy of the per-cell coefficients (cna_percell_coef_launch): 2 x n_pad
+  int64_t coef_dev_cap = 0;
+  hipEvent_t coef_ready = nullptr, coef_copied = nullptr;
+  bool coef_early = false;        // h_cell[0, n_out) already holds the coefficients of the current ncorrs
   void* h_cell = nullptr;         // pinned: per-cell outputs of cna_percell_fdr_pinned (coef | fdr)
   int64_t h_cell_cap = 0;
   // compressed copy of the state after the first walk step (single GPU, wide sample axis)

@@ -447,6 +447,21 @@ class Engine(_order.CellOrder):
               'cna_percell_fdr_pinned')
         return self._pinned_view(cp), self._pinned_view(fp)
 
+    def percell_coef_launch(self):
+        """Queue the per-cell coefficient column ahead of the local-null kernel (it only needs the
+        observed phenotype); False when this engine assembles per-cell outputs across ranks."""
+        if (self.nranks > 1 or self._has_comm) and not self.view_local:
+            return False
+        check(self.lib.cna_percell_coef_launch(self.h), 'cna_percell_coef_launch')
+        return True
+
+    def percell_coef_wait(self):
+        """The coefficient column queued by percell_coef_launch (pinned view, see percell()); callable
+        from a helper thread."""
+        cp = C.c_void_p()
+        check(self.lib.cna_percell_coef_wait(self.h, C.byref(cp)), 'cna_percell_coef_wait')
+        return self._pinned_view(cp)
+
     def _pinned_view(self, p):
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(self.n,))
 

@@ -12,6 +12,7 @@ Same call surface, result fields, warnings and error behaviour as the reference'
                                           observed ranks / num_detected (:105-108),
                                           data.obs columns incl. the per-cell FDR lookup (:230-237)
 """
+import os
 import warnings
 
 import numpy as np
@@ -38,6 +39,8 @@ def _background():
         _pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='cna-device')
     return _pool
 
+
+_EARLY_COEF = os.environ.get('CNA_EARLY_COEF', '1') not in ('0', 'off', 'no')     # ablation switch
 
 _TRACE = None      # list of (label, perf_counter) when tools/host_trace.py switches tracing on
 
@@ -67,7 +70,7 @@ def _draw_null(y, batches, donorids, Nnull=1000, force_permute_all=False, seed=N
 
 
 def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_progress=False,
-                 npcs=None, n_cells=None, conditioned=False, null_source=None, maxabs=None):
+                 npcs=None, n_cells=None, conditioned=False, null_source=None, maxabs=None, on_coef=None):
     """Body of the reference's ``_association`` (_association.py:24-129) against the
     residualised NAM held by ``engine`` (cells x samples), whose Gram-matrix kernels have been
     queued.  ``res`` is the namespace from the residualisation (M, r), ``y`` / ``y_`` the
@@ -106,6 +109,11 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         # the half of the local-null launch that needs the thresholds only (exact cuts, the threshold
         # counts of the observed coefficients) goes out now
         engine.null_local_prepare(Nloc, edges, thresholds)
+        # the coefficient column does not depend on the null: queued in front of the null kernel it is
+        # on the host while that kernel runs, and on_coef (a callable) may consume it from another thread
+        if on_coef is not None and _EARLY_COEF and getattr(engine, 'percell_coef_launch', None) is not None \
+                and engine.percell_coef_launch():
+            on_coef()
 
     if null_source is not None:
         y_, conditioned = null_source()
@@ -417,11 +425,37 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         y_null = null_future.result()[1]
         _mark('null drawn')
         return y_null, early.get('conditioned', False)
-    coef_all, fdr_all, U, svs = _association(engine, res, y_std, None, ks=ks, Nnull=Nnull,
-                                             local_test=kwargs.get('local_test', True),
-                                             show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_global,
-                                             null_source=drawn,
-                                             maxabs=getattr(plan, 'maxabs', None))
+    # data.obs[key_added] is written early, by the helper thread, while the local-null kernel runs
+    # (the main thread is inside LAPACK / the F-test call then); should the test still fail, the
+    # column is put back as it was, so that -- like upstream -- an exception leaves data.obs alone
+    early_coef = {}
+    had_key = key_added in data.obs
+    previous = data.obs[key_added] if had_key else None
+
+    def write_coef_early():
+        def job():
+            coef = engine.percell_coef_wait()
+            data.obs[key_added] = coef
+            return data.obs[key_added].values
+        early_coef['future'] = _background().submit(job)
+
+    try:
+        coef_all, fdr_all, U, svs = _association(engine, res, y_std, None, ks=ks, Nnull=Nnull,
+                                                 local_test=kwargs.get('local_test', True),
+                                                 show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_global,
+                                                 null_source=drawn,
+                                                 maxabs=getattr(plan, 'maxabs', None), on_coef=write_coef_early)
+    except BaseException:
+        fut = early_coef.get('future')
+        if fut is not None:
+            try:
+                fut.result()
+            finally:
+                if had_key:
+                    data.obs[key_added] = previous
+                elif key_added in data.obs:
+                    del data.obs[key_added]
+        raise
     _mark('_association returned')
     _defer_pcs(res, engine, U, svs, cell_index)
     res.kept = kept
@@ -436,13 +470,16 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     res._defer('nam', fetch_nam)
     _mark('lazies set')
 
-    if key_added in data.obs:
+    if had_key:
         warnings.warn(f"Key '{key_added}' already exists in data.obs. Overwriting.")
     _mark('warned')
     # coef_all / fdr_all may be views of the engine's pinned buffers: the DataFrame stores its own
     # copy, and that copy (not the view) is what res.ncorrs is built from when somebody reads it
-    data.obs[key_added] = coef_all
-    coef_kept = data.obs[key_added].values
+    if 'future' in early_coef:
+        coef_kept = early_coef['future'].result()        # written while the null kernel was running
+    else:
+        data.obs[key_added] = coef_all
+        coef_kept = data.obs[key_added].values
     if np.may_share_memory(coef_kept, coef_all):
         coef_kept = np.array(coef_all)
     res._defer('ncorrs', lambda: pd.Series(coef_kept if kept.all() else coef_kept[kept], index=cell_index()))

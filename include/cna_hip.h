@@ -234,6 +234,13 @@ int  cna_percell_fdr(cna_ctx* ctx, const double* thr, const double* runmin_fdr, 
  * call on this context): the D2H copies run at PCIe speed and the caller copies or consumes them */
 int  cna_percell_fdr_pinned(cna_ctx* ctx, const double* thr, const double* runmin_fdr, int T,
                             double** coef_ptr, double** fdr_ptr);
+/* The coefficient column alone, early: it depends on the observed phenotype only (not on the null),
+ * so after cna_ncorrs / cna_select_standardized(y) the caller may queue it ahead of the local-null
+ * kernel (launch: returns at once; the copy runs on the second stream under that kernel) and
+ * collect the pinned pointer with _wait -- from any thread.  A later cna_percell_fdr_pinned then
+ * delivers the FDR column only and returns the same coefficient pointer.  Single rank or local view. */
+int  cna_percell_coef_launch(cna_ctx* ctx);
+int  cna_percell_coef_wait(cna_ctx* ctx, double** coef_ptr);
 
 /* ---- device -> host for the lazily materialised result fields (a20) -------------------- */
 int  cna_matrix_shape(cna_ctx* ctx, int which, int64_t* n_rows_local, int* n_cols);
