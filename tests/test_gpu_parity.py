@@ -480,6 +480,41 @@ def test_ordered_fetch_on_device_equals_host_reorder(monkeypatch):
         np.testing.assert_array_equal(a, b)
 
 
+def test_failed_test_leaves_obs_untouched(eng, monkeypatch):
+    """data.obs[key_added] is written early (helper thread, under the local-null kernel).  When the
+    association test then fails, the column is put back -- absent if it was absent, the old values if
+    it existed -- and the next call works: like upstream, an exception leaves data.obs alone."""
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.tools import _association as A
+    assert A._EARLY_COEF
+    data, meta = synth.make_dataset(5000, 24, k=15, seed=3)
+    kw = dict(Nnull=100, seed=1, nsteps=3)
+
+    def boom(*a, **k):
+        raise FloatingPointError('injected')
+    real = eng.global_test
+    monkeypatch.setattr(eng, 'global_test', boom)
+    with pytest.raises(FloatingPointError):
+        cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+    assert 'coef' not in data.obs and 'coef_fdr' not in data.obs
+    monkeypatch.setattr(eng, 'global_test', real)
+    p1 = cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+    before = data.obs['coef'].values.copy()
+    y2 = pd.Series(np.random.RandomState(2).randn(24), index=meta['y'].index)
+    monkeypatch.setattr(eng, 'global_test', boom)
+    with pytest.raises(FloatingPointError):
+        cna.tl.association(data, y2, 'id', engine=eng, **kw)
+    np.testing.assert_array_equal(data.obs['coef'].values, before)
+    monkeypatch.setattr(eng, 'global_test', real)
+    assert cna.tl.association(data, meta['y'], 'id', engine=eng, **kw) == p1
+    np.testing.assert_array_equal(data.obs['coef'].values, before)
+    # the early path and the one-shot path write the same column
+    monkeypatch.setattr(A, '_EARLY_COEF', False)
+    assert cna.tl.association(data, meta['y'], 'id', engine=eng, **kw) == p1
+    np.testing.assert_array_equal(data.obs['coef'].values, before)
+
+
 def test_nam_cache_on_device(eng):
     """A second phenotype on the same dataset reuses the resident NAM (no diffusion kernels) and gives
     the results of a from-scratch run."""
