@@ -178,7 +178,7 @@ def main():
     A = get_connectivity(data)
     nnz = int(A.nnz)
     deg_full = np.diff(A.indptr)
-    sharded_inputs = world > 1 and args.inputs == 'sharded'
+    sharded_inputs = (world > 1 or args.force_dist) and args.inputs == 'sharded'
     if sharded_inputs:
         from cna_amd import dist
         data = dist.shard(data, rank, world)     # from here on this rank knows its own cells only
