@@ -182,6 +182,7 @@ int cna_ctx_create(int device, cna_ctx** out) {
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->gram_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->coef_ready, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->gt_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->coef_copied, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->null_done, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -208,6 +209,8 @@ int cna_ctx_destroy(cna_ctx* c) {
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->gram_done) (void)hipEventDestroy(c->gram_done);
   if (c->coef_ready) (void)hipEventDestroy(c->coef_ready);
+  if (c->gt_done) (void)hipEventDestroy(c->gt_done);
+  if (c->h_gt) (void)hipHostFree(c->h_gt);
   if (c->coef_copied) (void)hipEventDestroy(c->coef_copied);
   if (c->null_done) (void)hipEventDestroy(c->null_done);
   if (c->h_res) (void)hipHostFree(c->h_res);
@@ -277,6 +280,7 @@ int cna_graph_upload(cna_ctx* c, int64_t n_global, int64_t row0, int64_t n_local
   c->x_valid = false;
   c->ncorrs_valid = false;
   c->coef_early = false;
+  c->fdr_inline = false;
   c->steps_done = 0;
   return 0;
 }
@@ -755,6 +759,7 @@ int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_
   c->x_from_nam = true;
   c->ncorrs_valid = false;
   c->coef_early = false;
+  c->fdr_inline = false;
   return 0;
 }
 
@@ -807,6 +812,7 @@ int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep,
   c->x_from_nam = true;
   c->ncorrs_valid = y != nullptr;     // meaningful only when no cell had zero variance (the caller checks)
   c->coef_early = false;
+  c->fdr_inline = false;
   return 0;
 }
 
@@ -829,6 +835,7 @@ int cna_upload_x(cna_ctx* c, const double* x_local, int64_t n_rows, int n_cols) 
   c->x_from_nam = false;
   c->ncorrs_valid = false;
   c->coef_early = false;
+  c->fdr_inline = false;
   return 0;
 }
 
@@ -847,6 +854,7 @@ int cna_resid_apply(cna_ctx* c, const double* M, int center) {
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->ncorrs_valid = false;
   c->coef_early = false;
+  c->fdr_inline = false;
   return 0;
 }
 
@@ -856,6 +864,7 @@ int cna_standardize(cna_ctx* c, int center) {
   CNA_TRY(launch_standardize(c, center));
   c->ncorrs_valid = false;
   c->coef_early = false;
+  c->fdr_inline = false;
   return 0;
 }
 
@@ -955,6 +964,7 @@ int cna_ncorrs(cna_ctx* c, const double* y, double* out_local, double* max_abs) 
   if (max_abs) *max_abs = m;
   c->ncorrs_valid = true;
   c->coef_early = false;
+  c->fdr_inline = false;
   return 0;
 }
 
@@ -1037,6 +1047,7 @@ static int null_local_prepare(cna_ctx* c, int P, const double* edges, int T, int
   for (int t = 1; t < T; ++t)
     if (!(edges[t] >= edges[t - 1])) CNA_FAIL(CNA_EINVAL, "cna_null_local: edges must ascend");
   c->null_prepared = 0;
+  c->fdr_inline = false;
   std::vector<double> cuts;
   exact_cuts(edges, T, c->Nx, cuts, &c->null_cut0, &c->null_inv_step, &c->null_eps);
   const int64_t obs_off = 8 * (int64_t)T + (want_tails ? 8 * (int64_t)P * T : 0);
@@ -1066,6 +1077,8 @@ static int null_local_prepare(cna_ctx* c, int P, const double* edges, int T, int
     if (!c->ncorrs_valid) CNA_FAIL(CNA_ESTATE, "threshold counts need cna_ncorrs");
     double thr0, ostep;
     guess_from_thr(thr, T, &thr0, &ostep);
+    c->null_thr0 = thr0;
+    c->null_thr_step = ostep;
     HIP_TRY(hipMemcpyAsync(oed, edges, 8 * T, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(otd, thr, 8 * T, hipMemcpyHostToDevice, c->stream));
     CNA_TRY(launch_obs_counts(c, oed, otd, T, thr0, ostep, ohist));
@@ -1098,10 +1111,36 @@ static int null_local_go(cna_ctx* c, int col0) {
   // columns beyond col0+P inside the last 64-wide tile are other phenotypes: the kernel only
   // flushes counters of p < P, and reads stay inside the zero-padded leading dimension
   CNA_TRY(launch_null_local(c, c->zc + col0, c->zc_ld, P, ed, T, c->null_cut0, c->null_inv_step, c->null_eps, hist));
-  CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)P * T));
+  // suffix sums and the sum over permutations are linear: when only the sums are wanted the ranks
+  // exchange T integers instead of the P x T histogram
+  if (c->null_has_tails) CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)P * T));
   CNA_TRY(launch_suffix_sum(c, hist, P, T, tails));
   CNA_TRY(launch_tail_sums(c, tails, P, T, sums));
+  if (!c->null_has_tails) CNA_TRY(comm_allreduce_i64_sum(c, sums, (size_t)T));
   HIP_TRY(hipMemcpyAsync(c->h_res, sums, 8 * (size_t)T, hipMemcpyDeviceToHost, c->stream));
+  if (c->coef_early && c->null_has_obs && T <= 512) {
+    // the caller already has the coefficient column (cna_percell_coef_launch): the FDR column can
+    // follow the null without the host in between -- FDR table from the tail sums and the observed
+    // counts (still in the scratch carve of the prepare half), per-cell lookup, copy to the pinned block
+    cv.take<double>(T);                                    // oed
+    double* otd = cv.take<double>(T);
+    cv.take<unsigned long long>(2 * (int64_t)T);           // ohist
+    int64_t* otails = cv.take<int64_t>(2 * (int64_t)T);    // [ranks | num_detected]
+    const int64_t n_out = c->local_view ? c->n_local : c->n_global;
+    double* coef_local = c->coef_dev;
+    double* fdr_local = c->coef_dev + 2 * c->n_pad;
+    double* fdr_u = c->coef_dev + 3 * c->n_pad;
+    double* tab = c->coef_dev + 4 * c->n_pad;
+    CNA_TRY(launch_fdr_table(c, sums, otails, T, P, tab, tab + 512));
+    CNA_TRY(launch_percell_lookup(c, coef_local, otd, tab + 512, T, c->null_thr0, c->null_thr_step, fdr_local));
+    const double* src = fdr_local;
+    if (c->orig_idx) {
+      CNA_TRY(launch_unpermute2(c, fdr_local, nullptr, c->orig_idx, c->n_local, fdr_u, nullptr));
+      src = fdr_u;
+    }
+    CNA_TRY(launch_store_host(c, src, n_out, (double*)c->h_cell + n_out));   // not a memcpy: see k_store_host
+    c->fdr_inline = true;
+  }
   if (c->null_has_tails)
     HIP_TRY(hipMemcpyAsync((char*)c->h_res + 8 * (size_t)T, tails, 8 * (size_t)P * T, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipEventRecord(c->null_done, c->stream));
@@ -1204,14 +1243,17 @@ int cna_condition_phenotypes(cna_ctx* c, const double* M, const double* Y, int N
   return 0;
 }
 
-int cna_global_test(cna_ctx* c, const double* U, int kmax, const int32_t* ks, int K, int r, double* minp_out,
-                    double* r2_out, int32_t* kidx_out) {
+// The global F-tests in two halves: launch stages U and ks in pinned memory, queues upload, kernels
+// and the copy of the three result vectors back into the pinned block on the second stream, and
+// returns; fetch waits for them.  The caller can do host work (write the coefficient column) between.
+int cna_global_test_launch(cna_ctx* c, const double* U, int kmax, const int32_t* ks, int K, int r) {
   CHECK_CTX(c);
   if (!c->zc || c->zc_cols < 1 || c->zc_rows != c->Nx) CNA_FAIL(CNA_ESTATE, "cna_global_test needs cna_condition_phenotypes");
   const int N = c->Nx, P = c->zc_cols;
   if (kmax < 1 || kmax > N || K < 1) CNA_FAIL(CNA_EINVAL, "cna_global_test: bad kmax / K");
   for (int a = 0; a < K; ++a)
     if (ks[a] < 1 || ks[a] > kmax) CNA_FAIL(CNA_EINVAL, "cna_global_test: ks must lie in [1, kmax]");
+  if (c->gt_pending_P) CNA_FAIL(CNA_ESTATE, "a global test is still pending: fetch it first");
   void* g = c->gt;
   CNA_TRY(dev_reserve(c, &g, &c->gt_cap, carve_bytes({8 * (int64_t)N * kmax, 4 * (int64_t)K, 8 * (int64_t)P, 8 * (int64_t)P, 4 * (int64_t)P})));
   c->gt = g;
@@ -1221,17 +1263,50 @@ int cna_global_test(cna_ctx* c, const double* U, int kmax, const int32_t* ks, in
   double* mp = cv.take<double>(P);
   double* r2 = cv.take<double>(P);
   int32_t* ki = cv.take<int32_t>(P);
+  const int64_t off_ks = 8 * (int64_t)N * kmax;
+  const int64_t off_out = round_up(off_ks + 4 * (int64_t)K, 64);
+  const int64_t need = off_out + 20 * (int64_t)P + 64;
+  if (need > c->h_gt_cap) {
+    if (c->h_gt) HIP_TRY(hipHostFree(c->h_gt));
+    c->h_gt = nullptr;
+    HIP_TRY(hipHostMalloc(&c->h_gt, (size_t)need, hipHostMallocDefault));
+    c->h_gt_cap = need;
+  }
+  char* h = (char*)c->h_gt;
+  std::memcpy(h, U, 8 * (size_t)N * kmax);
+  std::memcpy(h + off_ks, ks, 4 * (size_t)K);
   // Runs on the copy stream: Zc is complete (cna_condition_phenotypes synchronised) and only read, so
   // these tiny kernels need not queue behind a local-null pass in flight on the main stream.
   hipStream_t st = c->copy_stream;
-  HIP_TRY(hipMemcpyAsync(Ud, U, 8 * (size_t)N * kmax, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(ksd, ks, 4 * (size_t)K, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(Ud, h, 8 * (size_t)N * kmax, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(ksd, h + off_ks, 4 * (size_t)K, hipMemcpyHostToDevice, st));
   CNA_TRY(launch_global_test(c, st, c->zc, c->zc_ld, N, P, Ud, kmax, ksd, K, r, mp, r2, ki));
-  HIP_TRY(hipMemcpyAsync(minp_out, mp, 8 * (size_t)P, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(r2_out, r2, 8 * (size_t)P, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(kidx_out, ki, 4 * (size_t)P, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipMemcpyAsync(h + off_out, mp, 8 * (size_t)P, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h + off_out + 8 * (size_t)P, r2, 8 * (size_t)P, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(h + off_out + 16 * (size_t)P, ki, 4 * (size_t)P, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipEventRecord(c->gt_done, st));
+  c->gt_pending_P = P;
+  c->gt_off_out = off_out;
   return 0;
+}
+
+int cna_global_test_fetch(cna_ctx* c, double* minp_out, double* r2_out, int32_t* kidx_out) {
+  CHECK_CTX(c);
+  if (!c->gt_pending_P) CNA_FAIL(CNA_ESTATE, "no global test pending");
+  const size_t P = (size_t)c->gt_pending_P;
+  c->gt_pending_P = 0;
+  HIP_TRY(hipEventSynchronize(c->gt_done));
+  const char* o = (const char*)c->h_gt + c->gt_off_out;
+  if (minp_out) std::memcpy(minp_out, o, 8 * P);
+  if (r2_out) std::memcpy(r2_out, o + 8 * P, 8 * P);
+  if (kidx_out) std::memcpy(kidx_out, o + 16 * P, 4 * P);
+  return 0;
+}
+
+int cna_global_test(cna_ctx* c, const double* U, int kmax, const int32_t* ks, int K, int r, double* minp_out,
+                    double* r2_out, int32_t* kidx_out) {
+  CNA_TRY(cna_global_test_launch(c, U, kmax, ks, K, r));
+  return cna_global_test_fetch(c, minp_out, r2_out, kidx_out);
 }
 
 int cna_obs_counts(cna_ctx* c, const double* edges, const double* thr, int T, int64_t* ranks_out,
@@ -1266,6 +1341,7 @@ static int ensure_cell_pinned(cna_ctx* c, int64_t n_out) {
     if (c->h_cell) HIP_TRY(hipHostFree(c->h_cell));
     c->h_cell = nullptr;
     c->coef_early = false;
+  c->fdr_inline = false;
     HIP_TRY(hipHostMalloc(&c->h_cell, (size_t)need, hipHostMallocDefault));
     c->h_cell_cap = need;
   }
@@ -1284,7 +1360,7 @@ int cna_percell_coef_launch(cna_ctx* c) {
   const int64_t n_out = c->local_view ? c->n_local : c->n_global;
   CNA_TRY(ensure_cell_pinned(c, n_out));
   void* p = c->coef_dev;
-  CNA_TRY(dev_reserve(c, &p, &c->coef_dev_cap, 16 * std::max<int64_t>(c->n_pad, 1)));
+  CNA_TRY(dev_reserve(c, &p, &c->coef_dev_cap, 32 * std::max<int64_t>(c->n_pad, 1) + 16 * 512));   // coef, coef_u, fdr, fdr_u, FDR table
   c->coef_dev = (double*)p;
   double* tmp = c->coef_dev;
   double* out = tmp;
@@ -1320,6 +1396,13 @@ int cna_percell_fdr_pinned(cna_ctx* c, const double* thr, const double* runmin_f
   double* hc = (double*)c->h_cell;
   const bool want_fdr = fdr_ptr && thr && runmin_fdr && T > 0;
   if (c->coef_early) HIP_TRY(hipEventSynchronize(c->coef_copied));     // coefficients already on the host
+  if (c->coef_early && c->fdr_inline && want_fdr && T == c->null_T && !c->null_pending) {
+    // both columns are in the pinned block already (the FDR one was queued behind the local null)
+    HIP_TRY(hipEventSynchronize(c->null_done));
+    *coef_ptr = hc;
+    *fdr_ptr = hc + n_out;
+    return 0;
+  }
   CNA_TRY(cna_percell_fdr(c, thr, runmin_fdr, T, c->coef_early ? nullptr : hc, want_fdr ? hc + n_out : nullptr));
   *coef_ptr = hc;
   if (fdr_ptr) *fdr_ptr = want_fdr ? hc + n_out : nullptr;

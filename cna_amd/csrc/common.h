@@ -137,10 +137,17 @@ struct cna_ctx {
   double null_cut0 = 0, null_inv_step = 0, null_eps = 0;
   int null_has_obs = 0;
   int64_t null_obs_off = 0;
+  void* h_gt = nullptr;           // pinned staging of cna_global_test_launch / _fetch: U, ks | minp, r2, kidx
+  int64_t h_gt_cap = 0;
+  hipEvent_t gt_done = nullptr;
+  int gt_pending_P = 0;           // > 0: a launched global test waits to be fetched (its number of columns)
+  int64_t gt_off_out = 0;
   double* coef_dev = nullptr;     // early copy of the per-cell coefficients (cna_percell_coef_launch): 2 x n_pad
   int64_t coef_dev_cap = 0;
   hipEvent_t coef_ready = nullptr, coef_copied = nullptr;
   bool coef_early = false;        // h_cell[0, n_out) already holds the coefficients of the current ncorrs
+  bool fdr_inline = false;        // ... and h_cell[n_out, 2 n_out) the per-cell FDRs of the last local-null pass
+  double null_thr0 = 0, null_thr_step = 0;   // linear guess over the thresholds of the prepared pass
   void* h_cell = nullptr;         // pinned: per-cell outputs of cna_percell_fdr_pinned (coef | fdr)
   int64_t h_cell_cap = 0;
   // compressed copy of the state after the first walk step (single GPU, wide sample axis)
@@ -216,6 +223,10 @@ int launch_obs_counts(cna_ctx* c, const double* edges_dev, const double* thr_dev
                       double inv_step, unsigned long long* hist_dev /* 2*T */);
 int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, int64_t* tails);
 int launch_tail_sums(cna_ctx* c, const int64_t* tails, int P, int T, int64_t* sums);
+int launch_store_host(cna_ctx* c, const double* src, int64_t n, double* dst_host);
+int launch_fdr_table(cna_ctx* c, const int64_t* sums, const int64_t* ranks, int T, int P, double* fdr, double* runmin);
+int launch_percell_lookup(cna_ctx* c, const double* coef_local, const double* thr_dev, const double* runmin_dev, int T,
+                          double thr0, double inv_step, double* fdr_local);
 int launch_unpermute2(cna_ctx* c, const double* a, const double* b, const int64_t* idx, int64_t n, double* oa,
                       double* ob);
 int launch_percell_fdr(cna_ctx* c, const double* thr_dev, const double* runmin_dev, int T, double thr0,

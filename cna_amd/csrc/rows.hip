@@ -694,6 +694,64 @@ int launch_percell_fdr(cna_ctx* c, const double* thr_dev, const double* runmin_d
   return 0;
 }
 
+// fdr[t] = sums[t] / ranks[t] / P and its running fmin (reference _stats.py:79-80, _association.py:234):
+// the per-threshold FDR table, on the device so that the per-cell lookup can follow the local null
+// without a host round trip.  Same operations in the same order as the numpy expressions.
+__global__ __launch_bounds__(512) void k_fdr_table(const int64_t* __restrict__ sums, const int64_t* __restrict__ ranks,
+                                                   int T, int P, double* __restrict__ fdr, double* __restrict__ runmin) {
+  // one thread per threshold (T <= 512); the running fmin is an inclusive scan -- fmin with NaN as
+  // its neutral element is associative, so the scan equals numpy's left-to-right accumulate
+  __shared__ double sh[2][512];
+  const int t = threadIdx.x;
+  double f = __builtin_nan("");
+  if (t < T) {
+    f = __ddiv_rn(__ddiv_rn((double)sums[t], (double)ranks[t]), (double)P);
+    fdr[t] = f;
+  }
+  int cur = 0;
+  sh[0][t] = f;
+  __syncthreads();
+  for (int d = 1; d < 512; d <<= 1) {
+    const double v = t >= d ? fmin(sh[cur][t - d], sh[cur][t]) : sh[cur][t];
+    sh[cur ^ 1][t] = v;
+    cur ^= 1;
+    __syncthreads();
+  }
+  if (t < T) runmin[t] = sh[cur][t];
+}
+
+// device -> pinned host by store instructions (a hipMemcpyAsync queued behind a long kernel holds up
+// the copy engine's queue for every other stream's copies until that kernel is done)
+__global__ void k_store_host(const double* __restrict__ src, int64_t n, double* __restrict__ dst_host) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    __builtin_nontemporal_store(src[i], &dst_host[i]);
+}
+
+int launch_store_host(cna_ctx* c, const double* src, int64_t n, double* dst_host) {
+  if (n == 0) return 0;
+  const int64_t want = (n + 255) / 256;
+  hipLaunchKernelGGL(k_store_host, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(256), 0, c->stream, src, n, dst_host);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_fdr_table(cna_ctx* c, const int64_t* sums, const int64_t* ranks, int T, int P, double* fdr, double* runmin) {
+  hipLaunchKernelGGL(k_fdr_table, dim3(1), dim3(512), 0, c->stream, sums, ranks, T, P, fdr, runmin);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_percell_lookup(cna_ctx* c, const double* coef_local, const double* thr_dev, const double* runmin_dev, int T,
+                          double thr0, double inv_step, double* fdr_local) {
+  const int64_t n = c->n_local;
+  if (n == 0) return 0;
+  ProfScope ps(c, CNA_K_PERCELL_FDR);
+  hipLaunchKernelGGL(k_percell_fdr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, coef_local, n, thr_dev,
+                     runmin_dev, T, thr0, inv_step, fdr_local);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int launch_unpermute2(cna_ctx* c, const double* a, const double* b, const int64_t* idx, int64_t n, double* oa,
                       double* ob) {
   if (n == 0) return 0;

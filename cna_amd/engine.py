@@ -426,6 +426,19 @@ class Engine(_order.CellOrder):
               'cna_global_test')
         return kidx, minp, r2
 
+    def global_test_launch(self, U, ks, r):
+        """First half of global_test(): queue it and return; collect with global_test_fetch()."""
+        ks = np.ascontiguousarray(ks, dtype=np.int32)
+        kmax = int(ks.max())
+        Uk = _f64(U[:, :kmax])
+        check(self.lib.cna_global_test_launch(self.h, ptr(Uk), kmax, ptr(ks), len(ks), int(r)), 'cna_global_test_launch')
+
+    def global_test_fetch(self):
+        P = self._zc_cols
+        minp, r2, kidx = np.empty(P), np.empty(P), np.empty(P, dtype=np.int32)
+        check(self.lib.cna_global_test_fetch(self.h, ptr(minp), ptr(r2), ptr(kidx)), 'cna_global_test_fetch')
+        return kidx, minp, r2
+
     def obs_counts(self, edges, thr):
         edges, thr = _f64(edges), _f64(thr)
         T = len(thr)

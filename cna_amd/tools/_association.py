@@ -99,6 +99,7 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     if maxabs is None:
         _, maxabs = engine.ncorrs(y, fetch=False)
     pending = False
+    coef_early = False
     thresholds = edges = None
     if local_test:
         Nloc = min(1000, Nnull)
@@ -110,10 +111,9 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         # counts of the observed coefficients) goes out now
         engine.null_local_prepare(Nloc, edges, thresholds)
         # the coefficient column does not depend on the null: queued in front of the null kernel it is
-        # on the host while that kernel runs, and on_coef (a callable) may consume it from another thread
-        if on_coef is not None and _EARLY_COEF and getattr(engine, 'percell_coef_launch', None) is not None \
-                and engine.percell_coef_launch():
-            on_coef()
+        # on the host while that kernel runs (consumed below, between the two halves of the F-tests)
+        coef_early = (on_coef is not None and _EARLY_COEF and getattr(engine, 'percell_coef_launch', None) is not None
+                      and getattr(engine, 'global_test_launch', None) is not None and engine.percell_coef_launch())
 
     if null_source is not None:
         y_, conditioned = null_source()
@@ -134,7 +134,16 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105), and the global F-tests of the
         # observed phenotype and every permutation (second stream), all under the local-null kernel
         U, svs, _ = _small_svd(engine.gram_fetch())
-        best, pv, r2v = engine.global_test(U, ks_arr, r)
+        if coef_early:
+            # F-tests queued (second stream); while they and the local null run, the coefficient
+            # column -- already on the host -- goes into data.obs
+            engine.global_test_launch(U, ks_arr, r)
+            try:
+                on_coef(engine.percell_coef_wait())
+            finally:
+                best, pv, r2v = engine.global_test_fetch()
+        else:
+            best, pv, r2v = engine.global_test(U, ks_arr, r)
     finally:
         if pending:
             tail_sums, ranks, num_detected = engine.null_local_fetch()   # never leave a pass pending behind an exception
@@ -425,19 +434,18 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         y_null = null_future.result()[1]
         _mark('null drawn')
         return y_null, early.get('conditioned', False)
-    # data.obs[key_added] is written early, by the helper thread, while the local-null kernel runs
-    # (the main thread is inside LAPACK / the F-test call then); should the test still fail, the
-    # column is put back as it was, so that -- like upstream -- an exception leaves data.obs alone
+    # data.obs[key_added] is written early, while the local-null kernel runs (between the two halves
+    # of the F-test call); should the test still fail, the column is put back as it was, so that --
+    # like upstream -- an exception leaves data.obs alone
     early_coef = {}
     had_key = key_added in data.obs
     previous = data.obs[key_added] if had_key else None
 
-    def write_coef_early():
-        def job():
-            coef = engine.percell_coef_wait()
-            data.obs[key_added] = coef
-            return data.obs[key_added].values
-        early_coef['future'] = _background().submit(job)
+    def write_coef_early(coef):
+        early_coef['written'] = True
+        data.obs[key_added] = coef
+        early_coef['values'] = data.obs[key_added].values
+        _mark('coef column written')
 
     try:
         coef_all, fdr_all, U, svs = _association(engine, res, y_std, None, ks=ks, Nnull=Nnull,
@@ -446,15 +454,11 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                                                  null_source=drawn,
                                                  maxabs=getattr(plan, 'maxabs', None), on_coef=write_coef_early)
     except BaseException:
-        fut = early_coef.get('future')
-        if fut is not None:
-            try:
-                fut.result()
-            finally:
-                if had_key:
-                    data.obs[key_added] = previous
-                elif key_added in data.obs:
-                    del data.obs[key_added]
+        if early_coef.get('written'):
+            if had_key:
+                data.obs[key_added] = previous
+            elif key_added in data.obs:
+                del data.obs[key_added]
         raise
     _mark('_association returned')
     _defer_pcs(res, engine, U, svs, cell_index)
@@ -475,8 +479,8 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     _mark('warned')
     # coef_all / fdr_all may be views of the engine's pinned buffers: the DataFrame stores its own
     # copy, and that copy (not the view) is what res.ncorrs is built from when somebody reads it
-    if 'future' in early_coef:
-        coef_kept = early_coef['future'].result()        # written while the null kernel was running
+    if 'values' in early_coef:
+        coef_kept = early_coef['values']                 # written while the null kernel was running
     else:
         data.obs[key_added] = coef_all
         coef_kept = data.obs[key_added].values

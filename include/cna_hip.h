@@ -221,6 +221,9 @@ int  cna_null_local_fetch(cna_ctx* ctx, int64_t* tails_out, int64_t* tail_sums_o
                           int64_t* ranks_out, int64_t* num_detected_out /* both NULL unless thr was given */);
 int  cna_global_test(cna_ctx* ctx, const double* U, int kmax, const int32_t* ks, int K, int r,
                      double* minp_out, double* r2_out, int32_t* kidx_out);
+/* The same in two halves (launch returns at once; U and ks are copied before it returns). */
+int  cna_global_test_launch(cna_ctx* ctx, const double* U, int kmax, const int32_t* ks, int K, int r);
+int  cna_global_test_fetch(cna_ctx* ctx, double* minp_out, double* r2_out, int32_t* kidx_out);
 /* ranks[t] = #{i : ncorrs_i^2 >= edges[t]} (_stats.py:74) and
  * num_detected[t] = #{i : |ncorrs_i| > thr[t]} (_association.py:108), summed over ranks */
 int  cna_obs_counts(cna_ctx* ctx, const double* edges, const double* thr, int T,

@@ -481,7 +481,8 @@ def test_ordered_fetch_on_device_equals_host_reorder(monkeypatch):
 
 
 def test_failed_test_leaves_obs_untouched(eng, monkeypatch):
-    """data.obs[key_added] is written early (helper thread, under the local-null kernel).  When the
+    """data.obs[key_added] is written early (between the two halves of the F-test call, under the
+    local-null kernel).  When the
     association test then fails, the column is put back -- absent if it was absent, the old values if
     it existed -- and the next call works: like upstream, an exception leaves data.obs alone."""
     import cna_amd as cna
@@ -491,28 +492,36 @@ def test_failed_test_leaves_obs_untouched(eng, monkeypatch):
     data, meta = synth.make_dataset(5000, 24, k=15, seed=3)
     kw = dict(Nnull=100, seed=1, nsteps=3)
 
-    def boom(*a, **k):
+    real = eng.global_test_fetch
+
+    def boom(*a, **k):                       # fails after the coefficient column has been written
+        real()
+        assert 'coef' in data.obs
         raise FloatingPointError('injected')
-    real = eng.global_test
-    monkeypatch.setattr(eng, 'global_test', boom)
+    monkeypatch.setattr(eng, 'global_test_fetch', boom)
     with pytest.raises(FloatingPointError):
         cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
     assert 'coef' not in data.obs and 'coef_fdr' not in data.obs
-    monkeypatch.setattr(eng, 'global_test', real)
+    monkeypatch.setattr(eng, 'global_test_fetch', real)
     p1 = cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
     before = data.obs['coef'].values.copy()
+    before_fdr = data.obs['coef_fdr'].values.copy()
+    assert (before_fdr < 1).any() and (before_fdr == 1).any()
     y2 = pd.Series(np.random.RandomState(2).randn(24), index=meta['y'].index)
-    monkeypatch.setattr(eng, 'global_test', boom)
+    monkeypatch.setattr(eng, 'global_test_fetch', boom)
     with pytest.raises(FloatingPointError):
         cna.tl.association(data, y2, 'id', engine=eng, **kw)
     np.testing.assert_array_equal(data.obs['coef'].values, before)
-    monkeypatch.setattr(eng, 'global_test', real)
+    monkeypatch.setattr(eng, 'global_test_fetch', real)
     assert cna.tl.association(data, meta['y'], 'id', engine=eng, **kw) == p1
     np.testing.assert_array_equal(data.obs['coef'].values, before)
-    # the early path and the one-shot path write the same column
+    np.testing.assert_array_equal(data.obs['coef_fdr'].values, before_fdr)
+    # the early / inline path (coefficients ahead of the null, FDR column queued behind it with the
+    # FDR table formed on the device) and the one-shot path write the same two columns, bit for bit
     monkeypatch.setattr(A, '_EARLY_COEF', False)
     assert cna.tl.association(data, meta['y'], 'id', engine=eng, **kw) == p1
     np.testing.assert_array_equal(data.obs['coef'].values, before)
+    np.testing.assert_array_equal(data.obs['coef_fdr'].values, before_fdr)
 
 
 def test_nam_cache_on_device(eng):
