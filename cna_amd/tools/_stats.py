@@ -60,14 +60,19 @@ def conditional_permutation(B, Y, num, clean=False):
 
     RNG consumption: one ``randn(len(level), num)`` block per level, levels in
     ``np.unique`` order.  ``clean``: see legacy_randn."""
-    members = [np.flatnonzero(B == b) for b in np.unique(B)]
-    shuffled = []
-    for m in members:
-        shuffled.append(m[np.argsort(legacy_randn(len(m), num, clean), axis=0)])
+    levels = np.unique(B)
+    if len(levels) == 1 and len(B) == len(Y):
+        # one level: members = arange(n), so src is the argsort itself
+        return Y[np.argsort(legacy_randn(len(Y), num, clean), axis=0)]
+    # several levels: out[m] = Y[m[argsort]] = (Y[m])[argsort], level by level, without forming src
+    out = np.empty((len(Y), num), dtype=Y.dtype)
+    if len(Y):
+        out[:] = Y[0]                         # rows of no level (NaN batch labels): upstream's src stays 0 there
+    for b in levels:
+        m = np.flatnonzero(B == b)
+        out[m] = Y[m][np.argsort(legacy_randn(len(m), num, clean), axis=0)]
         clean = clean and (len(m) * num) % 2 == 0
-    src = np.zeros((len(Y), num), dtype=int)
-    src[np.concatenate(members)] = np.concatenate(shuffled)
-    return Y[src]
+    return out
 
 
 def grouplevel_permutation(G, Y, num, clean=False):
