@@ -35,9 +35,9 @@ F64_MFMA_PEAK_TF = 78.6      # AMD MI355X datasheet: FP64 matrix 78.6 TFLOP/s (t
 # gfx950 correction, re-calibrated here on k_ncorrs (streams the 83.2 MB matrix once, FETCH_SIZE reads 41.6 MB).
 # Counted at the L2's fabric side, i.e. Infinity-Cache hits included.  Only valid for the profiled workload.
 PMC_TRAFFIC = {
-    ('C2', 'nam_step'): 2 * 184100e3 + 83530e3,
+    ('C2', 'nam_step'): 2 * 195300e3 + 84590e3,
     ('C2', 'nam_first'): 2 * 37780e3 + 81250e3,
-    ('C2', 'null_local'): 2 * (2 * 41630e3 + 18750e3),     # two launches per pass
+    ('C2', 'null_local'): 2 * (2 * 41660e3 + 18750e3),     # two launches per pass
 }
 
 WORKLOADS = {
