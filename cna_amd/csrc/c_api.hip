@@ -816,6 +816,65 @@ int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep,
   return 0;
 }
 
+// thresholds = np.arange(maxcorr/4, maxcorr, maxcorr/400) and edges = thr**2 - 1e-8 - 1e-5*thr**2
+// exactly as numpy evaluates them (_association.py:101-103, _stats.py:47): arange's length is
+// ceil((stop - start) / step) and its values start + i*delta with delta = (start + step) - start;
+// the edge expression rounds after every operation, left to right.  Returns T (0: out of range).
+static int null_local_prepare(cna_ctx* c, int P, const double* edges, int T, int want_tails, const double* thr);
+
+int cna_reference_thresholds(double maxabs, int cap, double* thr, double* edges) {
+#pragma clang fp contract(off)
+  const double maxcorr = maxabs > 0.001 ? maxabs : 0.001;
+  if (!(maxcorr < 1e300)) return 0;
+  const double start = maxcorr / 4, stop = maxcorr, step = maxcorr / 400;
+  const double len = std::ceil((stop - start) / step);
+  if (!(len >= 1) || len > cap) return 0;
+  const int T = (int)len;
+  const double next = start + step;
+  const double delta = next - start;
+  for (int i = 0; i < T; ++i) {
+    volatile double t = i == 0 ? start : (i == 1 ? next : start + (double)i * delta);
+    thr[i] = t;
+    volatile double z2 = t * t;
+    volatile double a = z2 - 1e-8;
+    volatile double b = 1e-5 * z2;
+    edges[i] = a - b;
+  }
+  return T;
+}
+
+// select + standardise + coefficients (cna_select_standardized with y) and, when no selected cell has
+// zero variance, everything the host would issue next from values it has to wait for anyway -- the
+// Gram kernels, the thresholds of the local null from max|ncorrs|, the threshold-only half of the
+// local-null pass (cna_null_local_prepare) and the early coefficient column -- in the same call, so
+// that none of it waits for the interpreter.  *T_out = 0: nothing beyond the selection was issued.
+int cna_select_standardized_fused(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
+                                  int64_t* n_zero_out, const double* y, double* max_abs_out, int null_P, int* T_out,
+                                  double* thr_out, int* gram_queued, int* coef_queued) {
+  if (T_out) *T_out = 0;
+  if (gram_queued) *gram_queued = 0;
+  if (coef_queued) *coef_queued = 0;
+  int64_t nz = 0;
+  double m = 0.0;
+  CNA_TRY(cna_select_standardized(c, keep_idx, n_keep, colmap, n_sel, &nz, y, &m));
+  if (n_zero_out) *n_zero_out = nz;
+  if (max_abs_out) *max_abs_out = m;
+  if (nz != 0 || !y) return 0;
+  CNA_TRY(cna_gram_launch(c));
+  if (gram_queued) *gram_queued = 1;
+  if (null_P < 1 || !T_out || !thr_out || c->null_pending) return 0;
+  double edges[512];
+  const int T = cna_reference_thresholds(m, 512, thr_out, edges);
+  if (T < 1) return 0;
+  CNA_TRY(null_local_prepare(c, null_P, edges, T, 0, thr_out));
+  *T_out = T;
+  if (coef_queued && !((c->nranks > 1 || comm_active(c)) && !c->local_view)) {
+    CNA_TRY(cna_percell_coef_launch(c));
+    *coef_queued = 1;
+  }
+  return 0;
+}
+
 int cna_upload_x(cna_ctx* c, const double* x_local, int64_t n_rows, int n_cols) {
   CHECK_CTX(c);
   if (n_rows < 0 || n_cols < 1 || n_cols > 512) CNA_FAIL(CNA_EINVAL, "cna_upload_x: bad shape");

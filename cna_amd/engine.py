@@ -288,20 +288,48 @@ class Engine(_order.CellOrder):
         check(self.lib.cna_select(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm)), 'cna_select')
         self.x_epoch += 1
 
-    def select_standardized(self, keep_global, colmap, y=None):
+    def select_standardized(self, keep_global, colmap, y=None, fuse_null=0):
         """select() + centre + divide by std in one pass (M = I); returns the number of selected
         cells with zero variance (non-zero: redo with zero_variance()/select()).  With ``y`` (the
         standardised phenotype in the selected samples' order) the neighbourhood coefficients are
-        taken in the same pass and (n_zero, max |ncorrs|) is returned -- ncorrs(y) is then done."""
+        taken in the same pass and (n_zero, max |ncorrs|) is returned -- ncorrs(y) is then done.
+        ``fuse_null`` = P > 0 (with y): when no cell has zero variance the same call also queues what
+        would follow from values it returns -- gram_launch(), the thresholds of the local null from
+        max|ncorrs|, null_local_prepare(P, ...) and percell_coef_launch(); those methods then find
+        their work done (they compare arguments) and return at once."""
         cm = None if colmap is None else np.ascontiguousarray(colmap, dtype=np.int32)
         idx, nk = self._selection(keep_global)
         nz = C.c_int64(0)
         m = C.c_double(0.0)
         yv = None if y is None else _f64(y)
+        self._fused = None
+        if yv is not None and fuse_null > 0:
+            T, gq, cq = C.c_int(0), C.c_int(0), C.c_int(0)
+            thr = np.empty(512)
+            check(self.lib.cna_select_standardized_fused(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm),
+                                                         C.byref(nz), ptr(yv), C.byref(m), int(fuse_null), C.byref(T),
+                                                         ptr(thr), C.byref(gq), C.byref(cq)),
+                  'cna_select_standardized_fused')
+            self.x_epoch += 1
+            self._fused = dict(epoch=self.x_epoch, P=int(fuse_null), thr=thr[:T.value], gram=bool(gq.value),
+                               coef=bool(cq.value), prepared=T.value > 0)
+            if gq.value:
+                self._gram_cols = self.N if cm is None else len(cm)
+            if T.value:
+                self._null_T, self._null_obs = T.value, True
+            return nz.value, m.value
         check(self.lib.cna_select_standardized(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm),
                                                C.byref(nz), ptr(yv), C.byref(m)), 'cna_select_standardized')
         self.x_epoch += 1
         return nz.value if y is None else (nz.value, m.value)
+
+    def _fused_done(self, what):
+        """True once: the fused selection call already issued `what` for the current working matrix."""
+        f = getattr(self, '_fused', None)
+        if f is None or f['epoch'] != self.x_epoch or not f.get(what):
+            return False
+        f[what] = False
+        return True
 
     def upload_x(self, x_local):
         x_local = _f64(x_local)
@@ -325,6 +353,8 @@ class Engine(_order.CellOrder):
         return G
 
     def gram_launch(self):
+        if self._fused_done('gram'):
+            return
         check(self.lib.cna_gram_launch(self.h), 'cna_gram_launch')
         self._gram_cols = self.matrix_shape(MAT_X)[1]
 
@@ -385,6 +415,13 @@ class Engine(_order.CellOrder):
         finish with null_local_launch(col0, P, None)."""
         edges = _f64(edges)
         thr = None if thr is None else _f64(thr)
+        f = getattr(self, '_fused', None)
+        if (thr is not None and f is not None and f['epoch'] == self.x_epoch and f['prepared'] and f['P'] == int(P)
+                and np.array_equal(f['thr'], thr)):
+            f['prepared'] = False             # the fused selection call prepared exactly this pass
+            return
+        if f is not None:
+            f['coef'] = False                 # a fresh prepare: whatever rode along with the fused one is void
         check(self.lib.cna_null_local_prepare(self.h, int(P), ptr(edges), len(edges), 0, ptr(thr)),
               'cna_null_local_prepare')
         self._null_T = len(edges)
@@ -465,6 +502,8 @@ class Engine(_order.CellOrder):
         observed phenotype); False when this engine assembles per-cell outputs across ranks."""
         if (self.nranks > 1 or self._has_comm) and not self.view_local:
             return False
+        if self._fused_done('coef'):
+            return True
         check(self.lib.cna_percell_coef_launch(self.h), 'cna_percell_coef_launch')
         return True
 

@@ -40,7 +40,8 @@ def _background():
     return _pool
 
 
-_EARLY_COEF = os.environ.get('CNA_EARLY_COEF', '1') not in ('0', 'off', 'no')     # ablation switch
+_EARLY_COEF = os.environ.get('CNA_EARLY_COEF', '1') not in ('0', 'off', 'no')     # ablation switches
+_FUSE = os.environ.get('CNA_FUSE_SELECT', '1') not in ('0', 'off', 'no')
 
 _TRACE = None      # list of (label, perf_counter) when tools/host_trace.py switches tracing on
 
@@ -265,7 +266,7 @@ def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_si
 
 def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
                             show_progress, codes_labels=None, overlap=None, nam_queued=None, y_std=None,
-                            **kwargs):
+                            fuse_null=0, **kwargs):
     """Reference compute_nam_and_reindex (_association.py:175-191) on the device: build the NAM,
     QC it, put the sample axis in ``y.index`` order restricted to ``filter_samples``, drop the
     cells whose remaining entries have zero variance.  Leaves the selected NAM in the engine's
@@ -304,7 +305,8 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     if plan is not None and plan.kind == 'identity':
         # nothing to regress out: select + centre + /std in one pass over the NAM
         if y_std is not None and len(y_std) == len(colmap):
-            nzero, maxabs = engine.select_standardized(None if kept.all() else kept, colmap, y=y_std)
+            nzero, maxabs = engine.select_standardized(None if kept.all() else kept, colmap, y=y_std,
+                                                       fuse_null=fuse_null)
             plan.maxabs = maxabs if nzero == 0 else None
         else:
             nzero = engine.select_standardized(None if kept.all() else kept, colmap)
@@ -409,7 +411,8 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         kept, sample_index, colmap, batches, covs, donorids, filter_samples, plan = \
             compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
                                     show_progress, codes_labels=(codes, labels, counts, token), overlap=host_side,
-                                    nam_queued=nam_queued, y_std=y_std)
+                                    nam_queued=nam_queued, y_std=y_std,
+                                    fuse_null=min(1000, Nnull) if kwargs.get('local_test', True) and _FUSE else 0)
     except BaseException:
         null_future.cancel() or null_future.exception()     # do not leave the helper thread running
         raise

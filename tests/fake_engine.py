@@ -259,7 +259,7 @@ class FakeEngine(_order.CellOrder):
         self.x_rows_total = self.n if keep_global is None else int(np.sum(keep_global))
         self.x_epoch += 1
 
-    def select_standardized(self, keep_global, colmap, y=None):
+    def select_standardized(self, keep_global, colmap, y=None, fuse_null=0):
         self.select(keep_global, colmap)
         with np.errstate(all='ignore'):
             nz = int((self.X.std(axis=1, ddof=1) == 0).sum())

@@ -524,6 +524,39 @@ def test_failed_test_leaves_obs_untouched(eng, monkeypatch):
     np.testing.assert_array_equal(data.obs['coef_fdr'].values, before_fdr)
 
 
+def test_fused_selection_call_equals_separate_calls(eng, monkeypatch):
+    """cna_select_standardized_fused queues the Gram kernels, the local null's thresholds (numpy's
+    arange / edge arithmetic restated in C), the threshold-only half of the null pass and the early
+    coefficient column inside the selection call.  Results must be those of the separate calls, bit
+    for bit, and the C thresholds must be numpy's for any max|ncorrs|."""
+    import ctypes as C
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.tools import _association as A
+    rs = np.random.RandomState(0)
+    for trial in range(3000):
+        m = float(np.exp(rs.uniform(np.log(1e-4), np.log(5))))
+        maxcorr = max(m, 0.001)
+        thr = np.arange(maxcorr / 4, maxcorr, maxcorr / 400)
+        edges = thr ** 2 - 1e-8 - 1e-5 * thr ** 2
+        t, e = np.empty(512), np.empty(512)
+        T = eng.lib.cna_reference_thresholds(m, 512, t.ctypes.data, e.ctypes.data)
+        assert T == len(thr) and np.array_equal(t[:T], thr) and np.array_equal(e[:T], edges), m
+    data, meta = synth.make_dataset(20000, 30, k=15, seed=8)
+    out = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(A, '_FUSE', fuse)
+        eng.prof_reset(); eng.prof_enable(True)
+        res = cna.tl.association(data, meta['y'], 'id', Nnull=300, seed=5, nsteps=3, return_full=True, engine=eng)
+        eng.sync(); eng.prof_enable(False)
+        out[fuse] = (res.p, int(res.k), res.ncorrs.values.copy(), res.fdrs.values.copy(), data.obs['coef'].values.copy(),
+                     data.obs['coef_fdr'].values.copy(), res.namresid_sampleXpc.values.copy(), eng.prof()['gram'][1])
+    assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
+    assert out[True][7] == out[False][7] == 1                 # the Gram kernels ran once either way
+    for a, b in zip(out[True][2:7], out[False][2:7]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_nam_cache_on_device(eng):
     """A second phenotype on the same dataset reuses the resident NAM (no diffusion kernels) and gives
     the results of a from-scratch run."""
