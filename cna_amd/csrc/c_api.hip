@@ -728,6 +728,17 @@ int cna_zero_variance(cna_ctx* c, const int32_t* colmap, int n_sel, uint8_t* fla
   return 0;
 }
 
+// Row stride of the working matrix X: a multiple of 4 (MFMA k-depth).  Beyond 128 samples a stride
+// that is a multiple of 256 bytes sends the 16 rows of every MFMA A tile to the same memory channels
+// (local null at N = 160 / 192 / 224: 37.6 TFLOP/s; with one more quad of zero columns 51 / 56 / 57);
+// up to 128 samples the plain stride is as fast or faster (measured at 64, 96, 128).  N = 256 stays
+// as it is: the MFMA kernels' instantiations end at 64 quads.
+static int x_ld(int Nx) {
+  int ld = round_up(Nx, 4);
+  if (ld > 128 && (ld * 8) % 256 == 0 && ld + 4 <= 256 && !getenv("CNA_X_LD_PLAIN")) ld += 4;
+  return ld;
+}
+
 int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel) {
   CHECK_CTX(c);
   if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
@@ -736,7 +747,7 @@ int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_
   if (nx < 0 || nx > c->n_local || Nx < 1) CNA_FAIL(CNA_EINVAL, "cna_select: bad sizes");
   c->nx = nx;
   c->Nx = Nx;
-  c->ldx = round_up(Nx, 4);
+  c->ldx = x_ld(Nx);
   void* xp = c->X;
   CNA_TRY(dev_reserve(c, &xp, &c->x_cap, (int64_t)sizeof(double) * std::max<int64_t>(nx, 1) * c->ldx));
   c->X = (double*)xp;
@@ -772,7 +783,7 @@ int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep,
   if (nx < 0 || nx > c->n_local || Nx < 2) CNA_FAIL(CNA_EINVAL, "cna_select_standardized: bad sizes");
   c->nx = nx;
   c->Nx = Nx;
-  c->ldx = round_up(Nx, 4);
+  c->ldx = x_ld(Nx);
   void* xp = c->X;
   CNA_TRY(dev_reserve(c, &xp, &c->x_cap, (int64_t)sizeof(double) * std::max<int64_t>(nx, 1) * c->ldx));
   c->X = (double*)xp;
@@ -880,7 +891,7 @@ int cna_upload_x(cna_ctx* c, const double* x_local, int64_t n_rows, int n_cols) 
   if (n_rows < 0 || n_cols < 1 || n_cols > 512) CNA_FAIL(CNA_EINVAL, "cna_upload_x: bad shape");
   c->nx = n_rows;
   c->Nx = n_cols;
-  c->ldx = round_up(n_cols, 4);
+  c->ldx = x_ld(n_cols);
   void* xp = c->X;
   CNA_TRY(dev_reserve(c, &xp, &c->x_cap, (int64_t)sizeof(double) * std::max<int64_t>(n_rows, 1) * c->ldx));
   c->X = (double*)xp;

@@ -370,7 +370,7 @@ int launch_null_t(cna_ctx* c, dim3 grid, size_t smem, int64_t chunk_rows, const 
   // register set (four waves hide the A loads better than two waves with a prefetch: -6 % at N = 100,
   // -9 % at N = 60, -1 % at N = 128), with it up to N = 52; 8 waves beyond
   constexpr bool PF = KQ <= 13;
-  constexpr int NW = KQ <= 32 ? 16 : 8;
+  constexpr int NW = KQ <= 32 ? 16 : 8;      // (two register halves of the A tile at 16 waves for N > 128: measured slower, +11 % at N = 200)
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_null<KQ, NS, PF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -120,7 +120,8 @@ def _random_x(rs, n, N):
     return rs.randn(n, N) * rs.rand(1, N) + rs.randn(n, 1)
 
 
-@pytest.mark.parametrize('n,N', [(1000, 20), (777, 50), (513, 3), (300, 130), (257, 200), (64, 256), (5, 17)])
+@pytest.mark.parametrize('n,N', [(1000, 20), (777, 50), (513, 3), (300, 130), (257, 200), (64, 256), (5, 17),
+                                 (301, 160), (130, 192)])      # 160 / 192: row stride padded off a 256-byte multiple
 def test_dense_row_kernels_vs_numpy(eng, orc, n, N):
     from cna_amd import _ffi
     rs = np.random.RandomState(n + N)
@@ -168,7 +169,7 @@ def test_dense_row_kernels_vs_numpy(eng, orc, n, N):
 
 
 @pytest.mark.parametrize('n,N,P', [(3000, 20, 100), (2049, 50, 200), (1000, 100, 70), (600, 200, 130),
-                                   (100, 256, 64), (16, 12, 5)])
+                                   (100, 256, 64), (16, 12, 5), (700, 160, 90), (333, 224, 33)])
 def test_local_null_counts_are_exact(eng, n, N, P):
     """tails / ranks / num_detected are integers: they must equal a brute-force count."""
     from cna_amd import _ffi
@@ -368,6 +369,7 @@ def test_global_test_matches_scipy(eng, N, P, r, ks):
 
 
 @pytest.mark.parametrize('n,N,extra', [(3000, 70, {}), (2500, 130, dict(n_covs=3)), (2000, 200, dict(n_covs=2, n_batches=4)),
+                                       (2400, 160, dict(n_covs=1)),
                                        (1500, 256, {}), (4000, 33, dict(n_batches=9, n_covs=1))])
 def test_association_wide_sample_axis_vs_oracle(eng, orc, n, N, extra):
     """end to end at sample counts the golden fixtures do not reach (several 64-lane chunks per row,
