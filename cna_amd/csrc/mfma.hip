@@ -366,10 +366,11 @@ typedef int (*null_launch_fn)(cna_ctx*, dim3, size_t, int64_t, const double*, in
 template <int KQ, int NS>
 int launch_null_t(cna_ctx* c, dim3 grid, size_t smem, int64_t chunk_rows, const double* Yc, int ldy, int P,
                   const double* cuts, int T, double cut0, double inv_step, double eps, unsigned int* partial) {
-  // 16 waves per block (4 per SIMD) while a wave fits 128 VGPRs: up to N = 128 without the second A
-  // register set (four waves hide the A loads better than two waves with a prefetch: -6 % at N = 100,
-  // -9 % at N = 60, -1 % at N = 128), with it up to N = 52; 8 waves beyond
-  constexpr bool PF = KQ <= 13;
+  // 16 waves per block (4 per SIMD) while a wave fits 128 VGPRs, i.e. up to N = 128, 8 waves beyond;
+  // no second A register set: four waves per SIMD hide the A loads better than a software prefetch
+  // (-6 % at N = 100, -9 % at N = 60, -1 % at N = 128 against 8 waves with it; -2 % at N = 50 against
+  // 16 waves with it)
+  constexpr bool PF = false;
   constexpr int NW = KQ <= 32 ? 16 : 8;      // (two register halves of the A tile at 16 waves for N > 128: measured slower, +11 % at N = 200)
   static bool attr_set = false;
   if (!attr_set) {
@@ -511,7 +512,7 @@ int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const do
   ProfScope ps(c, CNA_K_NULL_LOCAL);
   if (const char* dbg = getenv("CNA_NULL_DEBUG")) {                    // experiments, N=50 only
     if (kq == 13 && NS == 4 && atoi(dbg) >= 1 && atoi(dbg) <= 2) {
-      auto kfn = atoi(dbg) == 1 ? k_null<13, 4, true, 16, 1> : k_null<13, 4, true, 16, 2>;
+      auto kfn = atoi(dbg) == 1 ? k_null<13, 4, false, 16, 1> : k_null<13, 4, false, 16, 2>;
       HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       hipLaunchKernelGGL(kfn, grid, dim3(1024), lds(NS), c->stream, c->X, c->nx, chunk_rows, Yc_dev, ldy, P, cuts_dev, T,
                          cut0, inv_step, eps, (unsigned int*)c->null_part, 0);
