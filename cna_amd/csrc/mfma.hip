@@ -91,13 +91,13 @@ __global__ __launch_bounds__(512) void k_xb(const double* __restrict__ X, int64_
 }
 
 // ======================================================================== G = X^T X
-// 8 waves per workgroup; the nt*(nt+1)/2 upper-triangular 16x16 tiles of G are dealt to the
+// 16 waves per workgroup; the nt*(nt+1)/2 upper-triangular 16x16 tiles of G are dealt to the
 // waves (TPW accumulator tiles each, kept in registers for the whole kernel); the workgroup
 // streams 32-cell slabs of X through LDS and every wave feeds its tiles with 8 k-steps of 4
 // cells.  Per-workgroup partial tiles are written out and summed in a fixed order by
 // k_gram_reduce (deterministic; no float atomics).
-template <int TPW>
-__global__ __launch_bounds__(512) void k_gram(const double* __restrict__ X, int64_t nx, int ldx, int nt,
+template <int TPW, int NW = 8>
+__global__ __launch_bounds__(64 * NW) void k_gram(const double* __restrict__ X, int64_t nx, int ldx, int nt,
                                               int ldp, int ntri, const int32_t* __restrict__ tiles,
                                               double* __restrict__ partial) {
   extern __shared__ double sm[];
@@ -111,18 +111,18 @@ __global__ __launch_bounds__(512) void k_gram(const double* __restrict__ X, int6
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const int tix = (blockIdx.y * 8 + wv) * TPW + t;
+    const int tix = (blockIdx.y * NW + wv) * TPW + t;
     live[t] = tix < ntri;
     const int packed = live[t] ? __builtin_amdgcn_readfirstlane(tiles[tix]) : 0;
     off_i[t] = (packed >> 16) * 16;
     off_j[t] = (packed & 0xffff) * 16;
   }
-  for (int i = tid; i < 32 * ldp; i += 512) sm[i] = 0.0;
+  for (int i = tid; i < 32 * ldp; i += 64 * NW) sm[i] = 0.0;
   const int64_t nslab = (nx + 31) / 32;
   for (int64_t slab = blockIdx.x; slab < nslab; slab += gridDim.x) {
     __syncthreads();
     const int64_t r0 = slab * 32;
-    for (int r = wv; r < 32; r += 8) {
+    for (int r = wv; r < 32; r += NW) {
       const int64_t gr = r0 + r;
       for (int col = lane; col < ldx; col += 64) sm[r * ldp + col] = (gr < nx) ? X[gr * ldx + col] : 0.0;
     }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(512) void k_gram(const double* __restrict__ X, int6
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     if (live[t]) {
-      const int tix = (blockIdx.y * 8 + wv) * TPW + t;
+      const int tix = (blockIdx.y * NW + wv) * TPW + t;
       double* p = partial + ((size_t)blockIdx.x * ntri + tix) * 256;
 #pragma unroll
       for (int r = 0; r < 4; ++r) p[r * 64 + lane] = acc[t][r];
@@ -351,11 +351,11 @@ __global__ void k_hist_reduce(const unsigned int* __restrict__ partial, int nchu
   hist[i] = s;
 }
 
-template <int TPW>
+template <int TPW, int NW = 8>
 int launch_gram_t(cna_ctx* c, int nt, int ldp, int ntri, const int32_t* tiles_dev, double* partial, int nblocks,
                   size_t smem) {
-  const int npass = (ntri + 8 * TPW - 1) / (8 * TPW);
-  hipLaunchKernelGGL((k_gram<TPW>), dim3(nblocks, npass), dim3(512), smem, c->stream, c->X, c->nx, c->ldx, nt, ldp,
+  const int npass = (ntri + NW * TPW - 1) / (NW * TPW);
+  hipLaunchKernelGGL((k_gram<TPW, NW>), dim3(nblocks, npass), dim3(64 * NW), smem, c->stream, c->X, c->nx, c->ldx, nt, ldp,
                      ntri, tiles_dev, partial);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -440,7 +440,6 @@ int launch_gram(cna_ctx* c, double* G_dev) {
   const int nt = (Nx + 15) / 16;
   const int ntri = nt * (nt + 1) / 2;
   const int ldp = 16 * nt + ((nt & 1) ? 0 : 16);
-  const int tpw = (ntri + 7) / 8;
   HIP_TRY(hipMemsetAsync(G_dev, 0, sizeof(double) * Nx * Nx, c->stream));
   if (c->nx == 0) return 0;
   // tile table (ti<<16 | tj), upper triangle, row-major
@@ -464,11 +463,20 @@ int launch_gram(cna_ctx* c, double* G_dev) {
   {
     ProfScope ps(c, CNA_K_GRAM);
     int r;
-    if (tpw <= 1) r = launch_gram_t<1>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem);
-    else if (tpw <= 2) r = launch_gram_t<2>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem);
-    else if (tpw <= 4) r = launch_gram_t<4>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem);
-    else if (tpw <= 8) r = launch_gram_t<8>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem);
-    else r = launch_gram_t<12>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem);   // extra passes beyond 96 tiles
+    // 16 waves per workgroup, the tiles dealt ceil(ntri/16) to a wave: against 8 waves with up to 12
+    // tiles each (154 VGPRs, one workgroup of two waves per SIMD per CU) 2025 -> 1489 us at 1M x 200,
+    // 3958 -> 2034 us at 1M x 256, 57 -> 45 us at 200k x 50; faster at every N tried (20 ... 256)
+    switch ((ntri + 15) / 16) {
+      case 1: r = launch_gram_t<1, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
+      case 2: r = launch_gram_t<2, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
+      case 3: r = launch_gram_t<3, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
+      case 4: r = launch_gram_t<4, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
+      case 5: r = launch_gram_t<5, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
+      case 6: r = launch_gram_t<6, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
+      case 7: r = launch_gram_t<7, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
+      case 8: r = launch_gram_t<8, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
+      default: r = launch_gram_t<9, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;   // up to 144 tiles (N <= 256)
+    }
     CNA_TRY(r);
   }
   {
