@@ -54,6 +54,7 @@ static hipEvent_t ev_get(cna_ctx* c) {
   return e;
 }
 void prof_begin(cna_ctx* c, int kid, hipStream_t st) {
+  std::lock_guard<std::mutex> lock(c->prof_mu);
   ProfSpan s;
   s.kid = kid;
   s.a = ev_get(c);
@@ -62,6 +63,7 @@ void prof_begin(cna_ctx* c, int kid, hipStream_t st) {
   c->prof_pending.push_back(s);
 }
 void prof_end(cna_ctx* c, int kid, hipStream_t st) {
+  std::lock_guard<std::mutex> lock(c->prof_mu);
   for (size_t i = c->prof_pending.size(); i-- > 0;) {
     if (c->prof_pending[i].kid == kid) {
       (void)hipEventRecord(c->prof_pending[i].b, st);
@@ -70,9 +72,10 @@ void prof_end(cna_ctx* c, int kid, hipStream_t st) {
   }
 }
 static void prof_flush(cna_ctx* c) {
-  if (c->prof_pending.empty()) return;
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->copy_stream);
+  std::lock_guard<std::mutex> lock(c->prof_mu);
+  if (c->prof_pending.empty()) return;
   for (auto& s : c->prof_pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <mutex>
 #include <vector>
 #include "../../include/cna_hip.h"
 
@@ -169,6 +170,7 @@ struct cna_ctx {
   int64_t prof_n[CNA_K_COUNT] = {0};
   std::vector<ProfSpan> prof_pending;
   std::vector<hipEvent_t> ev_pool;
+  std::mutex prof_mu;            // the helper thread's cna_condition_phenotypes records spans while the main thread launches kernels
 };
 
 // profiling helpers (c_api.hip)
