@@ -25,8 +25,14 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // completely before it writes any of them, so OUT may be X itself (in-place residualisation).
 // (The first version fed one dependent chain per wave with B fragments read from global for every
 // MFMA: 28.9 ms at 2M x 200, 0.07 of the f64 MFMA peak.)
+// N = 132 ... 208: capped at 128 VGPRs (a handful of spills) two workgroups share a CU, 4928 -> 4176 us
+// at 2M x 200; deeper tiles spill too much (N = 256: 3853 -> 4996 us) and keep the full register file
+#ifndef CNA_XB_CAP
+#define CNA_XB_CAP 52
+#endif
+#define XB_MIN_WAVES(KQ) (((KQ) > 32 && (KQ) <= CNA_XB_CAP) ? 4 : 1)
 template <int KQ, int NS>
-__global__ __launch_bounds__(512) void k_xb(const double* __restrict__ X, int64_t nx, int Nx,
+__global__ __launch_bounds__(512, XB_MIN_WAVES(KQ)) void k_xb(const double* __restrict__ X, int64_t nx, int Nx,
                                             const double* __restrict__ B, int ldb, int center,
                                             double* out, int ld_out) {
   constexpr int LDX = 4 * KQ, PT = 16 * NS, LDB = PT + 16;   // LDB = 16 mod 32: conflict-free B fragments
