@@ -96,6 +96,78 @@ __global__ __launch_bounds__(512, XB_MIN_WAVES(KQ)) void k_xb(const double* __re
   }
 }
 
+// Up to 128 samples the whole of B fits in LDS: one load per workgroup, then 16 waves walk the row
+// tiles with no further barrier (k_xb re-stages B and synchronises twice per 16 x 64 output strip,
+// which at N = 100 leaves only 200 MFMAs per wave between barriers: 0.35 of the MFMA peak).
+template <int KQ>
+__global__ __launch_bounds__(1024) void k_xb_res(const double* __restrict__ X, int64_t nx, int Nx,
+                                                 const double* __restrict__ B, int ldb, int center,
+                                                 double* out, int ld_out, int64_t ntile) {
+  constexpr int LDX = 4 * KQ, NS = 4;
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ai = lane & 15, ak = lane >> 4;
+  const int nct = ((ldb + 63) / 64) * 4;                // 16-column tiles of B, padded with zero tiles to whole strips of 4
+  const int LDB = 16 * nct + 16;                        // = 16 mod 32: conflict-free B fragments
+  for (int i = tid; i < LDX * LDB; i += 1024) {
+    const int k = i / LDB, j = i - k * LDB;
+    sm[i] = j < ldb ? B[(size_t)k * ldb + j] : 0.0;
+  }
+  __syncthreads();
+  const double* bp = sm + ak * LDB + ai;
+  for (int64_t tile = (int64_t)blockIdx.x * 16 + wv; tile < ntile; tile += (int64_t)gridDim.x * 16) {
+    const int64_t r0 = tile * 16;
+    double a[KQ];
+    {
+      const int64_t row = r0 + ai;
+      if (row < nx) {
+        const double* __restrict__ xp = X + row * LDX + ak;
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) a[q] = xp[4 * q];
+      } else {
+#pragma unroll
+        for (int q = 0; q < KQ; ++q) a[q] = 0.0;
+      }
+    }
+    if (center) {
+      double s = 0.0;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) s += a[q];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const double mean = s / (double)Nx;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q)
+        if (4 * q + ak < Nx) a[q] -= mean;
+    }
+    for (int ct = 0; ct < nct; ct += NS) {
+      v4d acc[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+      const double* bs = bp + 16 * ct;
+#pragma unroll
+      for (int q = 0; q < KQ; ++q) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+          acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bs[4 * q * LDB + 16 * s], acc[s], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const int col = 16 * (ct + s) + ai;
+        if (col < ld_out) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t gr = r0 + ak + 4 * r;
+            if (gr < nx) out[gr * ld_out + col] = acc[s][r];
+          }
+        }
+      }
+    }
+  }
+}
+
 // ======================================================================== G = X^T X
 // 16 waves per workgroup; the nt*(nt+1)/2 upper-triangular 16x16 tiles of G are dealt to the
 // waves (TPW accumulator tiles each, kept in registers for the whole kernel); the workgroup
@@ -424,6 +496,25 @@ constexpr std::array<xb_launch_fn, sizeof...(KQ)> xb_table(std::integer_sequence
   return {{&launch_xb_t<KQ + 1, NS>...}};
 }
 const auto kXbNS4 = xb_table<4>(std::make_integer_sequence<int, 32>{});   // KQ 1..32
+typedef int (*xbres_launch_fn)(cna_ctx*, unsigned, size_t, const double*, int, int, double*, int, int64_t);
+template <int KQ>
+int launch_xbres_t(cna_ctx* c, unsigned grid, size_t smem, const double* B_dev, int ldb, int center, double* out,
+                   int ld_out, int64_t ntile) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_xb_res<KQ>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_xb_res<KQ>), dim3(grid), dim3(1024), smem, c->stream, c->X, c->nx, c->Nx, B_dev, ldb, center, out,
+                     ld_out, ntile);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+template <int... KQ>
+constexpr std::array<xbres_launch_fn, sizeof...(KQ)> xbres_table(std::integer_sequence<int, KQ...>) {
+  return {{&launch_xbres_t<KQ + 1>...}};
+}
+const auto kXbRes = xbres_table(std::make_integer_sequence<int, 32>{});     // KQ 1..32
 const auto kXbNS2 = xb_table<2>(std::make_integer_sequence<int, 64>{});   // KQ 1..64
 }  // namespace
 
@@ -434,8 +525,16 @@ int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, 
   if (kq < 1 || kq > 64) CNA_FAIL(CNA_EINVAL, "more than 256 samples are not supported by the residualisation kernel yet");
   ProfScope ps(c, out == c->X ? CNA_K_RESID : CNA_K_PROJECT);
   const int NS = kq <= 32 ? 4 : 2;
-  const size_t smem = sizeof(double) * (size_t)c->ldx * (16 * NS + 16);
   const int64_t ntile = (c->nx + 15) / 16;
+  {
+    const int nct = ((ldb + 63) / 64) * 4;
+    const size_t whole = sizeof(double) * (size_t)c->ldx * (16 * nct + 16);
+    if (kq <= 32 && whole <= 160 * 1024 && ntile >= 64 && !getenv("CNA_XB_STRIPS")) {   // all of B resident in LDS
+      const int64_t want = (ntile + 15) / 16;
+      return kXbRes[kq - 1](c, (unsigned)(want < 512 ? want : 512), whole, B_dev, ldb, center ? 1 : 0, out, ld_out, ntile);
+    }
+  }
+  const size_t smem = sizeof(double) * (size_t)c->ldx * (16 * NS + 16);
   const unsigned grid = (unsigned)((ntile + 7) / 8);
   xb_launch_fn fn = NS == 4 ? kXbNS4[kq - 1] : kXbNS2[kq - 1];
   return fn(c, grid, smem, B_dev, ldb, center ? 1 : 0, out, ld_out);
