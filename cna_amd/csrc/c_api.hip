@@ -186,6 +186,7 @@ int cna_ctx_create(int device, cna_ctx** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->gram_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->coef_ready, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->gt_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->stage_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->coef_copied, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->null_done, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -213,6 +214,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   if (c->gram_done) (void)hipEventDestroy(c->gram_done);
   if (c->coef_ready) (void)hipEventDestroy(c->coef_ready);
   if (c->gt_done) (void)hipEventDestroy(c->gt_done);
+  if (c->stage_done) (void)hipEventDestroy(c->stage_done);
   if (c->h_gt) (void)hipHostFree(c->h_gt);
   if (c->coef_copied) (void)hipEventDestroy(c->coef_copied);
   if (c->null_done) (void)hipEventDestroy(c->null_done);
@@ -1124,8 +1126,11 @@ static int null_local_prepare(cna_ctx* c, int P, const double* edges, int T, int
   std::vector<double> cuts;
   exact_cuts(edges, T, c->Nx, cuts, &c->null_cut0, &c->null_inv_step, &c->null_eps);
   const int64_t obs_off = 8 * (int64_t)T + (want_tails ? 8 * (int64_t)P * T : 0);
-  const int64_t hbytes = obs_off + 16 * (int64_t)T;
+  const int64_t stage_off = obs_off + 16 * (int64_t)T;      // pinned copies of cuts | edges | thr: uploads need no wait
+  const int64_t hbytes = stage_off + 24 * (int64_t)T;
+  HIP_TRY(hipEventSynchronize(c->stage_done));            // uploads of the previous pass out of the staging area (long done)
   if (hbytes > c->h_res_cap) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->h_res) HIP_TRY(hipHostFree(c->h_res));
     c->h_res = nullptr;
     HIP_TRY(hipHostMalloc(&c->h_res, (size_t)hbytes, hipHostMallocDefault));
@@ -1152,8 +1157,11 @@ static int null_local_prepare(cna_ctx* c, int P, const double* edges, int T, int
     guess_from_thr(thr, T, &thr0, &ostep);
     c->null_thr0 = thr0;
     c->null_thr_step = ostep;
-    HIP_TRY(hipMemcpyAsync(oed, edges, 8 * T, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(otd, thr, 8 * T, hipMemcpyHostToDevice, c->stream));
+    double* st = (double*)((char*)c->h_res + stage_off);
+    std::memcpy(st + T, edges, 8 * (size_t)T);
+    std::memcpy(st + 2 * T, thr, 8 * (size_t)T);
+    HIP_TRY(hipMemcpyAsync(oed, st + T, 8 * T, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(otd, st + 2 * T, 8 * T, hipMemcpyHostToDevice, c->stream));
     CNA_TRY(launch_obs_counts(c, oed, otd, T, thr0, ostep, ohist));
     CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)ohist, (size_t)2 * T));
     CNA_TRY(launch_suffix_sum(c, ohist, 2, T, otails));
@@ -1161,8 +1169,9 @@ static int null_local_prepare(cna_ctx* c, int P, const double* edges, int T, int
     c->null_has_obs = 1;
     c->null_obs_off = obs_off;
   }
-  HIP_TRY(hipMemcpyAsync(ed, cuts.data(), 8 * T, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));               // `cuts`, `edges`, `thr` are the caller's; the stream is nearly idle here
+  std::memcpy((char*)c->h_res + stage_off, cuts.data(), 8 * (size_t)T);
+  HIP_TRY(hipMemcpyAsync(ed, (char*)c->h_res + stage_off, 8 * T, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipEventRecord(c->stage_done, c->stream));
   c->null_P = P;
   c->null_T = T;
   c->null_has_tails = want_tails;
