@@ -93,7 +93,7 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
             f'Currently it is {max(ks)+r} while n is {n}. Either reduce the number of covariates ' +
             'or reduce the number of PCs to consider using the optional argument ks=[...].')
     ks_arr = np.asarray(ks)
-    Mv = np.asarray(M, dtype=np.float64)
+    Mv = M.values if isinstance(M, pd.DataFrame) and M.values.dtype == np.float64 else np.asarray(M, dtype=np.float64)
 
     # neighbourhood coefficients -> thresholds (needs y only; already taken with the selection pass
     # when nothing had to be regressed out)
@@ -252,7 +252,8 @@ def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_si
     else:
         filter_samples = ~np.isnan(y) & present
 
-    N = filter_samples.sum()
+    fvals = getattr(filter_samples, 'values', None)
+    N = int(np.count_nonzero(fvals)) if fvals is not None and fvals.dtype == bool else filter_samples.sum()
     if N < 10 and not allow_low_sample_size:
         raise ValueError(
             'You are supplying phenotype information on fewer than 10 samples. This may lead to ' +
