@@ -74,6 +74,7 @@ void prof_end(cna_ctx* c, int kid, hipStream_t st) {
 static void prof_flush(cna_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->copy_stream);
+  if (c->coef_stream) (void)hipStreamSynchronize(c->coef_stream);
   std::lock_guard<std::mutex> lock(c->prof_mu);
   if (c->prof_pending.empty()) return;
   for (auto& s : c->prof_pending) {
@@ -182,6 +183,7 @@ int cna_ctx_create(int device, cna_ctx** out) {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     e = hipStreamCreateWithPriority(&c->copy_stream, hipStreamNonBlocking, hi);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->coef_stream, hipStreamNonBlocking);
   }
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->gram_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->coef_ready, hipEventDisableTiming);
@@ -211,6 +213,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
   (void)hipStreamDestroy(c->stream);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->coef_stream) (void)hipStreamDestroy(c->coef_stream);
   if (c->gram_done) (void)hipEventDestroy(c->gram_done);
   if (c->coef_ready) (void)hipEventDestroy(c->coef_ready);
   if (c->gt_done) (void)hipEventDestroy(c->gt_done);
@@ -1452,10 +1455,11 @@ int cna_percell_coef_launch(cna_ctx* c) {
     CNA_TRY(launch_unpermute2(c, tmp, nullptr, c->orig_idx, c->n_local, out, nullptr));
   }
   HIP_TRY(hipEventRecord(c->coef_ready, c->stream));
-  HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->coef_ready, 0));
+  hipStream_t cs = c->coef_stream;   // not copy_stream: the helper thread's conditioning call waits on that one
+  HIP_TRY(hipStreamWaitEvent(cs, c->coef_ready, 0));
   if (n_out > 0)
-    HIP_TRY(hipMemcpyAsync(c->h_cell, out, 8 * n_out, hipMemcpyDeviceToHost, c->copy_stream));
-  HIP_TRY(hipEventRecord(c->coef_copied, c->copy_stream));
+    HIP_TRY(hipMemcpyAsync(c->h_cell, out, 8 * n_out, hipMemcpyDeviceToHost, cs));
+  HIP_TRY(hipEventRecord(c->coef_copied, cs));
   c->coef_early = true;
   return 0;
 }

@@ -45,6 +45,7 @@ struct cna_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;   // D2H of small results that must not queue behind long kernels
+  hipStream_t coef_stream = nullptr;   // the early coefficient column's copy: the helper thread waits on copy_stream and must not wait for this
   hipEvent_t gram_done = nullptr;
   double* gram_buf = nullptr;          // Gram matrix of the last cna_gram_launch
   hipEvent_t null_done = nullptr;      // results of the last local-null launch are in h_res
