@@ -22,6 +22,18 @@ import numpy as np
 import scipy.sparse as sp
 
 
+def usable_cpus(limit=None):
+    """CPUs this process may really use: the cgroup v2 quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n if limit is None else max(1, min(n, int(limit)))
+
+
 def locality_order(A):
     """Reverse Cuthill-McKee order of the (structurally symmetrised) graph, or None when the
     reordering is switched off (CNA_REORDER=0) or pointless."""
@@ -30,6 +42,41 @@ def locality_order(A):
     from scipy.sparse.csgraph import reverse_cuthill_mckee
     perm = reverse_cuthill_mckee(sp.csr_matrix(A), symmetric_mode=False)
     return np.ascontiguousarray(perm, dtype=np.int64)
+
+
+def cluster_order(A, B):
+    """Order in which clusters of B cells that share neighbours are consecutive (csrc/host_graph.c:
+    cna_host_cluster_order): order[i] = caller's index of device row i.  Integer work on the host, a
+    few tenths of a second per million cells."""
+    from . import _ffi
+    n = A.shape[0]
+    order = np.empty(n, dtype=np.int64)
+    if n == 0:
+        return order
+    indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+    got = _ffi.load().cna_host_cluster_order(n, _ffi.ptr(indptr), _ffi.ptr(indices), int(B), _ffi.ptr(order))
+    if got < 0:
+        raise MemoryError('cna_host_cluster_order')
+    return order
+
+
+def block_sources(indptr, indices, n_cols, B, cap):
+    """(src_ptr, src, slot) of cna_host_block_sources for the device-ordered CSR rows (indptr int64,
+    indices int32): per block of B rows the distinct columns, per edge the column's position in it."""
+    from . import _ffi
+    n_local = len(indptr) - 1
+    nblocks = (n_local + B - 1) // B
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    src_ptr = np.zeros(nblocks + 1, dtype=np.int64)
+    src = np.empty(max(len(indices), 1), dtype=np.int32)
+    slot = np.empty(max(len(indices), 1), dtype=np.uint16)
+    tot = _ffi.load().cna_host_block_sources(n_local, int(n_cols), _ffi.ptr(indptr), _ffi.ptr(indices), int(B), int(cap),
+                                             _ffi.ptr(src_ptr), _ffi.ptr(src), _ffi.ptr(slot))
+    if tot < 0:
+        raise MemoryError('cna_host_block_sources')
+    return src_ptr, src[:tot].copy(), slot[:len(indices)]
 
 
 def inverse(perm):

@@ -1103,7 +1103,10 @@ static void exact_cuts(const double* edges, int T, int Nx, std::vector<double>& 
 
 static int ensure_zc(cna_ctx* c, int N, int P, hipStream_t st) {
   const int ldy = round_up(P, 64) + 64;   // one spare tile: a resident read may start at any column
-  const int rows = round_up(N, 4);        // = ldx of a working matrix with N samples
+  // = ldx of a working matrix with N samples, INCLUDING the bank-spreading pad quad x_ld() adds at
+  // N = 157...160 / 189...192 / 221...224: the local-null kernel loads ldx rows of Zc (the matching
+  // pad columns of X are zero, but 0 * whatever-lies-past-the-buffer is only 0 while that is finite)
+  const int rows = x_ld(N);
   void* p = c->zc;
   CNA_TRY(dev_reserve(c, &p, &c->zc_cap, (int64_t)sizeof(double) * rows * ldy));
   c->zc = (double*)p;
@@ -1186,7 +1189,8 @@ static int null_local_go(cna_ctx* c, int col0) {
   if (!c->null_prepared) CNA_FAIL(CNA_ESTATE, "local-null pass not prepared");
   c->null_prepared = 0;
   const int P = c->null_P, T = c->null_T;
-  if (!c->zc || col0 < 0 || col0 + P > c->zc_cols || c->zc_rows != c->Nx)
+  if (!c->zc || col0 < 0 || col0 + P > c->zc_cols || c->zc_rows != c->Nx ||
+      c->zc_cap < (int64_t)sizeof(double) * c->ldx * c->zc_ld)
     CNA_FAIL(CNA_ESTATE, "no conditioned phenotypes resident for these columns");
   Carver cv(c->scratch);                                   // same carve as in null_local_prepare
   double* ed = cv.take<double>(T);

@@ -13,6 +13,7 @@
 // rows so the neighbour rows it gathers stay in that XCD's 4 MiB L2.
 #include "common.h"
 #include <cstdlib>
+#include <algorithm>
 
 // The walk's products and sums are meant to round like scipy's csr_matvecs (a multiply, then an add).
 // hipcc contracts a*b+c into an fma by default -- also through __dmul_rn / __dadd_rn, which are plain
@@ -505,12 +506,156 @@ __global__ void k_cellinfo(const double* __restrict__ colsum, const int32_t* __r
   }
 }
 
-template <typename VT>
-__global__ void k_colsum(const int32_t* __restrict__ idx, const VT* __restrict__ val, int64_t nnz,
-                         double* colsum) {
+// ---- column sums, deterministic: colsums = A.sum(axis=0) (_nam.py:28) --------------------------------
+// scipy sums a CSR over axis 0 by walking the rows in ascending order and adding every entry into its
+// column's accumulator: column j receives its entries in ascending (row, position in row) order.  In
+// float64 that order matters as soon as the weights of a column span more than 2^29 in magnitude (at 2M
+// cells some do), so the sums here are formed in exactly that order, without float atomics:
+//   k_col_count    in-degree of every column (integer atomics: the result is order-free)
+//   k_scan_*       exclusive prefix sum -> first slot of every column
+//   k_col_scatter  every edge drops {key = caller's row << 32 | position in row, value} into a slot of its
+//                  column (integer atomic cursor: WHICH slot is arbitrary, the set per column is not)
+//   k_col_sum      one wave per column ranks the column's keys and adds the values by rank
+// Rows keep the caller's row index (c->orig_idx) and their entries the caller's order, whatever the
+// device numbering.  Sharded runs sum their own rows this way and all-reduce the partial sums.
+__global__ void k_col_count(const int32_t* __restrict__ idx, int64_t nnz, unsigned int* __restrict__ cnt) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride)
-    unsafeAtomicAdd(&colsum[idx[e]], (double)val[e]);
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) atomicAdd(&cnt[idx[e]], 1u);
+}
+
+constexpr int SCAN_TILE = 1024;           // elements per workgroup of 256 threads
+__global__ __launch_bounds__(256) void k_scan_tiles(const unsigned int* __restrict__ cnt, int64_t n,
+                                                    unsigned long long* __restrict__ tile_sum) {
+  __shared__ unsigned long long part[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+  unsigned long long s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) s += base + k < n ? cnt[base + k] : 0u;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(1024) void k_scan_tile_sums(unsigned long long* __restrict__ tile_sum, int64_t ntiles) {
+  // one workgroup, exclusive scan in place, 1024 tiles per round
+  __shared__ unsigned long long sm[1024];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t base = 0; base < ntiles; base += 1024) {
+    const int64_t i = base + threadIdx.x;
+    const unsigned long long v = i < ntiles ? tile_sum[i] : 0ull;
+    sm[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const unsigned long long a = threadIdx.x >= o ? sm[threadIdx.x - o] : 0ull;
+      __syncthreads();
+      sm[threadIdx.x] += a;
+      __syncthreads();
+    }
+    const unsigned long long c0 = carry;
+    if (i < ntiles) tile_sum[i] = c0 + sm[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c0 + sm[1023];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void k_scan_finish(const unsigned int* __restrict__ cnt, int64_t n,
+                                                     const unsigned long long* __restrict__ tile_sum,
+                                                     unsigned long long* __restrict__ first /* n + 1 */) {
+  __shared__ unsigned long long part[4];
+  const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * 4;
+  unsigned long long v[4], s = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { v[k] = base + k < n ? cnt[base + k] : 0u; s += v[k]; }
+  unsigned long long incl = s;                 // inclusive scan of the per-thread sums inside the wave
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long a = __shfl_up(incl, o);
+    if ((int)(threadIdx.x & 63) >= o) incl += a;
+  }
+  if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  unsigned long long off = tile_sum[blockIdx.x] + incl - s;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) off += part[w];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < n) first[base + k] = off;
+    off += v[k];
+    if (base + k == n - 1) first[n] = off;
+  }
+}
+
+struct ColEntry { unsigned long long key; double val; };
+
+template <typename VT>
+__global__ __launch_bounds__(256) void k_col_scatter(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
+                                                     const VT* __restrict__ val, const int64_t* __restrict__ orig,
+                                                     int64_t n_local, int64_t row0_key,
+                                                     const unsigned long long* __restrict__ first,
+                                                     unsigned int* __restrict__ cursor, ColEntry* __restrict__ ent) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n_local; row += nw) {
+    const int64_t start = indptr[row], end = indptr[row + 1];
+    const unsigned long long rk = (unsigned long long)(orig ? orig[row] : row0_key + row) << 32;
+    for (int64_t e = start + lane; e < end; e += 64) {
+      const int32_t j = idx[e];
+      const unsigned long long slot = first[j] + atomicAdd(&cursor[j], 1u);
+      ColEntry ce;
+      ce.key = rk | (unsigned long long)(e - start);
+      ce.val = (double)val[e];
+      ent[slot] = ce;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_col_sum(const unsigned long long* __restrict__ first,
+                                                 const ColEntry* __restrict__ ent, int64_t n, double* __restrict__ colsum) {
+  __shared__ double sorted[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t j = (int64_t)blockIdx.x * 4 + wv; j < n; j += nw) {
+    const unsigned long long lo = first[j];
+    const int64_t cnt = (int64_t)(first[j + 1] - lo);
+    double s = 0.0;
+    if (cnt <= 64) {
+      // rank = number of smaller keys (keys of a column are distinct); values to LDS by rank, summed in order
+      const bool ok = lane < cnt;
+      const ColEntry me = ok ? ent[lo + lane] : ColEntry{~0ull, 0.0};
+      const unsigned klo = (unsigned)me.key, khi = (unsigned)(me.key >> 32);
+      int rank = 0;
+      for (int m = 0; m < (int)cnt; ++m) {
+        const unsigned long long km = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi, m) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)klo, m);
+        rank += km < me.key ? 1 : 0;
+      }
+      if (ok) sorted[wv][rank] = me.val;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      for (int r = 0; r < (int)cnt; ++r) s = add_rn(s, sorted[wv][r]);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } else {
+      // a hub column: repeatedly take the smallest key above the last one taken (cnt^2 / 64 loads)
+      unsigned long long last = 0;
+      bool any = false;
+      for (int64_t r = 0; r < cnt; ++r) {
+        unsigned long long best = ~0ull;
+        double bv = 0.0;
+        for (int64_t e = lane; e < cnt; e += 64) {
+          const ColEntry ce = ent[lo + e];
+          if ((!any || ce.key > last) && ce.key < best) { best = ce.key; bv = ce.val; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+          const unsigned long long ob = __shfl_xor(best, o);
+          const double ov = __shfl_xor(bv, o);
+          if (ob < best) { best = ob; bv = ov; }
+        }
+        s = add_rn(s, bv);
+        last = best;
+        any = true;
+      }
+    }
+    if (lane == 0) colsum[j] = s;
+  }
 }
 
 __global__ void k_add_scalar(double* v, int64_t n, double s) {
@@ -598,17 +743,44 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
 int launch_colsum(cna_ctx* c) {
   ProfScope ps(c, CNA_K_COLSUM);
   HIP_TRY(hipMemsetAsync(c->colsum, 0, sizeof(double) * c->n_pad, c->stream));
-  if (c->nnz > 0) {
-    const int64_t want = (c->nnz + 255) / 256;
-    const unsigned grid = (unsigned)(want < 8192 ? want : 8192);
+  if (c->nnz == 0) return 0;
+  const int64_t n = c->n_global;
+  const int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  // scratch: cnt u32[n] | cursor u32[n] | tile sums u64[ntiles] | first u64[n+1] | entries 16 B x nnz
+  const int64_t b_cnt = round_up64(4 * n, 256), b_tiles = round_up64(8 * ntiles, 256), b_first = round_up64(8 * (n + 1), 256);
+  const int64_t need = 2 * b_cnt + b_tiles + b_first + (int64_t)sizeof(ColEntry) * c->nnz;
+  void* buf = nullptr;
+  CNA_TRY(dev_alloc(c, &buf, (size_t)need));
+  char* p = (char*)buf;
+  unsigned int* cnt = (unsigned int*)p; p += b_cnt;
+  unsigned int* cursor = (unsigned int*)p; p += b_cnt;
+  unsigned long long* tiles = (unsigned long long*)p; p += b_tiles;
+  unsigned long long* first = (unsigned long long*)p; p += b_first;
+  ColEntry* ent = (ColEntry*)p;
+  int rc = 0;
+  do {
+    if (hipMemsetAsync(cnt, 0, (size_t)(2 * b_cnt), c->stream) != hipSuccess) { rc = 1; break; }
+    const unsigned g_edges = (unsigned)std::min<int64_t>((c->nnz + 255) / 256, 16384);
+    hipLaunchKernelGGL(k_col_count, dim3(g_edges), dim3(256), 0, c->stream, c->indices, c->nnz, cnt);
+    hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(256), 0, c->stream, cnt, n, tiles);
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, c->stream, tiles, ntiles);
+    hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)ntiles), dim3(256), 0, c->stream, cnt, n, tiles, first);
+    const unsigned g_rows = (unsigned)std::min<int64_t>((c->n_local + 3) / 4, 65536);
     if (c->data_f64)
-      hipLaunchKernelGGL(k_colsum<double>, dim3(grid), dim3(256), 0, c->stream, c->indices,
-                         (const double*)c->data, c->nnz, c->colsum);
+      hipLaunchKernelGGL(k_col_scatter<double>, dim3(g_rows), dim3(256), 0, c->stream, c->indptr, c->indices,
+                         (const double*)c->data, c->orig_idx, c->n_local, c->row0, first, cursor, ent);
     else
-      hipLaunchKernelGGL(k_colsum<float>, dim3(grid), dim3(256), 0, c->stream, c->indices,
-                         (const float*)c->data, c->nnz, c->colsum);
-    HIP_TRY(hipGetLastError());
-  }
+      hipLaunchKernelGGL(k_col_scatter<float>, dim3(g_rows), dim3(256), 0, c->stream, c->indptr, c->indices,
+                         (const float*)c->data, c->orig_idx, c->n_local, c->row0, first, cursor, ent);
+    const unsigned g_cols = (unsigned)std::min<int64_t>((n + 3) / 4, 65536);
+    hipLaunchKernelGGL(k_col_sum, dim3(g_cols), dim3(256), 0, c->stream, first, ent, n, c->colsum);
+  } while (0);
+  const hipError_t le = hipGetLastError();
+  const hipError_t se = hipStreamSynchronize(c->stream);      // the scratch goes away below
+  dev_free(c, buf, (size_t)need);
+  if (rc) CNA_FAIL(CNA_EINVAL, "launch_colsum: memset failed");
+  HIP_TRY(le);
+  HIP_TRY(se);
   return 0;
 }
 

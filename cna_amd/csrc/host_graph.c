@@ -1,0 +1,229 @@
+/* Host-side helpers for graph preparation (plain C, no device code, no floating-point arithmetic of
+ * the analysis): nothing here computes a result of the path, it identifies and orders the input.
+ *
+ *   cna_host_hash64     content hash of a buffer on several threads: the engine recognises "this very
+ *                       graph is already resident" by the full content of data / indices / indptr, so an
+ *                       in-place edit of a single entry is seen (the reference reads the matrix afresh on
+ *                       every call, /root/reference/src/cna/tools/_nam.py:25-28)
+ *   cna_host_cluster_order   (below) the cell order of the device copy of the graph
+ */
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define P1 0x9E3779B185EBCA87ull
+#define P2 0xC2B2AE3D27D4EB4Full
+#define P3 0x165667B19E3779F9ull
+
+static inline uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t mixin(uint64_t acc, uint64_t w) { return rotl(acc + w * P2, 31) * P1; }
+static inline uint64_t fin(uint64_t h) {
+  h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+  return h;
+}
+
+/* one chunk: four independent multiply-rotate lanes over 32-byte stripes, then the tail bytewise */
+static uint64_t hash_chunk(const unsigned char* p, size_t n, uint64_t seed) {
+  uint64_t a = seed + P1, b = seed ^ P2, c = seed + P3, d = seed - P1;
+  size_t i = 0;
+  for (; i + 32 <= n; i += 32) {
+    uint64_t w[4];
+    memcpy(w, p + i, 32);
+    a = mixin(a, w[0]); b = mixin(b, w[1]); c = mixin(c, w[2]); d = mixin(d, w[3]);
+  }
+  uint64_t h = rotl(a, 1) + rotl(b, 7) + rotl(c, 12) + rotl(d, 18) + (uint64_t)n;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    memcpy(&w, p + i, 8);
+    h = mixin(h, w);
+  }
+  for (; i < n; ++i) h = mixin(h, (uint64_t)p[i] + 0x100);
+  return fin(h);
+}
+
+#define HASH_CHUNK ((size_t)1 << 20)
+
+struct hash_job {
+  const unsigned char* p;
+  size_t n, nchunks;
+  uint64_t* out;
+  int tid, nthreads;
+};
+
+static void* hash_worker(void* arg) {
+  struct hash_job* j = (struct hash_job*)arg;
+  for (size_t c = (size_t)j->tid; c < j->nchunks; c += (size_t)j->nthreads) {
+    const size_t off = c * HASH_CHUNK;
+    const size_t len = j->n - off < HASH_CHUNK ? j->n - off : HASH_CHUNK;
+    j->out[c] = hash_chunk(j->p + off, len, (uint64_t)c);
+  }
+  return NULL;
+}
+
+/* 64-bit content hash of nbytes at p (1 MiB chunks hashed on up to nthreads threads, chunk digests
+ * chained in order: the result does not depend on the thread count). */
+uint64_t cna_host_hash64(const void* p, int64_t nbytes, int nthreads) {
+  if (nbytes <= 0 || !p) return fin(P3);
+  const size_t n = (size_t)nbytes;
+  const size_t nchunks = (n + HASH_CHUNK - 1) / HASH_CHUNK;
+  uint64_t* dig = (uint64_t*)malloc(8 * nchunks);
+  if (!dig) return 0;
+  if (nthreads > 64) nthreads = 64;
+  if ((size_t)nthreads > nchunks) nthreads = (int)nchunks;
+  if (nthreads < 1) nthreads = 1;
+  struct hash_job jobs[64];
+  pthread_t th[64];
+  int started[64];
+  for (int t = 0; t < nthreads; ++t) {
+    jobs[t].p = (const unsigned char*)p; jobs[t].n = n; jobs[t].nchunks = nchunks; jobs[t].out = dig;
+    jobs[t].tid = t; jobs[t].nthreads = nthreads;
+    started[t] = 0;
+  }
+  for (int t = 1; t < nthreads; ++t) started[t] = pthread_create(&th[t], NULL, hash_worker, &jobs[t]) == 0;
+  hash_worker(&jobs[0]);
+  for (int t = 1; t < nthreads; ++t) {
+    if (started[t]) pthread_join(th[t], NULL);
+    else hash_worker(&jobs[t]);            /* could not start the thread: do its share here */
+  }
+  uint64_t h = P1 ^ (uint64_t)n;
+  for (size_t c = 0; c < nchunks; ++c) h = mixin(h, dig[c]);
+  free(dig);
+  return fin(h);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Cell order of the device copy: clusters of `B` cells that share neighbours.
+ *
+ * The walk kernel (csrc/diffuse_lds.hip) gives a workgroup a block of B consecutive device rows and
+ * stages the state rows of ALL their neighbours in LDS once; what it saves over a row-by-row gather is
+ * edges / distinct neighbour rows of the block.  A bandwidth-reducing order (reverse Cuthill-McKee)
+ * reaches 2.0 (B = 64) ... 2.4 (B = 128) on a k = 30 graph of 8-d points; growing each block greedily --
+ * start from a seed, keep adding the not yet placed cell with the most edges into the block -- reaches
+ * 3.0 ... 3.6 (tools/kbench_reorder.py).  Integer work only; the numbering never changes a result (rows
+ * keep their neighbours in the caller's order).
+ *
+ * Seeds: the oldest not yet placed cell among those that were candidates of an earlier cluster (FIFO),
+ * else the next unplaced cell in index order -- successive clusters are therefore graph neighbours, which
+ * keeps a workgroup's neighbours' neighbours in the XCD's L2.  Clusters that run out of candidates before
+ * reaching B cells are collected and laid out, in creation order, behind the full ones.
+ *
+ * n cells; CSR (indptr int64[n+1], indices int32) of the graph rows; only columns < n are followed (a
+ * sharded caller passes the diagonal part of its row block).  order_out[i] = caller's index of device
+ * row i.  Returns the number of cells in full clusters, or -1 (out of memory). */
+int64_t cna_host_cluster_order(int64_t n, const int64_t* indptr, const int32_t* indices, int B, int64_t* order_out) {
+  if (n <= 0) return 0;
+  if (B < 1) B = 1;
+  unsigned char* placed = (unsigned char*)calloc((size_t)n, 1);
+  int32_t* links = (int32_t*)calloc((size_t)n, 4);            /* edges from the growing cluster into a candidate */
+  int32_t* touched = (int32_t*)malloc(4 * (size_t)n);         /* candidates of the current cluster */
+  int32_t* fifo = (int32_t*)malloc(4 * (size_t)n);            /* seeds-to-be: every cell enters at most once */
+  unsigned char* queued = (unsigned char*)calloc((size_t)n, 1);
+  int64_t* shorts = (int64_t*)malloc(8 * (size_t)n);          /* members of short clusters */
+  int32_t* members = (int32_t*)malloc(4 * (size_t)B);
+  /* lazy bucket queue: level[c] holds cells whose link count was c when pushed; stale entries are
+   * skipped when popped.  Pushes per cluster <= edges of its members. */
+  int32_t** level = (int32_t**)calloc((size_t)B + 2, sizeof(int32_t*));
+  int64_t* lsize = (int64_t*)calloc((size_t)B + 2, 8);
+  int64_t* lcap = (int64_t*)calloc((size_t)B + 2, 8);
+  if (!placed || !links || !touched || !fifo || !queued || !shorts || !members || !level || !lsize || !lcap) return -1;
+  int64_t n_full = 0, n_short = 0, fifo_head = 0, fifo_tail = 0, next_index = 0;
+  for (;;) {
+    int64_t seed = -1;
+    while (fifo_head < fifo_tail) {
+      const int32_t c = fifo[fifo_head++];
+      if (!placed[c]) { seed = c; break; }
+    }
+    if (seed < 0) {
+      while (next_index < n && placed[next_index]) ++next_index;
+      if (next_index >= n) break;
+      seed = next_index;
+    }
+    int m = 0, top = 0;
+    int64_t ntouched = 0;
+    int32_t cur = (int32_t)seed;
+    for (;;) {
+      placed[cur] = 1;
+      members[m++] = cur;
+      if (m == B) break;
+      for (int64_t e = indptr[cur]; e < indptr[cur + 1]; ++e) {
+        const int32_t j = indices[e];
+        if (j < 0 || j >= n || placed[j]) continue;
+        if (links[j] == 0) touched[ntouched++] = j;
+        const int c = ++links[j];                             /* <= m <= B */
+        if (lsize[c] == lcap[c]) {
+          lcap[c] = lcap[c] ? 2 * lcap[c] : 256;
+          level[c] = (int32_t*)realloc(level[c], 4 * (size_t)lcap[c]);
+          if (!level[c]) return -1;
+        }
+        level[c][lsize[c]++] = j;
+        if (c > top) top = c;
+      }
+      int32_t pick = -1;
+      while (top > 0) {
+        if (lsize[top] == 0) { --top; continue; }
+        const int32_t j = level[top][--lsize[top]];
+        if (!placed[j] && links[j] == top) { pick = j; break; }
+      }
+      if (pick < 0) break;                                    /* no candidate left: a short cluster */
+      cur = pick;
+    }
+    for (int c = 0; c <= B; ++c) lsize[c] = 0;
+    for (int64_t t = 0; t < ntouched; ++t) {
+      const int32_t j = touched[t];
+      links[j] = 0;
+      if (!placed[j] && !queued[j]) { queued[j] = 1; fifo[fifo_tail++] = j; }
+    }
+    if (m == B) {
+      for (int i = 0; i < m; ++i) order_out[n_full + i] = members[i];
+      n_full += m;
+    } else {
+      for (int i = 0; i < m; ++i) shorts[n_short + i] = members[i];
+      n_short += m;
+    }
+  }
+  for (int64_t i = 0; i < n_short; ++i) order_out[n_full + i] = shorts[i];
+  for (int c = 0; c <= B + 1; ++c) free(level[c]);
+  free(level); free(lsize); free(lcap); free(placed); free(links); free(touched); free(fifo); free(queued);
+  free(shorts); free(members);
+  return n_full;
+}
+
+/* Per block of B consecutive local rows: the distinct columns its rows reference ("sources", in order of
+ * first appearance, at most `cap` per block) and, per edge, the position of its column in that list
+ * (0xFFFF: the block's list was full -- the kernel fetches such a neighbour row from memory instead).
+ *   indptr int64[n_local+1], indices int32 (device numbering, < n_cols)
+ *   src_ptr int64[nblocks+1] out; src out, capacity nnz; slot uint16[nnz] out.
+ * Returns the total number of sources, or -1. */
+int64_t cna_host_block_sources(int64_t n_local, int64_t n_cols, const int64_t* indptr, const int32_t* indices, int B,
+                               int cap, int64_t* src_ptr, int32_t* src, uint16_t* slot) {
+  if (cap > 0xFFFE) cap = 0xFFFE;
+  int32_t* stamp = (int32_t*)malloc(4 * (size_t)(n_cols > 0 ? n_cols : 1));    /* block that last listed the column */
+  uint16_t* where = (uint16_t*)malloc(2 * (size_t)(n_cols > 0 ? n_cols : 1));
+  if (!stamp || !where) return -1;
+  memset(stamp, 0xff, 4 * (size_t)(n_cols > 0 ? n_cols : 1));
+  const int64_t nblocks = (n_local + B - 1) / B;
+  int64_t total = 0;
+  for (int64_t b = 0; b < nblocks; ++b) {
+    src_ptr[b] = total;
+    int count = 0;
+    const int64_t r1 = (b + 1) * B < n_local ? (b + 1) * B : n_local;
+    for (int64_t e = indptr[b * B]; e < indptr[r1]; ++e) {
+      const int32_t j = indices[e];
+      if (stamp[j] == (int32_t)b) { slot[e] = where[j]; continue; }
+      if (count < cap) {
+        stamp[j] = (int32_t)b;
+        where[j] = (uint16_t)count;
+        slot[e] = (uint16_t)count;
+        src[total + count] = j;
+        ++count;
+      } else {
+        slot[e] = 0xFFFF;
+      }
+    }
+    total += count;
+  }
+  src_ptr[nblocks] = total;
+  free(stamp); free(where);
+  return total;
+}

@@ -42,6 +42,8 @@ class Engine(_order.CellOrder):
             check(self.lib.cna_comm_init(self.h, self.rank, self.nranks, C.cast(buf, C.c_void_p)), 'cna_comm_init')
         self._graph_key = None
         self._graph_ref = None
+        self._pinned = None
+        self._host_threads = _order.usable_cpus(8)
         self._colsum_w = None
         self._codes_token = self._codes_graph = None
         self.n = 0            # cells in the caller's view: all of them, or (view_local) this rank's block
@@ -90,23 +92,41 @@ class Engine(_order.CellOrder):
         r0 = min(self.rank * rpr, n)
         return r0, min(r0 + rpr, n)
 
+    def _key(self, A):
+        """Identity of a resident graph: shape, dtype and a 64-bit hash of the FULL content of data,
+        indices and indptr (csrc/host_graph.c, several threads: ~1.5 ms for the 66 MB of a 200k-cell
+        graph, ~13 ms at 2M cells) -- an in-place edit of any entry is seen and the graph goes to the
+        device again, as the reference re-reads the matrix on every call (_nam.py:25-28).
+
+        `pin_graph(A)` is the caller's promise not to edit A in place: a pinned matrix is recognised
+        by identity (object, buffers, sizes) plus a hash of three 64 KB windows only."""
+        ident = (A.shape, int(A.nnz), str(A.data.dtype), str(A.indices.dtype), str(A.indptr.dtype))
+        if self._pinned is not None and self._pinned[0]() is A and self._pinned[1] == self._buffers(A):
+            w = 16384
+            mid = max(0, A.nnz // 2 - w // 2)
+            parts = [slice(0, w), slice(mid, mid + w), slice(max(0, A.nnz - w), A.nnz)]
+            probe = tuple(self._hash(arr[p_]) for arr in (A.data, A.indices) for p_ in parts)
+            return ident + ('pinned', id(A)) + self._buffers(A) + probe
+        return ident + tuple(self._hash(arr) for arr in (A.data, A.indices, A.indptr))
+
     @staticmethod
-    def _key(A):
-        """Identity of a resident graph: the scipy object, its buffers, and a hash of three 64 KB
-        windows (head, middle, tail) of values and indices -- ~20 us, catches bulk in-place edits such
-        as ``A.data *= 2``.  Editing single entries of a matrix that is resident is not detected:
-        upload again with ``engine.ensure_graph(A.copy())`` (hashing all of a 66 MB graph would cost
-        more than the whole analysis)."""
-        w = 16384
-        mid = max(0, A.nnz // 2 - w // 2)
-        parts = [slice(0, w), slice(mid, mid + w), slice(max(0, A.nnz - w), A.nnz)]
-        try:
-            from xxhash import xxh3_64_intdigest as h
-            probe = tuple(h(np.ascontiguousarray(arr[p])) for arr in (A.data, A.indices) for p in parts)
-        except Exception:
-            probe = tuple(float(np.asarray(arr[p], dtype=np.float64).sum()) for arr in (A.data, A.indices) for p in parts)
-        return (id(A), A.shape, A.nnz, A.data.ctypes.data, A.indices.ctypes.data, A.indptr.ctypes.data,
-                str(A.data.dtype), probe)
+    def _buffers(A):
+        return (A.data.ctypes.data, A.indices.ctypes.data, A.indptr.ctypes.data)
+
+    def _hash(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return int(self.lib.cna_host_hash64(ptr(arr), arr.nbytes, self._host_threads))
+
+    def pin_graph(self, A):
+        """Promise that the connectivities matrix A will not be edited in place while it is resident:
+        later calls then recognise it without hashing all of it (what a loop over many phenotypes of
+        one dataset wants; bench.py does this and says so).  `unpin_graph()` withdraws the promise."""
+        if not sp.isspmatrix_csr(A) and not isinstance(A, sp.csr_array):
+            raise TypeError('pin_graph needs the CSR matrix that is passed to the analysis')
+        self._pinned = (weakref.ref(A), self._buffers(A))
+
+    def unpin_graph(self):
+        self._pinned = None
 
     def ensure_graph(self, A, shard=None):
         """Upload the connectivities graph unless this very matrix is already resident.  The cells

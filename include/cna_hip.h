@@ -278,6 +278,25 @@ int  cna_allgather_host(cna_ctx* ctx, const double* local, int64_t count_local, 
  * No context: callable from any thread. */
 int  cna_host_legacy_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss, int64_t n, double* out);
 
+/* ---- host-side helpers: graph identity and the device cell order (csrc/host_graph.c) ------- */
+/* 64-bit content hash of a buffer, computed on up to nthreads threads (the value does not depend on the
+ * thread count).  The engine keys the resident graph on the hash of ALL of data / indices / indptr, so an
+ * in-place edit of any entry re-uploads the graph -- the reference reads `data.obsp['connectivities']`
+ * afresh on every call (_nam.py:25-28). */
+uint64_t cna_host_hash64(const void* p, int64_t nbytes, int nthreads);
+/* Device cell order: clusters of B cells grown greedily by "most edges into the cluster" so that the
+ * rows of one block share neighbours (edges / distinct neighbour rows of a block: 3.0 at B = 64 against
+ * 2.0 for reverse Cuthill-McKee).  indptr int64[n+1], indices int32 of the rows' columns (columns outside
+ * [0, n) are ignored); order_out[i] = caller's index of device row i.  Returns the number of cells placed
+ * in full clusters, -1 when out of memory.  Only the numbering changes: every row keeps its neighbours in
+ * the caller's CSR order, so no sum is reordered (_nam.py:33). */
+int64_t cna_host_cluster_order(int64_t n, const int64_t* indptr, const int32_t* indices, int B, int64_t* order_out);
+/* Per block of B consecutive rows: the distinct columns referenced (<= cap per block, in order of first
+ * appearance) and, per edge, its column's position in the block's list (0xFFFF: not listed).  src_ptr
+ * int64[nblocks+1], src int32[>= nnz], slot uint16[nnz].  Returns the total length of the lists or -1. */
+int64_t cna_host_block_sources(int64_t n_local, int64_t n_cols, const int64_t* indptr, const int32_t* indices, int B,
+                               int cap, int64_t* src_ptr, int32_t* src, uint16_t* slot);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 /* HIP-event timing of every kernel launch on the context's stream (bench.py roofline) */
 int  cna_prof_enable(cna_ctx* ctx, int on);

@@ -60,7 +60,9 @@ def test_diffusion_steps_vs_oracle_and_golden(eng, orc, name):
     z = case['z']
     A, codes, N = _setup_nam(eng, orc, case)
     cs = eng.fetch_colsums()
-    np.testing.assert_allclose(cs, orc.column_sums(A, 1, 'f64'), rtol=1e-15)
+    # column sums are formed in scipy's order (ascending row, position in row) without float atomics:
+    # bit-identical to the float64 oracle for float32 AND float64 graphs, in any device cell order
+    np.testing.assert_array_equal(cs, orc.column_sums(A, 1, 'f64'))
     S = np.zeros((A.shape[0], N), dtype=bool)
     S[np.arange(A.shape[0]), codes] = True
     s = S
@@ -72,10 +74,9 @@ def test_diffusion_steps_vs_oracle_and_golden(eng, orc, name):
         got = eng.nam_full()
         want = s / S.sum(axis=0)
         assert relerr(got, want) < 1e-13, (i, relerr(got, want))
-        if A.dtype == np.float32:
-            # float32 graphs (what scanpy emits): column sums are exact in float64 whatever the order, and
-            # the kernels round like scipy's csr_matvecs (unfused multiply and add, CSR order) -- bit-identical
-            np.testing.assert_array_equal(got, want)
+        # deterministic column sums + kernels that round like scipy's csr_matvecs (unfused multiply and add,
+        # CSR order): bit-identical, float64 graphs included
+        np.testing.assert_array_equal(got, want)
         assert relerr(got, z['steps'][i] / S.sum(axis=0)) < 1e-5          # the reference itself
         kurt = eng.cell_stat(A.shape[0])
         np.testing.assert_allclose(kurt, orc.row_kurtosis(want), rtol=1e-9, atol=1e-12)
@@ -83,6 +84,32 @@ def test_diffusion_steps_vs_oracle_and_golden(eng, orc, name):
     # the walk is column-stochastic: every sample's row of the (samples x cells) NAM sums to 1
     got = eng.nam_full()
     np.testing.assert_allclose(got.sum(axis=0), 1.0, rtol=1e-10)
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'float64'])
+def test_column_sums_are_scipys_sequential_sums(eng, orc, dtype):
+    """colsums = A.sum(axis=0) + w (_nam.py:28) bit for bit in float64, for weights spanning 60 binades
+    (where the order of addition matters), hub columns with more than 64 and more than 4096 entries,
+    empty columns, an asymmetric pattern, and whatever order the device keeps the cells in."""
+    rs = np.random.RandomState(7)
+    n = 9000
+    rows = rs.randint(0, n, size=40 * n)
+    cols = rs.randint(0, n, size=40 * n)
+    cols[:5000] = 17                       # a hub column (~5000 entries)
+    cols[5000:5200] = 23                   # > 64 entries
+    cols[cols == 99] = 98                  # an empty column
+    vals = np.exp(rs.uniform(-40, 0, size=len(rows)))
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(n, n))
+    A.sum_duplicates()
+    A = A.astype(dtype)
+    A.indices = A.indices.astype(np.int32)
+    eng.ensure_graph(A)
+    for w in (1, 0.25):
+        eng.colsums(w)
+        got = eng.fetch_colsums()
+        want = np.asarray(A.astype(np.float64).sum(axis=0)).ravel() + w
+        np.testing.assert_array_equal(got, want)
+    assert eng.fetch_colsums()[99] == 0.25
 
 
 def test_dense_diffusion_and_self_weight(eng, orc):
@@ -169,7 +196,8 @@ def test_dense_row_kernels_vs_numpy(eng, orc, n, N):
 
 
 @pytest.mark.parametrize('n,N,P', [(3000, 20, 100), (2049, 50, 200), (1000, 100, 70), (600, 200, 130),
-                                   (100, 256, 64), (16, 12, 5), (700, 160, 90), (333, 224, 33)])
+                                   (100, 256, 64), (16, 12, 5), (700, 160, 90), (333, 224, 33),
+                                   (500, 192, 40), (250, 157, 70), (260, 221, 65)])
 def test_local_null_counts_are_exact(eng, n, N, P):
     """tails / ranks / num_detected are integers: they must equal a brute-force count."""
     from cna_amd import _ffi
@@ -784,6 +812,42 @@ def test_resident_graph_notices_bulk_in_place_edits(eng, orc):
         assert relerr(a, b) > 1e-3
     finally:
         A.data *= 2.0
+
+
+def test_resident_graph_notices_single_entry_edits_unless_pinned(eng, orc):
+    """The resident graph is keyed on a hash of its whole content (csrc/host_graph.c): changing ONE value
+    or ONE column index in place re-uploads it (the reference reads the matrix on every call,
+    _nam.py:25-28).  engine.pin_graph(A) is the caller's promise not to do that; the matrix is then
+    recognised by identity."""
+    import cna_amd as cna
+    from cna_amd import synth
+    data, _ = synth.make_dataset(40000, 20, k=15, seed=9)           # > 3 x 64 KB of values: edits fall outside any window
+    A = data.obsp['connectivities']
+    s0 = np.random.RandomState(3).rand(A.shape[0], 2)
+    a = cna.tl.diffuse(data, s0, 2, engine=eng)
+    assert eng.ensure_graph(A) is False
+    e = A.nnz // 3
+    old_v, old_j = A.data[e], A.indices[e]
+    try:
+        A.data[e] = old_v * 3 + 1                                # one value
+        b = cna.tl.diffuse(data, s0, 2, engine=eng)
+        assert relerr(b, orc.diffuse(sp.csr_matrix(A), s0, 2, mode='f64')) < 1e-13 and not np.array_equal(a, b)
+        A.data[e] = old_v
+        row = np.searchsorted(A.indptr, e, side='right') - 1
+        free = np.setdiff1d(np.arange(A.shape[0]), A.indices[A.indptr[row]:A.indptr[row + 1]])
+        A.indices[e] = free[0]                                   # one column index
+        c = cna.tl.diffuse(data, s0, 2, engine=eng)
+        assert relerr(c, orc.diffuse(sp.csr_matrix((A.data, A.indices, A.indptr), shape=A.shape), s0, 2, mode='f64')) < 1e-13
+        assert not np.array_equal(a, c)
+        A.indices[e] = old_j
+        d = cna.tl.diffuse(data, s0, 2, engine=eng)
+        assert np.array_equal(a, d)
+        eng.pin_graph(A)
+        assert eng.ensure_graph(A) is True                       # the key changes kind once ...
+        assert eng.ensure_graph(A) is False                      # ... and then holds
+    finally:
+        A.data[e], A.indices[e] = old_v, old_j
+        eng.unpin_graph()
 
 
 def _fuzz_config(seed):

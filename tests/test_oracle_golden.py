@@ -138,3 +138,25 @@ def test_tail_counts_matches_histogram_definition():
     edges = thr ** 2 - 1e-8 - 1e-5 * thr ** 2
     ref = np.array([[(zn[:, j] ** 2 >= e).sum() for e in edges] for j in range(7)])
     assert np.array_equal(tc, ref)
+
+
+@pytest.mark.parametrize('name', ['c01_plain_f32', 'c06_nnull_cap', 'c10_categorical_ids'])
+def test_reference_cost_baseline_matches_reference(name):
+    """oracle/reference_cost.py (bench.py's cpu_baseline: the reference's own sequence of library calls,
+    per-permutation / per-column / per-cell Python loops included) returns what the reference returned."""
+    from oracle import reference_cost as rc
+    case = load_case(name)
+    z = case['z']
+    call = case['call']
+    out = rc.association(case['data'], case['y'], case['sid_name'], nsteps=call['nsteps'], Nnull=call['Nnull'],
+                         seed=call['seed'])
+    assert out['k'] == int(z['k'])
+    assert out['p'] == pytest.approx(float(z['p']), rel=1e-12)
+    assert relerr(out['ncorrs'], z['ncorrs']) < 1e-9
+    assert relerr(out['nullminps'], z['nullminps']) < 1e-8
+    T = min(len(out['fdr']), len(z['fdr_fdr']))
+    assert T >= 300
+    assert np.array_equal(out['num_detected'][:T], z['fdr_num_detected'][:T])
+    assert relerr(out['fdr'][:T], z['fdr_fdr'][:T]) < 1e-8
+    np.testing.assert_allclose(out['coef_fdr'], z['obs_coef_fdr'], rtol=1e-8, atol=1e-12)
+    assert set(out['stages']) == {'nam', 'resid_svd', 'global_test', 'local_test', 'percell_apply'}
