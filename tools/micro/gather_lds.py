@@ -28,7 +28,7 @@ def main():
     print('graph %.1fs nnz/row %.1f' % (time.time() - t, A.nnz / n), flush=True)
     indptr0 = A.indptr.astype(np.int64)
     indices0 = A.indices.astype(np.int32)
-    for B, caps in ((32, (512,)), (64, (896, 1024)), (128, (1792,))):
+    for B, caps in ((32, (544,)), (64, (960, 1920))):
         order = np.zeros(n, np.int64)
         t = time.time()
         nf = lib.cna_host_cluster_order(n, indptr0.ctypes.data, indices0.ctypes.data, B, order.ctypes.data)
