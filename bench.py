@@ -287,7 +287,7 @@ def main():
                          'weak = the workload size PER GPU')
     ap.add_argument('--no-extra', action='store_true', help='N=1: skip the additional C3 and C2 lines')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-sample-cells', type=int, default=40_000)
+    ap.add_argument('--cpu-sample-cells', type=int, default=150_000)
     ap.add_argument('--profile-host', default=None, help='write a cProfile of 3 extra steps to this file')
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'shm'],
                     help="shm: plumbing check of the N>1 path on ONE GPU (all ranks on device 0, gloo for the "

@@ -3,8 +3,8 @@
 The random walk gathers, for every cell, the state rows of its ~30 graph neighbours.  How many of
 those rows are already in L2 / Infinity Cache depends only on how the cells are numbered, and the
 caller's numbering is arbitrary (the reference never looks at it).  So the engine is free to keep
-the cells in a locality-preserving order of its own -- reverse Cuthill-McKee of the kNN graph,
-which turns the adjacency into a band -- as long as nothing order-dependent leaks out.
+the cells in a locality-preserving order of its own -- clusters of cells that share neighbours
+(round 1: reverse Cuthill-McKee of the kNN graph) -- as long as nothing order-dependent leaks out.
 
 Invariants that keep results bit-identical to the caller's order:
   * only rows are renumbered; inside a row the neighbours stay in the caller's CSR order, so every
@@ -13,7 +13,7 @@ Invariants that keep results bit-identical to the caller's order:
     `cna_amd.tools` and the tests only ever see the caller's order.
 
 `perm[i]` is the caller's index of device row i.  Multi-GPU: every rank computes the same `perm`
-from the same graph (RCM is deterministic) and owns a contiguous block of *device* rows; with a
+from the same graph (the ordering is deterministic) and owns a contiguous block of *device* rows; with a
 banded adjacency most neighbours of a block live in the block itself.
 """
 import os
@@ -34,11 +34,25 @@ def usable_cpus(limit=None):
     return n if limit is None else max(1, min(n, int(limit)))
 
 
+DEFAULT_CLUSTER = 512
+
+
 def locality_order(A):
-    """Reverse Cuthill-McKee order of the (structurally symmetrised) graph, or None when the
-    reordering is switched off (CNA_REORDER=0) or pointless."""
+    """Device order of the cells, or None when the reordering is switched off (CNA_REORDER=0) or
+    pointless.  Default: clusters of DEFAULT_CLUSTER cells grown greedily by "most edges into the
+    cluster" (csrc/host_graph.c), laid out in breadth-first order of the clusters; each XCD then walks
+    one cluster at a time (diffuse.hip: xcd_chunk) and finds most of its neighbours' rows in its own
+    4 MB L2.  Measured on MI355X, us per dense walk step (tools/kbench_order.py,
+    profiles/r02_kbench_order.txt): 2M x 200: 10877 (reverse Cuthill-McKee, one contiguous eighth of
+    the rows per XCD) -> 7757; 1M x 100: 2160 -> 1980; 200k x 50: 202 -> 203.  It is also cheaper to
+    compute than scipy's RCM (0.15 s against 0.6 s at 1M cells).  CNA_ORDER=rcm selects RCM,
+    CNA_ORDER=cluster:B another cluster size."""
     if os.environ.get('CNA_REORDER', '1') in ('0', 'off', 'no') or A.shape[0] < 2:
         return None
+    kind = os.environ.get('CNA_ORDER', 'cluster')
+    if kind.startswith('cluster'):
+        B = int(kind.split(':')[1]) if ':' in kind else DEFAULT_CLUSTER
+        return cluster_order(sp.csr_matrix(A), B)
     from scipy.sparse.csgraph import reverse_cuthill_mckee
     perm = reverse_cuthill_mckee(sp.csr_matrix(A), symmetric_mode=False)
     return np.ascontiguousarray(perm, dtype=np.int64)

@@ -703,6 +703,10 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
   // measured (tools/kbench.py): one contiguous eighth per XCD is best at 200k x 50 (+4 % over
   // round-robin) and within 2 % of every chunk size at 1M x 100
   int64_t chunk = cpx;
+  // wide states (wave-per-row kernels): 128 workgroups = 512 consecutive rows = one cluster of the device
+  // order (cna_amd/_order.py) per XCD at a time -- the cluster's neighbour rows then stay in that XCD's L2
+  // (2M x 200, dense step: 10.9 ms with one contiguous eighth per XCD under RCM, 7.8 ms this way)
+  if (!pair && a.ld > 64 && cpx > 128) chunk = 128;
   if (const char* e = getenv("CNA_XCD_CHUNK")) { const int64_t v = atoll(e); if (v > 0 && v < cpx) chunk = v; }   // experiments
   cpx = (cpx + chunk - 1) / chunk * chunk;      // whole chunks per XCD
   a.xcd_chunk = (int)chunk;
