@@ -207,7 +207,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   prof_flush(c);
   comm_destroy(c);
   void* bufs[] = {c->coef_dev, c->proj, c->sp_idx, c->sp_val, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
-                  c->nam, c->X, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
+                  c->nam, c->X, c->X2, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -399,7 +399,7 @@ static int ensure_sparse_state(cna_ctx* c) {
 int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const double* counts) {
   CHECK_CTX(c);
   if (!c->indptr) CNA_FAIL(CNA_ESTATE, "cna_set_samples before cna_graph_upload");
-  if (n_samples < 1 || n_samples > 512) CNA_FAIL(CNA_EINVAL, "n_samples must be in [1, 512]");
+  if (n_samples < 1 || n_samples > 1024) CNA_FAIL(CNA_EINVAL, "n_samples must be in [1, 1024]");
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (!c->sid || !c->counts || c->N != n_samples || c->sid_n != c->n_global) {
     if (c->sid) dev_free(c, c->sid, sizeof(int32_t) * c->sid_n);
@@ -623,7 +623,7 @@ int cna_stat_median(cna_ctx* c, double* median_out) {
 int cna_dense_load(cna_ctx* c, const double* s_local, int m) {
   CHECK_CTX(c);
   if (!c->have_colsum) CNA_FAIL(CNA_ESTATE, "cna_dense_load needs cna_colsums");
-  if (m < 1 || m > 512) CNA_FAIL(CNA_EINVAL, "dense state must have 1..512 columns");
+  if (m < 1 || m > 1024) CNA_FAIL(CNA_EINVAL, "dense state must have 1..1024 columns");
   const int ld = round_up(m, 4);
   CNA_TRY(ensure_T(c, ld));
   void* ds = c->dense_s;
@@ -896,7 +896,7 @@ int cna_select_standardized_fused(cna_ctx* c, const int64_t* keep_idx, int64_t n
 
 int cna_upload_x(cna_ctx* c, const double* x_local, int64_t n_rows, int n_cols) {
   CHECK_CTX(c);
-  if (n_rows < 0 || n_cols < 1 || n_cols > 512) CNA_FAIL(CNA_EINVAL, "cna_upload_x: bad shape");
+  if (n_rows < 0 || n_cols < 1 || n_cols > 1024) CNA_FAIL(CNA_EINVAL, "cna_upload_x: bad shape");
   c->nx = n_rows;
   c->Nx = n_cols;
   c->ldx = x_ld(n_cols);
@@ -1344,7 +1344,8 @@ int cna_global_test_launch(cna_ctx* c, const double* U, int kmax, const int32_t*
     if (ks[a] < 1 || ks[a] > kmax) CNA_FAIL(CNA_EINVAL, "cna_global_test: ks must lie in [1, kmax]");
   if (c->gt_pending_P) CNA_FAIL(CNA_ESTATE, "a global test is still pending: fetch it first");
   void* g = c->gt;
-  CNA_TRY(dev_reserve(c, &g, &c->gt_cap, carve_bytes({8 * (int64_t)N * kmax, 4 * (int64_t)K, 8 * (int64_t)P, 8 * (int64_t)P, 4 * (int64_t)P})));
+  const int64_t nwork = global_test_scratch_doubles(P, kmax, K);
+  CNA_TRY(dev_reserve(c, &g, &c->gt_cap, carve_bytes({8 * (int64_t)N * kmax, 4 * (int64_t)K, 8 * (int64_t)P, 8 * (int64_t)P, 4 * (int64_t)P, 8 * nwork})));
   c->gt = g;
   Carver cv(c->gt);
   double* Ud = cv.take<double>((int64_t)N * kmax);
@@ -1352,6 +1353,7 @@ int cna_global_test_launch(cna_ctx* c, const double* U, int kmax, const int32_t*
   double* mp = cv.take<double>(P);
   double* r2 = cv.take<double>(P);
   int32_t* ki = cv.take<int32_t>(P);
+  double* work = cv.take<double>(nwork);
   const int64_t off_ks = 8 * (int64_t)N * kmax;
   const int64_t off_out = round_up(off_ks + 4 * (int64_t)K, 64);
   const int64_t need = off_out + 20 * (int64_t)P + 64;
@@ -1369,7 +1371,7 @@ int cna_global_test_launch(cna_ctx* c, const double* U, int kmax, const int32_t*
   hipStream_t st = c->copy_stream;
   HIP_TRY(hipMemcpyAsync(Ud, h, 8 * (size_t)N * kmax, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(ksd, h + off_ks, 4 * (size_t)K, hipMemcpyHostToDevice, st));
-  CNA_TRY(launch_global_test(c, st, c->zc, c->zc_ld, N, P, Ud, kmax, ksd, K, r, mp, r2, ki));
+  CNA_TRY(launch_global_test(c, st, c->zc, c->zc_ld, N, P, Ud, kmax, ksd, K, r, work, mp, r2, ki));
   HIP_TRY(hipMemcpyAsync(h + off_out, mp, 8 * (size_t)P, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(h + off_out + 8 * (size_t)P, r2, 8 * (size_t)P, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(h + off_out + 16 * (size_t)P, ki, 4 * (size_t)P, hipMemcpyDeviceToHost, st));

@@ -107,6 +107,8 @@ struct cna_ctx {
   // ---- X (nx x ldx): selected NAM -> residualised NAM
   double* X = nullptr;
   int64_t x_cap = 0;
+  double* X2 = nullptr;          // second working matrix: target of the k-split residualisation (N > 256), swapped with X
+  int64_t x2_cap = 0;
   int64_t nx = 0;
   int Nx = 0, ldx = 0;
   int64_t* keep_idx = nullptr;    // active map: local NAM row of each X row; null = identity
@@ -245,8 +247,9 @@ int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const do
 // stats.hip
 int launch_condition(cna_ctx* c, hipStream_t st, const double* M_dev, const double* Y_dev, int N, int P,
                      double* Zc_dev, int ldy);
+int64_t global_test_scratch_doubles(int P, int kmax, int K);
 int launch_global_test(cna_ctx* c, hipStream_t st, const double* Zc_dev, int ldy, int N, int P, const double* U_dev,
-                       int kmax, const int32_t* ks_dev, int K, int r, double* minp_dev, double* r2_dev,
+                       int kmax, const int32_t* ks_dev, int K, int r, double* work, double* minp_dev, double* r2_dev,
                        int32_t* kidx_dev);
 
 // ---- device helpers shared by the kernel files

@@ -208,9 +208,8 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
 // lanes cost half the load instructions of 8-byte ones, -18 % time at N=100).  Neighbour index
 // and weight travel lane -> SGPR by v_readlane, the row base T + j*ld is scalar arithmetic, and
 // products / sums are unfused and in CSR order (scipy's csr_matvecs rounding sequence).
-template <typename VT, int NQ2>
+template <typename VT, int NQ2, int U = 8>       // U: neighbour rows in flight per wave (8 beats 16 and 32; 4 beyond 512 columns: registers)
 __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
-  constexpr int U = 8;                          // neighbour rows in flight per wave (8 beats 16 and 32)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t row = my_row(wv, a.xcd_chunk);
@@ -680,9 +679,9 @@ int launch_first_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
                      (const CellInfo*)c->cellinfo);
   return 0;
 }
-template <typename VT, int NQ2>
+template <typename VT, int NQ2, int U = 8>
 int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
-  hipLaunchKernelGGL((k_nam_step<VT, NQ2>), grid, dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL((k_nam_step<VT, NQ2, U>), grid, dim3(256), 0, c->stream, a);
   return 0;
 }
 
@@ -711,7 +710,7 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
   cpx = (cpx + chunk - 1) / chunk * chunk;      // whole chunks per XCD
   a.xcd_chunk = (int)chunk;
   dim3 grid((unsigned)(cpx * 8));
-  if (a.ld > 512) CNA_FAIL(CNA_EINVAL, "more than 512 samples / state columns are not supported");
+  if (a.ld > 1024) CNA_FAIL(CNA_EINVAL, "more than 1024 samples / state columns are not supported");
   if (first) {
     switch ((a.ld + 63) / 64) {
       case 1: launch_first_t<VT, 1>(c, a, grid); break;
@@ -719,14 +718,18 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
       case 3: launch_first_t<VT, 3>(c, a, grid); break;
       case 4: launch_first_t<VT, 4>(c, a, grid); break;
       case 5: case 6: launch_first_t<VT, 6>(c, a, grid); break;
-      default: launch_first_t<VT, 8>(c, a, grid); break;
+      case 7: case 8: launch_first_t<VT, 8>(c, a, grid); break;
+      case 9: case 10: case 11: case 12: launch_first_t<VT, 12>(c, a, grid); break;
+      default: launch_first_t<VT, 16>(c, a, grid); break;
     }
   } else if (a.sp_cnt) {
     switch ((a.ld / 2 + 63) / 64) {
       case 1: launch_step_sparse_t<VT, 1>(c, a, grid); break;
       case 2: launch_step_sparse_t<VT, 2>(c, a, grid); break;
       case 3: launch_step_sparse_t<VT, 3>(c, a, grid); break;
-      default: launch_step_sparse_t<VT, 4>(c, a, grid); break;
+      case 4: launch_step_sparse_t<VT, 4>(c, a, grid); break;
+      case 5: case 6: launch_step_sparse_t<VT, 6>(c, a, grid); break;
+      default: launch_step_sparse_t<VT, 8>(c, a, grid); break;
     }
   } else if (pair) {
     hipLaunchKernelGGL((k_nam_step_pair<VT>), grid, dim3(256), 0, c->stream, a);
@@ -735,7 +738,9 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
       case 1: launch_step_t<VT, 1>(c, a, grid); break;
       case 2: launch_step_t<VT, 2>(c, a, grid); break;
       case 3: launch_step_t<VT, 3>(c, a, grid); break;
-      default: launch_step_t<VT, 4>(c, a, grid); break;
+      case 4: launch_step_t<VT, 4>(c, a, grid); break;
+      case 5: case 6: launch_step_t<VT, 6, 4>(c, a, grid); break;
+      default: launch_step_t<VT, 8, 4>(c, a, grid); break;
     }
   }
   HIP_TRY(hipGetLastError());

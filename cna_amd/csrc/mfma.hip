@@ -31,10 +31,15 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 #define CNA_XB_CAP 52
 #endif
 #define XB_MIN_WAVES(KQ) (((KQ) > 32 && (KQ) <= CNA_XB_CAP) ? 4 : 1)
+// More than 256 samples (k-depth beyond 64 quads): the product is split along k into parts of up to 256
+// columns; part p reads columns [k_off, k_off + 4 KQ) of X (row stride ldx) and the matching rows of B, and
+// adds into OUT (accumulate), which then cannot be X itself -- launch_xb works into a second buffer and
+// swaps.  Centring uses row means taken beforehand over the whole row (k_row_means).
 template <int KQ, int NS>
 __global__ __launch_bounds__(512, XB_MIN_WAVES(KQ)) void k_xb(const double* __restrict__ X, int64_t nx, int Nx,
                                             const double* __restrict__ B, int ldb, int center,
-                                            double* out, int ld_out) {
+                                            double* out, int ld_out, int ldx, int k_off,
+                                            const double* __restrict__ means, int accumulate) {
   constexpr int LDX = 4 * KQ, PT = 16 * NS, LDB = PT + 16;   // LDB = 16 mod 32: conflict-free B fragments
   extern __shared__ double sm[];
   const int tid = threadIdx.x;
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(512, XB_MIN_WAVES(KQ)) void k_xb(const double* __re
   {
     const int64_t row = r0 + ai;
     if (row < nx) {
-      const double* __restrict__ xp = X + row * LDX + ak;
+      const double* __restrict__ xp = X + row * ldx + k_off + ak;
 #pragma unroll
       for (int q = 0; q < KQ; ++q) a[q] = xp[4 * q];
     } else {
@@ -54,7 +59,13 @@ __global__ __launch_bounds__(512, XB_MIN_WAVES(KQ)) void k_xb(const double* __re
       for (int q = 0; q < KQ; ++q) a[q] = 0.0;
     }
   }
-  if (center) {                              // pad columns of X are zero, so they do not disturb the sum
+  if (means) {                               // split product: the row mean comes from k_row_means
+    const int64_t row = r0 + ai;
+    const double mean = row < nx ? means[row] : 0.0;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q)
+      if (k_off + 4 * q + ak < Nx) a[q] -= mean;
+  } else if (center) {                       // pad columns of X are zero, so they do not disturb the sum
     double s = 0.0;
 #pragma unroll
     for (int q = 0; q < KQ; ++q) s += a[q];
@@ -89,11 +100,23 @@ __global__ __launch_bounds__(512, XB_MIN_WAVES(KQ)) void k_xb(const double* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t gr = r0 + ak + 4 * r;
-          if (gr < nx) out[gr * ld_out + col] = acc[s][r];
+          if (gr < nx) out[gr * ld_out + col] = accumulate ? out[gr * ld_out + col] + acc[s][r] : acc[s][r];
         }
       }
     }
   }
+}
+
+// mean over the Nx columns of every row of X (pad columns are zero); one wave per row
+__global__ __launch_bounds__(256) void k_row_means(const double* __restrict__ X, int64_t nx, int Nx, int ldx,
+                                                   double* __restrict__ means) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nx) return;
+  double s = 0.0;
+  for (int col = lane; col < Nx; col += 64) s += X[row * ldx + col];
+  s = wave_sum(s);
+  if (lane == 0) means[row] = s / (double)Nx;
 }
 
 // Up to 128 samples the whole of B fits in LDS: one load per workgroup, then 16 waves walk the row
@@ -174,7 +197,7 @@ __global__ __launch_bounds__(1024) void k_xb_res(const double* __restrict__ X, i
 // streams 32-cell slabs of X through LDS and every wave feeds its tiles with 8 k-steps of 4
 // cells.  Per-workgroup partial tiles are written out and summed in a fixed order by
 // k_gram_reduce (deterministic; no float atomics).
-template <int TPW, int NW = 8>
+template <int TPW, int NW = 8, int SLAB = 32>
 __global__ __launch_bounds__(64 * NW) void k_gram(const double* __restrict__ X, int64_t nx, int ldx, int nt,
                                               int ldp, int ntri, const int32_t* __restrict__ tiles,
                                               double* __restrict__ partial) {
@@ -195,18 +218,18 @@ __global__ __launch_bounds__(64 * NW) void k_gram(const double* __restrict__ X, 
     off_i[t] = (packed >> 16) * 16;
     off_j[t] = (packed & 0xffff) * 16;
   }
-  for (int i = tid; i < 32 * ldp; i += 64 * NW) sm[i] = 0.0;
-  const int64_t nslab = (nx + 31) / 32;
+  for (int i = tid; i < SLAB * ldp; i += 64 * NW) sm[i] = 0.0;
+  const int64_t nslab = (nx + SLAB - 1) / SLAB;
   for (int64_t slab = blockIdx.x; slab < nslab; slab += gridDim.x) {
     __syncthreads();
-    const int64_t r0 = slab * 32;
-    for (int r = wv; r < 32; r += NW) {
+    const int64_t r0 = slab * SLAB;
+    for (int r = wv; r < SLAB; r += NW) {
       const int64_t gr = r0 + r;
       for (int col = lane; col < ldx; col += 64) sm[r * ldp + col] = (gr < nx) ? X[gr * ldx + col] : 0.0;
     }
     __syncthreads();
 #pragma unroll 1
-    for (int kq = 0; kq < 8; ++kq) {
+    for (int kq = 0; kq < SLAB / 4; ++kq) {
       const double* rowp = sm + (4 * kq + ak) * ldp + ai;
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
@@ -419,6 +442,96 @@ __global__ __launch_bounds__(64 * NW) void k_null(const double* __restrict__ X, 
   }
 }
 
+// More than 256 samples: the k-depth is a run-time loop, the A operand comes from memory at every step
+// (two 16-cell tiles per wave share each B fragment), one strip of 16 permutations per block.  Same
+// counting rule as k_null (exact cuts; the linear guess with the table walk inside the margin).  A
+// fallback for large cohorts, not a tuned kernel: ~0.1-0.2 of the MFMA peak.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_null_big(const double* __restrict__ X, int64_t nx, int64_t chunk_rows, int ldx,
+                                                      const double* __restrict__ Yc, int ldy, int P,
+                                                      const double* __restrict__ cuts, int T, double cut0,
+                                                      double inv_step, double eps, unsigned int* __restrict__ partial,
+                                                      int LDB) {
+  extern __shared__ double sm[];
+  constexpr int PT = 16;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ak = lane >> 4, aj = lane & 15;
+  const int TP = (T + 4) & ~1, TW = T + 1;
+  double* c_s = sm;
+  double* bs = sm + TP;                                       // ldx x LDB
+  unsigned int* hist = (unsigned int*)(bs + (size_t)ldx * LDB);
+  const int pt = blockIdx.y;
+  for (int i = tid; i < TP; i += 64 * NW) c_s[i] = i == 0 ? 0.0 : (i <= T ? cuts[i - 1] : __builtin_inf());
+  for (int i = tid; i < PT * TW; i += 64 * NW) hist[i] = 0u;
+  for (int i = tid; i < ldx * PT; i += 64 * NW) {
+    const int k = i / PT, j = i - k * PT;
+    bs[k * LDB + j] = Yc[(size_t)k * ldy + pt * PT + j];
+  }
+  __syncthreads();
+  const int64_t row_begin = (int64_t)blockIdx.x * chunk_rows;
+  int64_t row_end = row_begin + chunk_rows;
+  if (row_end > nx) row_end = nx;
+  const int64_t ntile = row_begin < row_end ? (row_end - row_begin + 15) / 16 : 0;
+  const double* bp = bs + ak * LDB + aj;
+  unsigned int* hrow = hist + aj * TW;
+  const double ratio = cut0 * inv_step;
+  const bool linear = eps < 0.25 && ratio < 60000.0;
+  const int OFF = linear ? (int)ratio + 2 : 1;
+  const double K1 = inv_step * 65536.0, K0 = ((double)OFF - ratio) * 65536.0;
+  const unsigned E = linear ? (unsigned)(eps * 65536.0) + 3u : 65536u;
+  const unsigned lim = linear ? 65536u - 2u * E : 0u;
+  auto count = [&](const v4d& acc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double x = fabs(acc[i]);
+      const unsigned u = (unsigned)__builtin_fma(x, K1, K0);
+      int h = (int)(u >> 16) - (OFF - 1);
+      h = h < T ? h : T;
+      if (!(((u & 0xffffu) - E) < lim)) {
+        int hh = h > 0 ? h : 0;
+        while (c_s[hh + 1] <= x) ++hh;
+        while (c_s[hh] > x) --hh;
+        h = hh;
+      }
+      if (h > 0) atomicAdd(&hrow[h], 1u);
+    }
+  };
+  const int kq = ldx / 4;
+  for (int64_t t = 2 * (int64_t)wv; t < ntile; t += 2 * NW) {
+    const int64_t row0 = row_begin + 16 * t + aj, row1 = row0 + 16;
+    const bool ok0 = row0 < row_end, ok1 = row1 < row_end;
+    const double* __restrict__ x0 = X + (ok0 ? row0 : row_begin) * ldx + ak;
+    const double* __restrict__ x1 = X + (ok1 ? row1 : row_begin) * ldx + ak;
+    v4d acc0 = (v4d){0.0, 0.0, 0.0, 0.0}, acc1 = (v4d){0.0, 0.0, 0.0, 0.0};
+    int q = 0;
+    for (; q + 4 <= kq; q += 4) {
+      double a0[4], a1[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a0[u] = x0[4 * (q + u)]; a1[u] = x1[4 * (q + u)]; b[u] = bp[(size_t)4 * (q + u) * LDB]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ok0 ? a0[u] : 0.0, b[u], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ok1 ? a1[u] : 0.0, b[u], acc1, 0, 0, 0);
+      }
+    }
+    for (; q < kq; ++q) {
+      const double b = bp[(size_t)4 * q * LDB];
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ok0 ? x0[4 * q] : 0.0, b, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ok1 ? x1[4 * q] : 0.0, b, acc1, 0, 0, 0);
+    }
+    count(acc0);                                              // zero rows never reach cut0 > 0
+    count(acc1);
+  }
+  __syncthreads();
+  unsigned int* out = partial + ((size_t)blockIdx.x * P + (size_t)pt * PT) * T;
+  for (int i = tid; i < PT * T; i += 64 * NW) {
+    const int pl = i / T, tt = i - pl * T;
+    if (pt * PT + pl < P) out[(size_t)pl * T + tt] = hist[pl * TW + tt + 1];
+  }
+}
+
 // hist[p][t] = sum over row chunks of the per-block slabs (fixed order, integers)
 __global__ void k_hist_reduce(const unsigned int* __restrict__ partial, int nchunks, int64_t PT_total,
                               unsigned long long* __restrict__ hist) {
@@ -429,11 +542,16 @@ __global__ void k_hist_reduce(const unsigned int* __restrict__ partial, int nchu
   hist[i] = s;
 }
 
-template <int TPW, int NW = 8>
+template <int TPW, int NW = 8, int SLAB = 32>
 int launch_gram_t(cna_ctx* c, int nt, int ldp, int ntri, const int32_t* tiles_dev, double* partial, int nblocks,
                   size_t smem) {
   const int npass = (ntri + NW * TPW - 1) / (NW * TPW);
-  hipLaunchKernelGGL((k_gram<TPW, NW>), dim3(nblocks, npass), dim3(64 * NW), smem, c->stream, c->X, c->nx, c->ldx, nt, ldp,
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIP_TRY(hipFuncSetAttribute((const void*)k_gram<TPW, NW, SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_gram<TPW, NW, SLAB>), dim3(nblocks, npass), dim3(64 * NW), smem, c->stream, c->X, c->nx, c->ldx, nt, ldp,
                      ntri, tiles_dev, partial);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -479,15 +597,17 @@ const auto kNullNS1 = null_table<1>(std::make_integer_sequence<int, 64>{});   //
 }  // namespace
 
 namespace {
-typedef int (*xb_launch_fn)(cna_ctx*, unsigned, size_t, const double*, int, int, double*, int);
+typedef int (*xb_launch_fn)(cna_ctx*, unsigned, size_t, const double*, int, int, double*, int, int, const double*, int);
 template <int KQ, int NS>
-int launch_xb_t(cna_ctx* c, unsigned grid, size_t smem, const double* B_dev, int ldb, int center, double* out, int ld_out) {
+int launch_xb_t(cna_ctx* c, unsigned grid, size_t smem, const double* B_dev, int ldb, int center, double* out, int ld_out,
+                int k_off, const double* means, int accumulate) {
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_xb<KQ, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_xb<KQ, NS>), dim3(grid), dim3(512), smem, c->stream, c->X, c->nx, c->Nx, B_dev, ldb, center, out, ld_out);
+  hipLaunchKernelGGL((k_xb<KQ, NS>), dim3(grid), dim3(512), smem, c->stream, c->X, c->nx, c->Nx, B_dev, ldb, center, out, ld_out,
+                     c->ldx, k_off, means, accumulate);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -522,10 +642,38 @@ int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, 
   (void)n_out;
   if (c->nx == 0) return 0;
   const int kq = c->ldx / 4;
-  if (kq < 1 || kq > 64) CNA_FAIL(CNA_EINVAL, "more than 256 samples are not supported by the residualisation kernel yet");
+  if (kq < 1 || kq > 256) CNA_FAIL(CNA_EINVAL, "more than 1024 samples are not supported");
   ProfScope ps(c, out == c->X ? CNA_K_RESID : CNA_K_PROJECT);
-  const int NS = kq <= 32 ? 4 : 2;
   const int64_t ntile = (c->nx + 15) / 16;
+  if (kq > 64) {
+    // k-split: parts of up to 64 quads (256 samples) accumulated into a buffer other than X
+    double* dst = out;
+    if (out == c->X) {
+      void* p2 = c->X2;
+      CNA_TRY(dev_reserve(c, &p2, &c->x2_cap, (int64_t)sizeof(double) * std::max<int64_t>(c->nx, 1) * ld_out));
+      c->X2 = (double*)p2;
+      dst = c->X2;
+    }
+    const double* means = nullptr;
+    if (center) {
+      CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, (int64_t)sizeof(double) * c->nx));
+      hipLaunchKernelGGL(k_row_means, dim3((unsigned)((c->nx + 3) / 4)), dim3(256), 0, c->stream, c->X, c->nx, c->Nx, c->ldx,
+                         (double*)c->scratch2);
+      means = (const double*)c->scratch2;
+    }
+    const unsigned grid = (unsigned)((ntile + 7) / 8);
+    for (int q0 = 0; q0 < kq; q0 += 64) {
+      const int kqp = kq - q0 < 64 ? kq - q0 : 64;
+      const size_t smem = sizeof(double) * (size_t)(4 * kqp) * (16 * 2 + 16);
+      CNA_TRY(kXbNS2[kqp - 1](c, grid, smem, B_dev + (size_t)(4 * q0) * ldb, ldb, 0, dst, ld_out, 4 * q0, means, q0 > 0));
+    }
+    if (out == c->X) {                        // in-place request: the result replaces X
+      std::swap(c->X, c->X2);
+      std::swap(c->x_cap, c->x2_cap);
+    }
+    return 0;
+  }
+  const int NS = kq <= 32 ? 4 : 2;
   {
     const int nct = ((ldb + 63) / 64) * 4;
     const size_t whole = sizeof(double) * (size_t)c->ldx * (16 * nct + 16);
@@ -537,7 +685,7 @@ int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, 
   const size_t smem = sizeof(double) * (size_t)c->ldx * (16 * NS + 16);
   const unsigned grid = (unsigned)((ntile + 7) / 8);
   xb_launch_fn fn = NS == 4 ? kXbNS4[kq - 1] : kXbNS2[kq - 1];
-  return fn(c, grid, smem, B_dev, ldb, center ? 1 : 0, out, ld_out);
+  return fn(c, grid, smem, B_dev, ldb, center ? 1 : 0, out, ld_out, 0, nullptr, 0);
 }
 
 int launch_gram(cna_ctx* c, double* G_dev) {
@@ -551,8 +699,14 @@ int launch_gram(cna_ctx* c, double* G_dev) {
   std::vector<int32_t> tiles;
   for (int i = 0; i < nt; ++i)
     for (int j = i; j < nt; ++j) tiles.push_back((i << 16) | j);
-  const int64_t nslab = (c->nx + 31) / 32;
-  const int nblocks = (int)(nslab < 512 ? nslab : 512);
+  // 32-cell slabs of X in LDS (32 x ldp doubles) up to 512 samples, 16-cell slabs up to 1024; beyond 256
+  // samples the upper-triangular tiles exceed one pass of 16 waves x 9 tiles and grid.y walks the passes
+  const int slab_rows = (size_t)32 * ldp * sizeof(double) <= 150 * 1024 ? 32 : 16;
+  if ((size_t)slab_rows * ldp * sizeof(double) > 160 * 1024) CNA_FAIL(CNA_EINVAL, "more than 1024 samples are not supported");
+  const int64_t nslab = (c->nx + slab_rows - 1) / slab_rows;
+  int nblocks = (int)(nslab < 512 ? nslab : 512);
+  const int64_t blocks_1g = ((int64_t)1 << 30) / ((int64_t)ntri * 2048);      // per-block partial tiles: keep the slab under 1 GiB
+  if (nblocks > blocks_1g) nblocks = (int)(blocks_1g > 1 ? blocks_1g : 1);
   CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, (int64_t)sizeof(double) * nblocks * ntri * 256));
   double* partial = (double*)c->scratch2;
   if (c->gram_tiles_nt != nt) {                          // the tile table depends on nt only: upload once
@@ -564,7 +718,7 @@ int launch_gram(cna_ctx* c, double* G_dev) {
     c->gram_tiles_nt = nt;
   }
   int32_t* tiles_dev = (int32_t*)c->gram_tiles_ptr;
-  const size_t smem = sizeof(double) * 32 * ldp;
+  const size_t smem = sizeof(double) * slab_rows * ldp;
   {
     ProfScope ps(c, CNA_K_GRAM);
     int r;
@@ -580,7 +734,9 @@ int launch_gram(cna_ctx* c, double* G_dev) {
       case 6: r = launch_gram_t<6, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
       case 7: r = launch_gram_t<7, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
       case 8: r = launch_gram_t<8, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
-      default: r = launch_gram_t<9, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;   // up to 144 tiles (N <= 256)
+      default: r = slab_rows == 32 ? launch_gram_t<9, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem)   // 144 tiles per pass
+                                   : launch_gram_t<9, 16, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem);
+               break;
     }
     CNA_TRY(r);
   }
@@ -600,8 +756,39 @@ int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const do
     return 0;
   }
   const int kq = c->ldx / 4;
-  if (kq > 64) CNA_FAIL(CNA_EINVAL, "more than 256 samples are not supported by the local-null kernel yet");
   if (!(cut0 > 0.0)) CNA_FAIL(CNA_EINVAL, "local-null kernel needs strictly positive thresholds");
+  if (kq > 64) {
+    // generic depth (more than 256 samples): k_null_big, 16 permutations per block
+    const size_t cap = 160 * 1024;
+    auto lds_big = [&](int ldb) {
+      return sizeof(double) * ((T + 4) & ~1) + sizeof(double) * (size_t)c->ldx * ldb + sizeof(unsigned int) * (size_t)16 * (T + 1);
+    };
+    const int LDB = lds_big(32) <= cap ? 32 : 16;
+    if (lds_big(LDB) > cap) CNA_FAIL(CNA_EINVAL, "local-null kernel: thresholds/samples exceed LDS (more than 1024 samples?)");
+    const int nptile = (P + 15) / 16;
+    const int64_t ntile = (c->nx + 15) / 16;
+    int64_t nchunks = (512 + nptile - 1) / nptile;
+    if (nchunks > (ntile + 31) / 32) nchunks = (ntile + 31) / 32;
+    if (nchunks < 1) nchunks = 1;
+    const int64_t chunk_rows = ((ntile + nchunks - 1) / nchunks) * 16;
+    nchunks = (c->nx + chunk_rows - 1) / chunk_rows;
+    void* part = c->null_part;
+    CNA_TRY(dev_reserve(c, &part, &c->null_part_cap, (int64_t)sizeof(unsigned int) * nchunks * P * T));
+    c->null_part = part;
+    ProfScope ps(c, CNA_K_NULL_LOCAL);
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_null_big<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(k_null_big<8>, dim3((unsigned)nchunks, (unsigned)nptile), dim3(512), lds_big(LDB), c->stream, c->X, c->nx,
+                       chunk_rows, c->ldx, Yc_dev, ldy, P, cuts_dev, T, cut0, inv_step, eps, (unsigned int*)c->null_part, LDB);
+    const int64_t tot = (int64_t)P * T;
+    hipLaunchKernelGGL(k_hist_reduce, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
+                       (const unsigned int*)c->null_part, (int)nchunks, tot, hist_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   // LDS: cuts, the Yc strip (4kq x (PT+16) doubles), PT x (T+1) 32-bit counters
   auto lds = [&](int ns) {
     return sizeof(double) * ((T + 4) & ~1) + sizeof(double) * (size_t)c->ldx * (16 * ns + 16) +

@@ -12,7 +12,7 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {
   return ((int64_t)hi << 32) | (uint32_t)lo;
 }
 
-constexpr int MAXQ = 8;  // up to 512 columns per row
+constexpr int MAXQ = 16;  // up to 1024 columns per row
 
 // ---- _batch_kurtosis (_nam.py:78-82) -------------------------------------------------
 // order[] lists the sample columns grouped by batch (stable), boff[b]..boff[b+1] is batch b.
@@ -588,12 +588,13 @@ int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long*
   HIP_TRY(hipMemsetAsync(nzero_dev, 0, sizeof(unsigned long long), c->stream));
   if (maxbits_dev) HIP_TRY(hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned long long), c->stream));
   if (c->nx == 0) return 0;
-  if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 512 samples are not supported");
+  if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 1024 samples are not supported");
   ProfScope ps(c, CNA_K_SELECT);
   const unsigned grid = wave_grid((c->nx + 3) / 4);
   switch ((c->ldx + 63) / 64) {
 #define SS_CASE(Q) case Q: hipLaunchKernelGGL(k_select_std<Q>, dim3(grid), dim3(256), 0, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev, y_dev, c->ncorrs, maxbits_dev ? maxbits_dev + 1 : nullptr); break
     SS_CASE(1); SS_CASE(2); SS_CASE(3); SS_CASE(4);
+    case 5: case 6: case 7: SS_CASE(8);
     default: hipLaunchKernelGGL(k_select_std<MAXQ>, dim3(grid), dim3(256), 0, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev, y_dev, c->ncorrs, maxbits_dev ? maxbits_dev + 1 : nullptr);
 #undef SS_CASE
   }
@@ -616,12 +617,13 @@ int launch_digit_hist(cna_ctx* c, const double* v, int64_t n, unsigned long long
 
 int launch_standardize(cna_ctx* c, int center) {
   if (c->nx == 0) return 0;
-  if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 512 samples are not supported");
+  if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 1024 samples are not supported");
   ProfScope ps(c, CNA_K_STANDARDIZE);
   const unsigned grid = wave_grid((c->nx + 3) / 4);
   switch ((c->Nx + 63) / 64) {
 #define STD_CASE(Q) case Q: hipLaunchKernelGGL(k_standardize<Q>, dim3(grid), dim3(256), 0, c->stream, c->X, c->nx, c->Nx, c->ldx, center); break
     STD_CASE(1); STD_CASE(2); STD_CASE(3); STD_CASE(4);
+    case 5: case 6: case 7: STD_CASE(8);
     default: hipLaunchKernelGGL(k_standardize<MAXQ>, dim3(grid), dim3(256), 0, c->stream, c->X, c->nx, c->Nx, c->ldx, center);
 #undef STD_CASE
   }
@@ -633,13 +635,14 @@ int launch_ncorrs(cna_ctx* c, const double* y_dev, unsigned long long* maxbits_d
   // maxbits_dev[0] = result, maxbits_dev[1 ..] = per-workgroup partials (caller reserves 2049 words)
   HIP_TRY(hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned long long), c->stream));
   if (c->nx == 0) return 0;
-  if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 512 samples are not supported");
+  if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 1024 samples are not supported");
   ProfScope ps(c, CNA_K_NCORRS);
   const int64_t want = (c->nx + 15) / 16;
   const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
   switch ((c->Nx + 63) / 64) {
 #define NC_CASE(Q) case Q: hipLaunchKernelGGL(k_ncorrs<Q>, dim3(grid), dim3(256), 0, c->stream, c->X, c->nx, c->Nx, c->ldx, y_dev, c->ncorrs, maxbits_dev + 1); break
     NC_CASE(1); NC_CASE(2); NC_CASE(3); NC_CASE(4);
+    case 5: case 6: case 7: NC_CASE(8);
     default: hipLaunchKernelGGL(k_ncorrs<MAXQ>, dim3(grid), dim3(256), 0, c->stream, c->X, c->nx, c->Nx, c->ldx, y_dev, c->ncorrs, maxbits_dev + 1);
 #undef NC_CASE
   }

@@ -1,10 +1,11 @@
 // Sample-space kernels of the permutation test (reference _association.py:35-61,84,96-97).
-// They are tiny (N x Nnull) but sit on the host's critical path otherwise:
-//   k_condition   Zc = M.Y / std(M.Y, ddof=1) per phenotype column (observed + permutations);
-//                 the result stays resident: it is both the input of the global F-tests and the
-//                 B operand of the local-null kernel
-//   k_global_test per column: projections on the first kmax sample-PCs, F-test for every k in ks
-//                 (regularised incomplete beta), min-p and its r2
+// Small (N x Nnull) but on the critical path at Nnull = 10000; as batched GEMMs on the matrix cores:
+//   k_cond_gemm + k_cond_scale   Zc = M.Y / std(M.Y, ddof=1) for the observed + permuted phenotypes; the
+//                 result stays resident: input of the global F-tests and B operand of the local-null kernel
+//   k_gt_project  squared projections on the first kmax sample-PCs (U^T.Zc) and ssered per column
+//   k_gt_ftest    one thread per (k in ks, column): F statistic and its survival function (regularised
+//                 incomplete beta); k_gt_min: min-p over ks and its r2
+// (round 1: one wave per column with serial N-length loops and at most len(ks) busy lanes)
 #include "common.h"
 
 namespace {
@@ -57,87 +58,124 @@ __device__ double f_sf(double f, double d1, double d2) {
   return incbet(0.5 * d2, 0.5 * d1, d2 / (d2 + d1 * f));
 }
 
-// one workgroup (one wave) per phenotype column
-__global__ __launch_bounds__(64) void k_condition(const double* __restrict__ M, const double* __restrict__ Y,
-                                                  int N, int P, double* __restrict__ Zc, int ldy) {
-  extern __shared__ double sm[];          // z[N]
-  const int p = blockIdx.x, lane = threadIdx.x;
-  for (int j = lane; j < N; j += 64) sm[j] = Y[(size_t)j * P + p];
-  __syncthreads();
-  constexpr int Q = 8;                    // up to 512 samples
-  double zc[Q];
-  double s = 0.0;
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int i = lane + 64 * q;
-    zc[q] = 0.0;
-    if (i < N) {
-      double acc = 0.0;
-      for (int j = 0; j < N; ++j) acc += M[(size_t)i * N + j] * sm[j];
-      zc[q] = acc;
-      s += acc;
-    }
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ---- Zc = M.Y / std(M.Y, ddof=1)  (_association.py:51-52, 96-97) ---------------------------------------
+// M.Y on the matrix cores: one wave per 16 x 16 tile of the product, v_mfma_f64_16x16x4_f64 over the
+// sample axis (operand layouts as in mfma.hip: A lane (m = l & 15, k = l >> 4), B lane (k = l >> 4,
+// n = l & 15), C register r of lane l = element (m = (l >> 4) + 4 r, n = l & 15)).  M (N x N) and Y
+// (N x P, row-major) are L2 resident; rows and columns past the edge enter as zeros.
+__global__ __launch_bounds__(256) void k_cond_gemm(const double* __restrict__ M, const double* __restrict__ Y, int N,
+                                                   int P, double* __restrict__ Z, int ldy) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int i0 = blockIdx.y * 16, p0 = (blockIdx.x * 4 + wv) * 16;
+  if (p0 >= P) return;
+  const int ai = lane & 15, ak = lane >> 4;
+  const bool arow = i0 + ai < N, bcol = p0 + ai < P;
+  const double* __restrict__ mp = M + (size_t)(arow ? i0 + ai : 0) * N;
+  v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int j0 = 0; j0 < N; j0 += 4) {
+    const int j = j0 + ak;
+    const double a = (arow && j < N) ? mp[j] : 0.0;
+    const double b = (bcol && j < N) ? Y[(size_t)j * P + p0 + ai] : 0.0;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
   }
-  const double mean = wave_sum(s) / (double)N;
-  double ss = 0.0;
+  if (bcol) {
 #pragma unroll
-  for (int q = 0; q < Q; ++q)
-    if (lane + 64 * q < N) {
-      const double d = zc[q] - mean;
-      ss += d * d;
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + ak + 4 * r;
+      if (i < N) Z[(size_t)i * ldy + p0 + ai] = acc[r];
     }
-  const double sd = sqrt(wave_sum(ss) / (double)(N - 1));     // ddof = 1 (_association.py:52)
-#pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    const int i = lane + 64 * q;
-    if (i < N) Zc[(size_t)i * ldy + p] = zc[q] / sd;
   }
 }
 
-__global__ __launch_bounds__(64) void k_global_test(const double* __restrict__ Zc, int ldy, int N, int P,
+// per column: mean and standard deviation (ddof = 1) over the N rows, then the division -- one thread per
+// column, consecutive threads on consecutive columns (coalesced), rows walked in order (two passes, like
+// pandas / numpy: mean first, then squared deviations)
+__global__ __launch_bounds__(256) void k_cond_scale(double* __restrict__ Z, int N, int P, int ldy) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  double s = 0.0;
+  for (int i = 0; i < N; ++i) s += Z[(size_t)i * ldy + p];
+  const double mean = s / (double)N;
+  double ss = 0.0;
+  for (int i = 0; i < N; ++i) {
+    const double d = Z[(size_t)i * ldy + p] - mean;
+    ss += d * d;
+  }
+  const double sd = sqrt(ss / (double)(N - 1));
+  for (int i = 0; i < N; ++i) Z[(size_t)i * ldy + p] /= sd;
+}
+
+// ---- global F-tests of every column (_association.py:35-61,84) ------------------------------------------
+// beta = U[:, :kmax]^T . Zc on the matrix cores (one wave per 16 PCs x 16 columns), stored squared; the
+// B-operand lanes also sum zc^2 per column (= ssered, _association.py:43)
+__global__ __launch_bounds__(256) void k_gt_project(const double* __restrict__ Zc, int ldy, int N, int P,
                                                     const double* __restrict__ U, int kmax,
-                                                    const int32_t* __restrict__ ks, int K, int r,
-                                                    double* __restrict__ minp, double* __restrict__ r2out,
-                                                    int32_t* __restrict__ kidx) {
-  extern __shared__ double sm[];          // zc[N] | beta2[kmax] | pk[K] | r2k[K]
-  double* zc = sm;
-  double* beta2 = sm + N;
-  double* pk = beta2 + kmax;
-  double* r2k = pk + K;
-  const int p = blockIdx.x, lane = threadIdx.x;
+                                                    double* __restrict__ beta2 /* kmax x P */,
+                                                    double* __restrict__ ssered /* P */) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int k0 = blockIdx.y * 16, p0 = (blockIdx.x * 4 + wv) * 16;
+  if (p0 >= P) return;
+  const int ai = lane & 15, ak = lane >> 4;
+  const bool arow = k0 + ai < kmax, bcol = p0 + ai < P;
+  v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
   double s2 = 0.0;
-  for (int i = lane; i < N; i += 64) {
-    const double v = Zc[(size_t)i * ldy + p];
-    zc[i] = v;
-    s2 += v * v;
+  for (int i0 = 0; i0 < N; i0 += 4) {
+    const int i = i0 + ak;
+    const double a = (arow && i < N) ? U[(size_t)i * kmax + k0 + ai] : 0.0;      // U^T: PC k, sample i
+    const double b = (bcol && i < N) ? Zc[(size_t)i * ldy + p0 + ai] : 0.0;
+    s2 += b * b;
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
   }
-  const double ssered = wave_sum(s2);
-  __syncthreads();
-  for (int j = lane; j < kmax; j += 64) {                       // beta_j = U_j . zc  (_association.py:37)
-    double b = 0.0;
-    for (int i = 0; i < N; ++i) b += U[(size_t)i * kmax + j] * zc[i];
-    beta2[j] = b * b;
+  if (blockIdx.y == 0) {
+    s2 += __shfl_xor(s2, 16);
+    s2 += __shfl_xor(s2, 32);
+    if (ak == 0 && bcol) ssered[p0 + ai] = s2;
   }
-  __syncthreads();
-  for (int a = lane; a < K; a += 64) {
-    const int k = ks[a];
-    double fit = 0.0;
-    for (int j = 0; j < k; ++j) fit += beta2[j];                // ||Uk Uk^T z||^2
-    const double ssefull = ssered - fit;
-    const double n = (double)N;
-    const double f = ((ssered - ssefull) / (double)k) / (ssefull / n);     // _association.py:45
-    pk[a] = f_sf(f, (double)k, n - (1.0 + r + k));
-    r2k[a] = 1.0 - ssefull / ssered;
+  if (bcol) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = k0 + ak + 4 * r;
+      if (k < kmax) beta2[(size_t)k * P + p0 + ai] = acc[r] * acc[r];
+    }
   }
-  __syncthreads();
-  if (lane == 0) {                                              // np.nanargmin (_association.py:60)
-    int best = -1;
-    for (int a = 0; a < K; ++a)
-      if (pk[a] == pk[a] && (best < 0 || pk[a] < pk[best])) best = a;
-    kidx[p] = best;
-    minp[p] = best < 0 ? __builtin_nan("") : pk[best];
-    r2out[p] = best < 0 ? __builtin_nan("") : r2k[best];
+}
+
+// one thread per (k in ks, column): fit = sum of the first k squared projections, F statistic, survival
+// function (K x P independent incomplete-beta evaluations), r2
+__global__ __launch_bounds__(256) void k_gt_ftest(const double* __restrict__ beta2, const double* __restrict__ ssered,
+                                                  int N, int P, const int32_t* __restrict__ ks, int K, int r,
+                                                  double* __restrict__ pk /* K x P */, double* __restrict__ r2k) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)K * P) return;
+  const int a = (int)(t / P), p = (int)(t - (int64_t)a * P);
+  const int k = ks[a];
+  double fit = 0.0;
+  for (int j = 0; j < k; ++j) fit += beta2[(size_t)j * P + p];      // ||Uk Uk^T z||^2
+  const double red = ssered[p];
+  const double ssefull = red - fit;
+  const double n = (double)N;
+  const double f = ((red - ssefull) / (double)k) / (ssefull / n);     // _association.py:45
+  pk[t] = f_sf(f, (double)k, n - (1.0 + r + k));
+  r2k[t] = 1.0 - ssefull / red;
+}
+
+// np.nanargmin over ks (_association.py:60)
+__global__ __launch_bounds__(256) void k_gt_min(const double* __restrict__ pk, const double* __restrict__ r2k, int P, int K,
+                                                double* __restrict__ minp, double* __restrict__ r2out,
+                                                int32_t* __restrict__ kidx) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  int best = -1;
+  double pb = 0.0;
+  for (int a = 0; a < K; ++a) {
+    const double v = pk[(size_t)a * P + p];
+    if (v == v && (best < 0 || v < pb)) { best = a; pb = v; }
   }
+  kidx[p] = best;
+  minp[p] = best < 0 ? __builtin_nan("") : pb;
+  r2out[p] = best < 0 ? __builtin_nan("") : r2k[(size_t)best * P + p];
 }
 
 }  // namespace
@@ -145,21 +183,30 @@ __global__ __launch_bounds__(64) void k_global_test(const double* __restrict__ Z
 int launch_condition(cna_ctx* c, hipStream_t st, const double* M_dev, const double* Y_dev, int N, int P,
                      double* Zc_dev, int ldy) {
   if (P == 0) return 0;
-  if (N > 512) CNA_FAIL(CNA_EINVAL, "more than 512 samples are not supported");
   ProfScope ps(c, CNA_K_CONDITION, st);
-  hipLaunchKernelGGL(k_condition, dim3(P), dim3(64), sizeof(double) * N, st, M_dev, Y_dev, N, P, Zc_dev, ldy);
+  hipLaunchKernelGGL(k_cond_gemm, dim3((P + 63) / 64, (N + 15) / 16), dim3(256), 0, st, M_dev, Y_dev, N, P, Zc_dev, ldy);
+  hipLaunchKernelGGL(k_cond_scale, dim3((P + 255) / 256), dim3(256), 0, st, Zc_dev, N, P, ldy);
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
+// scratch of the global test: beta2 kmax x P | ssered P | pk K x P | r2k K x P  (doubles)
+int64_t global_test_scratch_doubles(int P, int kmax, int K) { return (int64_t)P * (kmax + 1 + 2 * K); }
+
 int launch_global_test(cna_ctx* c, hipStream_t st, const double* Zc_dev, int ldy, int N, int P, const double* U_dev,
-                       int kmax, const int32_t* ks_dev, int K, int r, double* minp_dev, double* r2_dev,
+                       int kmax, const int32_t* ks_dev, int K, int r, double* work, double* minp_dev, double* r2_dev,
                        int32_t* kidx_dev) {
   if (P == 0) return 0;
   ProfScope ps(c, CNA_K_GLOBAL_TEST, st);
-  const size_t sm = sizeof(double) * (N + kmax + 2 * K);
-  hipLaunchKernelGGL(k_global_test, dim3(P), dim3(64), sm, st, Zc_dev, ldy, N, P, U_dev, kmax, ks_dev, K, r,
-                     minp_dev, r2_dev, kidx_dev);
+  double* beta2 = work;
+  double* ssered = beta2 + (size_t)kmax * P;
+  double* pk = ssered + P;
+  double* r2k = pk + (size_t)K * P;
+  hipLaunchKernelGGL(k_gt_project, dim3((P + 63) / 64, (kmax + 15) / 16), dim3(256), 0, st, Zc_dev, ldy, N, P, U_dev, kmax,
+                     beta2, ssered);
+  const int64_t nt = (int64_t)K * P;
+  hipLaunchKernelGGL(k_gt_ftest, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, st, beta2, ssered, N, P, ks_dev, K, r, pk, r2k);
+  hipLaunchKernelGGL(k_gt_min, dim3((P + 255) / 256), dim3(256), 0, st, pk, r2k, P, K, minp_dev, r2_dev, kidx_dev);
   HIP_TRY(hipGetLastError());
   return 0;
 }

@@ -148,7 +148,8 @@ def _random_x(rs, n, N):
 
 
 @pytest.mark.parametrize('n,N', [(1000, 20), (777, 50), (513, 3), (300, 130), (257, 200), (64, 256), (5, 17),
-                                 (301, 160), (130, 192)])      # 160 / 192: row stride padded off a 256-byte multiple
+                                 (301, 160), (130, 192),       # 160 / 192: row stride padded off a 256-byte multiple
+                                 (333, 260), (200, 400), (180, 513), (100, 1024)])   # k-split GEMM, multi-pass Gram
 def test_dense_row_kernels_vs_numpy(eng, orc, n, N):
     from cna_amd import _ffi
     rs = np.random.RandomState(n + N)
@@ -197,7 +198,8 @@ def test_dense_row_kernels_vs_numpy(eng, orc, n, N):
 
 @pytest.mark.parametrize('n,N,P', [(3000, 20, 100), (2049, 50, 200), (1000, 100, 70), (600, 200, 130),
                                    (100, 256, 64), (16, 12, 5), (700, 160, 90), (333, 224, 33),
-                                   (500, 192, 40), (250, 157, 70), (260, 221, 65)])
+                                   (500, 192, 40), (250, 157, 70), (260, 221, 65),
+                                   (400, 300, 40), (200, 700, 33), (150, 1024, 17)])
 def test_local_null_counts_are_exact(eng, n, N, P):
     """tails / ranks / num_detected are integers: they must equal a brute-force count."""
     from cna_amd import _ffi
@@ -361,7 +363,8 @@ def test_rccl_path_with_one_rank(orc, monkeypatch, selftest):
 
 
 @pytest.mark.parametrize('N,P,r,ks', [(50, 1001, 0, [1, 2, 3, 4]), (24, 37, 2, [2, 5]), (200, 300, 5, [4, 8, 12, 16]),
-                                       (12, 5, 0, [1]), (130, 64, 1, [3, 26])])
+                                       (12, 5, 0, [1]), (130, 64, 1, [3, 26]), (200, 10001, 5, [4, 8, 12, 16]),
+                                       (600, 333, 2, [12, 24, 36, 48, 100]), (1024, 50, 0, [20, 40])])
 def test_global_test_matches_scipy(eng, N, P, r, ks):
     """Device F-tests (incomplete-beta continued fraction) against scipy's fdtrc through the
     host restatement of _minp_stats; includes strong signals (p down to ~1e-60)."""
@@ -398,7 +401,9 @@ def test_global_test_matches_scipy(eng, N, P, r, ks):
 
 @pytest.mark.parametrize('n,N,extra', [(3000, 70, {}), (2500, 130, dict(n_covs=3)), (2000, 200, dict(n_covs=2, n_batches=4)),
                                        (2400, 160, dict(n_covs=1)),
-                                       (1500, 256, {}), (4000, 33, dict(n_batches=9, n_covs=1))])
+                                       (1500, 256, {}), (4000, 33, dict(n_batches=9, n_covs=1)),
+                                       (2000, 300, dict(n_covs=2)), (2500, 520, {}), (3000, 600, dict(n_covs=1, n_batches=3)),
+                                       (3000, 1024, {})])
 def test_association_wide_sample_axis_vs_oracle(eng, orc, n, N, extra):
     """end to end at sample counts the golden fixtures do not reach (several 64-lane chunks per row,
     deep k-loops in the MFMA kernels, every local-null instantiation family), against the f64 oracle."""
