@@ -220,8 +220,7 @@ def time_workload(name, args, rank, world, td, on_gpu_group, steps, warmup, want
         nnz_loc = int(deg_full[eng.perm[rows_loc]].sum() if eng.perm is not None else deg_full[rows_loc].sum())
     return dict(name=name, n=n, N=N, k=k, nsteps=nsteps, Nnull=Nnull, n_covs=n_covs, nnz=nnz, wA=wA, dt=dt, t_cold=t_cold,
                 t_gen=t_gen, prof=prof, p=p_last, n_loc=n_loc, nnz_loc=nnz_loc, halo=getattr(eng, 'halo', None),
-                sharded_inputs=sharded_inputs, data=data, meta=meta, kw=kw, steps=steps, warmup=warmup,
-                walk=getattr(eng, 'walk_kernel', None))
+                sharded_inputs=sharded_inputs, data=data, meta=meta, kw=kw, steps=steps, warmup=warmup, comm=eng.comm_info())
 
 
 def kernel_table(m, world):
@@ -415,7 +414,9 @@ def main():
                                                      else ', dataset and per-cell results replicated on every rank'),
                        '' if m['halo'] is None else ', halo exchange %d/%d rows out/in on rank 0' % m['halo'],
                        ' [--comm shm: ranks share one GPU, plumbing check only]' if args.comm == 'shm' and world > 1 else ''),
-                   'walk_kernel': m['walk'], 'p_value': m['p']},
+                   'communicator': {'backend': m['comm'][0], 'nranks_reported_by_communicator': m['comm'][1],
+                                    'halo_rows_out_in_rank0': m['halo']},
+                   'p_value': m['p']},
         'roofline': main_sum['roofline'],
         'cpu_baseline': cpu,
         'gpu_kernel_ms_per_step': main_sum['gpu_kernel_ms_per_step'],

@@ -20,6 +20,7 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -42,6 +43,7 @@ int rccl_load() {
   SYM(GetUniqueId);
   SYM(CommInitRank);
   SYM(CommDestroy);
+  SYM(CommCount);
   SYM(AllReduce);
   SYM(AllGather);
   SYM(Send);
@@ -237,6 +239,19 @@ extern "C" int cna_comm_init(cna_ctx* c, int rank, int nranks, const void* id128
   ncclComm_t comm;
   NCCL_TRY(g_rccl.CommInitRank(&comm, nranks, id, rank));
   c->comm = (void*)comm;
+  return 0;
+}
+
+extern "C" int cna_comm_info(cna_ctx* c, int* backend, int* nranks) {
+  if (!c) CNA_FAIL(CNA_EINVAL, "null context");
+  int b = 0, n = c->nranks;
+  if (c->shm) b = 2;
+  else if (c->comm) {
+    b = 1;
+    NCCL_TRY(g_rccl.CommCount((ncclComm_t)c->comm, &n));       // what RCCL itself reports, not what we passed in
+  }
+  if (backend) *backend = b;
+  if (nranks) *nranks = n;
   return 0;
 }
 

@@ -70,6 +70,12 @@ class Engine(_order.CellOrder):
         except Exception:
             pass
 
+    def comm_info(self):
+        """(backend, nranks) of the communicator: 'none' | 'rccl' | 'shm', and the rank count it reports."""
+        b, n = C.c_int(0), C.c_int(0)
+        check(self.lib.cna_comm_info(self.h, C.byref(b), C.byref(n)), 'cna_comm_info')
+        return ('none', 'rccl', 'shm')[b.value], n.value
+
     def sync(self):
         check(self.lib.cna_ctx_sync(self.h), 'cna_ctx_sync')
 

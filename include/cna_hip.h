@@ -69,6 +69,9 @@ int  cna_comm_init(cna_ctx* ctx, int rank, int nranks, const void* id128);
  * (one slot of slot_bytes per rank), so that several ranks can share ONE GPU -- which RCCL refuses --
  * and the multi-rank paths of this library run on a single-GPU box.  Not for production use. */
 int  cna_comm_init_shm(cna_ctx* ctx, int rank, int nranks, const char* name, int64_t slot_bytes);
+/* which communicator the context holds (0 none, 1 RCCL, 2 the shared-memory test communicator) and the
+ * number of ranks as the communicator itself reports it (ncclCommCount) -- bench.py prints both */
+int  cna_comm_info(cna_ctx* ctx, int* backend, int* nranks);
 
 /* Neighbour ("halo") exchange of the diffusion state between steps instead of the all-gather.
  * After cna_graph_upload on every rank: send_rows = LOCAL row indices other ranks need, grouped by
