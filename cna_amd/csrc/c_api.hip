@@ -9,7 +9,12 @@ static thread_local std::string g_err;
 void cna_set_error(const std::string& msg) { g_err = msg; }
 
 // ------------------------------------------------------------------ memory / profiling
+// Two host threads may use one context at a time (the association's helper thread conditions the
+// phenotypes -- its own buffers, the second stream -- while the main thread launches kernels): the
+// allocator's bookkeeping and the alloc / free calls themselves are serialised by c->alloc_mu.  Each
+// buffer still has one owner: the helper only ever (re)allocates zc and gt.
 int dev_alloc(cna_ctx* c, void** p, size_t bytes) {
+  std::lock_guard<std::recursive_mutex> lk(c->alloc_mu);
   *p = nullptr;
   if (bytes == 0) bytes = 256;
   hipError_t e = hipMalloc(p, bytes);
@@ -21,6 +26,7 @@ int dev_alloc(cna_ctx* c, void** p, size_t bytes) {
   return 0;
 }
 int dev_free(cna_ctx* c, void* p, size_t bytes) {
+  std::lock_guard<std::recursive_mutex> lk(c->alloc_mu);
   if (p) {
     (void)hipFree(p);
     c->dev_bytes -= (int64_t)(bytes ? bytes : 256);
@@ -30,6 +36,7 @@ int dev_free(cna_ctx* c, void* p, size_t bytes) {
 static void halo_clear(cna_ctx* c);
 
 int dev_reserve(cna_ctx* c, void** p, int64_t* cap, int64_t need) {
+  std::lock_guard<std::recursive_mutex> lk(c->alloc_mu);
   if (need <= *cap && *p) return 0;
   if (*p) {
     HIP_TRY(hipStreamSynchronize(c->stream));

@@ -55,6 +55,7 @@ struct cna_ctx {
   int64_t gram_cap = 0;
   int gram_n = 0;
   int64_t dev_bytes = 0;
+  std::recursive_mutex alloc_mu;   // dev_alloc / dev_free / dev_reserve (two host threads may share the context)
 
   // ---- communicator
   int rank = 0, nranks = 1;

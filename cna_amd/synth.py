@@ -159,3 +159,42 @@ def make_dataset(n_cells, n_samples, k=30, seed=0, dim=8, n_clusters=20,
         'props': props, 'cluster': cl, 'sid': sid,
     }
     return data, meta
+
+
+def make_demo_like(n_samples=50, n_genes=50, cells_per_sample=200, noise=1.0, k=15, seed=0,
+                   graph_dtype=np.float32):
+    """The reference's demo dataset, regenerated (recipe: /root/reference/demo/makedata.ipynb cells 2-4):
+    `n_samples` samples of `cells_per_sample` cells over `n_genes` genes, three cell populations whose
+    per-sample proportions depend on the sample-level covariates `case` and `male`, five batches
+    tiled over the samples; expression = population profile + unit Gaussian noise drawn from
+    numpy's legacy generator seeded with `seed`, in the notebook's order.  The notebook then calls
+    scanpy.pp.neighbors (not installed here): the graph below is this module's own fuzzy kNN stand-in
+    on the expression matrix (k = scanpy's default 15), so the dataset is demo-LIKE, not the demo.
+
+    Returns (data, samplem) with samplem a DataFrame indexed by sample id with columns case, male, batch."""
+    N, G, C = int(n_samples), int(n_genes), int(cells_per_sample)
+    rs = np.random.RandomState(seed)
+    samplem = pd.DataFrame(index=pd.Index(np.arange(N), name='id'))
+    samplem['case'] = [0] * (N // 2) + [1] * (N - N // 2)
+    q = int(2 * N / 8)
+    samplem['male'] = [0] * q + [1] * q + [0] * q + [1] * (N - 3 * q)
+    H = np.zeros((3, G))
+    H[0, :G // 2] = 1
+    H[1, G // 2:] = 1
+    H[2, :G // 2] = 1
+    H[2, :G // 4] = 2
+    props = np.array([[0.2, -0.2], [-0.2, 0.0], [0.5, 0.5]])        # rows: case, male, baseline
+    blocks = []
+    for _, row in samplem.iterrows():
+        pr = np.array([row['case'], row['male'], 1.0]).dot(props)     # proportions of populations 0 and 1
+        ids = np.concatenate([np.full(int(p * C), i) for i, p in enumerate(pr)])
+        ids = np.concatenate([ids, np.full(C - len(ids), len(pr))]).astype(int)
+        W = np.zeros((C, len(pr) + 1))
+        W[np.arange(C), ids] = 1
+        blocks.append(W.dot(H) + noise * rs.randn(C, G))
+    X = np.concatenate(blocks).astype(np.float32)
+    samplem['batch'] = np.tile(np.arange(5), -(-N // 5))[:N]
+    A = fuzzy_knn_graph(X, k=k, dtype=graph_dtype)
+    obs = pd.DataFrame({'id': np.repeat(samplem.index.values, C)},
+                       index=pd.Index(['cell_%d' % i for i in range(N * C)], name='cell'))
+    return CellData(obs, A), samplem

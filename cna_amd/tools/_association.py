@@ -32,7 +32,11 @@ _pool = None
 
 def _background():
     """One helper thread: lets a blocking device call (ctypes drops the GIL) run while the
-    host does sample-space numpy work.  Never more than one engine call is in flight."""
+    host does sample-space numpy work.  It shares the engine's context with the main thread in
+    exactly one place: after the permutation draw it may call engine.condition() -- sample space
+    only, the second stream, buffers nobody else touches (zc / gt) -- while the main thread issues
+    set_samples / nam_step / select.  The library serialises its allocator for that
+    (cna_ctx::alloc_mu) and keeps its last-error text per thread."""
     global _pool
     if _pool is None:
         from concurrent.futures import ThreadPoolExecutor
@@ -186,10 +190,15 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         with np.errstate(all='ignore'):
             # mean over permutations of tails/ranks (_stats.py:79-80) from the per-threshold sums
             fdr_vals = tail_sums / ranks / Nloc
-        with np.errstate(invalid='ignore'):
-            if not np.min(fdr_vals) > 0.05:
+        # the reference takes np.min of a pandas Series (_association.py:111-118), which skips NaN (0/0 at
+        # thresholds nothing reaches); a table without a single finite entry fails there with an
+        # IndexError, and so does this
+        with np.errstate(invalid='ignore'), warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)          # all-NaN slice
+            fdr_min = np.nanmin(fdr_vals) if len(fdr_vals) else np.nan
+            if not fdr_min > 0.05:
                 fdr_5p_t = thresholds[np.flatnonzero(fdr_vals <= 0.05)[0]]
-            if not np.min(fdr_vals) > 0.1:
+            if not fdr_min > 0.1:
                 fdr_10p_t = thresholds[np.flatnonzero(fdr_vals <= 0.1)[0]]
         res._defer('fdrs', lambda: pd.DataFrame({'threshold': thresholds, 'fdr': fdr_vals,
                                                  'num_detected': num_detected}))
@@ -393,8 +402,8 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                 engine.condition(M_, np.column_stack([out_[0], out_[1]]))
                 early['conditioned'] = True
                 _mark('conditioned (helper)')
-            except Exception:
-                pass
+            except Exception as exc:          # the main thread conditions again and reports what it finds
+                early['condition_error'] = exc
         return out_
     _mark('checked')
     null_future = _background().submit(null_job)

@@ -292,8 +292,51 @@ def run_case(case):
     return out
 
 
+def run_demo_like():
+    """BASELINE.json configs[0]: the demo recipe (10 000 cells, 50 samples, 5 batches; makedata.ipynb) with
+    the demo's analysis (demo.ipynb: association with `case`, covs = male, batches = batch), nsteps=3,
+    Nnull=100.  Cells-sized matrices are kept for every 25th cell only (fixture size)."""
+    data, samplem = synth.make_demo_like()
+    call = dict(nsteps=3, Nnull=100, seed=0)
+    y = samplem['case'].astype(float)
+    covs = samplem[['male']].astype(float)
+    batches = samplem['batch']
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter('always')
+        res = cna.tl.association(data, y, 'id', batches=batches, covs=covs, return_full=True, **call)
+    A = data.obsp['connectivities']
+    out = dict(in_indptr=A.indptr.astype(np.int64), in_indices=A.indices.astype(np.int32), in_data=A.data,
+               in_sid=np.asarray(data.obs['id'].values), call=np.array(json.dumps(call)))
+    out['warnings'] = np.array(json.dumps([str(w.message) for w in wlist if issubclass(w.category, UserWarning)]))
+    f = result_fields(res)
+    sub = np.arange(0, A.shape[0], 25)
+    kept_pos = np.flatnonzero(f['kept'])
+    assert f['kept'].all()
+    for key in ('p', 'k', 'ks', 'r', 'nullminps', 'ncorrs', 'kept', 'M', 'svs', 'varexp', 'yresid', 'yresid_hat', 'beta',
+                'r2', 'r2_perpc', 'nullr2_mean', 'nullr2_std', 'fdr_threshold', 'fdr_fdr', 'fdr_num_detected',
+                'fdr_5p_t', 'fdr_10p_t'):
+        out[key] = f[key]
+    out['sub'] = sub
+    out['nam_sub'] = f['nam'][:, sub]
+    out['namresid_sub'] = f['namresid'][:, sub]
+    out['U'] = f['U']
+    out['V_sub'] = f['V'][sub]
+    out['obs_coef'] = data.obs['coef'].values.astype(np.float64)
+    out['obs_coef_fdr'] = data.obs['coef_fdr'].values.astype(np.float64)
+    out['versions'] = np.array(json.dumps(dict(numpy=np.__version__, scipy=scipy.__version__, pandas=pd.__version__,
+                                               python=sys.version.split()[0], cna='0.2.3 (/root/reference)')))
+    path = os.path.join(HERE, 'd01_demo_like.npz')
+    np.savez_compressed(path, **out)
+    print('%-36s p=%.6g k=%d detected@first=%d  %.0f KB' % ('d01_demo_like', out['p'], out['k'],
+                                                           out['fdr_num_detected'][0], os.path.getsize(path) / 1024))
+
+
 def main():
     only = set(sys.argv[1:])
+    if not only or 'd01_demo_like' in only:
+        run_demo_like()
+    if only == {'d01_demo_like'}:
+        return
     for case in build_cases():
         if only and case['name'] not in only:
             continue

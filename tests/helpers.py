@@ -130,3 +130,42 @@ def assert_matches_golden(res, data, z, tol=1e-5, check_lazy=True):
         V, Vref = sign_align(res.namresid_nbhdXpc.values, z['V'], kk)
         assert relerr(V, Vref) < 1e-4
         assert res.nam.shape == z['nam'].shape and list(res.nam.columns) == list(data.obs.index[z['kept']])
+
+
+def load_demo_case():
+    """tests/golden/d01_demo_like.npz: BASELINE.json configs[0] -- the demo recipe (10 000 cells x 50 samples,
+    makedata.ipynb) analysed as in demo.ipynb (y = case, covs = male, batches = batch), nsteps=3, Nnull=100."""
+    z = np.load(os.path.join(GOLDEN_DIR, 'd01_demo_like.npz'))
+    n = len(z['in_indptr']) - 1
+    A = sp.csr_matrix((z['in_data'], z['in_indices'], z['in_indptr']), shape=(n, n))
+    A.indptr = A.indptr.astype(np.int32)
+    obs = pd.DataFrame({'id': z['in_sid']}, index=pd.Index(['cell_%d' % i for i in range(n)], name='cell'))
+    N = 50
+    samplem = pd.DataFrame(index=pd.Index(np.arange(N), name='id'))
+    samplem['case'] = [0] * (N // 2) + [1] * (N - N // 2)
+    q = int(2 * N / 8)
+    samplem['male'] = [0] * q + [1] * q + [0] * q + [1] * (N - 3 * q)
+    samplem['batch'] = np.tile(np.arange(5), N // 5)
+    return dict(data=CellData(obs, A), y=samplem['case'].astype(float), covs=samplem[['male']].astype(float),
+                batches=samplem['batch'], call=json.loads(z['call'].item()), z=z)
+
+
+def assert_matches_demo(out, z, tol, obs=None):
+    """out: dict-like with the oracle's keys (p, k, ks, r, kept, ncorrs, nullminps, svs, nam, namresid,
+    fdrs{...}); cells-sized matrices are compared on the fixture's subsample of cells."""
+    sub = z['sub']
+    assert int(out['k']) == int(z['k']) and np.array_equal(out['ks'], z['ks']) and int(out['r']) == int(z['r'])
+    assert np.array_equal(out['kept'], z['kept'])
+    assert abs(float(out['p']) - float(z['p'])) < 1e-12
+    assert relerr(out['ncorrs'], z['ncorrs']) < tol
+    assert relerr(out['nullminps'], z['nullminps']) < tol * 10
+    assert relerr(out['svs'], z['svs']) < tol
+    assert relerr(np.asarray(out['nam'])[sub].T, z['nam_sub']) < tol
+    assert relerr(np.asarray(out['namresid'])[sub].T, z['namresid_sub']) < tol
+    f = out['fdrs']
+    T = min(len(f['threshold']), len(z['fdr_threshold']))
+    assert T >= 300 and np.array_equal(np.asarray(f['num_detected'])[:T], z['fdr_num_detected'][:T])
+    assert relerr(np.asarray(f['fdr'])[:T], z['fdr_fdr'][:T]) < tol * 10
+    if obs is not None:
+        np.testing.assert_allclose(obs['coef'], z['obs_coef'], rtol=0, atol=tol * np.nanmax(np.abs(z['obs_coef'])))
+        np.testing.assert_allclose(obs['coef_fdr'], z['obs_coef_fdr'], rtol=tol * 10, atol=1e-12)

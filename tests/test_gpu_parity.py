@@ -271,6 +271,25 @@ def test_association_matches_f64_oracle_tightly(eng, orc, name):
     np.testing.assert_allclose(res.fdrs.fdr.values[:T], ref['fdrs']['fdr'][:T], rtol=1e-9, atol=1e-13)
 
 
+def test_demo_like_config1(eng):
+    """BASELINE.json configs[0]: the demo recipe (10 000 cells x 50 samples; covs = male, batches = batch,
+    y = case; nsteps=3, Nnull=100) against what the reference returned (tests/golden/d01_demo_like.npz)."""
+    import cna_amd as cna
+    import warnings
+    from helpers import load_demo_case, assert_matches_demo
+    case = load_demo_case()
+    data = case['data']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        res = cna.tl.association(data, case['y'], 'id', batches=case['batches'], covs=case['covs'], return_full=True,
+                                 engine=eng, **case['call'])
+    out = dict(k=res.k, ks=res.ks, r=res.r, kept=res.kept, p=res.p, ncorrs=res.ncorrs.values, nullminps=res.nullminps,
+               svs=res.namresid_svs.values, nam=res.nam.values.T, namresid=res.namresid.values.T,
+               fdrs=dict(threshold=res.fdrs.threshold.values, fdr=res.fdrs.fdr.values,
+                         num_detected=res.fdrs.num_detected.values))
+    assert_matches_demo(out, case['z'], 1e-5, obs=dict(coef=data.obs['coef'].values, coef_fdr=data.obs['coef_fdr'].values))
+
+
 def test_svd_nam_public(eng):
     import cna_amd as cna
     z = load_case('c01_plain_f32')['z']

@@ -160,3 +160,13 @@ def test_reference_cost_baseline_matches_reference(name):
     assert relerr(out['fdr'][:T], z['fdr_fdr'][:T]) < 1e-8
     np.testing.assert_allclose(out['coef_fdr'], z['obs_coef_fdr'], rtol=1e-8, atol=1e-12)
     assert set(out['stages']) == {'nam', 'resid_svd', 'global_test', 'local_test', 'percell_apply'}
+
+
+@pytest.mark.parametrize('mode,tol', [('reference', 1e-9), ('f64', 1e-5)])
+def test_demo_like_config1(mode, tol):
+    """BASELINE.json configs[0] (demo recipe, 10 000 cells x 50 samples, covs + 5 batches, nsteps=3, Nnull=100)."""
+    from helpers import load_demo_case, assert_matches_demo
+    case = load_demo_case()
+    out = orc.association(case['data'], case['y'], 'id', batches=case['batches'], covs=case['covs'], mode=mode,
+                          **case['call'])
+    assert_matches_demo(out, case['z'], tol, obs=dict(coef=out['obs_coef'], coef_fdr=out['obs_coef_fdr']))
