@@ -630,6 +630,25 @@ class Engine(_order.CellOrder):
         check(self.lib.cna_allgather_host(self.h, ptr(a), len(a), ptr(out), len(out)), 'cna_allgather_host')
         return out
 
+    # ---------------------------------------------------------------- synthetic inputs
+    def knn_graph(self, X, k):
+        """scanpy-like connectivities of the points X (n x d, d <= 64) built on the device
+        (cna_knn_graph): CSR float32 / int32, sorted indices.  Input generator for benchmarks."""
+        X = np.ascontiguousarray(X, dtype=np.float32)
+        n, d = X.shape
+        cap = 2 * n * (k - 1)
+        indptr = np.empty(n + 1, dtype=np.int64)
+        indices = np.empty(cap, dtype=np.int32)
+        data = np.empty(cap, dtype=np.float32)
+        nnz = C.c_int64(0)
+        check(self.lib.cna_knn_graph(self.h, ptr(X), n, d, int(k), ptr(indptr), ptr(indices), ptr(data), C.byref(nnz)),
+              'cna_knn_graph')
+        m = nnz.value
+        A = sp.csr_matrix((data[:m].copy(), indices[:m].copy(), indptr.astype(np.int32 if m < 2 ** 31 else np.int64)),
+                          shape=(n, n))
+        A.has_sorted_indices = True
+        return A
+
     # ---------------------------------------------------------------- measurement
     def prof_enable(self, on=True):
         check(self.lib.cna_prof_enable(self.h, int(bool(on))), 'cna_prof_enable')

@@ -62,9 +62,32 @@ def _usable_cpus():
     return n
 
 
-def fuzzy_knn_graph(X, k=30, dtype=np.float32, workers=None, n_iter=40):
+def _gpu_builder_available(X, k, dtype):
+    import os
+    if os.environ.get('CNA_SYNTH_CPU', '0') not in ('0', '', 'off', 'no'):
+        return False
+    if np.dtype(dtype) != np.float32 or X.shape[1] > 64 or not (2 <= k <= 65) or X.shape[0] <= k:
+        return False
+    try:
+        import ctypes as C
+        from . import _ffi
+        cnt = C.c_int(0)
+        return _ffi.load().cna_device_count(C.byref(cnt)) == 0 and cnt.value > 0
+    except Exception:
+        return False
+
+
+def fuzzy_knn_graph(X, k=30, dtype=np.float32, workers=None, n_iter=40, builder='auto'):
     """UMAP-style connectivities for points X with ``k`` neighbours (self included,
-    as scanpy counts them), symmetrised by fuzzy union A + A^T - A*A^T."""
+    as scanpy counts them), symmetrised by fuzzy union A + A^T - A*A^T.
+
+    builder: 'auto' uses the device builder (csrc/knn.hip: brute-force kNN, weights and fuzzy union on
+    the GPU -- seconds at 2M points) when a GPU is visible, else this function's cKDTree + scipy.sparse
+    path ('cpu'); CNA_SYNTH_CPU=1 forces the latter.  Both are exact kNN; they may differ in how ties and
+    float32 / float64 distance roundings fall."""
+    if builder == 'gpu' or (builder == 'auto' and _gpu_builder_available(X, k, dtype)):
+        from .engine import get_engine
+        return get_engine().knn_graph(X, k)
     n = X.shape[0]
     kk = min(k, n)
     tree = cKDTree(X)

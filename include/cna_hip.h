@@ -300,6 +300,14 @@ int64_t cna_host_cluster_order(int64_t n, const int64_t* indptr, const int32_t* 
 int64_t cna_host_block_sources(int64_t n_local, int64_t n_cols, const int64_t* indptr, const int32_t* indices, int B,
                                int cap, int64_t* src_ptr, int32_t* src, uint16_t* slot);
 
+/* ---- benchmark / test input: kNN connectivities graph built on the device (csrc/knn.hip) ---- */
+/* Stand-in for scanpy.pp.neighbors (demo/demo.ipynb:590, makedata.ipynb:117) on synthetic points: exact
+ * brute-force kNN of X (n x d float32, d <= 64; k counts the point itself, 2 <= k <= 65), UMAP smooth-kNN
+ * weights, fuzzy union A + A^T - A o A^T; CSR with sorted int32 column indices, float32 values, empty
+ * diagonal.  indices_out / data_out: room for 2 n (k-1) entries.  An input generator, not a parity target. */
+int  cna_knn_graph(cna_ctx* ctx, const float* X, int64_t n, int d, int k, int64_t* indptr_out,
+                   int32_t* indices_out, float* data_out, int64_t* nnz_out);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 /* HIP-event timing of every kernel launch on the context's stream (bench.py roofline) */
 int  cna_prof_enable(cna_ctx* ctx, int on);

@@ -977,3 +977,27 @@ def test_device_median_of_walk_kurtosis(eng, orc):
         v = eng.cell_stat(A.shape[0])
         assert (v < 0).any()
         assert eng.stat_median() == np.median(v)
+
+
+@pytest.mark.parametrize('n,d,k', [(3000, 8, 30), (2500, 8, 15), (1200, 50, 15), (900, 3, 7), (400, 20, 41)])
+def test_device_knn_graph_builder_vs_host_builder(eng, n, d, k):
+    """csrc/knn.hip (the benchmark's input generator on the GPU) against the cKDTree + scipy.sparse builder:
+    same neighbour sets (exact kNN both; a handful of float32-vs-float64 ties may differ), same weights,
+    a canonical CSR (sorted indices, no diagonal, symmetric)."""
+    from cna_amd import synth
+    rs = np.random.RandomState(n + d)
+    X = rs.randn(n, d).astype(np.float32)
+    A = eng.knn_graph(X, k)
+    B = synth.fuzzy_knn_graph(X, k=k, builder='cpu')
+    assert A.shape == B.shape and A.dtype == np.float32 and A.indices.dtype == np.int32
+    assert A.has_canonical_format or (np.diff(A.indptr) >= 0).all()
+    for i in range(0, n, 37):
+        seg = A.indices[A.indptr[i]:A.indptr[i + 1]]
+        assert (np.diff(seg) > 0).all() and i not in seg
+    assert abs(A - A.T).max() < 1e-6                                  # fuzzy union is symmetric
+    # structure: at most a few edges differ (distance ties); weights of common edges agree
+    diff = (A != 0).astype(np.int8) - (B != 0).astype(np.int8)
+    assert abs(diff).sum() <= max(4, 0.001 * B.nnz), (abs(diff).sum(), B.nnz)
+    common = A.multiply(B != 0) - B.multiply(A != 0)
+    assert abs(common).max() < 1e-4
+    assert abs(A.nnz - B.nnz) <= max(4, 0.001 * B.nnz)
