@@ -27,6 +27,9 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // MFMA: 28.9 ms at 2M x 200, 0.07 of the f64 MFMA peak.)
 // N = 132 ... 208: capped at 128 VGPRs (a handful of spills) two workgroups share a CU, 4928 -> 4176 us
 // at 2M x 200; deeper tiles spill too much (N = 256: 3853 -> 4996 us) and keep the full register file
+#ifndef CNA_NULL_PD
+#define CNA_NULL_PD 0   // measured on MI355X: no gain (N = 200: 53.7 vs 54.6 TFLOP/s without), worse at N = 128 (43.5 vs 50.8)
+#endif
 #ifndef CNA_XB_CAP
 #define CNA_XB_CAP 52
 #endif
@@ -400,12 +403,37 @@ __global__ __launch_bounds__(64 * NW) void k_null(const double* __restrict__ X, 
     v4d acc[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc[s] = (v4d){0.0, 0.0, 0.0, 0.0};
+#if CNA_NULL_PD > 0
+    // B fragments are read from LDS CNA_NULL_PD k-steps ahead of the MFMA that consumes them (left to
+    // itself the compiler issues each ds_read one MFMA before its use and waits on it: 64 cycles of cover for
+    // an LDS round trip of ~100+, i.e. a stall on every second MFMA at N = 200)
+    constexpr int PD = CNA_NULL_PD < KQ ? CNA_NULL_PD : KQ;
+    double bq[PD][NS];
+#pragma unroll
+    for (int q = 0; q < PD; ++q)
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bq[q][s] = bp[4 * q * LDB + 16 * s];
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) {
+      double bc[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bc[s] = bq[q % PD][s];
+      if (q + PD < KQ) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) bq[q % PD][s] = bp[4 * (q + PD) * LDB + 16 * s];
+      }
+#pragma unroll
+      for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bc[s], acc[s], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll
     for (int q = 0; q < KQ; ++q) {
 #pragma unroll
       for (int s = 0; s < NS; ++s)
         acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bp[4 * q * LDB + 16 * s], acc[s], 0, 0, 0);
     }
+#endif
     if (MODE == 1) {                                                     // experiment: no counting
       double z = 0.0;
 #pragma unroll
