@@ -255,6 +255,94 @@ __global__ __launch_bounds__(64 * NW) void k_gram(const double* __restrict__ X, 
   }
 }
 
+// The same with two LDS slabs: the next slab's global loads are issued before the MFMAs of the current one
+// and written to the other buffer after them -- one barrier per slab instead of two, and the load latency
+// (~2 us per 53 KB slab at N = 200) disappears behind 48 MFMAs per wave.
+template <int TPW, int NW, int SLAB>
+__global__ __launch_bounds__(64 * NW) void k_gram_db(const double* __restrict__ X, int64_t nx, int ldx, int nt,
+                                                 int ldp, int ntri, const int32_t* __restrict__ tiles,
+                                                 double* __restrict__ partial) {
+  extern __shared__ double sm[];
+  constexpr int NT = 64 * NW, PF = 5;                  // PF double2 per thread cover SLAB x ldx doubles up to ldx = 320
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ak = lane >> 4, ai = lane & 15;
+  v4d acc[TPW];
+  int off_i[TPW], off_j[TPW];
+  bool live[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int tix = (blockIdx.y * NW + wv) * TPW + t;
+    live[t] = tix < ntri;
+    const int packed = live[t] ? __builtin_amdgcn_readfirstlane(tiles[tix]) : 0;
+    off_i[t] = (packed >> 16) * 16;
+    off_j[t] = (packed & 0xffff) * 16;
+  }
+  for (int i = tid; i < 2 * SLAB * ldp; i += NT) sm[i] = 0.0;
+  const int64_t nslab = (nx + SLAB - 1) / SLAB;
+  const int slab2 = SLAB * ldx / 2;                     // double2 elements of a slab (contiguous in X)
+  int lrow[PF], lcol[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int i = 2 * (tid + u * NT);
+    lrow[u] = i / ldx;
+    lcol[u] = i - lrow[u] * ldx;
+  }
+  double2 v[PF];
+  auto gload = [&](int64_t slab) {
+    const int64_t r0 = slab * SLAB;
+    const int64_t rows = nx - r0 < SLAB ? nx - r0 : SLAB;
+    const int lim = (int)(rows * ldx / 2);
+    const double2* __restrict__ src = (const double2*)(X + r0 * ldx);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i2 = tid + u * NT;
+      v[u] = i2 < lim ? src[i2] : make_double2(0.0, 0.0);
+    }
+  };
+  auto lstore = [&](double* buf) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (tid + u * NT < slab2) *(double2*)(buf + lrow[u] * ldp + lcol[u]) = v[u];
+  };
+  int64_t slab = blockIdx.x;
+  __syncthreads();                                      // zero fill done
+  if (slab < nslab) { gload(slab); lstore(sm); }
+  __syncthreads();
+  int cur = 0;
+  for (; slab < nslab; slab += gridDim.x) {
+    const int64_t next = slab + gridDim.x;
+    if (next < nslab) gload(next);
+    const double* buf = sm + cur * SLAB * ldp;
+#pragma unroll 1
+    for (int kq = 0; kq < SLAB / 4; ++kq) {
+      const double* rowp = buf + (4 * kq + ak) * ldp + ai;
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        if (live[t]) {
+          const double a = rowp[off_i[t]];
+          const double b = rowp[off_j[t]];
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+      }
+    }
+    if (next < nslab) lstore(sm + (cur ^ 1) * SLAB * ldp);
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    if (live[t]) {
+      const int tix = (blockIdx.y * NW + wv) * TPW + t;
+      double* p = partial + ((size_t)blockIdx.x * ntri + tix) * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r * 64 + lane] = acc[t][r];
+    }
+  }
+}
+
 __global__ __launch_bounds__(1024) void k_gram_reduce(const double* __restrict__ partial, int nblocks, int ntri,
                                                       const int32_t* __restrict__ tiles, int Nx,
                                                       double* __restrict__ G) {
@@ -578,6 +666,19 @@ int launch_gram_t(cna_ctx* c, int nt, int ldp, int ntri, const int32_t* tiles_de
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_gram<TPW, NW, SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
+  }
+  // two slabs in LDS when they fit (up to ~256 samples): loads of the next slab overlap the MFMAs
+  static const bool use_db = !getenv("CNA_GRAM_SINGLE");
+  if (use_db && SLAB == 32 && 2 * smem <= 150 * 1024 && c->ldx <= 320) {
+    static bool attr_db = false;
+    if (!attr_db) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_gram_db<TPW, NW, SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_db = true;
+    }
+    hipLaunchKernelGGL((k_gram_db<TPW, NW, SLAB>), dim3(nblocks, npass), dim3(64 * NW), 2 * smem, c->stream, c->X, c->nx, c->ldx,
+                       nt, ldp, ntri, tiles_dev, partial);
+    HIP_TRY(hipGetLastError());
+    return 0;
   }
   hipLaunchKernelGGL((k_gram<TPW, NW, SLAB>), dim3(nblocks, npass), dim3(64 * NW), smem, c->stream, c->X, c->nx, c->ldx, nt, ldp,
                      ntri, tiles_dev, partial);
