@@ -103,16 +103,28 @@ def permuted_rows(A, perm, r0, r1, col_map=None):
     """CSR pieces (indptr int64, indices int32, data) of device rows [r0, r1) of P A P^T: row i
     is the caller's row perm[i] with its columns relabelled and left in their original order.
     col_map (sharded callers, whose A holds the rows of one block only): device column of every
-    global caller column, instead of the inverse of `perm`."""
-    inv = inverse(perm) if col_map is None else col_map
-    rows = perm[r0:r1]
-    ptr = A.indptr.astype(np.int64, copy=False)
-    deg = ptr[rows + 1] - ptr[rows]
-    indptr = np.zeros(len(rows) + 1, dtype=np.int64)
-    np.cumsum(deg, out=indptr[1:])
-    src = np.repeat(ptr[rows] - indptr[:-1], deg) + np.arange(indptr[-1], dtype=np.int64)
-    indices = inv[A.indices[src]].astype(np.int32)
-    return indptr, indices, np.ascontiguousarray(A.data[src])
+    global caller column, instead of the inverse of `perm`.  Done by the library's threaded host
+    helper (cna_host_permute_rows: 0.1 s for the 80M edges of a 2M-cell graph; numpy fancy indexing
+    took 0.8 s)."""
+    from . import _ffi
+    lib = _ffi.load()
+    inv = np.ascontiguousarray(inverse(perm) if col_map is None else col_map, dtype=np.int64)
+    perm = np.ascontiguousarray(perm, dtype=np.int64)
+    ptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    idx = np.ascontiguousarray(A.indices, dtype=np.int32)
+    dat = np.ascontiguousarray(A.data)
+    if dat.dtype.itemsize not in (4, 8):
+        dat = dat.astype(np.float64)
+    nnz = int(lib.cna_host_permuted_nnz(_ffi.ptr(perm), int(r0), int(r1), _ffi.ptr(ptr)))
+    indptr = np.empty(r1 - r0 + 1, dtype=np.int64)
+    indices = np.empty(max(nnz, 1), dtype=np.int32)
+    data = np.empty(max(nnz, 1), dtype=dat.dtype)
+    rc = lib.cna_host_permute_rows(_ffi.ptr(perm), int(r0), int(r1), _ffi.ptr(ptr), _ffi.ptr(idx), _ffi.ptr(dat),
+                                   dat.dtype.itemsize, _ffi.ptr(inv), _ffi.ptr(indptr), _ffi.ptr(indices), _ffi.ptr(data),
+                                   usable_cpus(16))
+    if rc != 0:
+        raise ValueError('cna_host_permute_rows: bad arguments')
+    return indptr, indices[:nnz], data[:nnz]
 
 
 def halo_plan(indices, row0, n_local, rows_per_rank, rank, nranks, allgather_i64, force_self=0):

@@ -227,3 +227,68 @@ int64_t cna_host_block_sources(int64_t n_local, int64_t n_cols, const int64_t* i
   free(stamp); free(where);
   return total;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Rows [r0, r1) of P A P^T for the device order: out row i = caller's row perm[r0 + i] with its columns
+ * relabelled through col_map (caller's column -> device column) and LEFT IN THEIR ORIGINAL ORDER (no sum
+ * is reordered).  indptr of A as int64; vbytes = 4 or 8 (float32 / float64 values, copied bit for bit).
+ * out_indptr int64[r1 - r0 + 1] (rebased to 0), out_indices / out_data sized by the caller from
+ * cna_host_permuted_nnz.  Threads split the rows; the result does not depend on the thread count. */
+int64_t cna_host_permuted_nnz(const int64_t* perm, int64_t r0, int64_t r1, const int64_t* indptr) {
+  int64_t s = 0;
+  for (int64_t i = r0; i < r1; ++i) s += indptr[perm[i] + 1] - indptr[perm[i]];
+  return s;
+}
+
+struct perm_job {
+  const int64_t* perm; const int64_t* indptr; const int32_t* indices; const char* data; const int64_t* col_map;
+  const int64_t* out_indptr; int32_t* out_indices; char* out_data;
+  int64_t r0, row_a, row_b;
+  int vbytes;
+};
+
+static void* perm_worker(void* arg) {
+  struct perm_job* j = (struct perm_job*)arg;
+  for (int64_t i = j->row_a; i < j->row_b; ++i) {
+    const int64_t src = j->indptr[j->perm[j->r0 + i]];
+    const int64_t len = j->indptr[j->perm[j->r0 + i] + 1] - src;
+    const int64_t dst = j->out_indptr[i];
+    for (int64_t e = 0; e < len; ++e) j->out_indices[dst + e] = (int32_t)j->col_map[j->indices[src + e]];
+    memcpy(j->out_data + (size_t)dst * j->vbytes, j->data + (size_t)src * j->vbytes, (size_t)len * j->vbytes);
+  }
+  return NULL;
+}
+
+int cna_host_permute_rows(const int64_t* perm, int64_t r0, int64_t r1, const int64_t* indptr, const int32_t* indices,
+                          const void* data, int vbytes, const int64_t* col_map, int64_t* out_indptr,
+                          int32_t* out_indices, void* out_data, int nthreads) {
+  const int64_t nr = r1 - r0;
+  if (nr < 0 || (vbytes != 4 && vbytes != 8)) return -1;
+  out_indptr[0] = 0;
+  for (int64_t i = 0; i < nr; ++i) out_indptr[i + 1] = out_indptr[i] + (indptr[perm[r0 + i] + 1] - indptr[perm[r0 + i]]);
+  if (nthreads > 64) nthreads = 64;
+  if (nthreads < 1 || nr < 4096) nthreads = 1;
+  struct perm_job jobs[64];
+  pthread_t th[64];
+  int started[64];
+  const int64_t total = out_indptr[nr];
+  int64_t row = 0;
+  for (int t = 0; t < nthreads; ++t) {                 /* equal shares of the EDGES, cut at row boundaries */
+    const int64_t want = total * (t + 1) / nthreads;
+    int64_t b = row;
+    if (t == nthreads - 1) b = nr;
+    else while (b < nr && out_indptr[b] < want) ++b;
+    jobs[t].perm = perm; jobs[t].indptr = indptr; jobs[t].indices = indices; jobs[t].data = (const char*)data;
+    jobs[t].col_map = col_map; jobs[t].out_indptr = out_indptr; jobs[t].out_indices = out_indices;
+    jobs[t].out_data = (char*)out_data; jobs[t].r0 = r0; jobs[t].row_a = row; jobs[t].row_b = b; jobs[t].vbytes = vbytes;
+    row = b;
+    started[t] = 0;
+  }
+  for (int t = 1; t < nthreads; ++t) started[t] = pthread_create(&th[t], NULL, perm_worker, &jobs[t]) == 0;
+  perm_worker(&jobs[0]);
+  for (int t = 1; t < nthreads; ++t) {
+    if (started[t]) pthread_join(th[t], NULL);
+    else perm_worker(&jobs[t]);
+  }
+  return 0;
+}

@@ -696,7 +696,10 @@ int launch_null_t(cna_ctx* c, dim3 grid, size_t smem, int64_t chunk_rows, const 
   // (-6 % at N = 100, -9 % at N = 60, -1 % at N = 128 against 8 waves with it; -2 % at N = 50 against
   // 16 waves with it)
   constexpr bool PF = false;
-  constexpr int NW = KQ <= 32 ? 16 : 8;      // (two register halves of the A tile at 16 waves for N > 128: measured slower, +11 % at N = 200)
+#ifndef CNA_NULL_NW_DEEP
+#define CNA_NULL_NW_DEEP 8    // 12 waves (3 per SIMD) measured: 53.4 vs 54.6 TFLOP/s at N = 200, +3 % at N = 160
+#endif
+  constexpr int NW = KQ <= 32 ? 16 : CNA_NULL_NW_DEEP;      // (two register halves of the A tile at 16 waves for N > 128: measured slower, +11 % at N = 200)
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_null<KQ, NS, PF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -300,6 +300,14 @@ int64_t cna_host_cluster_order(int64_t n, const int64_t* indptr, const int32_t* 
 int64_t cna_host_block_sources(int64_t n_local, int64_t n_cols, const int64_t* indptr, const int32_t* indices, int B,
                                int cap, int64_t* src_ptr, int32_t* src, uint16_t* slot);
 
+/* Rows [r0, r1) of the graph in the device order: out row i = caller's row perm[r0 + i], columns relabelled
+ * through col_map and left in their original order; values (vbytes = 4 | 8) copied bit for bit.  Sizes from
+ * cna_host_permuted_nnz.  Threaded; integer work only. */
+int64_t cna_host_permuted_nnz(const int64_t* perm, int64_t r0, int64_t r1, const int64_t* indptr);
+int  cna_host_permute_rows(const int64_t* perm, int64_t r0, int64_t r1, const int64_t* indptr, const int32_t* indices,
+                           const void* data, int vbytes, const int64_t* col_map, int64_t* out_indptr,
+                           int32_t* out_indices, void* out_data, int nthreads);
+
 /* ---- benchmark / test input: kNN connectivities graph built on the device (csrc/knn.hip) ---- */
 /* Stand-in for scanpy.pp.neighbors (demo/demo.ipynb:590, makedata.ipynb:117) on synthetic points: exact
  * brute-force kNN of X (n x d float32, d <= 64; k counts the point itself, 2 <= k <= 65), UMAP smooth-kNN

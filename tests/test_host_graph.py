@@ -82,3 +82,21 @@ def test_block_sources_lists_every_column_once_per_block():
                 assert listed.all() and set(mine.tolist()) == set(cols.tolist())
             else:
                 assert not np.isin(cols[~listed], mine).any()       # unlisted columns really are not in the list
+
+
+def test_permute_rows_equals_numpy_formulation():
+    """cna_host_permute_rows (threaded) = rows perm[r0:r1] of A with columns relabelled, values bit for bit,
+    neighbours in their original order."""
+    rs = np.random.RandomState(0)
+    n = 5000
+    A = sp.random(n, n, density=0.004, random_state=rs, format='csr', dtype=np.float32)
+    A.indices = A.indices.astype(np.int32)
+    for dt in (np.float32, np.float64):
+        B = A.astype(dt)
+        perm = rs.permutation(n).astype(np.int64)
+        for r0, r1 in ((0, n), (100, 4000), (7, 7)):
+            ip, ix, da = _order.permuted_rows(B, perm, r0, r1)
+            ref = sp.csr_matrix(B)[perm[r0:r1]]
+            assert np.array_equal(ip, ref.indptr.astype(np.int64))
+            assert np.array_equal(ix, _order.inverse(perm)[ref.indices]) and ix.dtype == np.int32
+            assert np.array_equal(da, ref.data) and da.dtype == dt
