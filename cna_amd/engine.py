@@ -41,6 +41,9 @@ class Engine(_order.CellOrder):
             buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
             check(self.lib.cna_comm_init(self.h, self.rank, self.nranks, C.cast(buf, C.c_void_p)), 'cna_comm_init')
         self._graph_key = None
+        self._graph_hash = None
+        self._pending_check = None
+        self._defer_graph_check = False
         self._graph_ref = None
         self._pinned = None
         self._host_threads = _order.usable_cpus(8)
@@ -98,30 +101,30 @@ class Engine(_order.CellOrder):
         r0 = min(self.rank * rpr, n)
         return r0, min(r0 + rpr, n)
 
-    def _key(self, A):
-        """Identity of a resident graph: shape, dtype and a 64-bit hash of the FULL content of data,
-        indices and indptr (csrc/host_graph.c, several threads: ~1.5 ms for the 66 MB of a 200k-cell
-        graph, ~13 ms at 2M cells) -- an in-place edit of any entry is seen and the graph goes to the
-        device again, as the reference re-reads the matrix on every call (_nam.py:25-28).
-
-        `pin_graph(A)` is the caller's promise not to edit A in place: a pinned matrix is recognised
-        by identity (object, buffers, sizes) plus a hash of three 64 KB windows only."""
+    def _quick_key(self, A):
+        """Cheap identity of a graph: the scipy object, its buffers, sizes and dtypes, and a hash of three
+        64 KB windows (head, middle, tail) of values and indices (~20 us).  Necessary, not sufficient."""
         ident = (A.shape, int(A.nnz), str(A.data.dtype), str(A.indices.dtype), str(A.indptr.dtype))
-        if self._pinned is not None and self._pinned[0]() is A and self._pinned[1] == self._buffers(A):
-            w = 16384
-            mid = max(0, A.nnz // 2 - w // 2)
-            parts = [slice(0, w), slice(mid, mid + w), slice(max(0, A.nnz - w), A.nnz)]
-            probe = tuple(self._hash(arr[p_]) for arr in (A.data, A.indices) for p_ in parts)
-            return ident + ('pinned', id(A)) + self._buffers(A) + probe
-        return ident + tuple(self._hash(arr) for arr in (A.data, A.indices, A.indptr))
+        w = 16384
+        mid = max(0, A.nnz // 2 - w // 2)
+        parts = [slice(0, w), slice(mid, mid + w), slice(max(0, A.nnz - w), A.nnz)]
+        probe = tuple(self._hash(arr[p_], 1) for arr in (A.data, A.indices) for p_ in parts)
+        return ident + (id(A),) + self._buffers(A) + probe
+
+    def _full_hash(self, A):
+        """64-bit hashes of the FULL content of data, indices and indptr (csrc/host_graph.c, several
+        threads: ~0.5 ms for the 66 MB of a 200k-cell graph, 4.6 ms at 2M cells) -- an in-place edit of
+        any entry changes it, and the graph then goes to the device again, as the reference re-reads the
+        matrix on every call (_nam.py:25-28)."""
+        return tuple(self._hash(arr) for arr in (A.data, A.indices, A.indptr))
 
     @staticmethod
     def _buffers(A):
         return (A.data.ctypes.data, A.indices.ctypes.data, A.indptr.ctypes.data)
 
-    def _hash(self, arr):
+    def _hash(self, arr, threads=None):
         arr = np.ascontiguousarray(arr)
-        return int(self.lib.cna_host_hash64(ptr(arr), arr.nbytes, self._host_threads))
+        return int(self.lib.cna_host_hash64(ptr(arr), arr.nbytes, self._host_threads if threads is None else threads))
 
     def pin_graph(self, A):
         """Promise that the connectivities matrix A will not be edited in place while it is resident:
@@ -134,10 +137,15 @@ class Engine(_order.CellOrder):
     def unpin_graph(self):
         self._pinned = None
 
-    def ensure_graph(self, A, shard=None):
-        """Upload the connectivities graph unless this very matrix is already resident.  The cells
-        are kept on the device in a locality-preserving order (see _order.py); everything that
-        crosses this class's boundary is in the caller's order.
+    def ensure_graph(self, A, shard=None, defer=False):
+        """Upload the connectivities graph unless this very matrix -- same object, same content -- is
+        already resident.  The cells are kept on the device in a locality-preserving order (see
+        _order.py); everything that crosses this class's boundary is in the caller's order.
+
+        Content check: the full hash of data / indices / indptr (`_full_hash`), unless the matrix is
+        pinned (`pin_graph`).  defer=True (one GPU only): when the cheap identity matches, return at once
+        and take the full hash on a helper thread; the caller MUST call `confirm_graph()` before it lets
+        any result out and start over if that returns False (tools._association does).
 
         shard=None: A is the whole n x n graph (on every rank; each keeps its row block).
         shard=(row0, n_global): A holds only the rows [row0, row0 + A.shape[0]) of the graph, with
@@ -149,9 +157,20 @@ class Engine(_order.CellOrder):
             A = sp.csr_matrix(A)
         if shard is None and A.shape[0] != A.shape[1]:
             raise ValueError('connectivities must be square')
-        key = self._key(A) + (None if shard is None else tuple(int(v) for v in shard),)
-        if self._graph_key == key and self._graph_ref is not None and self._graph_ref() is A:
-            return False
+        self._pending_check = None
+        quick = self._quick_key(A) + (None if shard is None else tuple(int(v) for v in shard),)
+        pinned = self._pinned is not None and self._pinned[0]() is A and self._pinned[1] == self._buffers(A)
+        full = None
+        if self._graph_key == quick and self._graph_ref is not None and self._graph_ref() is A:
+            if pinned:
+                return False
+            if defer and self.nranks == 1 and not self._has_comm:
+                self._pending_check = _checker().submit(self._full_hash, A)
+                return False
+            full = self._full_hash(A)
+            if full == self._graph_hash:
+                return False
+        key = quick
         if shard is None:
             n = A.shape[0]
             r0, r1 = self.block(n)
@@ -205,6 +224,7 @@ class Engine(_order.CellOrder):
         self.n_global, self.row0, self.n_local = n, r0, r1 - r0
         self.n = self.n_local if self.view_local else n
         self._graph_key = key
+        self._graph_hash = full if full is not None else self._full_hash(A)
         try:
             self._graph_ref = weakref.ref(A)
         except TypeError:
@@ -212,6 +232,18 @@ class Engine(_order.CellOrder):
         self._colsum_w = None
         self._codes_token = self._codes_graph = None
         return True
+
+    def confirm_graph(self):
+        """Outcome of the deferred content check of ensure_graph(defer=True): True = the resident graph is
+        the caller's graph (or nothing was deferred).  False: the matrix was edited in place since it went
+        to the device; the resident copy is dropped and the caller has to redo its work."""
+        fut, self._pending_check = self._pending_check, None
+        if fut is None or fut.result() == self._graph_hash:
+            return True
+        self._graph_key = None
+        self._graph_hash = None
+        self._nam_sig = None
+        return False
 
     def colsums(self, self_weight=1):
         w = float(self_weight)
@@ -665,6 +697,18 @@ class Engine(_order.CellOrder):
             if n.value:
                 out[name] = (ms.value, n.value)
         return out
+
+
+_check_pool = None
+
+
+def _checker():
+    """One thread for deferred graph checks (the hash itself runs on the library's own threads)."""
+    global _check_pool
+    if _check_pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _check_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix='cna-graph-check')
+    return _check_pool
 
 
 _default = None

@@ -339,8 +339,28 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
     ``nam``, ``namresid``, ``namresid_nbhdXpc`` -- are copied off the GPU when first read).
     Writes ``data.obs[key_added]`` and ``data.obs[key_added + '_fdr']``."""
     with host_blas_threads(1):
-        return _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added, max_frac_pcs, nsteps,
-                                 show_progress, allow_low_sample_size, return_full, ridges, engine, **kwargs)
+        eng = engine or get_engine()
+        # The resident graph is validated by a hash of its full content (engine.ensure_graph).  On one GPU
+        # that hash runs on a helper thread while the kernels are already working on the resident copy
+        # (optimistic); before anything leaves this call -- the first data.obs write, the return value --
+        # the outcome is collected, and if the matrix was edited in place the call starts over on a fresh
+        # upload, with numpy's global RNG put back where it was.
+        rng_state = np.random.get_state() if kwargs.get('seed') is None else None
+        for attempt in (0, 1):
+            eng._defer_graph_check = attempt == 0 and hasattr(eng, 'confirm_graph')
+            try:
+                return _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added, max_frac_pcs, nsteps,
+                                         show_progress, allow_low_sample_size, return_full, ridges, eng, **kwargs)
+            except _StaleGraph:
+                if rng_state is not None:
+                    np.random.set_state(rng_state)
+            finally:
+                eng._defer_graph_check = False
+        raise RuntimeError('the connectivities matrix keeps changing while it is being analysed')
+
+
+class _StaleGraph(Exception):
+    """The deferred content check found the resident graph out of date (engine.confirm_graph)."""
 
 
 def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added, max_frac_pcs, nsteps,
@@ -454,7 +474,12 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     had_key = key_added in data.obs
     previous = data.obs[key_added] if had_key else None
 
+    def confirm_graph():
+        if hasattr(engine, 'confirm_graph') and not engine.confirm_graph():
+            raise _StaleGraph()
+
     def write_coef_early(coef):
+        confirm_graph()                                   # nothing reaches data.obs from a stale graph
         early_coef['written'] = True
         data.obs[key_added] = coef
         early_coef['values'] = data.obs[key_added].values
@@ -474,6 +499,7 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                 del data.obs[key_added]
         raise
     _mark('_association returned')
+    confirm_graph()
     _defer_pcs(res, engine, U, svs, cell_index)
     res.kept = kept
 

@@ -219,7 +219,7 @@ def global_samples(engine, codes, labels, counts, token):
 
 def _prepare_graph(engine, data, self_weight):
     A = _as_csr(get_connectivity(data))
-    if engine.ensure_graph(A, shard=shard_of(data)):
+    if engine.ensure_graph(A, shard=shard_of(data), defer=getattr(engine, '_defer_graph_check', False)):
         engine._nam_sig = None          # new graph: whatever NAM the device holds is stale
     engine.colsums(self_weight)
     return A

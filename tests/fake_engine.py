@@ -114,7 +114,7 @@ class FakeEngine(_order.CellOrder):
         return r0, min(r0 + rpr, n)
 
     # -- graph
-    def ensure_graph(self, A, shard=None):
+    def ensure_graph(self, A, shard=None, defer=False):
         if getattr(self, '_graph_obj', None) is A:
             return False
         self._graph_obj = A

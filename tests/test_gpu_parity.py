@@ -867,11 +867,55 @@ def test_resident_graph_notices_single_entry_edits_unless_pinned(eng, orc):
         d = cna.tl.diffuse(data, s0, 2, engine=eng)
         assert np.array_equal(a, d)
         eng.pin_graph(A)
-        assert eng.ensure_graph(A) is True                       # the key changes kind once ...
-        assert eng.ensure_graph(A) is False                      # ... and then holds
+        assert eng.ensure_graph(A) is False                      # pinned: recognised by identity alone
+        A.data[e] = old_v * 3 + 1
+        assert eng.ensure_graph(A) is False                      # ... which is the caller's promise not to do this
+        A.data[e] = old_v
+        eng.unpin_graph()
+        assert eng.ensure_graph(A) is False                      # unpinned again: content checked, unchanged
+        A.data[e] = old_v * 3 + 1
+        assert eng.ensure_graph(A) is True                       # and an edit is seen
+        A.data[e] = old_v
     finally:
         A.data[e], A.indices[e] = old_v, old_j
         eng.unpin_graph()
+
+
+def test_association_sees_in_place_graph_edits_through_the_deferred_check(eng):
+    """association() validates the resident graph by a full content hash taken on a helper thread while
+    the kernels already run (engine.ensure_graph(defer=True)); if the matrix was edited in place the call
+    starts over on a fresh upload -- the result must equal that of a fresh engine state, data.obs must
+    hold the new numbers only, and the resident NAM must not be reused."""
+    import cna_amd as cna
+    from cna_amd import synth
+    data, meta = synth.make_dataset(30000, 24, k=15, seed=21)
+    A = data.obsp['connectivities']
+    kw = dict(nsteps=3, Nnull=100, seed=4, return_full=True)
+    r1 = cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+    c1 = data.obs['coef'].values.copy()
+    e = A.nnz // 2 + 12345
+    keep = A.data.copy()
+    try:
+        A.data[e:e + 2000] *= 0.25                              # far from the three probe windows
+        r2 = cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+        c2 = data.obs['coef'].values.copy()
+        assert not np.array_equal(c1, c2)
+        # reference point: the same analysis from scratch
+        from cna_amd.engine import Engine
+        fresh = Engine(device=0)
+        try:
+            data3 = type(data)(data.obs[['id']].copy(), A.copy())
+            r3 = cna.tl.association(data3, meta['y'], 'id', engine=fresh, **kw)
+            assert r2.p == r3.p and r2.k == r3.k
+            np.testing.assert_array_equal(c2, data3.obs['coef'].values)
+            np.testing.assert_array_equal(data.obs['coef_fdr'].values, data3.obs['coef_fdr'].values)
+        finally:
+            fresh.close()
+    finally:
+        A.data[:] = keep
+    r4 = cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+    np.testing.assert_array_equal(data.obs['coef'].values, c1)
+    assert r4.p == r1.p
 
 
 def _fuzz_config(seed):
