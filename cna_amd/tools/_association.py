@@ -45,6 +45,29 @@ def _background():
 
 
 _EARLY_COEF = os.environ.get('CNA_EARLY_COEF', '1') not in ('0', 'off', 'no')     # ablation switches
+_DRAW_THREAD = os.environ.get('CNA_DRAW_THREAD', '1') not in ('0', 'off', 'no')
+
+
+class _InlineJob:
+    """Future-like wrapper of a job that runs on the calling thread, at most once."""
+
+    def __init__(self, fn):
+        self._fn, self._done, self._val = fn, False, None
+
+    def run(self):
+        if not self._done:
+            self._val, self._done = self._fn(), True
+
+    def result(self):
+        self.run()
+        return self._val
+
+    def cancel(self):
+        self._done = True
+        return True
+
+    def exception(self):
+        return None
 _FUSE = os.environ.get('CNA_FUSE_SELECT', '1') not in ('0', 'off', 'no')
 
 _TRACE = None      # list of (label, perf_counter) when tools/host_trace.py switches tracing on
@@ -426,7 +449,11 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                 early['condition_error'] = exc
         return out_
     _mark('checked')
-    null_future = _background().submit(null_job)
+    # Where the draw runs.  Default: the helper thread, from now on, overlapping this thread's own host work
+    # (it shares the GIL, so the 0.4 ms draw takes ~0.9 ms in context -- still the better schedule at 200k
+    # cells: 1.96-1.99 ms per call against 2.2-2.4 ms with the draw on this thread after the walk is queued,
+    # CNA_DRAW_THREAD=0; no difference at 1M / 2M cells, where the walk hides either).
+    null_future = _background().submit(null_job) if _DRAW_THREAD else _InlineJob(null_job)
     _mark('submitted')
 
     def host_side(sample_index_, batches_, covs_, donorids_, filter_):
@@ -434,7 +461,9 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         plan = _resid_plan(sample_index_, covs_[filter_] if covs_ is not None else covs_,
                            batches_[filter_] if batches_ is not None else batches_, ridges=ridges)
         if plan.M is not None:
-            early['M'] = np.asarray(plan.M, dtype=np.float64)     # the helper conditions with it after the draw
+            early['M'] = np.asarray(plan.M, dtype=np.float64)     # the draw conditions with it
+        if not _DRAW_THREAD:
+            null_future.run()
         return plan
 
     try:
