@@ -46,6 +46,7 @@ def _background():
 
 _EARLY_COEF = os.environ.get('CNA_EARLY_COEF', '1') not in ('0', 'off', 'no')     # ablation switches
 _DRAW_THREAD = os.environ.get('CNA_DRAW_THREAD', '1') not in ('0', 'off', 'no')
+_SWITCH_INTERVAL = float(os.environ.get('CNA_SWITCH_INTERVAL', '5e-5'))   # GIL hand-over between the helper thread and this one: 2.08 -> 1.86 ms per call at 200k cells (default interval: 5 ms)
 
 
 class _InlineJob:
@@ -369,6 +370,21 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
         # the outcome is collected, and if the matrix was edited in place the call starts over on a fresh
         # upload, with numpy's global RNG put back where it was.
         rng_state = np.random.get_state() if kwargs.get('seed') is None else None
+        import sys
+        interval = sys.getswitchinterval()
+        if _SWITCH_INTERVAL > 0:
+            sys.setswitchinterval(_SWITCH_INTERVAL)       # helper thread and this one hand the GIL over promptly
+        try:
+            return _association_attempts(eng, rng_state, data, y, sid_name, batches, covs, donorids, ks, key_added,
+                                         max_frac_pcs, nsteps, show_progress, allow_low_sample_size, return_full, ridges,
+                                         kwargs)
+        finally:
+            sys.setswitchinterval(interval)
+
+
+def _association_attempts(eng, rng_state, data, y, sid_name, batches, covs, donorids, ks, key_added, max_frac_pcs, nsteps,
+                          show_progress, allow_low_sample_size, return_full, ridges, kwargs):
+    if True:
         for attempt in (0, 1):
             eng._defer_graph_check = attempt == 0 and hasattr(eng, 'confirm_graph')
             try:
