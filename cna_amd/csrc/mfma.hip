@@ -396,6 +396,20 @@ __global__ __launch_bounds__(1024) void k_gram_reduce(const double* __restrict__
 // instruction: 32-bit LDS counters (address = one shift-add, increment = 1), nine VALU
 // instructions per output.  Each block stores its counters as one plain slab; k_hist_reduce sums
 // the slabs (integers: bit-reproducible) -- global atomics cost 60 us here.
+#ifndef CNA_PAIR_A
+#define CNA_PAIR_A 1
+#endif
+// LDS row of sample (k index) `k` of a B operand whose A operand is loaded in 16-byte pairs: inside every
+// block of 8 samples the even ones come first (rows 0-3: MFMA step 2q', lanes ak = 0..3 hold samples
+// 8q' + 2ak) and the odd ones second (rows 4-7: step 2q' + 1); an unpaired last step keeps its rows
+template <int KQ>
+__device__ __forceinline__ int pair_row(int k) {
+#if CNA_PAIR_A
+  if (k < 8 * (KQ / 2)) return (k & ~7) + 4 * (k & 1) + ((k >> 1) & 3);
+#endif
+  return k;
+}
+
 template <int KQ, int NS, bool PFETCH, int NW, int MODE = 0>
 __global__ __launch_bounds__(64 * NW) void k_null(const double* __restrict__ X, int64_t nx, int64_t chunk_rows,
                                               const double* __restrict__ Yc, int ldy, int P,
@@ -418,7 +432,7 @@ __global__ __launch_bounds__(64 * NW) void k_null(const double* __restrict__ X, 
   for (int i = tid; i < PT * TW; i += 64 * NW) hist[i] = 0u;
   for (int i = tid; i < LDX * PT; i += 64 * NW) {
     const int k = i / PT, j = i - k * PT;
-    bs[k * LDB + j] = Yc[(size_t)k * ldy + pt * PT + j];
+    bs[pair_row<KQ>(k) * LDB + j] = Yc[(size_t)k * ldy + pt * PT + j];
   }
   __syncthreads();
 
@@ -432,9 +446,23 @@ __global__ __launch_bounds__(64 * NW) void k_null(const double* __restrict__ X, 
   auto load_a = [&](double (&a)[KQ], int64_t tile) {
     const int64_t row = row_begin + 16 * tile + aj;
     if (tile < ntile && row < row_end) {
+#if CNA_PAIR_A
+      // 16-byte loads: lane (row, ak) takes columns 8q' + 2ak, 8q' + 2ak + 1 -- the k index of MFMA steps 2q'
+      // and 2q' + 1 (the Yc strip sits in LDS with its rows permuted to match, pair_row) -- so that one
+      // load instruction covers 64 contiguous bytes of each of the 16 rows instead of 32
+      const double* __restrict__ xp = X + row * LDX + 2 * ak;
+#pragma unroll
+      for (int q2 = 0; q2 < KQ / 2; ++q2) {
+        const double2 v = *(const double2*)(xp + 8 * q2);
+        a[2 * q2] = v.x;
+        a[2 * q2 + 1] = v.y;
+      }
+      if (KQ & 1) a[KQ - 1] = X[row * LDX + 4 * (KQ - 1) + ak];
+#else
       const double* __restrict__ xp = X + row * LDX + ak;
 #pragma unroll
       for (int q = 0; q < KQ; ++q) a[q] = xp[4 * q];
+#endif
     } else {
 #pragma unroll
       for (int q = 0; q < KQ; ++q) a[q] = 0.0;               // zero rows never reach cut0 > 0
