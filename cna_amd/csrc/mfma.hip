@@ -410,7 +410,7 @@ __device__ __forceinline__ int pair_row(int k) {
   return k;
 }
 
-template <int KQ, int NS, bool PFETCH, int NW, int MODE = 0>
+template <int KQ, int NS, int LOOPM, int NW, int MODE = 0>      // LOOPM: 0 one tile at a time, 1 with A prefetch, 2 two tiles share every B fragment
 __global__ __launch_bounds__(64 * NW) void k_null(const double* __restrict__ X, int64_t nx, int64_t chunk_rows,
                                               const double* __restrict__ Yc, int ldy, int P,
                                               const double* __restrict__ cuts, int T, double cut0,
@@ -559,7 +559,60 @@ __global__ __launch_bounds__(64 * NW) void k_null(const double* __restrict__ X, 
     }
     count_all(acc);
   };
-  if (PFETCH) {
+  if (LOOPM == 2) {
+    // Two 16-cell tiles per wave and iteration: every B fragment read from LDS feeds 2 x NS MFMAs.  On this
+    // chip the LDS -> VGPR return of an operand is not hidden under f64 MFMAs (tools/micro/mfma_f64_rate.hip:
+    // 78 TFLOP/s from registers, 56 with one ds_read_b64 per MFMA at 4 waves x 4 chains per SIMD), so bytes
+    // of B per MFMA are what count: 512 -> 256.  Deep tiles take their A operands in two k halves (the
+    // accumulators persist) to stay within the register budget of two waves per SIMD.
+    constexpr int NPH = KQ > 28 ? 2 : 1;
+    constexpr int KH = (((KQ + NPH - 1) / NPH) + 1) & ~1;
+    auto load_part = [&](double (&a)[KH], int64_t tile, int ph) {
+      const int64_t row = row_begin + 16 * tile + aj;
+      const bool ok = tile < ntile && row < row_end;
+      const double* __restrict__ xr = X + (ok ? row : row_begin) * LDX;
+#pragma unroll
+      for (int j = 0; j < KH; j += 2) {
+        const int q = ph * KH + j;
+        if (q + 1 < 2 * (KQ / 2) + 0 && q < 2 * (KQ / 2)) {
+          const double2 v = *(const double2*)(xr + 8 * (q >> 1) + 2 * ak);
+          a[j] = ok ? v.x : 0.0;
+          a[j + 1] = ok ? v.y : 0.0;
+        } else if (q == KQ - 1) {
+          a[j] = ok ? xr[4 * q + ak] : 0.0;
+          a[j + 1] = 0.0;
+        } else {
+          a[j] = 0.0;
+          a[j + 1] = 0.0;
+        }
+      }
+    };
+    for (int64_t t = 2 * (int64_t)wv; t < ntile; t += 2 * NW) {
+      v4d acc0[NS], acc1[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { acc0[s] = (v4d){0.0, 0.0, 0.0, 0.0}; acc1[s] = (v4d){0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+      for (int ph = 0; ph < NPH; ++ph) {
+        double a0[KH], a1[KH];
+        load_part(a0, t, ph);
+        load_part(a1, t + 1, ph);
+#pragma unroll
+        for (int j = 0; j < KH; ++j) {
+          const int q = ph * KH + j;
+          if (q < KQ) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+              const double b = bp[4 * q * LDB + 16 * s];
+              acc0[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[j], b, acc0[s], 0, 0, 0);
+              acc1[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[j], b, acc1[s], 0, 0, 0);
+            }
+          }
+        }
+      }
+      count_all(acc0);
+      count_all(acc1);
+    }
+  } else if (LOOPM == 1) {
     double a0[KQ], a1[KQ];
     load_a(a0, wv);
     for (int64_t t = wv; t < ntile; t += 2 * NW) {
@@ -723,11 +776,16 @@ int launch_null_t(cna_ctx* c, dim3 grid, size_t smem, int64_t chunk_rows, const 
   // no second A register set: four waves per SIMD hide the A loads better than a software prefetch
   // (-6 % at N = 100, -9 % at N = 60, -1 % at N = 128 against 8 waves with it; -2 % at N = 50 against
   // 16 waves with it)
-  constexpr bool PF = false;
-#ifndef CNA_NULL_NW_DEEP
-#define CNA_NULL_NW_DEEP 8    // 12 waves (3 per SIMD) measured: 53.4 vs 54.6 TFLOP/s at N = 200, +3 % at N = 160
+#ifndef CNA_NULL_TWO
+#define CNA_NULL_TWO 0   // measured: 54.4 vs 55.3 TFLOP/s at N = 200, 49.1 vs 52.3 at N = 100, 38.2 vs 42.6 at N = 50 (the compiler waits on every shared fragment right before its four MFMAs)
 #endif
-  constexpr int NW = KQ <= 32 ? 16 : CNA_NULL_NW_DEEP;      // (two register halves of the A tile at 16 waves for N > 128: measured slower, +11 % at N = 200)
+  // loop shape: two tiles per wave (every B fragment feeds 2 x NS MFMAs) -- measured against one tile per
+  // wave in tools/kbench_null.py; A prefetch (shape 1) never paid (53.6 vs 55.3 TFLOP/s at N = 200)
+  constexpr int PF = CNA_NULL_TWO ? 2 : 0;
+#ifndef CNA_NULL_NW_DEEP
+#define CNA_NULL_NW_DEEP 8
+#endif
+  constexpr int NW = PF == 2 ? 8 : (KQ <= 32 ? 16 : CNA_NULL_NW_DEEP);
   static bool attr_set = false;
   if (!attr_set) {
     HIP_TRY(hipFuncSetAttribute((const void*)k_null<KQ, NS, PF, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -972,9 +1030,16 @@ int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const do
   ProfScope ps(c, CNA_K_NULL_LOCAL);
   if (const char* dbg = getenv("CNA_NULL_DEBUG")) {                    // experiments, N=50 only
     if (kq == 13 && NS == 4 && atoi(dbg) >= 1 && atoi(dbg) <= 2) {
-      auto kfn = atoi(dbg) == 1 ? k_null<13, 4, false, 16, 1> : k_null<13, 4, false, 16, 2>;
+      auto kfn = atoi(dbg) == 1 ? k_null<13, 4, 0, 16, 1> : k_null<13, 4, 0, 16, 2>;
       HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       hipLaunchKernelGGL(kfn, grid, dim3(1024), lds(NS), c->stream, c->X, c->nx, chunk_rows, Yc_dev, ldy, P, cuts_dev, T,
+                         cut0, inv_step, eps, (unsigned int*)c->null_part, 0);
+      return 0;
+    }
+    if (kq == 50 && NS == 2 && atoi(dbg) >= 1 && atoi(dbg) <= 2) {     // N = 200
+      auto kfn = atoi(dbg) == 1 ? k_null<50, 2, 0, 8, 1> : k_null<50, 2, 0, 8, 2>;
+      HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      hipLaunchKernelGGL(kfn, grid, dim3(512), lds(NS), c->stream, c->X, c->nx, chunk_rows, Yc_dev, ldy, P, cuts_dev, T,
                          cut0, inv_step, eps, (unsigned int*)c->null_part, 0);
       return 0;
     }
