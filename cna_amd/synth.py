@@ -77,6 +77,21 @@ def _gpu_builder_available(X, k, dtype):
         return False
 
 
+_knn_engine = None
+
+
+def _builder_engine():
+    """A context of its own, WITHOUT a communicator, for the input builder: in a multi-rank job only rank 0
+    generates the dataset, and creating the process-wide engine there would enter RCCL's collective
+    communicator set-up while the other ranks wait elsewhere."""
+    global _knn_engine
+    if _knn_engine is None:
+        from . import dist
+        from .engine import Engine
+        _knn_engine = Engine(device=dist.current().get('device'), rank=0, nranks=1)
+    return _knn_engine
+
+
 def fuzzy_knn_graph(X, k=30, dtype=np.float32, workers=None, n_iter=40, builder='auto'):
     """UMAP-style connectivities for points X with ``k`` neighbours (self included,
     as scanpy counts them), symmetrised by fuzzy union A + A^T - A*A^T.
@@ -86,8 +101,7 @@ def fuzzy_knn_graph(X, k=30, dtype=np.float32, workers=None, n_iter=40, builder=
     path ('cpu'); CNA_SYNTH_CPU=1 forces the latter.  Both are exact kNN; they may differ in how ties and
     float32 / float64 distance roundings fall."""
     if builder == 'gpu' or (builder == 'auto' and _gpu_builder_available(X, k, dtype)):
-        from .engine import get_engine
-        return get_engine().knn_graph(X, k)
+        return _builder_engine().knn_graph(X, k)
     n = X.shape[0]
     kk = min(k, n)
     tree = cKDTree(X)

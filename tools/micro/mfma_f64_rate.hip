@@ -33,6 +33,11 @@ __global__ void k(const double* __restrict__ g, double* out, int iters) {
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         // VAR 3: one LDS read feeds two chains, VAR 4: four chains (the b of chain c & ~1 / c & ~3: the compiler reads it once)
+        if (VAR == 5 || VAR == 6) {      // B operand from global memory (a 25.6 KB strip: L1 resident), one load per MFMA (5) / per two MFMAs (6)
+          const double bg = g[(size_t)(4 * q + (lane >> 4)) * 16 + (lane & 15) + 3200 * ((VAR == 5 ? c : (c >> 1)) & 1)];
+          acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bg, acc[c], 0, 0, 0);
+          continue;
+        }
         const double b = VAR == 3 ? bp[4 * q * 48 + 16 * ((c >> 1) & 1)] : VAR == 4 ? bp[4 * q * 48 + 16 * ((c >> 2) & 1)]
                          : VAR >= 1 ? bp[4 * q * 48 + 16 * (c & 1) + (c >> 1)] : a[(q + c + 1) % KQ];
         acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b, acc[c], 0, 0, 0);
@@ -70,6 +75,7 @@ int main() {
   for (int w : {1, 2, 4}) { run<2, 0>(w, g, out); run<4, 0>(w, g, out); }
   for (int w : {1, 2, 4}) { run<2, 1>(w, g, out); run<4, 1>(w, g, out); }
   for (int w : {2, 4}) { run<2, 2>(w, g, out); }
+  for (int w : {1, 2, 4}) { run<2, 5>(w, g, out); run<4, 5>(w, g, out); run<4, 6>(w, g, out); }
   for (int w : {1, 2, 4}) { run<4, 3>(w, g, out); run<4, 4>(w, g, out); run<8, 4>(w, g, out); }
   return 0;
 }
