@@ -789,6 +789,49 @@ int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_
   return 0;
 }
 
+// cna_select that also counts the selected cells with zero variance over the selected samples
+// (_association.py:182) in the same pass; *n_zero_out > 0: redo with cna_zero_variance + cna_select
+int cna_select_checked(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
+                       int64_t* n_zero_out) {
+  CHECK_CTX(c);
+  if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+  const int64_t nx = keep_idx ? n_keep : c->n_local;
+  const int Nx = colmap ? n_sel : c->N;
+  if (nx < 0 || nx > c->n_local || Nx < 1) CNA_FAIL(CNA_EINVAL, "cna_select_checked: bad sizes");
+  c->nx = nx;
+  c->Nx = Nx;
+  c->ldx = x_ld(Nx);
+  void* xp = c->X;
+  CNA_TRY(dev_reserve(c, &xp, &c->x_cap, (int64_t)sizeof(double) * std::max<int64_t>(nx, 1) * c->ldx));
+  c->X = (double*)xp;
+  if (keep_idx) {
+    void* kp = c->keep_store;
+    CNA_TRY(dev_reserve(c, &kp, &c->keep_cap, 8 * std::max<int64_t>(nx, 1)));
+    c->keep_store = (int64_t*)kp;
+    HIP_TRY(hipMemcpyAsync(c->keep_store, keep_idx, 8 * nx, hipMemcpyHostToDevice, c->stream));
+    c->keep_idx = c->keep_store;
+  } else {
+    c->keep_idx = nullptr;
+  }
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({4 * (int64_t)Nx, 8})));
+  Carver cv(c->scratch);
+  int32_t* cm = cv.take<int32_t>(Nx);
+  unsigned long long* cnt = cv.take<unsigned long long>(1);
+  if (colmap) HIP_TRY(hipMemcpyAsync(cm, colmap, 4 * Nx, hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(launch_select_zv(c, colmap ? cm : nullptr, cnt));
+  CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)cnt, 1));
+  unsigned long long h = 0;
+  HIP_TRY(hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n_zero_out) *n_zero_out = (int64_t)h;
+  c->x_valid = true;
+  c->x_from_nam = true;
+  c->ncorrs_valid = false;
+  c->coef_early = false;
+  c->fdr_inline = false;
+  return 0;
+}
+
 int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
                             int64_t* n_zero_out, const double* y, double* max_abs_out) {
   CHECK_CTX(c);

@@ -218,6 +218,7 @@ int launch_batch_kurtosis(cna_ctx* c, const double* mat, int64_t rows, int ncols
 int launch_zero_variance(cna_ctx* c, const int32_t* colmap_dev, int n_sel, uint8_t* flags_dev,
                          unsigned long long* count_dev);
 int launch_select(cna_ctx* c, const int32_t* colmap_dev);
+int launch_select_zv(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* count_dev);
 int launch_gather_rows(cna_ctx* c, const double* src, int ld, const int64_t* rows_dev, int64_t n_out,
                        const int32_t* cols_dev, int n_cols, double* dst, int transposed);
 int launch_digit_hist(cna_ctx* c, const double* v, int64_t n, unsigned long long prefix, int shift,

@@ -113,6 +113,34 @@ __global__ void k_select(const double* __restrict__ nam, int ld, const int64_t* 
   X[i] = v;
 }
 
+// ---- select + the zero-variance test of the selected rows in one pass (M != I path): X row = NAM[keep[i]]
+// over colmap; count of rows that are constant over the selected samples (the test of k_zero_variance)
+__global__ __launch_bounds__(256) void k_select_zv(const double* __restrict__ nam, int ld, const int64_t* __restrict__ keep,
+                                                   const int32_t* __restrict__ colmap, double* __restrict__ X, int64_t nx,
+                                                   int Nx, int ldx, unsigned long long* count) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < nx; r += nwaves) {
+    const double* __restrict__ src = nam + (keep ? keep[r] : r) * ld;
+    const double v0 = src[colmap ? colmap[0] : 0];
+    bool eq = true;
+    for (int c = lane; c < ldx; c += 64) {
+      double v = 0.0;
+      if (c < Nx) {
+        v = src[colmap ? colmap[c] : c];
+        eq = eq && (v == v0);
+      }
+      X[r * ldx + c] = v;
+    }
+    if (__all(eq) && lane == 0) {
+      double s = 0.0;
+      for (int c = 0; c < Nx; ++c) s += v0;               // pandas nanvar: zero iff sum/N == x
+      if (s / (double)Nx - v0 == 0.0) atomicAdd(count, 1ull);
+    }
+  }
+}
+
 // ---- X <- (X [- mean]) / std(ddof=1) per row (_nam.py:103-104,159) -----------------------
 // A wave walks RPW rows at a time: all their loads are issued before the first reduction so
 // the dependent shuffle chains of one row hide under the memory latency of the others.
@@ -578,6 +606,16 @@ int launch_select(cna_ctx* c, const int32_t* colmap_dev) {
   ProfScope ps(c, CNA_K_SELECT);
   hipLaunchKernelGGL(k_select, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream, c->nam, c->ld,
                      c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_select_zv(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* count_dev) {
+  HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), c->stream));
+  if (c->nx == 0) return 0;
+  ProfScope ps(c, CNA_K_SELECT);
+  hipLaunchKernelGGL(k_select_zv, dim3(wave_grid((c->nx + 3) / 4)), dim3(256), 0, c->stream, c->nam, c->ld, c->keep_idx,
+                     colmap_dev, c->X, c->nx, c->Nx, c->ldx, count_dev);
   HIP_TRY(hipGetLastError());
   return 0;
 }

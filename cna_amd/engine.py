@@ -346,6 +346,17 @@ class Engine(_order.CellOrder):
         check(self.lib.cna_select(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm)), 'cna_select')
         self.x_epoch += 1
 
+    def select_checked(self, keep_global, colmap):
+        """select() and, in the same pass, the number of selected cells with zero variance over the
+        selected samples (non-zero: redo with zero_variance() + select())."""
+        cm = None if colmap is None else np.ascontiguousarray(colmap, dtype=np.int32)
+        idx, nk = self._selection(keep_global)
+        nz = C.c_int64(0)
+        check(self.lib.cna_select_checked(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm), C.byref(nz)),
+              'cna_select_checked')
+        self.x_epoch += 1
+        return nz.value
+
     def select_standardized(self, keep_global, colmap, y=None, fuse_null=0):
         """select() + centre + divide by std in one pass (M = I); returns the number of selected
         cells with zero variance (non-zero: redo with zero_variance()/select()).  With ``y`` (the

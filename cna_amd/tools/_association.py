@@ -345,6 +345,9 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
         else:
             nzero = engine.select_standardized(None if kept.all() else kept, colmap)
         plan.standardized = nzero == 0
+    if nzero != 0 and hasattr(engine, 'select_checked'):
+        # something is regressed out: plain selection, with the zero-variance count taken in the same pass
+        nzero = engine.select_checked(None if kept.all() else kept, colmap)
     if nzero != 0:
         zero_var, nzero = engine.zero_variance(colmap)
         if nzero:

@@ -157,6 +157,10 @@ int  cna_select(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_keep,
  * with cna_zero_variance + cna_select and standardises again).  With y (n_sel doubles, the
  * standardised phenotype in X's column order) the rows are final when they leave the kernel, so
  * cna_ncorrs(y) is taken in the same pass: max_abs_out = max |ncorrs| over all ranks. */
+/* cna_select plus, in the same pass, the number of selected cells whose selected entries have zero variance
+ * (_association.py:182-185); non-zero: the caller redoes the step with cna_zero_variance + cna_select */
+int  cna_select_checked(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
+                        int64_t* n_zero_out);
 int  cna_select_standardized(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_keep,
                              const int32_t* colmap, int n_sel, int64_t* n_zero_out,
                              const double* y /* or NULL */, double* max_abs_out /* or NULL */);
