@@ -51,6 +51,7 @@ SIGNATURES = {
                                           C.c_void_p, C.POINTER(C.c_double)]),
     'cna_upload_x': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_int]),
     'cna_resid_apply': (C.c_int, [c_ctx, C.c_void_p, C.c_int]),
+    'cna_resid_lowrank': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, c_f64p]),
     'cna_standardize': (C.c_int, [c_ctx, C.c_int]),
     'cna_gram': (C.c_int, [c_ctx, C.c_void_p]),
     'cna_gram_launch': (C.c_int, [c_ctx]),

@@ -986,6 +986,48 @@ int cna_resid_apply(cna_ctx* c, const double* M, int center) {
   return 0;
 }
 
+// X <- (X - mean).M^T [/ std] [and ncorrs = X.y/N] for M = I - C.W given by its factors (C: N x r, W: r x N,
+// both row-major): one row-local pass (rows.hip:k_resid_lowrank) instead of cna_resid_apply + cna_standardize
+// + cna_ncorrs.  y == NULL: no coefficients.  r = 0: centring (and standardisation) only.
+int cna_resid_lowrank(cna_ctx* c, const double* C, const double* W, int r, int center, int standardize, const double* y,
+                      double* max_abs_out) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  if (r < 0 || (r > 0 && (!C || !W))) CNA_FAIL(CNA_EINVAL, "cna_resid_lowrank: bad factors");
+  const int Nx = c->Nx;
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({8 * (int64_t)std::max(r, 1) * Nx, 8 * (int64_t)std::max(r, 1) * Nx, 8 * (int64_t)Nx, 8 * 2049})));
+  Carver cv(c->scratch);
+  double* Wd = cv.take<double>((int64_t)std::max(r, 1) * Nx);
+  double* Ctd = cv.take<double>((int64_t)std::max(r, 1) * Nx);
+  double* yd = cv.take<double>(Nx);
+  unsigned long long* mb = cv.take<unsigned long long>(2049);
+  std::vector<double> Ct((size_t)std::max(r, 1) * Nx, 0.0);
+  for (int i = 0; i < Nx; ++i)
+    for (int k = 0; k < r; ++k) Ct[(size_t)k * Nx + i] = C[(size_t)i * r + k];
+  if (r > 0) {
+    HIP_TRY(hipMemcpyAsync(Wd, W, 8 * (size_t)r * Nx, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(Ctd, Ct.data(), 8 * (size_t)r * Nx, hipMemcpyHostToDevice, c->stream));
+  }
+  if (y) {
+    void* np = c->ncorrs;
+    CNA_TRY(dev_reserve(c, &np, &c->ncorrs_cap, 8 * std::max<int64_t>(c->nx, 1)));
+    c->ncorrs = (double*)np;
+    HIP_TRY(hipMemcpyAsync(yd, y, 8 * Nx, hipMemcpyHostToDevice, c->stream));
+  }
+  CNA_TRY(launch_resid_lowrank(c, Wd, Ctd, r, center, standardize, y ? yd : nullptr, mb));
+  double m = 0.0;
+  if (y) {
+    CNA_TRY(comm_allreduce_f64_max(c, (double*)mb, 1));
+    HIP_TRY(hipMemcpyAsync(&m, mb, 8, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));        // Ct is a local
+  if (max_abs_out) *max_abs_out = m;
+  c->ncorrs_valid = y != nullptr;
+  c->coef_early = false;
+  c->fdr_inline = false;
+  return 0;
+}
+
 int cna_standardize(cna_ctx* c, int center) {
   CHECK_CTX(c);
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");

@@ -227,6 +227,8 @@ int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long*
                       unsigned long long* maxbits_dev);
 int launch_standardize(cna_ctx* c, int center);
 int launch_ncorrs(cna_ctx* c, const double* y_dev, unsigned long long* maxbits_dev);
+int launch_resid_lowrank(cna_ctx* c, const double* W_dev, const double* Ct_dev, int r, int center, int standardize,
+                         const double* y_dev, unsigned long long* maxbits_dev);
 int launch_obs_counts(cna_ctx* c, const double* edges_dev, const double* thr_dev, int T, double thr0,
                       double inv_step, unsigned long long* hist_dev /* 2*T */);
 int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, int64_t* tails);

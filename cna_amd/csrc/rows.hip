@@ -299,6 +299,115 @@ __global__ __launch_bounds__(256) void k_select_std(const double* __restrict__ n
   }
 }
 
+// ---- X <- (X - mean).M^T for a projector of low rank defect, M = I - C.W (C: N x r standardised batches /
+// covariates, W = (C^T C + ridge N L)^-1 C^T: r x N; _nam.py:128-148), row by row:
+//   x.M^T = x - (x.W^T).C^T
+// i.e. r dot products and r axpys per cell instead of an N x N product: 2 n N r flops twice instead of
+// 2 n N^2, and -- being row-local -- fused with the centring before it and, when the caller asks, the
+// division by the std (ddof = 1, _nam.py:159) and the neighbourhood coefficients X.y/N (_association.py:77)
+// after it: ONE pass over X where the GEMM route takes three (M-apply, standardise, coefficients).
+// W and C^T sit in LDS (2 r N doubles).  Agrees with forming M and multiplying to rounding (1e-15).
+template <int NQ>
+__global__ __launch_bounds__(256) void k_resid_lowrank(double* __restrict__ X, int64_t nx, int Nx, int ldx,
+                                                       const double* __restrict__ Wg, const double* __restrict__ Ctg,
+                                                       int r, int center, int standardize,
+                                                       const double* __restrict__ y, double* __restrict__ nc,
+                                                       unsigned long long* __restrict__ blockmax) {
+  extern __shared__ double lw[];               // W (r x Nx) | C^T (r x Nx)
+  __shared__ unsigned long long wmax[4];
+  double* W = lw;
+  double* Ct = lw + (size_t)r * Nx;
+  for (int i = threadIdx.x; i < 2 * r * Nx; i += 256) lw[i] = i < r * Nx ? Wg[i] : Ctg[i - r * Nx];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  const double n = (double)Nx;
+  double yv[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) yv[q] = (y && lane + 64 * q < Nx) ? y[lane + 64 * q] : 0.0;
+  double vmax = 0.0;
+  bool any_nan = false;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < nx; row += stride) {
+    double x[NQ];
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int col = lane + 64 * q;
+      x[q] = col < Nx ? X[row * ldx + col] : 0.0;
+      s += x[q];
+    }
+    if (center) {
+      const double mean = wave_sum(s) / n;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (lane + 64 * q < Nx) x[q] -= mean;
+    }
+    // p = x.W^T (all r from the same x), then x -= p.C^T
+    double corr[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) corr[q] = 0.0;
+    for (int k = 0; k < r; ++k) {
+      double d = 0.0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int col = lane + 64 * q;
+        if (col < Nx) d += x[q] * W[k * Nx + col];
+      }
+      const double p = wave_sum(d);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int col = lane + 64 * q;
+        if (col < Nx) corr[q] += p * Ct[k * Nx + col];
+      }
+    }
+    double s2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      x[q] -= corr[q];
+      s2 += x[q];
+    }
+    double sd = 1.0;
+    if (standardize) {                          // pandas std: avg = sum/N ; sqrt(sum((avg-x)^2)/(N-1))
+      const double avg = wave_sum(s2) / n;
+      double ss = 0.0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (lane + 64 * q < Nx) {
+          const double dd = avg - x[q];
+          ss += dd * dd;
+        }
+      }
+      sd = sqrt(wave_sum(ss) / (n - 1.0));
+    }
+    double dot = 0.0;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int col = lane + 64 * q;
+      const double xs = col < Nx ? (standardize ? __ddiv_rn(x[q], sd) : x[q]) : 0.0;
+      if (col < ldx) X[row * ldx + col] = xs;
+      dot += yv[q] * xs;
+    }
+    if (y) {
+      const double v = wave_sum(dot) / n;
+      if (lane == 0) nc[row] = v;
+      const double av = fabs(v);
+      if (av > vmax) vmax = av;
+      any_nan = any_nan || (v != v);
+    }
+  }
+  if (y) {
+    if (lane == 0)
+      wmax[wv] = any_nan ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(vmax);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long m = wmax[0];
+      for (int i = 1; i < 4; ++i) m = wmax[i] > m ? wmax[i] : m;
+      blockmax[blockIdx.x] = m;
+    }
+  }
+}
+
 // ---- ncorrs = (y[:,None]*NAMresid).mean(axis=0) (_association.py:77) -----------------------
 template <int NQ>
 __global__ __launch_bounds__(256) void k_ncorrs(const double* __restrict__ X, int64_t nx, int Nx, int ldx,
@@ -665,6 +774,33 @@ int launch_standardize(cna_ctx* c, int center) {
     default: hipLaunchKernelGGL(k_standardize<MAXQ>, dim3(grid), dim3(256), 0, c->stream, c->X, c->nx, c->Nx, c->ldx, center);
 #undef STD_CASE
   }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// W_dev: r x Nx, Ct_dev: r x Nx (C transposed); maxbits_dev as in launch_ncorrs (only with y_dev)
+int launch_resid_lowrank(cna_ctx* c, const double* W_dev, const double* Ct_dev, int r, int center, int standardize,
+                         const double* y_dev, unsigned long long* maxbits_dev) {
+  if (y_dev) HIP_TRY(hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned long long), c->stream));
+  if (c->nx == 0) return 0;
+  if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 1024 samples are not supported");
+  const size_t smem = sizeof(double) * 2 * (size_t)r * c->Nx;
+  if (smem > 128 * 1024) CNA_FAIL(CNA_EINVAL, "cna_resid_lowrank: r x N too large for LDS");
+  ProfScope ps(c, CNA_K_RESID);
+  const int64_t want = (c->nx + 15) / 16;
+  const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
+#define LR_CASE(Q) { static bool once = false; if (!once) { HIP_TRY(hipFuncSetAttribute((const void*)k_resid_lowrank<Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)); once = true; } \
+    hipLaunchKernelGGL(k_resid_lowrank<Q>, dim3(grid), dim3(256), smem, c->stream, c->X, c->nx, c->Nx, c->ldx, W_dev, Ct_dev, r, center, standardize, y_dev, c->ncorrs, y_dev ? maxbits_dev + 1 : nullptr); }
+  switch ((c->Nx + 63) / 64) {
+    case 1: LR_CASE(1) break;
+    case 2: LR_CASE(2) break;
+    case 3: LR_CASE(3) break;
+    case 4: LR_CASE(4) break;
+    case 5: case 6: case 7: case 8: LR_CASE(8) break;
+    default: LR_CASE(MAXQ) break;
+  }
+#undef LR_CASE
+  if (y_dev) hipLaunchKernelGGL(k_max_fold, dim3(1), dim3(256), 0, c->stream, maxbits_dev + 1, (int)grid, maxbits_dev);
   HIP_TRY(hipGetLastError());
   return 0;
 }

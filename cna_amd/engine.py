@@ -412,6 +412,19 @@ class Engine(_order.CellOrder):
         M = None if M is None else _f64(M)
         check(self.lib.cna_resid_apply(self.h, ptr(M), int(bool(center))), 'cna_resid_apply')
 
+    def resid_lowrank(self, Cmat, W, center=True, standardize=False, y=None):
+        """X <- (X - mean).M^T [/ std] for M = I - Cmat.W (Cmat: N x r, W: r x N) in one row-local pass; with
+        `y` also the neighbourhood coefficients, returning max |ncorrs| (else None)."""
+        Cmat, W = _f64(Cmat), _f64(W)
+        r = Cmat.shape[1]
+        if W.shape != (r, Cmat.shape[0]):
+            raise ValueError('W must be r x N for an N x r C')
+        yv = None if y is None else _f64(y)
+        m = C.c_double(0.0)
+        check(self.lib.cna_resid_lowrank(self.h, ptr(Cmat), ptr(W), int(r), int(bool(center)), int(bool(standardize)),
+                                         ptr(yv), C.byref(m)), 'cna_resid_lowrank')
+        return m.value if y is not None else None
+
     def standardize(self, center=False):
         check(self.lib.cna_standardize(self.h, int(bool(center))), 'cna_standardize')
 

@@ -479,6 +479,8 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         # host-only sample-space work: runs while the diffusion kernels are executing
         plan = _resid_plan(sample_index_, covs_[filter_] if covs_ is not None else covs_,
                            batches_[filter_] if batches_ is not None else batches_, ridges=ridges)
+        if len(y_std) == len(sample_index_):
+            plan.y_std = y_std                        # lets the residualisation pass take the coefficients on its way out
         if plan.M is not None:
             early['M'] = np.asarray(plan.M, dtype=np.float64)     # the draw conditions with it
         if not _DRAW_THREAD:

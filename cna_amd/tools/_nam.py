@@ -418,9 +418,11 @@ def _resid_plan(sample_index, covs, batches, ridges=None):
             plan.M = pd.DataFrame(np.eye(N), columns=sample_index, index=sample_index)
         else:
             plan.kind = 'single'
-            M = np.eye(N) - covs.dot(np.linalg.solve(covs.T.dot(covs), covs.T))
+            W = np.linalg.solve(covs.T.dot(covs), covs.T)
+            M = np.eye(N) - covs.dot(W)
             M.columns = M.index
             plan.M = M
+            plan.W = np.asarray(W, dtype=np.float64)          # M = I - C.W: the device applies it in factored form
     else:
         plan.kind = 'ridge'
         B = pd.get_dummies(batches)
@@ -430,6 +432,14 @@ def _resid_plan(sample_index, covs, batches, ridges=None):
         plan.bcodes, plan.nb = _batch_codes(batches, sample_index)
     plan.r = len(plan.C.T)
     return plan
+
+
+def _lowrank_ok(engine, plan):
+    """Apply M = I - C.W in factored form (engine.resid_lowrank)?  When the engine has it and both factors
+    fit the kernel's LDS budget (2 r N doubles <= 128 KB); CNA_RESID_GEMM=1 forces the N x N product."""
+    import os
+    return (hasattr(engine, 'resid_lowrank') and 0 < plan.r and 2 * plan.r * plan.N * 8 <= 128 * 1024
+            and os.environ.get('CNA_RESID_GEMM', '0') in ('0', '', 'off', 'no'))
 
 
 def _resid_run(engine, plan, cell_index, show_progress=False):
@@ -445,17 +455,28 @@ def _resid_run(engine, plan, cell_index, show_progress=False):
             engine.standardize(center=True)
     elif plan.kind == 'single':
         M = plan.M
-        engine.resid_apply(M.values, center=True)
-        engine.standardize(center=False)
+        if _lowrank_ok(engine, plan):
+            # x.M^T = x - (x.W^T).C^T row by row, fused with centring, /std and (y known) the coefficients
+            y_std = getattr(plan, 'y_std', None)
+            m = engine.resid_lowrank(np.asarray(C.values, dtype=np.float64), plan.W, center=True, standardize=True, y=y_std)
+            if y_std is not None:
+                plan.maxabs = m
+        else:
+            engine.resid_apply(M.values, center=True)
+            engine.standardize(center=False)
     else:
         B = plan.B
         first = True
         M = None
         for ridge in plan.ridges:
             L = np.diag([1] * len(B.T) + [0] * (len(C.T) - len(B.T)))
-            M = np.eye(N) - C.dot(np.linalg.solve(C.T.dot(C) + ridge * len(C) * L, C.T))
+            W = np.linalg.solve(C.T.dot(C) + ridge * len(C) * L, C.T)
+            M = np.eye(N) - C.dot(W)
             M.columns = M.index
-            engine.resid_apply(np.asarray(M.values, dtype=np.float64), center=first)
+            if _lowrank_ok(engine, plan):
+                engine.resid_lowrank(np.asarray(C.values, dtype=np.float64), np.asarray(W, dtype=np.float64), center=first)
+            else:
+                engine.resid_apply(np.asarray(M.values, dtype=np.float64), center=first)
             first = False
             engine.batch_kurtosis(_ffi.MAT_X, plan.bcodes, plan.nb)
             med = engine.stat_median()

@@ -183,6 +183,12 @@ int  cna_upload_x(cna_ctx* ctx, const double* x_local, int64_t n_rows, int n_col
 int  cna_resid_apply(cna_ctx* ctx, const double* M, int center);
 /* X <- X / std(X over samples, ddof=1)  (_nam.py:159); center!=0 subtracts the mean first
  * (svd_nam's own re-standardisation, _nam.py:103-104). */
+/* the same residualisation for a projector given by its factors, M = I - C.W (C: N x r standardised batches /
+ * covariates, W = (C^T C + ridge N L)^-1 C^T: r x N, _nam.py:128-148): x.M^T = x - (x.W^T).C^T row by row, fused
+ * with the centring (_nam.py:122) and optionally the division by the std (_nam.py:159) and the neighbourhood
+ * coefficients X.y/N with their max |.| (_association.py:77,101): one pass over X instead of three */
+int  cna_resid_lowrank(cna_ctx* ctx, const double* C, const double* W, int r, int center, int standardize,
+                       const double* y, double* max_abs_out);
 int  cna_standardize(cna_ctx* ctx, int center);
 /* G = X^T X over all cells of all ranks (NAM.dot(NAM.T), _nam.py:105), n_cols x n_cols row-major */
 int  cna_gram(cna_ctx* ctx, double* G_out);
