@@ -46,6 +46,7 @@ SIGNATURES = {
     'cna_batch_kurtosis': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int]),
     'cna_zero_variance': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, c_i64p]),
     'cna_select': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]),
+    'cna_set_resid_factors': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     'cna_select_checked': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_int64)]),
     'cna_select_standardized': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_int64),
                                           C.c_void_p, C.POINTER(C.c_double)]),

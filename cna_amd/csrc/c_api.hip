@@ -214,7 +214,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   prof_flush(c);
   comm_destroy(c);
   void* bufs[] = {c->coef_dev, c->proj, c->sp_idx, c->sp_val, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
-                  c->nam, c->X, c->X2, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
+                  c->nam, c->X, c->X2, c->resid_f, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -789,6 +789,30 @@ int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_
   return 0;
 }
 
+// Factors of a projector M = I - C.W (C: N x r, W: r x N, row-major; see cna_resid_lowrank) for the NEXT
+// cna_select_standardized[_fused] call over N selected samples: that pass then leaves X residualised as well
+// (select + zero-variance count + centre + M + /std [+ coefficients] in one read of the NAM).  r = 0 clears.
+int cna_set_resid_factors(cna_ctx* c, const double* C, const double* W, int r, int N) {
+  CHECK_CTX(c);
+  if (r < 0 || N < 1 || (r > 0 && (!C || !W))) CNA_FAIL(CNA_EINVAL, "cna_set_resid_factors: bad arguments");
+  c->resid_rk = 0;
+  if (r == 0) return 0;
+  if ((int64_t)2 * r * N * 8 > 128 * 1024) CNA_FAIL(CNA_EINVAL, "cna_set_resid_factors: factors exceed 128 KB");
+  void* p = c->resid_f;
+  CNA_TRY(dev_reserve(c, &p, &c->resid_f_cap, 16 * (int64_t)r * N));
+  c->resid_f = (double*)p;
+  std::vector<double> buf((size_t)2 * r * N);
+  std::memcpy(buf.data(), W, 8 * (size_t)r * N);
+  for (int i = 0; i < N; ++i)
+    for (int k = 0; k < r; ++k) buf[(size_t)r * N + (size_t)k * N + i] = C[(size_t)i * r + k];
+  // on the copy stream: the main stream is busy with the walk kernels and this call must not wait for them
+  HIP_TRY(hipMemcpyAsync(c->resid_f, buf.data(), 16 * (size_t)r * N, hipMemcpyHostToDevice, c->copy_stream));
+  HIP_TRY(hipStreamSynchronize(c->copy_stream));                 // buf is a local; the kernels that read resid_f are issued later
+  c->resid_rk = r;
+  c->resid_n = N;
+  return 0;
+}
+
 // cna_select that also counts the selected cells with zero variance over the selected samples
 // (_association.py:182) in the same pass; *n_zero_out > 0: redo with cna_zero_variance + cna_select
 int cna_select_checked(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
@@ -867,7 +891,10 @@ int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep,
     c->ncorrs = (double*)np;
     HIP_TRY(hipMemcpyAsync(yd, y, 8 * Nx, hipMemcpyHostToDevice, c->stream));
   }
-  CNA_TRY(launch_select_std(c, colmap ? cm : nullptr, nz, y ? yd : nullptr, y ? mb : nullptr));
+  const int rk = (c->resid_rk > 0 && c->resid_n == Nx) ? c->resid_rk : 0;     // one-shot: cna_set_resid_factors
+  CNA_TRY(launch_select_std(c, colmap ? cm : nullptr, nz, y ? yd : nullptr, y ? mb : nullptr, c->resid_f,
+                            c->resid_f ? c->resid_f + (size_t)rk * Nx : nullptr, rk));
+  c->resid_rk = 0;
   CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)nz, 1));
   if (y) CNA_TRY(comm_allreduce_f64_max(c, (double*)mb, 1));
   unsigned long long h = 0;

@@ -108,6 +108,10 @@ struct cna_ctx {
   // ---- X (nx x ldx): selected NAM -> residualised NAM
   double* X = nullptr;
   int64_t x_cap = 0;
+  // projector factors for the next cna_select_standardized (cna_set_resid_factors): W | C^T, rk x Nx each
+  double* resid_f = nullptr;
+  int64_t resid_f_cap = 0;
+  int resid_rk = 0, resid_n = 0;
   double* X2 = nullptr;          // second working matrix: target of the k-split residualisation (N > 256), swapped with X
   int64_t x2_cap = 0;
   int64_t nx = 0;
@@ -224,7 +228,7 @@ int launch_gather_rows(cna_ctx* c, const double* src, int ld, const int64_t* row
 int launch_digit_hist(cna_ctx* c, const double* v, int64_t n, unsigned long long prefix, int shift,
                       unsigned long long* hist_dev);
 int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev, const double* y_dev,
-                      unsigned long long* maxbits_dev);
+                      unsigned long long* maxbits_dev, const double* W_dev, const double* Ct_dev, int rk);
 int launch_standardize(cna_ctx* c, int center);
 int launch_ncorrs(cna_ctx* c, const double* y_dev, unsigned long long* maxbits_dev);
 int launch_resid_lowrank(cna_ctx* c, const double* W_dev, const double* Ct_dev, int r, int center, int standardize,

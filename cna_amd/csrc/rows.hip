@@ -210,11 +210,19 @@ __global__ __launch_bounds__(256) void k_select_std(const double* __restrict__ n
                                                     const int32_t* __restrict__ colmap, double* __restrict__ X,
                                                     int64_t nx, int Nx, int ldx, unsigned long long* nzero,
                                                     const double* __restrict__ y, double* __restrict__ nc,
-                                                    unsigned long long* __restrict__ blockmax) {
-  // y != null: the rows leave this kernel final (M = I), so the neighbourhood coefficients
-  // ncorrs = X.y/N (_association.py:77) and their max |.| are taken on the way out, as k_ncorrs would
+                                                    unsigned long long* __restrict__ blockmax,
+                                                    const double* __restrict__ Wg, const double* __restrict__ Ctg, int rk) {
+  // y != null: the rows leave this kernel final, so the neighbourhood coefficients
+  // ncorrs = X.y/N (_association.py:77) and their max |.| are taken on the way out, as k_ncorrs would.
+  // rk > 0: a projector M = I - C.W in factored form (W: rk x Nx, C^T: rk x Nx, see k_resid_lowrank) is
+  // applied to the centred row before the std: selection + residualisation + standardisation in one pass
   constexpr int RPW = 4;
+  extern __shared__ double lw[];
   __shared__ unsigned long long wmax[4];
+  for (int i = threadIdx.x; i < 2 * rk * Nx; i += 256) lw[i] = i < rk * Nx ? Wg[i] : Ctg[i - rk * Nx];
+  if (rk > 0) __syncthreads();
+  const double* Wl = lw;
+  const double* Ctl = lw + (size_t)rk * Nx;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
@@ -256,10 +264,27 @@ __global__ __launch_bounds__(256) void k_select_std(const double* __restrict__ n
       // centre (_nam.py:122), then std with ddof=1 of the centred values (_nam.py:159)
       double s2 = 0.0;
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
+      for (int q = 0; q < NQ; ++q)
         if (lane + 64 * q < Nx) x[r][q] -= avg0;
-        s2 += x[r][q];
+      if (rk > 0) {                                          // x <- x - (x.W^T).C^T
+        double corr[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) corr[q] = 0.0;
+        for (int k = 0; k < rk; ++k) {
+          double d = 0.0;
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (lane + 64 * q < Nx) d += x[r][q] * Wl[k * Nx + lane + 64 * q];
+          const double pk = wave_sum(d);
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (lane + 64 * q < Nx) corr[q] += pk * Ctl[k * Nx + lane + 64 * q];
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) x[r][q] -= corr[q];
       }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) s2 += x[r][q];
       const double avg = wave_sum(s2) / n;
       double ss = 0.0;
 #pragma unroll
@@ -730,7 +755,7 @@ int launch_select_zv(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* 
 }
 
 int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev, const double* y_dev,
-                      unsigned long long* maxbits_dev) {
+                      unsigned long long* maxbits_dev, const double* W_dev, const double* Ct_dev, int rk) {
   // maxbits_dev (with y_dev): [0] = max |ncorrs| bits, [1 ..] per-workgroup partials (4097 words)
   HIP_TRY(hipMemsetAsync(nzero_dev, 0, sizeof(unsigned long long), c->stream));
   if (maxbits_dev) HIP_TRY(hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned long long), c->stream));
@@ -738,13 +763,19 @@ int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long*
   if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 1024 samples are not supported");
   ProfScope ps(c, CNA_K_SELECT);
   const unsigned grid = wave_grid((c->nx + 3) / 4);
+  const size_t smem = sizeof(double) * 2 * (size_t)rk * c->Nx;
+  if (smem > 128 * 1024) CNA_FAIL(CNA_EINVAL, "projector factors too large for LDS");
+#define SS_LAUNCH(Q) { static bool once = false; if (smem > 48 * 1024 && !once) { HIP_TRY(hipFuncSetAttribute((const void*)k_select_std<Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)); once = true; } \
+    hipLaunchKernelGGL(k_select_std<Q>, dim3(grid), dim3(256), smem, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev, y_dev, c->ncorrs, maxbits_dev ? maxbits_dev + 1 : nullptr, W_dev, Ct_dev, rk); }
   switch ((c->ldx + 63) / 64) {
-#define SS_CASE(Q) case Q: hipLaunchKernelGGL(k_select_std<Q>, dim3(grid), dim3(256), 0, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev, y_dev, c->ncorrs, maxbits_dev ? maxbits_dev + 1 : nullptr); break
-    SS_CASE(1); SS_CASE(2); SS_CASE(3); SS_CASE(4);
-    case 5: case 6: case 7: SS_CASE(8);
-    default: hipLaunchKernelGGL(k_select_std<MAXQ>, dim3(grid), dim3(256), 0, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev, y_dev, c->ncorrs, maxbits_dev ? maxbits_dev + 1 : nullptr);
-#undef SS_CASE
+    case 1: SS_LAUNCH(1) break;
+    case 2: SS_LAUNCH(2) break;
+    case 3: SS_LAUNCH(3) break;
+    case 4: SS_LAUNCH(4) break;
+    case 5: case 6: case 7: case 8: SS_LAUNCH(8) break;
+    default: SS_LAUNCH(MAXQ) break;
   }
+#undef SS_LAUNCH
   if (y_dev) hipLaunchKernelGGL(k_max_fold, dim3(1), dim3(256), 0, c->stream, maxbits_dev + 1, (int)grid, maxbits_dev);
   HIP_TRY(hipGetLastError());
   return 0;

@@ -346,6 +346,13 @@ class Engine(_order.CellOrder):
         check(self.lib.cna_select(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm)), 'cna_select')
         self.x_epoch += 1
 
+    def set_resid_factors(self, Cmat, W):
+        """The next select_standardized() also residualises: M = I - Cmat.W applied between centring and
+        the division by the std (one pass over the NAM for selection + residualisation + standardisation)."""
+        Cmat, W = _f64(Cmat), _f64(W)
+        check(self.lib.cna_set_resid_factors(self.h, ptr(Cmat), ptr(W), int(Cmat.shape[1]), int(Cmat.shape[0])),
+              'cna_set_resid_factors')
+
     def select_checked(self, keep_global, colmap):
         """select() and, in the same pass, the number of selected cells with zero variance over the
         selected samples (non-zero: redo with zero_variance() + select())."""

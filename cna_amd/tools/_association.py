@@ -336,8 +336,14 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
 
     plan = extra if hasattr(extra, 'kind') else None
     nzero = -1
-    if plan is not None and plan.kind == 'identity':
-        # nothing to regress out: select + centre + /std in one pass over the NAM
+    from ._nam import _lowrank_ok
+    single = (plan is not None and plan.kind == 'single' and hasattr(engine, 'set_resid_factors') and _lowrank_ok(engine, plan)
+              and os.environ.get('CNA_RESID_IN_SELECT', '1') not in ('0', 'off', 'no'))
+    if plan is not None and (plan.kind == 'identity' or single):
+        # nothing to regress out, or a projector that the selection pass applies in factored form
+        # (covariates without batches): select + centre [+ M] + /std in one pass over the NAM
+        if single:
+            engine.set_resid_factors(np.asarray(plan.C.values, dtype=np.float64), plan.W)
         if y_std is not None and len(y_std) == len(colmap):
             nzero, maxabs = engine.select_standardized(None if kept.all() else kept, colmap, y=y_std,
                                                        fuse_null=fuse_null)

@@ -455,7 +455,9 @@ def _resid_run(engine, plan, cell_index, show_progress=False):
             engine.standardize(center=True)
     elif plan.kind == 'single':
         M = plan.M
-        if _lowrank_ok(engine, plan):
+        if plan.standardized:                  # the selection pass already applied M (engine.set_resid_factors)
+            pass
+        elif _lowrank_ok(engine, plan):
             # x.M^T = x - (x.W^T).C^T row by row, fused with centring, /std and (y known) the coefficients
             y_std = getattr(plan, 'y_std', None)
             m = engine.resid_lowrank(np.asarray(C.values, dtype=np.float64), plan.W, center=True, standardize=True, y=y_std)

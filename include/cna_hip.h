@@ -157,6 +157,9 @@ int  cna_select(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_keep,
  * with cna_zero_variance + cna_select and standardises again).  With y (n_sel doubles, the
  * standardised phenotype in X's column order) the rows are final when they leave the kernel, so
  * cna_ncorrs(y) is taken in the same pass: max_abs_out = max |ncorrs| over all ranks. */
+/* one-shot: the next cna_select_standardized[_fused] over N selected samples also applies M = I - C.W
+ * (factors as in cna_resid_lowrank; _nam.py:128-135) between the centring and the division by the std */
+int  cna_set_resid_factors(cna_ctx* ctx, const double* C, const double* W, int r, int N);
 /* cna_select plus, in the same pass, the number of selected cells whose selected entries have zero variance
  * (_association.py:182-185); non-zero: the caller redoes the step with cna_zero_variance + cna_select */
 int  cna_select_checked(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
