@@ -79,6 +79,20 @@ CLONES static void candidates(const uint32_t* restrict w, int nc, double* restri
   }
 }
 
+#include <pthread.h>
+static int g_host_threads = 1;
+
+struct norm_job { const double *x1, *x2, *r2; double* out; int64_t n_out, a, b; };
+static void* norm_worker(void* arg) {
+  struct norm_job* j = (struct norm_job*)arg;
+  for (int64_t p = j->a; p < j->b; ++p) {
+    const double f = sqrt(-2.0 * log(j->r2[p]) / j->r2[p]);
+    j->out[2 * p] = f * j->x2[p];
+    if (2 * p + 1 < j->n_out) j->out[2 * p + 1] = f * j->x1[p];
+  }
+  return NULL;
+}
+
 /* n standard normals of numpy's legacy generator (RandomState.randn / standard_normal) into out.
  * key[624], *pos (0..624), *has_gauss, *gauss: the generator state as np.random.get_state() reports
  * it, updated in place to what numpy's own state would be after the same draws.  Returns 0, or -1
@@ -133,18 +147,122 @@ int cna_host_legacy_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss
     have = left + MT_N;
     p -= MT_N;                                       /* words[0] sits at position p (<= 0) relative to the new block */
   }
-  /* survivors -> normals, in order: the second value of a pair is numpy's cached one */
-  for (int64_t j = 0; j < pairs; j++) {
-    const double f = sqrt(-2.0 * log(ar2[j]) / ar2[j]);
-    const double second = f * ax1[j];
-    out[done++] = f * ax2[j];
-    if (done < n) {
-      out[done++] = second;
-    } else {
+  /* survivors -> normals, in order: the second value of a pair is numpy's cached one.  Every pair is
+   * independent (log and sqrt dominate the whole draw), so large draws split the pairs over threads; the
+   * values and their positions do not depend on the thread count. */
+  {
+    struct norm_job jobs[64];
+    pthread_t th[64];
+    int started[64];
+    int nt = g_host_threads;
+    if (nt > 64) nt = 64;
+    if (nt < 1 || pairs < (1 << 15)) nt = 1;
+    for (int t = 0; t < nt; ++t) {
+      jobs[t].x1 = ax1; jobs[t].x2 = ax2; jobs[t].r2 = ar2; jobs[t].out = out + done; jobs[t].n_out = n - done;
+      jobs[t].a = pairs * t / nt; jobs[t].b = pairs * (t + 1) / nt;
+      started[t] = 0;
+    }
+    for (int t = 1; t < nt; ++t) started[t] = pthread_create(&th[t], NULL, norm_worker, &jobs[t]) == 0;
+    norm_worker(&jobs[0]);
+    for (int t = 1; t < nt; ++t) {
+      if (started[t]) pthread_join(th[t], NULL);
+      else norm_worker(&jobs[t]);
+    }
+    if (2 * pairs > n - done) {                        /* odd count: the last second value stays cached */
+      const double f = sqrt(-2.0 * log(ar2[pairs - 1]) / ar2[pairs - 1]);
       *has_gauss = 1;
-      *gauss = second;
+      *gauss = f * ax1[pairs - 1];
     }
   }
   free(acc);
   return 0;
+}
+
+/* threads the host helpers of this file may use (large draws only); default 1 */
+void cna_host_set_threads(int n) { g_host_threads = n < 1 ? 1 : n; }
+
+/* out[rows[i] * ld_out + c] = y[ argsort(R[:, c])[i] ] for every column c of the m x num matrix R of normal
+ * draws (row-major): the permuted phenotypes of conditional_permutation / grouplevel_permutation
+ * (_stats.py:11-17,31: Y[m][argsort(randn(len(m), num), axis=0)]) for LARGE draws (10 000 permutations of
+ * 200 samples: numpy's argsort along axis 0 takes 24 ms on one thread), columns split over threads, each
+ * column merge-sorted as (value, row) pairs.  rows == NULL: identity.  The draws are distinct doubles (a tie
+ * has probability ~1e-16 per pair), so every correct sort yields numpy's permutation; ties keep row order. */
+struct sort_pair { double v; int32_t i; int32_t pad; };
+struct sort_job {
+  const double* R; const double* y; double* out; const int64_t* rows;
+  int64_t ld_out; int m, num, c0, c1;
+};
+
+#define SORT_CB 64                                        /* columns handled together: row segments of 512 bytes */
+static void* sort_worker(void* arg) {
+  struct sort_job* j = (struct sort_job*)arg;
+  const int m = j->m;
+  struct sort_pair* a = (struct sort_pair*)malloc(sizeof(struct sort_pair) * (size_t)m * 2);
+  double* blk = (double*)malloc(sizeof(double) * (size_t)m * SORT_CB * 2);     /* draws | results, m x SORT_CB each */
+  if (!a || !blk) { free(a); free(blk); return (void*)1; }
+  struct sort_pair* b = a + m;
+  double* res = blk + (size_t)m * SORT_CB;
+  for (int cb = j->c0; cb < j->c1; cb += SORT_CB) {
+    const int w = j->c1 - cb < SORT_CB ? j->c1 - cb : SORT_CB;
+    for (int i = 0; i < m; ++i) memcpy(blk + (size_t)i * SORT_CB, j->R + (size_t)i * j->num + cb, sizeof(double) * (size_t)w);
+    for (int cc = 0; cc < w; ++cc) {
+      for (int i = 0; i < m; ++i) { a[i].v = blk[(size_t)i * SORT_CB + cc]; a[i].i = i; }
+      for (int lo = 0; lo < m; lo += 8) {                /* runs of 8 by insertion */
+        const int hi = lo + 8 < m ? lo + 8 : m;
+        for (int i = lo + 1; i < hi; ++i) {
+          const struct sort_pair v = a[i];
+          int k = i - 1;
+          while (k >= lo && a[k].v > v.v) { a[k + 1] = a[k]; --k; }
+          a[k + 1] = v;
+        }
+      }
+      struct sort_pair *src = a, *dst = b;
+      for (int wd = 8; wd < m; wd *= 2) {                /* bottom-up merges (stable) */
+        for (int lo = 0; lo < m; lo += 2 * wd) {
+          const int mid = lo + wd < m ? lo + wd : m, hi = lo + 2 * wd < m ? lo + 2 * wd : m;
+          int i = lo, k = mid, o = lo;
+          while (i < mid && k < hi) dst[o++] = src[k].v < src[i].v ? src[k++] : src[i++];
+          while (i < mid) dst[o++] = src[i++];
+          while (k < hi) dst[o++] = src[k++];
+        }
+        struct sort_pair* t = src; src = dst; dst = t;
+      }
+      for (int i = 0; i < m; ++i) res[(size_t)i * SORT_CB + cc] = j->y[src[i].i];
+    }
+    for (int i = 0; i < m; ++i) {
+      const int64_t row = j->rows ? j->rows[i] : i;
+      memcpy(j->out + (size_t)row * j->ld_out + cb, res + (size_t)i * SORT_CB, sizeof(double) * (size_t)w);
+    }
+  }
+  free(a); free(blk);
+  return NULL;
+}
+
+int cna_host_argsort_gather(const double* R, int m, int num, const double* y, double* out, int64_t ld_out,
+                            const int64_t* rows) {
+  if (m < 0 || num < 0 || !R || !y || !out) return -1;
+  if (m == 0 || num == 0) return 0;
+  struct sort_job jobs[64];
+  pthread_t th[64];
+  int started[64];
+  int nt = g_host_threads;
+  if (nt > 64) nt = 64;
+  if (nt > num / 64) nt = num / 64;
+  if (nt < 1) nt = 1;
+  for (int t = 0; t < nt; ++t) {
+    jobs[t].R = R; jobs[t].y = y; jobs[t].out = out; jobs[t].rows = rows; jobs[t].ld_out = ld_out;
+    jobs[t].m = m; jobs[t].num = num;
+    jobs[t].c0 = (int)((int64_t)num * t / nt); jobs[t].c1 = (int)((int64_t)num * (t + 1) / nt);
+    started[t] = 0;
+  }
+  int bad = 0;
+  for (int t = 1; t < nt; ++t) started[t] = pthread_create(&th[t], NULL, sort_worker, &jobs[t]) == 0;
+  bad |= sort_worker(&jobs[0]) != NULL;
+  for (int t = 1; t < nt; ++t) {
+    void* rv = NULL;
+    if (started[t]) pthread_join(th[t], &rv);
+    else rv = sort_worker(&jobs[t]);
+    bad |= rv != NULL;
+  }
+  return bad ? -1 : 0;
 }

@@ -293,6 +293,13 @@ int  cna_allgather_host(cna_ctx* ctx, const double* local, int64_t count_local, 
  * np.random.get_state() reports it, advanced in place to where numpy's own draw would leave it.
  * No context: callable from any thread. */
 int  cna_host_legacy_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss, int64_t n, double* out);
+/* threads the two host helpers of csrc/host_rng.c may use for LARGE draws (default 1; results do not depend on it) */
+void cna_host_set_threads(int n);
+/* out[rows[i]][c] = y[argsort(R[:, c])[i]] for the m x num draws R (row-major): the permuted phenotypes of
+ * conditional_permutation / grouplevel_permutation (_stats.py:11-17,31) for large draws, columns split over
+ * threads (host only; rows NULL = identity) */
+int  cna_host_argsort_gather(const double* R, int m, int num, const double* y, double* out, int64_t ld_out,
+                             const int64_t* rows);
 
 /* ---- host-side helpers: graph identity and the device cell order (csrc/host_graph.c) ------- */
 /* 64-bit content hash of a buffer, computed on up to nthreads threads (the value does not depend on the

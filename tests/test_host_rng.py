@@ -66,3 +66,32 @@ def test_other_global_generators_are_left_to_numpy(monkeypatch):
     monkeypatch.setattr(np.random.mtrand, '_rand', Odd(), raising=False)
     out = _stats.legacy_randn(4, 5)
     assert out.shape == (4, 5)
+
+
+@pytest.mark.parametrize('n,num,nb', [(200, 10000, 1), (200, 2501, 1), (120, 4001, 3), (64, 7000, 2)])
+def test_large_draws_take_the_threaded_helpers_and_stay_bit_identical(n, num, nb):
+    """Large permutation draws (BASELINE config 5: 200 samples x 10 000 permutations) go through the threaded
+    host helpers -- normals' log/sqrt stage split over threads, argsort + gather per column in C --: same
+    permuted phenotypes and the same generator state as numpy's randn + argsort, whatever the thread count."""
+    from cna_amd import _ffi
+    from cna_amd.tools import _stats
+    lib = _ffi.load()
+    rs = np.random.RandomState(1)
+    Y = rs.randn(n)
+    B = np.arange(n) % nb
+    np.random.seed(7)
+    want = np.empty((n, num))
+    for b in np.unique(B):
+        m = np.flatnonzero(B == b)
+        want[m] = Y[m][np.argsort(np.random.randn(len(m), num), axis=0)]
+    st_want = np.random.get_state()
+    assert n * num >= _stats._BIG_DRAW or nb > 1
+    for threads in (1, 3, 8):
+        lib.cna_host_set_threads(threads)
+        _stats._threads_set = True
+        np.random.seed(7)
+        got = _stats.conditional_permutation(B, Y, num, clean=True)
+        st = np.random.get_state()
+        assert np.array_equal(got, want)
+        assert st[2] == st_want[2] and np.array_equal(st[1], st_want[1]) and st[3] == st_want[3] and st[4] == st_want[4]
+    _stats._threads_set = False
