@@ -213,7 +213,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_flush(c);
   comm_destroy(c);
-  void* bufs[] = {c->coef_dev, c->proj, c->sp_idx, c->sp_val, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+  void* bufs[] = {c->i8_buf, c->coef_dev, c->proj, c->sp_idx, c->sp_val, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
                   c->nam, c->X, c->X2, c->resid_f, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1318,12 +1318,24 @@ static int null_local_go(cna_ctx* c, int col0) {
   int64_t* sums = cv.take<int64_t>(T);
   // columns beyond col0+P inside the last 64-wide tile are other phenotypes: the kernel only
   // flushes counters of p < P, and reads stay inside the zero-padded leading dimension
-  CNA_TRY(launch_null_local(c, c->zc + col0, c->zc_ld, P, ed, T, c->null_cut0, c->null_inv_step, c->null_eps, hist));
+  // Only the sums over permutations wanted (the analysis): the integer matrix cores do the products
+  // (null_i8.hip: exact counts, outputs near a cut rechecked in f64); the f64 kernel is launched behind
+  // as a stand-by that returns at once unless the integer pass raised its status word.
+  int* i8_status = nullptr;
+  int64_t* i8_sums = nullptr;
+  c->i8_last = false;
+  if (!c->null_has_tails && null_i8_eligible(c, P, T, c->null_cut0, c->null_inv_step, c->null_eps))
+    CNA_TRY(launch_null_local_i8(c, c->zc + col0, c->zc_ld, P, ed, T, c->null_cut0, c->null_inv_step, c->null_eps,
+                                 &i8_sums, &i8_status));
+  c->i8_last = i8_status != nullptr;
+  CNA_TRY(launch_null_local(c, c->zc + col0, c->zc_ld, P, ed, T, c->null_cut0, c->null_inv_step, c->null_eps, hist,
+                            i8_status));
   // suffix sums and the sum over permutations are linear: when only the sums are wanted the ranks
   // exchange T integers instead of the P x T histogram
   if (c->null_has_tails) CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)P * T));
   CNA_TRY(launch_suffix_sum(c, hist, P, T, tails));
   CNA_TRY(launch_tail_sums(c, tails, P, T, sums));
+  if (i8_status) CNA_TRY(launch_i8_pick(c, i8_status, i8_sums, sums, T, sums));
   if (!c->null_has_tails) CNA_TRY(comm_allreduce_i64_sum(c, sums, (size_t)T));
   HIP_TRY(hipMemcpyAsync(c->h_res, sums, 8 * (size_t)T, hipMemcpyDeviceToHost, c->stream));
   if (c->coef_early && c->null_has_obs && T <= 512) {
@@ -1409,6 +1421,19 @@ int cna_null_local_fetch(cna_ctx* c, int64_t* tails_out, int64_t* tail_sums_out,
                          int64_t* num_detected_out) {
   CHECK_CTX(c);
   return null_local_collect(c, tails_out, tail_sums_out, ranks_out, num_detected_out);
+}
+
+int cna_null_local_i8_stats(cna_ctx* c, int* used_out, int64_t* rechecked_out, int* fallback_out) {
+  CHECK_CTX(c);
+  unsigned long long v[2] = {0, 0};
+  if (c->i8_last) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(v, c->i8_qcount, 16, hipMemcpyDeviceToHost));
+  }
+  if (used_out) *used_out = c->i8_last ? 1 : 0;
+  if (rechecked_out) *rechecked_out = (int64_t)v[0];
+  if (fallback_out) *fallback_out = (int)(v[1] & 0xffffffffull) != 0;
+  return 0;
 }
 
 int cna_null_local(cna_ctx* c, const double* Yc, int P, const double* edges, int T, int64_t* tails_out) {

@@ -165,6 +165,10 @@ struct cna_ctx {
   void* sp_val = nullptr;
   void* sp_cnt = nullptr;
   int64_t sp_rows = 0;
+  void* i8_buf = nullptr;         // digit planes, queue and slabs of the integer local-null path (null_i8.hip)
+  int64_t i8_cap = 0;
+  bool i8_last = false;           // the last local-null pass took the integer path
+  unsigned long long* i8_qcount = nullptr;   // device: [0] outputs sent to the f64 recheck by the last pass, [1] low word = status
   void* null_part = nullptr;      // per-block counter slabs of the local-null kernel
   int64_t null_part_cap = 0;
   void* scratch2 = nullptr;
@@ -190,9 +194,9 @@ struct ProfScope {
   int kid;
   hipStream_t st;
   ProfScope(cna_ctx* c_, int k, hipStream_t s = nullptr) : c(c_), kid(k), st(s ? s : c_->stream) {
-    if (c->prof) prof_begin(c, kid, st);
+    if (c->prof && kid >= 0) prof_begin(c, kid, st);
   }
-  ~ProfScope() { if (c->prof) prof_end(c, kid, st); }
+  ~ProfScope() { if (c->prof && kid >= 0) prof_end(c, kid, st); }
 };
 
 int dev_alloc(cna_ctx* c, void** p, size_t bytes);
@@ -250,7 +254,12 @@ int launch_transpose(cna_ctx* c, const double* in, int64_t rows, int cols, int l
 int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, double* out, int ld_out);
 int launch_gram(cna_ctx* c, double* G_dev);
 int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* cuts_dev, int T,
-                      double cut0, double inv_step, double eps, unsigned long long* hist_dev);
+                      double cut0, double inv_step, double eps, unsigned long long* hist_dev, const int* guard = nullptr);
+// null_i8.hip
+bool null_i8_eligible(const cna_ctx* c, int P, int T, double cut0, double inv_step, double eps);
+int launch_null_local_i8(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* cuts_dev, int T, double cut0,
+                         double inv_step, double eps, int64_t** sums_out, int** status_out);
+int launch_i8_pick(cna_ctx* c, const int* status, const int64_t* a, const int64_t* b, int T, int64_t* out);
 
 // stats.hip
 int launch_condition(cna_ctx* c, hipStream_t st, const double* M_dev, const double* Y_dev, int N, int P,

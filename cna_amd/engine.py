@@ -499,6 +499,13 @@ class Engine(_order.CellOrder):
               'cna_null_local_resident')
         return sums if sums_only else tails
 
+    def null_local_i8_stats(self):
+        """(integer path used, outputs rechecked in f64, fell back to the f64 kernel) of the last sums-only pass."""
+        used, fb = C.c_int(0), C.c_int(0)
+        rc = C.c_int64(0)
+        check(self.lib.cna_null_local_i8_stats(self.h, C.byref(used), C.byref(rc), C.byref(fb)), 'cna_null_local_i8_stats')
+        return bool(used.value), int(rc.value), bool(fb.value)
+
     def null_local_prepare(self, P, edges, thr=None):
         """First half of null_local_launch: needs the thresholds only (exact cuts, observed counts);
         finish with null_local_launch(col0, P, None)."""

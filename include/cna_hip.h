@@ -245,6 +245,13 @@ int  cna_null_local_launch(cna_ctx* ctx, int col0, int P, const double* edges, i
 int  cna_null_local_prepare(cna_ctx* ctx, int P, const double* edges, int T, int want_tails, const double* thr);
 int  cna_null_local_fetch(cna_ctx* ctx, int64_t* tails_out, int64_t* tail_sums_out,
                           int64_t* ranks_out, int64_t* num_detected_out /* both NULL unless thr was given */);
+/* Diagnostics of the last local-null pass that wanted only the sums over permutations (the
+ * analysis): such a pass forms the products on the integer matrix cores (csrc/null_i8.hip: 24-bit
+ * fixed point, exact int32 accumulation, outputs within the error bound of a cut recomputed in f64)
+ * with the f64 kernel as stand-by.  used_out: 1 when the integer path ran; rechecked_out: outputs it
+ * sent to the f64 recheck; fallback_out: 1 when it gave up (queue overflow) and the f64 kernel did
+ * the work.  Waits for the device.  Environment CNA_NULL_F64=1 disables the integer path. */
+int  cna_null_local_i8_stats(cna_ctx* ctx, int* used_out, int64_t* rechecked_out, int* fallback_out);
 int  cna_global_test(cna_ctx* ctx, const double* U, int kmax, const int32_t* ks, int K, int r,
                      double* minp_out, double* r2_out, int32_t* kidx_out);
 /* The same in two halves (launch returns at once; U and ks are copied before it returns). */

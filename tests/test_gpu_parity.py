@@ -227,6 +227,69 @@ def test_local_null_counts_are_exact(eng, n, N, P):
     assert np.array_equal(numdet, [(np.abs(nc) > t).sum() for t in thr])
 
 
+@pytest.mark.parametrize('n,N,P,heavy', [(3000, 20, 100, 0), (2049, 50, 200, 0), (5000, 100, 1000, 0), (4100, 200, 333, 0),
+                                         (100, 256, 64, 0), (16, 12, 5, 0), (700, 160, 90, 1), (333, 224, 33, 0),
+                                         (2500, 192, 1000, 1), (250, 157, 70, 0), (260, 33, 65, 1), (31, 64, 64, 0)])
+def test_local_null_i8_sums_equal_f64_kernel(eng, n, N, P, heavy):
+    """The sums-only pass (integer matrix cores, csrc/null_i8.hip) against the f64 kernel's per-permutation
+    tails on the same resident phenotypes: the same integers, every threshold.  `heavy`: rows with outliers
+    and zero rows (per-row scales), phenotypes with ties."""
+    rs = np.random.RandomState(7 * n + N + P)
+    X = rs.randn(n, N)
+    if heavy:
+        X[::7] = rs.standard_t(2, size=X[::7].shape)
+        X[3::50] *= 1e-3
+    X = (X - X.mean(axis=1, keepdims=True))
+    X /= X.std(axis=1, ddof=1)[:, None]
+    if heavy:
+        X[5::40] = 0.0
+    eng.upload_x(X)
+    y = rs.randn(N)
+    nc, maxabs = eng.ncorrs(y, fetch=True)
+    Yc = rs.randn(N, P) if not heavy else rs.randint(0, 3, size=(N, P)).astype(float) + 1e-3 * rs.randn(N, P)
+    Yc -= Yc.mean(axis=0)
+    Yc /= Yc.std(axis=0, ddof=1)
+    maxcorr = max(maxabs, 0.001)
+    thr = np.arange(maxcorr / 4, maxcorr, maxcorr / 400)
+    edges = thr ** 2 - 1e-8 - 1e-5 * thr ** 2
+    tails = eng.null_local(Yc, edges)                        # f64 kernel, leaves Yc resident
+    sums = eng.null_local_resident(0, P, edges, sums_only=True)
+    used, rechecked, fallback = eng.null_local_i8_stats()
+    assert used and not fallback
+    assert np.array_equal(sums, tails.sum(axis=0))
+    assert rechecked < 0.02 * n * P + 64, rechecked
+    # a sub-range of the resident columns
+    if P > 70:
+        sums = eng.null_local_resident(3, 67, edges, sums_only=True)
+        assert np.array_equal(sums, tails[3:70].sum(axis=0))
+
+
+def test_local_null_i8_falls_back_when_the_queue_overflows(eng, monkeypatch):
+    """A recheck queue too small for the outputs near a cut (forced here through CNA_I8_QCAP): the integer
+    pass gives up on the device (status word) and the stand-by f64 kernel behind it produces the sums."""
+    rs = np.random.RandomState(5)
+    n, N, P = 20000, 50, 640
+    X = rs.randn(n, N)
+    X = (X - X.mean(axis=1, keepdims=True))
+    X /= X.std(axis=1, ddof=1)[:, None]
+    eng.upload_x(X)
+    nc, maxabs = eng.ncorrs(rs.randn(N), fetch=True)
+    Yc = rs.randn(N, P)
+    Yc /= Yc.std(axis=0, ddof=1)
+    thr = np.arange(maxabs / 4, maxabs, maxabs / 400)
+    edges = thr ** 2 - 1e-8 - 1e-5 * thr ** 2
+    tails = eng.null_local(Yc, edges)
+    monkeypatch.setenv('CNA_I8_QCAP', '8')
+    sums = eng.null_local_resident(0, P, edges, sums_only=True)
+    used, rechecked, fallback = eng.null_local_i8_stats()
+    assert used and fallback and rechecked > 8
+    assert np.array_equal(sums, tails.sum(axis=0))
+    monkeypatch.delenv('CNA_I8_QCAP')
+    sums = eng.null_local_resident(0, P, edges, sums_only=True)
+    used, rechecked, fallback = eng.null_local_i8_stats()
+    assert used and not fallback and np.array_equal(sums, tails.sum(axis=0))
+
+
 def test_percell_lookup(eng, orc):
     case = load_case('c12_batchy_qc')
     res, err, _ = run_product(case, eng)
