@@ -37,6 +37,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F64_MFMA_PEAK_TF = 78.6      # AMD MI355X datasheet: FP64 matrix 78.6 TFLOP/s (the guide lists no f64 row)
+I8_MFMA_PEAK_TOPS = 5033.0   # dense i8 matrix: 2x the bf16 rate (guide: >= 4404 TOPS measured with 32x32x32): 1024 SIMDs x 2048 ops/clk x 2.4 GHz
 
 # HBM-side traffic per launch from rocprofv3 PMC passes of THIS bench command (tools/pmc_step.sh ->
 # profiles/*_pmc_traffic.json: bytes = 2 * FETCH_SIZE KB + WRITE_SIZE KB; the factor 2 on FETCH_SIZE is the
@@ -218,7 +219,11 @@ def time_workload(name, args, rank, world, td, on_gpu_group, steps, warmup, want
         nnz_loc = int(deg_full[rows_loc].sum())
     else:
         nnz_loc = int(deg_full[eng.perm[rows_loc]].sum() if eng.perm is not None else deg_full[rows_loc].sum())
-    return dict(name=name, n=n, N=N, k=k, nsteps=nsteps, Nnull=Nnull, n_covs=n_covs, nnz=nnz, wA=wA, dt=dt, t_cold=t_cold,
+    try:
+        i8 = eng.null_local_i8_stats()
+    except Exception:
+        i8 = (False, 0, False)
+    return dict(name=name, n=n, N=N, k=k, nsteps=nsteps, Nnull=Nnull, n_covs=n_covs, nnz=nnz, wA=wA, dt=dt, t_cold=t_cold, i8=i8,
                 t_gen=t_gen, prof=prof, p=p_last, n_loc=n_loc, nnz_loc=nnz_loc, halo=getattr(eng, 'halo', None),
                 sharded_inputs=sharded_inputs, data=data, meta=meta, kw=kw, steps=steps, warmup=warmup, comm=eng.comm_info())
 
@@ -234,6 +239,14 @@ def kernel_table(m, world):
         kernels[name] = dict(total_ms=round(ms, 4), launches=cnt, avg_us=round(ms / cnt * 1e3, 2), bound=bound,
                              achieved=round(ach, 3), peak=peak, unit='GB/s' if bound == 'hbm' else 'TFLOP/s',
                              frac=round(ach / peak, 4))
+        if name == 'null_local' and m.get('i8', (False,))[0]:
+            # the pass ran on the integer matrix cores (csrc/null_i8.hip): six exact i8 digit products stand in for
+            # one f64 product, so the algorithmic work is 6 x 2nNP' integer operations against the i8 peak; the time
+            # covers the whole pass (quantisation of X and Yc, products + binning, f64 recheck, reductions)
+            ach = 6.0 * work / avg_s / 1e12
+            kernels[name].update(achieved=round(ach, 1), peak=I8_MFMA_PEAK_TOPS, unit='TOP/s (i8)',
+                                 frac=round(ach / I8_MFMA_PEAK_TOPS, 4), f64_equivalent_tflops=round(work / avg_s / 1e12, 1),
+                                 rechecked_in_f64=m['i8'][1], fell_back_to_f64=m['i8'][2])
     return kernels
 
 
@@ -416,6 +429,10 @@ def main():
                        ' [--comm shm: ranks share one GPU, plumbing check only]' if args.comm == 'shm' and world > 1 else ''),
                    'communicator': {'backend': m['comm'][0], 'nranks_reported_by_communicator': m['comm'][1],
                                     'halo_rows_out_in_rank0': m['halo']},
+                   'arithmetic': 'f64 throughout (diffusion, QC, residualisation, Gram, F-tests); the local-null products '
+                                 'as exact 24-bit fixed-point digits on the i8 matrix cores with an f64 recheck of every '
+                                 'output within the error bound of a threshold (same integer counts as the f64 kernel)'
+                                 if m.get('i8', (False,))[0] else 'f64 throughout',
                    'p_value': m['p']},
         'roofline': main_sum['roofline'],
         'cpu_baseline': cpu,

@@ -180,26 +180,32 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
   double s[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) s[q] = add_rn(accl[lane + 64 * q], (lane + 64 * q == me.sid) ? self : 0.0);
-  finish_row<NQ, ColStride1>(a, row, grow, lane, s);
-  if (a.sp_cnt) {
-    // after one step a row is non-zero only at the samples of the cell's neighbours: keep those
-    // (sample, value) pairs side by side so the second step gathers ~40 entries instead of N
-    const double cs = a.colsum[grow];
-    int base = 0;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int col = lane + 64 * q;
-      const double t = col < a.width ? __ddiv_rn(s[q], cs) : 0.0;        // what finish_row stored in T
-      const unsigned long long m = __ballot(t != 0.0);
-      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-      if (t != 0.0 && pos < SP_CAP) {
-        a.sp_idx[grow * SP_CAP + pos] = (unsigned short)col;
-        a.sp_val[grow * SP_CAP + pos] = t;
-      }
-      base += __popcll(m);
-    }
-    if (lane == 0) a.sp_cnt[grow] = (unsigned char)(base <= SP_CAP ? base : SP_DENSE);
+  if (!a.sp_cnt) {
+    finish_row<NQ, ColStride1>(a, row, grow, lane, s);
+    return;
   }
+  // after one step a row is non-zero only at the samples of the cell's neighbours: keep those
+  // (sample, value) pairs side by side so the second step gathers ~40 entries instead of N.  The dense row
+  // of the state is then dead weight -- the second step (k_nam_step_sparse) reads the pairs, its own row
+  // included -- and is written only for rows that overflow the SP_CAP pairs.
+  const double cs = a.colsum[grow];
+  int base = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int col = lane + 64 * q;
+    const double t = col < a.width ? __ddiv_rn(s[q], cs) : 0.0;        // what finish_row stores in T
+    const unsigned long long m = __ballot(t != 0.0);
+    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (t != 0.0 && pos < SP_CAP) {
+      a.sp_idx[grow * SP_CAP + pos] = (unsigned short)col;
+      a.sp_val[grow * SP_CAP + pos] = t;
+    }
+    base += __popcll(m);
+  }
+  if (lane == 0) a.sp_cnt[grow] = (unsigned char)(base <= SP_CAP ? base : SP_DENSE);
+  StepArgs b = a;
+  b.write_t = a.write_t && base > SP_CAP;
+  finish_row<NQ, ColStride1>(b, row, grow, lane, s);
 }
 
 // Steps >= 2: gather-accumulate over neighbour rows of the scaled state T.  Each lane owns two
@@ -480,15 +486,28 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
         lds_add(&acc[a.sp_idx[(int64_t)j * SP_CAP + lane]], mul_rn(av, a.sp_val[(int64_t)j * SP_CAP + lane]));
     }
   }
+  // + w*s/colsums of the row itself, after the neighbours (the order of scipy's A.dot(s) + s): from its own
+  // pairs (adding w * 0 elsewhere would change nothing: the sums are non-negative), or from its dense row
+  // when it overflowed the pairs
+  const int own_cnt = (int)a.sp_cnt[grow];
+  if (own_cnt != SP_DENSE) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (lane < own_cnt) lds_add(&acc[a.sp_idx[grow * SP_CAP + lane]], mul_rn(a.w, a.sp_val[grow * SP_CAP + lane]));
+  }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   double s[2 * NQ2];
 #pragma unroll
   for (int q = 0; q < NQ2; ++q) {
     const int c2 = lane + 64 * q;
     const bool act = c2 < ld2;
-    const double2 own = act ? Tin[grow * ld2 + c2] : make_double2(0.0, 0.0);
-    s[2 * q] = add_rn(act ? acc[2 * c2] : 0.0, mul_rn(a.w, own.x));          // + w*s/colsums
-    s[2 * q + 1] = add_rn(act ? acc[2 * c2 + 1] : 0.0, mul_rn(a.w, own.y));
+    if (own_cnt == SP_DENSE) {
+      const double2 own = act ? Tin[grow * ld2 + c2] : make_double2(0.0, 0.0);
+      s[2 * q] = add_rn(act ? acc[2 * c2] : 0.0, mul_rn(a.w, own.x));
+      s[2 * q + 1] = add_rn(act ? acc[2 * c2 + 1] : 0.0, mul_rn(a.w, own.y));
+    } else {
+      s[2 * q] = act ? acc[2 * c2] : 0.0;
+      s[2 * q + 1] = act ? acc[2 * c2 + 1] : 0.0;
+    }
   }
   finish_row<2 * NQ2, ColPair>(a, row, grow, lane, s);
 }
