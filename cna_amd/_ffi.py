@@ -71,6 +71,7 @@ SIGNATURES = {
     'cna_host_legacy_randn': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_int64, C.c_void_p]),
     'cna_knn_graph': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, c_i64p]),
     'cna_host_hash64': (C.c_uint64, [C.c_void_p, C.c_int64, C.c_int]),
+    'cna_host_copy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     'cna_host_permuted_nnz': (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'cna_host_permute_rows': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

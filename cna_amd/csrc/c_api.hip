@@ -956,18 +956,21 @@ int cna_select_standardized_fused(cna_ctx* c, const int64_t* keep_idx, int64_t n
   if (n_zero_out) *n_zero_out = nz;
   if (max_abs_out) *max_abs_out = m;
   if (nz != 0 || !y) return 0;
-  CNA_TRY(cna_gram_launch(c));
-  if (gram_queued) *gram_queued = 1;
-  if (null_P < 1 || !T_out || !thr_out || c->null_pending) return 0;
   double edges[512];
-  const int T = cna_reference_thresholds(m, 512, thr_out, edges);
-  if (T < 1) return 0;
-  CNA_TRY(null_local_prepare(c, null_P, edges, T, 0, thr_out));
-  *T_out = T;
-  if (coef_queued && !((c->nranks > 1 || comm_active(c)) && !c->local_view)) {
+  int T = 0;
+  if (null_P >= 1 && T_out && thr_out && !c->null_pending) T = cna_reference_thresholds(m, 512, thr_out, edges);
+  // the coefficient column first: its kernels and copy are short, and the host writes it into the caller's
+  // frame while the Gram kernel runs (behind the Gram kernel it would arrive when the host should already
+  // be in LAPACK)
+  if (T >= 1 && coef_queued && !((c->nranks > 1 || comm_active(c)) && !c->local_view)) {
     CNA_TRY(cna_percell_coef_launch(c));
     *coef_queued = 1;
   }
+  CNA_TRY(cna_gram_launch(c));
+  if (gram_queued) *gram_queued = 1;
+  if (T < 1) return 0;
+  CNA_TRY(null_local_prepare(c, null_P, edges, T, 0, thr_out));
+  *T_out = T;
   return 0;
 }
 

@@ -92,6 +92,39 @@ uint64_t cna_host_hash64(const void* p, int64_t nbytes, int nthreads) {
   return fin(h);
 }
 
+/* memcpy on several threads: the per-cell result columns (8 bytes x cells) from the context's pinned
+ * staging into the caller's frame */
+struct copy_job { char* d; const char* s; size_t n; };
+static void* copy_worker(void* a) {
+  struct copy_job* j = (struct copy_job*)a;
+  memcpy(j->d, j->s, j->n);
+  return NULL;
+}
+int cna_host_copy(void* dst, const void* src, int64_t nbytes, int nthreads) {
+  if (nbytes <= 0) return 0;
+  if (!dst || !src) return 1;
+  if (nthreads > 16) nthreads = 16;
+  if ((int64_t)nthreads > nbytes / (1 << 20)) nthreads = (int)(nbytes / (1 << 20));
+  if (nthreads < 1) nthreads = 1;
+  struct copy_job jobs[16];
+  pthread_t th[16];
+  int started[16];
+  const size_t part = (((size_t)nbytes / nthreads) + 63) & ~(size_t)63;
+  for (int t = 0; t < nthreads; ++t) {
+    const size_t b = (size_t)t * part;
+    jobs[t].d = (char*)dst + b; jobs[t].s = (const char*)src + b;
+    jobs[t].n = b >= (size_t)nbytes ? 0 : ((size_t)nbytes - b < part || t == nthreads - 1 ? (size_t)nbytes - b : part);
+    started[t] = 0;
+  }
+  for (int t = 1; t < nthreads; ++t) started[t] = pthread_create(&th[t], NULL, copy_worker, &jobs[t]) == 0;
+  copy_worker(&jobs[0]);
+  for (int t = 1; t < nthreads; ++t) {
+    if (started[t]) pthread_join(th[t], NULL);
+    else copy_worker(&jobs[t]);
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Cell order of the device copy: clusters of `B` cells that share neighbours.
  *

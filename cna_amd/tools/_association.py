@@ -74,6 +74,22 @@ _FUSE = os.environ.get('CNA_FUSE_SELECT', '1') not in ('0', 'off', 'no')
 _TRACE = None      # list of (label, perf_counter) when tools/host_trace.py switches tracing on
 
 
+_COEF_FIRST_CELLS = int(os.environ.get('CNA_COEF_FIRST_CELLS', '500000'))
+
+
+def _host_copy(dst, src):
+    """dst[:] = src for two contiguous float64 arrays, on several threads when the library is there."""
+    try:
+        from .. import _ffi
+        from .._order import usable_cpus
+        lib = _ffi.load()
+        if lib.cna_host_copy(dst.ctypes.data, src.ctypes.data, dst.nbytes, min(8, usable_cpus(8))) == 0:
+            return
+    except Exception:
+        pass
+    np.copyto(dst, src)
+
+
 def _mark(label):
     if _TRACE is not None:
         import time
@@ -99,7 +115,8 @@ def _draw_null(y, batches, donorids, Nnull=1000, force_permute_all=False, seed=N
 
 
 def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_progress=False,
-                 npcs=None, n_cells=None, conditioned=False, null_source=None, maxabs=None, on_coef=None):
+                 npcs=None, n_cells=None, conditioned=False, null_source=None, maxabs=None, on_coef=None,
+                 coef_first=False, coef_launched=False):
     """Body of the reference's ``_association`` (_association.py:24-129) against the
     residualised NAM held by ``engine`` (cells x samples), whose Gram-matrix kernels have been
     queued.  ``res`` is the namespace from the residualisation (M, r), ``y`` / ``y_`` the
@@ -142,7 +159,8 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         # the coefficient column does not depend on the null: queued in front of the null kernel it is
         # on the host while that kernel runs (consumed below, between the two halves of the F-tests)
         coef_early = (on_coef is not None and _EARLY_COEF and getattr(engine, 'percell_coef_launch', None) is not None
-                      and getattr(engine, 'global_test_launch', None) is not None and engine.percell_coef_launch())
+                      and getattr(engine, 'global_test_launch', None) is not None
+                      and (coef_launched or engine.percell_coef_launch()))
 
     if null_source is not None:
         y_, conditioned = null_source()
@@ -162,13 +180,19 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     try:
         # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105), and the global F-tests of the
         # observed phenotype and every permutation (second stream), all under the local-null kernel
+        # the coefficient column (already on its way to the host) goes into data.obs under a kernel: with
+        # many cells under the Gram kernel, i.e. before this thread waits for it (2M cells: 0.7 ms of column
+        # copy against 2.2 ms of Gram; afterwards the host would be the critical path, the integer local null
+        # being as short as LAPACK + F-tests); with few cells between the two halves of the F-test call
+        coef_first = coef_early and coef_first
+        if coef_first:
+            on_coef(engine.percell_coef_wait())
         U, svs, _ = _small_svd(engine.gram_fetch())
         if coef_early:
-            # F-tests queued (second stream); while they and the local null run, the coefficient
-            # column -- already on the host -- goes into data.obs
-            engine.global_test_launch(U, ks_arr, r)
+            engine.global_test_launch(U, ks_arr, r)          # second stream
             try:
-                on_coef(engine.percell_coef_wait())
+                if not coef_first:
+                    on_coef(engine.percell_coef_wait())
             finally:
                 best, pv, r2v = engine.global_test_fetch()
         else:
@@ -487,6 +511,7 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                            batches_[filter_] if batches_ is not None else batches_, ridges=ridges)
         if len(y_std) == len(sample_index_):
             plan.y_std = y_std                        # lets the residualisation pass take the coefficients on its way out
+            plan.coef_first = _EARLY_COEF and len(data.obs) >= _COEF_FIRST_CELLS and kwargs.get('local_test', True)
         if plan.M is not None:
             early['M'] = np.asarray(plan.M, dtype=np.float64)     # the draw conditions with it
         if not _DRAW_THREAD:
@@ -534,11 +559,23 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         if hasattr(engine, 'confirm_graph') and not engine.confirm_graph():
             raise _StaleGraph()
 
+    fdr_key = f'{key_added}_fdr'
+    had_fdr = fdr_key in data.obs
+    previous_fdr = data.obs[fdr_key] if had_fdr else None
+    big = len(data.obs) >= _COEF_FIRST_CELLS
+
     def write_coef_early(coef):
         confirm_graph()                                   # nothing reaches data.obs from a stale graph
         early_coef['written'] = True
         data.obs[key_added] = coef
         early_coef['values'] = data.obs[key_added].values
+        if big:
+            # the FDR column's storage as well (the frame takes a private copy of whatever it is given: 16 MB at 2M
+            # cells): made now, under a kernel, and filled in place at the end by a threaded copy
+            data.obs[fdr_key] = np.empty(len(data.obs))
+            view = data.obs[fdr_key].values
+            if view.dtype == np.float64 and view.flags.c_contiguous and view.flags.writeable:
+                early_coef['fdr_view'] = view
         _mark('coef column written')
 
     try:
@@ -546,13 +583,20 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                                                  local_test=kwargs.get('local_test', True),
                                                  show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_global,
                                                  null_source=drawn,
-                                                 maxabs=getattr(plan, 'maxabs', None), on_coef=write_coef_early)
+                                                 maxabs=getattr(plan, 'maxabs', None), on_coef=write_coef_early,
+                                                 coef_first=len(data.obs) >= _COEF_FIRST_CELLS,
+                                                 coef_launched=getattr(plan, 'coef_launched', False))
     except BaseException:
         if early_coef.get('written'):
             if had_key:
                 data.obs[key_added] = previous
             elif key_added in data.obs:
                 del data.obs[key_added]
+            if 'fdr_view' in early_coef or (big and fdr_key in data.obs and not had_fdr):
+                if had_fdr:
+                    data.obs[fdr_key] = previous_fdr
+                elif fdr_key in data.obs:
+                    del data.obs[fdr_key]
         raise
     _mark('_association returned')
     confirm_graph()
@@ -586,7 +630,12 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     if fdr_all is None:
         # upstream dereferences res.fdrs here and dies when local_test=False (_association.py:235)
         raise AttributeError("'NoneType' object has no attribute 'loc'")
-    data.obs[f'{key_added}_fdr'] = fdr_all
+    view = early_coef.get('fdr_view')
+    if (view is not None and isinstance(fdr_all, np.ndarray) and fdr_all.dtype == np.float64 and fdr_all.flags.c_contiguous
+            and fdr_all.shape == view.shape and fdr_key in data.obs and np.shares_memory(data.obs[fdr_key].values, view)):
+        _host_copy(view, fdr_all)
+    else:
+        data.obs[fdr_key] = fdr_all
     _mark('obs written')
 
     if return_full:

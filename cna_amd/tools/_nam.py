@@ -489,6 +489,11 @@ def _resid_run(engine, plan, cell_index, show_progress=False):
             engine.resid_apply(None, center=True)
         engine.standardize(center=False)
 
+    # the caller's coefficient column, when the coefficients came with the residualisation pass: queued in front
+    # of the Gram kernels so that the host can write it into the frame while those run
+    if (getattr(plan, 'coef_first', False) and getattr(plan, 'maxabs', None) is not None
+            and getattr(engine, 'percell_coef_launch', None) is not None):
+        plan.coef_launched = bool(engine.percell_coef_launch())
     # svd_nam re-centres / re-standardises (_nam.py:103-104); X is already standardised, so
     # that is an identity up to 1 ulp and the Gram matrix is taken of X directly.
     engine.gram_launch()

@@ -314,6 +314,9 @@ int  cna_host_argsort_gather(const double* R, int m, int num, const double* y, d
  * in-place edit of any entry re-uploads the graph -- the reference reads `data.obsp['connectivities']`
  * afresh on every call (_nam.py:25-28). */
 uint64_t cna_host_hash64(const void* p, int64_t nbytes, int nthreads);
+/* memcpy on up to nthreads threads (the per-cell result columns into the caller's frame,
+ * _association.py:230-237 of the reference assigns them to data.obs) */
+int  cna_host_copy(void* dst, const void* src, int64_t nbytes, int nthreads);
 /* Device cell order: clusters of B cells grown greedily by "most edges into the cluster" so that the
  * rows of one block share neighbours (edges / distinct neighbour rows of a block: 3.0 at B = 64 against
  * 2.0 for reverse Cuthill-McKee).  indptr int64[n+1], indices int32 of the rows' columns (columns outside
