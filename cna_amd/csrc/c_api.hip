@@ -213,7 +213,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_flush(c);
   comm_destroy(c);
-  void* bufs[] = {c->i8_buf, c->coef_dev, c->proj, c->sp_idx, c->sp_val, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+  void* bufs[] = {c->i8_buf, c->xq, c->xq_scale, c->coef_dev, c->proj, c->sp_idx, c->sp_val, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
                   c->nam, c->X, c->X2, c->resid_f, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -293,7 +293,9 @@ int cna_graph_upload(cna_ctx* c, int64_t n_global, int64_t row0, int64_t n_local
   c->t_valid = false;
   c->nam_valid = false;
   c->x_valid = false;
+  c->xq_valid = false;
   c->ncorrs_valid = false;
+  c->xq_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   c->steps_done = 0;
@@ -435,6 +437,7 @@ int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const doubl
   c->t_valid = false;
   c->nam_valid = false;
   c->x_valid = false;
+  c->xq_valid = false;
   CNA_TRY(ensure_sparse_state(c));
   return 0;
 }
@@ -451,6 +454,7 @@ int cna_restart_nam(cna_ctx* c) {
   c->t_valid = false;
   c->nam_valid = false;
   c->x_valid = false;
+  c->xq_valid = false;
   return 0;
 }
 
@@ -784,6 +788,7 @@ int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_
   c->x_valid = true;
   c->x_from_nam = true;
   c->ncorrs_valid = false;
+  c->xq_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -851,6 +856,7 @@ int cna_select_checked(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, cons
   c->x_valid = true;
   c->x_from_nam = true;
   c->ncorrs_valid = false;
+  c->xq_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -892,8 +898,14 @@ int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep,
     HIP_TRY(hipMemcpyAsync(yd, y, 8 * Nx, hipMemcpyHostToDevice, c->stream));
   }
   const int rk = (c->resid_rk > 0 && c->resid_n == Nx) ? c->resid_rk : 0;     // one-shot: cna_set_resid_factors
+  // the rows leave this pass final: their fixed-point digit planes for the integer local null go out with them
+  c->xq_valid = false;
+  const bool with_q = y != nullptr && Nx <= 256 && nx > 0 && null_i8_enabled();
+  const int KSq = (Nx + 31) / 32;
+  if (with_q) CNA_TRY(ensure_xq(c, KSq));
   CNA_TRY(launch_select_std(c, colmap ? cm : nullptr, nz, y ? yd : nullptr, y ? mb : nullptr, c->resid_f,
-                            c->resid_f ? c->resid_f + (size_t)rk * Nx : nullptr, rk));
+                            c->resid_f ? c->resid_f + (size_t)rk * Nx : nullptr, rk,
+                            with_q ? (unsigned char*)c->xq : nullptr, with_q ? c->xq_scale : nullptr, 32 * KSq));
   c->resid_rk = 0;
   CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)nz, 1));
   if (y) CNA_TRY(comm_allreduce_f64_max(c, (double*)mb, 1));
@@ -907,6 +919,7 @@ int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep,
   c->x_valid = true;
   c->x_from_nam = true;
   c->ncorrs_valid = y != nullptr;     // meaningful only when no cell had zero variance (the caller checks)
+  c->xq_valid = with_q;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -992,6 +1005,7 @@ int cna_upload_x(cna_ctx* c, const double* x_local, int64_t n_rows, int n_cols) 
   c->x_valid = true;
   c->x_from_nam = false;
   c->ncorrs_valid = false;
+  c->xq_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1011,6 +1025,7 @@ int cna_resid_apply(cna_ctx* c, const double* M, int center) {
   CNA_TRY(launch_xb(c, (const double*)c->scratch, ldb, Nx, center != 0, c->X, ldx));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->ncorrs_valid = false;
+  c->xq_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1053,6 +1068,7 @@ int cna_resid_lowrank(cna_ctx* c, const double* C, const double* W, int r, int c
   HIP_TRY(hipStreamSynchronize(c->stream));        // Ct is a local
   if (max_abs_out) *max_abs_out = m;
   c->ncorrs_valid = y != nullptr;
+  c->xq_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1063,6 +1079,7 @@ int cna_standardize(cna_ctx* c, int center) {
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
   CNA_TRY(launch_standardize(c, center));
   c->ncorrs_valid = false;
+  c->xq_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;

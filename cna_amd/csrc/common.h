@@ -8,6 +8,7 @@
 #include "../../include/cna_hip.h"
 
 #define WAVE 64
+#define I8_QMAX 8355000.0   // largest |q| of the 24-bit fixed point of null_i8.hip: 127*65536 + 127*256 + 127 = 8355711
 
 void cna_set_error(const std::string& msg);
 
@@ -167,6 +168,13 @@ struct cna_ctx {
   int64_t sp_rows = 0;
   void* i8_buf = nullptr;         // digit planes, queue and slabs of the integer local-null path (null_i8.hip)
   int64_t i8_cap = 0;
+  void* xq = nullptr;             // digit planes of X ([row][digit][32 KS] bytes) and per-row {max |x|, sum |q|}, written by
+  int64_t xq_cap = 0;             //   the pass that produced X (k_select_std) or by k_quant_x
+  void* xq_scale = nullptr;
+  int64_t xq_scale_cap = 0;
+  bool xq_valid = false;          // they describe the current X
+  int64_t xq_rows = 0;
+  int xq_KS = 0;
   bool i8_last = false;           // the last local-null pass took the integer path
   unsigned long long* i8_qcount = nullptr;   // device: [0] outputs sent to the f64 recheck by the last pass, [1] low word = status
   void* null_part = nullptr;      // per-block counter slabs of the local-null kernel
@@ -232,7 +240,8 @@ int launch_gather_rows(cna_ctx* c, const double* src, int ld, const int64_t* row
 int launch_digit_hist(cna_ctx* c, const double* v, int64_t n, unsigned long long prefix, int shift,
                       unsigned long long* hist_dev);
 int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev, const double* y_dev,
-                      unsigned long long* maxbits_dev, const double* W_dev, const double* Ct_dev, int rk);
+                      unsigned long long* maxbits_dev, const double* W_dev, const double* Ct_dev, int rk,
+                      unsigned char* xq = nullptr, void* xscale = nullptr, int Kp = 0);
 int launch_standardize(cna_ctx* c, int center);
 int launch_ncorrs(cna_ctx* c, const double* y_dev, unsigned long long* maxbits_dev);
 int launch_resid_lowrank(cna_ctx* c, const double* W_dev, const double* Ct_dev, int r, int center, int standardize,
@@ -257,6 +266,8 @@ int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const do
                       double cut0, double inv_step, double eps, unsigned long long* hist_dev, const int* guard = nullptr);
 // null_i8.hip
 bool null_i8_eligible(const cna_ctx* c, int P, int T, double cut0, double inv_step, double eps);
+bool null_i8_enabled();
+int ensure_xq(cna_ctx* c, int KS);
 int launch_null_local_i8(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* cuts_dev, int T, double cut0,
                          double inv_step, double eps, int64_t** sums_out, int** status_out);
 int launch_i8_pick(cna_ctx* c, const int* status, const int64_t* a, const int64_t* b, int T, int64_t* out);
@@ -285,6 +296,11 @@ __device__ __forceinline__ double dpp_add(double v, const int ctrl_sel) {
     default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break; // row_mirror
   }
   return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  return v;
 }
 __device__ __forceinline__ double wave_sum(double v) {
   v = dpp_add(v, 0);

@@ -29,19 +29,14 @@
 // thresholds) a status word is raised and the f64 kernel, launched behind with a guard on that word,
 // does the work instead: no host round trip either way.
 #include "common.h"
+#include <algorithm>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-#define I8_Q 8355000.0                      // largest |q|: 127*65536 + 127*256 + 127 = 8355711
+#define I8_Q I8_QMAX                        // largest |q| (common.h)
 #define I8_DROP (2.0 * 128 * 128 * 256 + 128.0 * 128 + 0.25)
 #define I8_QBUF 192
-
-__device__ __forceinline__ double wave_maxd(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
-}
 
 // q -> three balanced base-256 digits (each as a byte)
 __device__ __forceinline__ void digits3(int q, unsigned& d0, unsigned& d1, unsigned& d2) {
@@ -64,7 +59,7 @@ __global__ __launch_bounds__(1024) void k_y_absmax(const double* __restrict__ Y,
     const int k = (int)(i / P), p = (int)(i - (int64_t)k * P);
     m = fmax(m, fabs(Y[(size_t)k * ldy + p]));
   }
-  m = wave_maxd(m);
+  m = wave_max_d(m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -126,37 +121,31 @@ __global__ __launch_bounds__(1024) void k_y_finish(const unsigned long long* __r
   }
 }
 
-// X (row per cell) -> digit planes, one block per tile of 32 cells: [tile][digit][k step][k half][row][16 bytes]
-// (= the A operands of a tile, one contiguous KB per instruction), and per row {a_r, m_r}:
-// position of an output = |w| * a_r + (1 - cut0/step), w = 256 S2 + S3 + (S4 >> 8); margin m_r as in the header.
-__global__ __launch_bounds__(256) void k_quant_x(const double* __restrict__ X, int ldx, int64_t nx, int N, int KS,
-                                                 const unsigned long long* __restrict__ scal, double inv_step, double slack,
-                                                 v4i* __restrict__ Xq, float2* __restrict__ rowinfo) {
-  extern __shared__ unsigned stg[];                         // 3*KS*64 int4
+// X (row per cell) -> digit planes [row][digit][32 KS] bytes and {max |x|, sum |q|} per row, for working matrices
+// whose producer did not write them itself (rows.hip:k_select_std does).  One wave per row, 4 samples per lane.
+__global__ __launch_bounds__(256) void k_quant_x(const double* __restrict__ X, int ldx, int64_t nx, int N, int Kp,
+                                                 unsigned char* __restrict__ Xq, double2* __restrict__ xscale) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int64_t tile = blockIdx.x;
-  const double ymax = __longlong_as_double((long long)scal[0]);
-  const double l1y = (double)scal[1];
-  const double sy = ymax / I8_Q;
   const int k0 = 4 * lane;
-  const bool act = k0 < 32 * KS;
+  const bool act = k0 < Kp;
   for (int r = 0; r < 8; ++r) {
-    const int i = wv * 8 + r;
-    const int64_t row = tile * 32 + i;
+    const int64_t row = (int64_t)blockIdx.x * 32 + wv * 8 + r;
+    if (row >= nx) return;
     double x[4] = {0.0, 0.0, 0.0, 0.0};
-    if (row < nx && act) {
+    if (act) {
       const double* xr = X + (size_t)row * ldx;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         if (k0 + j < N) x[j] = xr[k0 + j];
     }
-    const double rmax = wave_maxd(fmax(fmax(fabs(x[0]), fabs(x[1])), fmax(fabs(x[2]), fabs(x[3]))));
+    const double rmax = wave_max_d(fmax(fmax(fabs(x[0]), fabs(x[1])), fmax(fabs(x[2]), fabs(x[3]))));
     const double inv = rmax > 0.0 ? I8_Q / rmax : 0.0;
     unsigned w0 = 0, w1 = 0, w2 = 0;
     double l1 = 0.0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int q = (int)rint(x[j] * inv);
+      const double v = x[j] * inv;
+      const int q = v == v ? (int)rint(v) : 0;
       l1 += (double)(q < 0 ? -q : q);
       unsigned d0, d1, d2;
       digits3(q, d0, d1, d2);
@@ -166,56 +155,73 @@ __global__ __launch_bounds__(256) void k_quant_x(const double* __restrict__ X, i
     }
     l1 = wave_sum(l1);
     if (act) {
-      const int c16 = lane >> 2, s = c16 >> 1, kh = c16 & 1, dw = lane & 3;
-      stg[(((0 * KS + s) * 2 + kh) * 32 + i) * 4 + dw] = w0;
-      stg[(((1 * KS + s) * 2 + kh) * 32 + i) * 4 + dw] = w1;
-      stg[(((2 * KS + s) * 2 + kh) * 32 + i) * 4 + dw] = w2;
+      unsigned* rq = (unsigned*)(Xq + (size_t)row * 3 * Kp);
+      rq[lane] = w0;
+      rq[Kp / 4 + lane] = w1;
+      rq[2 * (Kp / 4) + lane] = w2;
     }
-    if (lane == 0) {
-      float a = 0.f, m = 0.f;
-      if (row < nx && rmax > 0.0) {
-        const double sx = rmax / I8_Q;
-        const double unit = sx * sy * inv_step;
-        // + 2 * 2^24: the low byte of S4, which the epilogue drops (w = 256 S2 + S3 + (S4 >> 8), exact in int32)
-        const double U = 0.5 * l1 + 0.5 * l1y + (double)N * I8_DROP + 2.0 * 16777216.0;
-        a = (float)(unit * 16777216.0);
-        m = (float)((unit * U + slack) * 1.0001);
-      }
-      rowinfo[row] = make_float2(a, m);                      // rowinfo has 32 * ntiles entries
+    if (lane == 0) xscale[row] = make_double2(rmax, l1);
+  }
+}
+
+// per row {a_r, m_r}: position of an output = |w| * a_r + (1 - cut0/step), w = 256 S2 + S3 + (S4 >> 8);
+// margin m_r as in the header
+__global__ void k_rowinfo(const double2* __restrict__ xscale, int64_t nx, int64_t nrows, int N,
+                          const unsigned long long* __restrict__ scal, double inv_step, double slack,
+                          float2* __restrict__ rowinfo) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nrows) return;
+  float a = 0.f, m = 0.f;
+  if (row < nx) {
+    const double2 sc = xscale[row];
+    if (sc.x > 0.0) {
+      const double ymax = __longlong_as_double((long long)scal[0]);
+      const double l1y = (double)scal[1];
+      const double unit = (sc.x / I8_Q) * (ymax / I8_Q) * inv_step;
+      // + 2 * 2^24: the low byte of S4, which the epilogue drops (w = 256 S2 + S3 + (S4 >> 8), exact in int32)
+      const double U = 0.5 * sc.y + 0.5 * l1y + (double)N * I8_DROP + 2.0 * 16777216.0;
+      a = (float)(unit * 16777216.0);
+      m = (float)((unit * U + slack) * 1.0001);
     }
   }
-  __syncthreads();
-  const v4i* src = (const v4i*)stg;
-  v4i* dst = Xq + (size_t)tile * (3 * KS * 64);
-  for (int t = threadIdx.x; t < 3 * KS * 64; t += 256) dst[t] = src[t];
+  rowinfo[row] = make_float2(a, m);
 }
 
 // The products.  Block = 8 waves, each with its own tile of 32 cells whose 3 x KS A operands stay in
-// registers while the block sweeps all permutation strips (64 wide, double-buffered in LDS, one barrier
-// per strip); then the next 8 tiles.  Lane (j = lane & 31, kh = lane >> 5) of a 32x32 result holds
-// column j and rows (reg & 3) + 8 (reg >> 2) + 4 kh.
-template <int KS, int MODE = 0>     // MODE: experiments (1: products only, 2: no counters, 3: no products)
-__global__ __launch_bounds__(512) void k_null_i8(const v4i* __restrict__ Xq, const float2* __restrict__ rowinfo,
-                                                 int64_t ntiles, const v4i* __restrict__ Yq, int nstrips, int nsplit,
+// registers while the block sweeps the permutations in stages of G strips of 64 (double-buffered in LDS by
+// LDS-DMA, one barrier per stage); then the next work item.  Lane (j = lane & 31, kh = lane >> 5) of a 32x32
+// result holds column j and rows (reg & 3) + 8 (reg >> 2) + 4 kh.
+//
+// Matrix and vector work of DIFFERENT waves of a SIMD overlap on this chip (tools/micro/mfma_i8_overlap.hip:
+// an i8 MFMA keeps the vector port for ~16 of its 32 cycles), but two waves that walk the same
+// "products, binning, products, binning" sequence between the same barriers do both at the same time.  So
+// the second wave of every SIMD (waves 4-7) runs the sequence rotated by half a period: it bins the LAST
+// column tile of a stage at the beginning of the next stage (the accumulators simply stay in registers
+// across the barrier), while its partner is in its first block of products.
+template <int KS, int G, int MODE = 0>     // MODE: experiments (1: products only, 2: no counters, 3: no products)
+__global__ __launch_bounds__(512) void k_null_i8(const unsigned char* __restrict__ Xq, const float2* __restrict__ rowinfo,
+                                                 int64_t ntiles, const v4i* __restrict__ Yq, int nstages, int nsplit,
                                                  int spp, int T, float bconst, unsigned int* __restrict__ partial,
                                                  uint2* __restrict__ queue, unsigned long long* __restrict__ qcount,
-                                                 unsigned long long qcap, int* __restrict__ status) {
+                                                 unsigned long long qcap, int* __restrict__ status, int rotate) {
   extern __shared__ v4i sm[];
-  constexpr int SB = 3 * KS * 128;                            // int4 per strip
-  constexpr int LPT = (SB + 511) / 512;
+  constexpr int SB = 3 * KS * 128;                            // int4 per strip of 64 permutations
+  constexpr int SG = G * SB;                                  // per stage
+  constexpr int LPT = (SG + 511) / 512;
+  constexpr int NCT = 2 * G;                                  // column tiles (32 permutations) per stage
   const int TW = T + 1;
   v4i* bbuf = sm;
-  unsigned* hist = (unsigned*)(sm + 2 * SB);                  // [TW][32]
+  unsigned* hist = (unsigned*)(sm + 2 * SG);                  // [TW][32]; row 0 takes what does not count
   uint2* qb_all = (uint2*)(hist + (size_t)TW * 32 + 64);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, kh = lane >> 5;
   uint2* qb = qb_all + wv * I8_QBUF;                          // (not volatile: a volatile generic pointer into LDS trips the gfx950 backend)
   const float Thi = (float)T + 0.5f;
-  const int dumpi = TW * 32 + lane;                           // this lane's word of the dump row
+  const bool rot = rotate != 0 && wv >= 4;
   for (int i = tid; i < TW * 32 + 64; i += 512) hist[i] = 0u;
 
-  // work items: (group of 8 tiles, part of the strips); dealt round-robin so that short inputs still balance
+  // work items: (group of 8 tiles, part of the stages); dealt round-robin so that short inputs still balance
   const int64_t nitems = ((ntiles + 7) / 8) * nsplit;
   int wcount = 0;
 
@@ -226,12 +232,7 @@ __global__ __launch_bounds__(512) void k_null_i8(const v4i* __restrict__ Xq, con
     base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
            (unsigned)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffu));
     if (base + (unsigned long long)wcount <= qcap) {
-      for (int i = lane; i < wcount; i += 64) {
-        uint2 e;
-        e.x = qb[i].x;
-        e.y = qb[i].y;
-        queue[base + i] = e;
-      }
+      for (int i = lane; i < wcount; i += 64) queue[base + i] = qb[i];
     } else if (lane == 0) {
       atomicOr(status, 1);
     }
@@ -240,16 +241,16 @@ __global__ __launch_bounds__(512) void k_null_i8(const v4i* __restrict__ Xq, con
   };
 
   if (blockIdx.x < nitems) {
-    // strips travel global -> LDS by LDS-DMA (16 bytes per lane to a wave-uniform base + 16 * lane: the strip is
+    // stages travel global -> LDS by LDS-DMA (16 bytes per lane to a wave-uniform base + 16 * lane: the stage is
     // stored in exactly that order), no staging registers; the issuing wave waits for its own copies (vmcnt) in
     // front of the barrier that hands the buffer over
-    auto stage = [&](int strip, int b) {
-      const v4i* src = Yq + (size_t)strip * SB;
-      __attribute__((address_space(3))) v4i* dst = (__attribute__((address_space(3))) v4i*)sm + b * SB;
+    auto stage = [&](int st, int b) {
+      const v4i* src = Yq + (size_t)st * SG;
+      __attribute__((address_space(3))) v4i* dst = (__attribute__((address_space(3))) v4i*)sm + b * SG;
 #pragma unroll
       for (int u = 0; u < LPT; ++u) {
         const int ch = (u * 8 + wv) * 64;
-        if (ch < SB)
+        if (ch < SG)
           __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)(src + ch + lane),
                                            (__attribute__((address_space(3))) void*)(dst + ch), 16, 0, 0);
       }
@@ -258,21 +259,26 @@ __global__ __launch_bounds__(512) void k_null_i8(const v4i* __restrict__ Xq, con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     int it = 0;
+    v16i S2, S3, S4;
+    bool carry = false;
+    unsigned carry_perm0 = 0;
     for (int64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
       const int64_t tile = (item / nsplit) * 8 + wv;
       const int st0 = (int)(item % nsplit) * spp;
-      const int st1 = st0 + spp < nstrips ? st0 + spp : nstrips;
+      const int st1 = st0 + spp < nstages ? st0 + spp : nstages;
       const bool last = item + gridDim.x >= nitems;
       const int nxt0 = (int)((item + gridDim.x) % nsplit) * spp;
       const bool have = tile < ntiles;
       v4i a[3][KS];
       float ai[16], mi[16];
       {
-        const v4i* ap = Xq + (size_t)(have ? tile : 0) * (3 * KS * 64) + lane;
+        // row i = lane & 31 of the tile, bytes [32 s + 16 kh, + 16) of digit plane d (the k order inside a step is
+        // the same for A and B, whatever the instruction makes of it)
+        const unsigned char* ap = Xq + ((size_t)(have ? tile : 0) * 32 + j) * (3 * 32 * KS) + 16 * kh;
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
-          for (int s = 0; s < KS; ++s) a[d][s] = have ? ap[(d * KS + s) * 64] : (v4i){0, 0, 0, 0};
+          for (int s = 0; s < KS; ++s) a[d][s] = have ? *(const v4i*)(ap + d * 32 * KS + 32 * s) : (v4i){0, 0, 0, 0};
         const float2* rp = rowinfo + (size_t)(have ? tile : 0) * 32 + 4 * kh;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -281,29 +287,68 @@ __global__ __launch_bounds__(512) void k_null_i8(const v4i* __restrict__ Xq, con
           mi[r] = have ? 0.5f - ri.y : 0.5f;                  // zero rows (a = m = 0): never near
         }
       }
+      // Branch-free binning of the 16 outputs a lane holds of one column tile.  u = position clamped to
+      // [1/2, T + 1/2]: out-of-range outputs get the fraction 1/2 (never near a cut) and the bins 0 / T.  Bin 0
+      // (below the first cut) and the outputs within the margin of a cut land in row 0 of the counters, which
+      // nobody reads; the latter go to the recheck queue.
+      auto epilogue = [&](unsigned perm0) {
+        unsigned long long nm[16], anym = 0ull;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int w = S2[r] * 256 + S3[r] + (S4[r] >> 8);          // v / 256, the low byte of S4 is inside the margin
+          const float t = fmaf(fabsf((float)w), ai[r], bconst);
+          const float u = __builtin_amdgcn_fmed3f(t, 0.5f, Thi);
+          const bool near = fabsf(__builtin_amdgcn_fractf(u) - 0.5f) > mi[r];   // mi = 1/2 - margin
+          int h = (int)u;
+          nm[r] = __ballot(near);
+          anym |= nm[r];
+          h = near ? 0 : h;
+          if (MODE == 2) { if (h == 0x7fffff) atomicAdd(&hist[j], 1u); }
+          else atomicAdd(&hist[h * 32 + j], 1u);
+        }
+        if (__builtin_expect(anym != 0ull, 0)) {
+          const unsigned perm = perm0 + (unsigned)j;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const unsigned long long bal = nm[r];
+            if (bal == 0ull) continue;
+            if ((bal >> lane) & 1ull) {
+              const int pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+              qb[pos].x = (unsigned)(tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh);
+              qb[pos].y = perm;
+            }
+            wcount += __popcll(bal);
+            if (wcount > I8_QBUF - 64) flush();
+          }
+        }
+      };
       for (int st = st0; st < st1; ++st, ++it) {
-        // next strip (of this item or the first one of the next) on its way while this one is used
+        // next stage (of this item or the first one of the next) on its way while this one is used
         const bool more = st + 1 < st1 || !last;
         const int nst = st + 1 < st1 ? st + 1 : nxt0;
         if (more) stage(nst, (it + 1) & 1);
-        const v4i* buf = bbuf + ((it & 1) * SB + kh * 64 + j);
+        if (carry) {                                          // rotated waves: the last column tile of the previous stage
+          epilogue(carry_perm0);
+          carry = false;
+        }
+        const v4i* buf = bbuf + ((it & 1) * SG + kh * 64 + j);
         // B fragments one k step ahead of the products that use them, across the column-tile boundary as well
         v4i bq[2][3];
 #pragma unroll
         for (int d = 0; d < 3; ++d) bq[0][d] = buf[((d * KS) * 2) * 64];
         if (MODE != 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          v16i S2, S3, S4;
+        for (int c = 0; c < NCT; ++c) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) { S2[r] = 0; S3[r] = 0; S4[r] = 0; }
 #pragma unroll
           for (int s = 0; s < KS; ++s) {
             const int cs = c * KS + s;
-            if (cs + 1 < 2 * KS) {
+            if (cs + 1 < NCT * KS) {
               const int c1 = (cs + 1) / KS, s1 = (cs + 1) % KS;
 #pragma unroll
-              for (int d = 0; d < 3; ++d) bq[(cs + 1) & 1][d] = buf[((d * KS + s1) * 2) * 64 + c1 * 32];
+              for (int d = 0; d < 3; ++d)
+                bq[(cs + 1) & 1][d] = buf[(c1 >> 1) * SB + ((d * KS + s1) * 2) * 64 + (c1 & 1) * 32];
             }
             const v4i b0 = bq[cs & 1][0], b1 = bq[cs & 1][1], b2 = bq[cs & 1][2];
             if (MODE == 3) { S4[0] += b0[0] + a[0][s][0]; S3[1] += b1[1] + a[1][s][1]; S2[2] += b2[2] + a[2][s][2]; }
@@ -316,47 +361,23 @@ __global__ __launch_bounds__(512) void k_null_i8(const v4i* __restrict__ Xq, con
               S4 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[2][s], b0, S4, 0, 0, 0);
               // pin the order "three fragment reads of the next step, then the six products of this one": left alone the
               // scheduler sinks every read to just before its first use (one register quad, a wait per fragment)
-              if (cs + 1 < 2 * KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+              if (cs + 1 < NCT * KS) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
               __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
             }
           }
-          // Branch-free binning.  u = position clamped to [1/2, T + 1/2]: out-of-range outputs get the fraction
-          // 1/2 (never near a cut) and the bins 0 / T.  Outputs that count go to hist[h][j]; the others (below the
-          // first cut, or within the margin of a cut) add into a dump row of 64 words, one per lane.
           if (MODE == 1) {
             int z = 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z |= S2[r] ^ S3[r] ^ S4[r];
-            if (z == 0x12345678) atomicAdd(&hist[dumpi], 1u);
+            if (z == 0x12345678) atomicAdd(&hist[j], 1u);
             continue;
           }
-          unsigned long long nm[16], anym = 0ull;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int w = S2[r] * 256 + S3[r] + (S4[r] >> 8);        // v / 256, the low byte of S4 is inside the margin
-            const float t = fmaf(fabsf((float)w), ai[r], bconst);
-            const float u = __builtin_amdgcn_fmed3f(t, 0.5f, Thi);
-            const bool near = fabsf(__builtin_amdgcn_fractf(u) - 0.5f) > mi[r];   // mi = 1/2 - margin
-            const int h = (int)u;
-            nm[r] = __ballot(near);
-            anym |= nm[r];
-            if (MODE == 2) { if (h == 0x7fffff) atomicAdd(&hist[dumpi], 1u); }
-            else atomicAdd(&hist[((h > 0) & !near) ? h * 32 + j : dumpi], 1u);
-          }
-          if (__builtin_expect(anym != 0ull, 0)) {
-            const unsigned perm = (unsigned)(st * 64 + c * 32 + j);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const unsigned long long bal = nm[r];
-              if (bal == 0ull) continue;
-              if ((bal >> lane) & 1ull) {
-                const int pos = wcount + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                qb[pos].x = (unsigned)(tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh);
-                qb[pos].y = perm;
-              }
-              wcount += __popcll(bal);
-              if (wcount > I8_QBUF - 64) flush();
-            }
+          const unsigned perm0 = (unsigned)((st * G + (c >> 1)) * 64 + (c & 1) * 32);
+          if (c == NCT - 1 && rot && st + 1 < st1) {          // binned at the top of the next stage
+            carry = true;
+            carry_perm0 = perm0;
+          } else {
+            epilogue(perm0);
           }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -434,30 +455,36 @@ __global__ void k_i8_pick(const int* __restrict__ status, const int64_t* __restr
   if (t < T) out[t] = *status ? b[t] : a[t];
 }
 
-typedef int (*i8_launch_fn)(cna_ctx*, unsigned, size_t, const v4i*, const float2*, int64_t, const v4i*, int, int, int, int, float,
+typedef int (*i8_launch_fn)(cna_ctx*, unsigned, size_t, const unsigned char*, const float2*, int64_t, const v4i*, int, int, int, int, float,
                             unsigned int*, uint2*, unsigned long long*, unsigned long long, int*);
+// strips of 64 permutations per stage: as many as keep a stage near 40-50 KB (two stages + the counters in LDS)
+constexpr int i8_stage_strips(int KS) { return KS >= 5 ? 1 : (KS >= 3 ? 2 : 4); }
 template <int KS>
-static int launch_i8_t(cna_ctx* c, unsigned grid, size_t smem, const v4i* Xq, const float2* rowinfo, int64_t ntiles,
-                       const v4i* Yq, int nstrips, int nsplit, int spp, int T, float bconst, unsigned int* partial, uint2* queue,
+static int launch_i8_t(cna_ctx* c, unsigned grid, size_t smem, const unsigned char* Xq, const float2* rowinfo, int64_t ntiles,
+                       const v4i* Yq, int nstages, int nsplit, int spp, int T, float bconst, unsigned int* partial, uint2* queue,
                        unsigned long long* qcount, unsigned long long qcap, int* status) {
+  constexpr int G = i8_stage_strips(KS);
   static bool attr_set = false;
   if (!attr_set) {
-    HIP_TRY(hipFuncSetAttribute((const void*)k_null_i8<KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)k_null_i8<KS, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
+  static const int rotate = getenv("CNA_I8_ROT") ? atoi(getenv("CNA_I8_ROT")) : 0;   // measured: 2.53 -> 2.76 ms at 2M x 200, no change at N = 100 / 50 (tools/i8_rot.sh)
   if (const char* dbg = getenv("CNA_I8_MODE")) {                          // experiments
     const int m = atoi(dbg);
     if ((KS == 7 || KS == 2) && m >= 1 && m <= 3) {
-      auto kfn = m == 1 ? k_null_i8<(KS == 7 || KS == 2) ? KS : 7, 1> : (m == 2 ? k_null_i8<(KS == 7 || KS == 2) ? KS : 7, 2> : k_null_i8<(KS == 7 || KS == 2) ? KS : 7, 3>);
+      constexpr int K2 = (KS == 7 || KS == 2) ? KS : 7;
+      constexpr int G2 = i8_stage_strips(K2);
+      auto kfn = m == 1 ? k_null_i8<K2, G2, 1> : (m == 2 ? k_null_i8<K2, G2, 2> : k_null_i8<K2, G2, 3>);
       HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, c->stream, Xq, rowinfo, ntiles, Yq, nstrips, nsplit, spp, T, bconst, partial,
-                         queue, qcount, qcap, status);
+      hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, c->stream, Xq, rowinfo, ntiles, Yq, nstages, nsplit, spp, T, bconst, partial,
+                         queue, qcount, qcap, status, rotate);
       HIP_TRY(hipGetLastError());
       return 0;
     }
   }
-  hipLaunchKernelGGL(k_null_i8<KS>, dim3(grid), dim3(512), smem, c->stream, Xq, rowinfo, ntiles, Yq, nstrips, nsplit, spp, T,
-                     bconst, partial, queue, qcount, qcap, status);
+  hipLaunchKernelGGL((k_null_i8<KS, G>), dim3(grid), dim3(512), smem, c->stream, Xq, rowinfo, ntiles, Yq, nstages, nsplit, spp, T,
+                     bconst, partial, queue, qcount, qcap, status, rotate);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -465,19 +492,40 @@ static const i8_launch_fn kI8[8] = {launch_i8_t<1>, launch_i8_t<2>, launch_i8_t<
                                     launch_i8_t<5>, launch_i8_t<6>, launch_i8_t<7>, launch_i8_t<8>};
 
 static size_t i8_lds(int KS, int T) {
-  return (size_t)2 * 3 * KS * 128 * 16 + (size_t)(T + 1) * 32 * 4 + 256 + (size_t)8 * I8_QBUF * 8;
+  return (size_t)2 * i8_stage_strips(KS) * 3 * KS * 128 * 16 + (size_t)(T + 1) * 32 * 4 + 256 + (size_t)8 * I8_QBUF * 8;
 }
 
 // usable for this pass?  (samples within the register budget of the A operands, cuts an arithmetic
 // progression to well within a step and starting more than a step above zero -- zero rows and the
 // padding must stay below the first cut by more than any margin -- and the counters fit in LDS)
-bool null_i8_eligible(const cna_ctx* c, int P, int T, double cut0, double inv_step, double eps) {
+bool null_i8_enabled() {
   static const int off = getenv("CNA_NULL_F64") ? atoi(getenv("CNA_NULL_F64")) : 0;
-  if (off) return false;
+  return off == 0;
+}
+bool null_i8_eligible(const cna_ctx* c, int P, int T, double cut0, double inv_step, double eps) {
+  if (!null_i8_enabled()) return false;
   if (c->Nx > 256 || c->Nx < 2 || c->nx < 1) return false;
   if (!(inv_step > 0.0) || !(eps < 0.05) || !(cut0 * inv_step > 2.0) || !(cut0 * inv_step + T < 5e4)) return false;
   const int KS = (c->Nx + 31) / 32;
   return i8_lds(KS, T) <= 160 * 1024 && c->nx < (int64_t)1 << 31;
+}
+
+// Room for the digit planes of the current X: (tiles of 32 rows) x 3 x 32 KS bytes and one {max |x|, sum |q|} per
+// row; the rows past nx of the last tile are zero.  A change of shape invalidates what is there.
+int ensure_xq(cna_ctx* c, int KS) {
+  const int64_t rows = (c->nx + 31) / 32 * 32;
+  const int64_t need = rows * 3 * 32 * KS, need_s = rows * 16;
+  if (c->xq_valid && (c->xq_rows != rows || c->xq_KS != KS)) c->xq_valid = false;
+  if (c->xq_valid) return 0;
+  CNA_TRY(dev_reserve(c, &c->xq, &c->xq_cap, std::max<int64_t>(need, 256)));
+  CNA_TRY(dev_reserve(c, &c->xq_scale, &c->xq_scale_cap, std::max<int64_t>(need_s, 256)));
+  if (rows > c->nx) {
+    HIP_TRY(hipMemsetAsync((char*)c->xq + c->nx * 3 * 32 * KS, 0, (size_t)(rows - c->nx) * 3 * 32 * KS, c->stream));
+    HIP_TRY(hipMemsetAsync((char*)c->xq_scale + c->nx * 16, 0, (size_t)(rows - c->nx) * 16, c->stream));
+  }
+  c->xq_rows = rows;
+  c->xq_KS = KS;
+  return 0;
 }
 
 // sums_dev[t] = sum over permutations of #{cells : |x.yc| >= cuts[t]}; *status_out (device) = 0 when they are valid
@@ -493,11 +541,13 @@ int launch_null_local_i8(cna_ctx* c, const double* Yc_dev, int ldy, int P, const
   const double slack = eps + (cut0 * inv_step + T + 2.0) * 5e-7 + 1e-6;
   const int64_t ngroups = (ntiles + 7) / 8;
   // short inputs: split the strips of a group over several work items (>= ~12 items per workgroup)
+  const int G = i8_stage_strips(KS);
+  const int nstages = (nstrips + G - 1) / G;                 // the strips past P are zero: below every cut
   int nsplit = (int)((12 * 256 + ngroups - 1) / ngroups);
-  if (nsplit > nstrips / 2) nsplit = nstrips / 2;
+  if (nsplit > nstages) nsplit = nstages;
   if (nsplit < 1) nsplit = 1;
-  const int spp = (nstrips + nsplit - 1) / nsplit;
-  nsplit = (nstrips + spp - 1) / spp;
+  const int spp = (nstages + nsplit - 1) / nsplit;
+  nsplit = (nstages + spp - 1) / spp;
   const int64_t nitems = ngroups * nsplit;
   const unsigned grid = (unsigned)(nitems < 256 ? nitems : 256);
   const int nslabs = (int)grid + nrecheck;
@@ -505,9 +555,9 @@ int launch_null_local_i8(cna_ctx* c, const double* Yc_dev, int ldy, int P, const
   if (qcap < ((uint64_t)1 << 20)) qcap = (uint64_t)1 << 20;
   if (const char* e = getenv("CNA_I8_QCAP")) qcap = (uint64_t)atoll(e) > 0 ? (uint64_t)atoll(e) : qcap;   // tests: force the overflow path
   const int64_t sizes[] = {
-      (int64_t)16 * 3 * KS * 64 * ntiles,            // Xq
+      (int64_t)256,                                  // (X digit planes live in c->xq: written with X where possible)
       (int64_t)8 * 32 * ntiles,                      // rowinfo
-      (int64_t)16 * 3 * KS * 128 * nstrips,          // Yq
+      (int64_t)16 * 3 * KS * 128 * nstages * G,      // Yq
       (int64_t)8 * Ppad * ldt,                       // Yt
       (int64_t)8 * Ppad + 64,                        // colL1 | scal[2] | qcount | status
       (int64_t)8 * (int64_t)qcap,                    // queue
@@ -519,7 +569,9 @@ int launch_null_local_i8(cna_ctx* c, const double* Yc_dev, int ldy, int P, const
   char* base = (char*)c->i8_buf;
   int64_t off = 0;
   auto take = [&](int idx) { char* p = base + off; off += round_up64(sizes[idx], 256); return p; };
-  v4i* Xq = (v4i*)take(0);
+  take(0);
+  CNA_TRY(ensure_xq(c, KS));
+  const unsigned char* Xq = (const unsigned char*)c->xq;
   float2* rowinfo = (float2*)take(1);
   v4i* Yq = (v4i*)take(2);
   double* Yt = (double*)take(3);
@@ -533,6 +585,8 @@ int launch_null_local_i8(cna_ctx* c, const double* Yc_dev, int ldy, int P, const
   int64_t* sums_dev = (int64_t*)take(8);
   ProfScope ps(c, CNA_K_NULL_LOCAL);
   HIP_TRY(hipMemsetAsync(colL1, 0, (size_t)8 * Ppad + 64, c->stream));
+  if (nstages * G > nstrips)
+    HIP_TRY(hipMemsetAsync(Yq + (size_t)nstrips * 3 * KS * 128, 0, (size_t)16 * 3 * KS * 128 * (nstages * G - nstrips), c->stream));
   hipLaunchKernelGGL(k_y_absmax, dim3(16), dim3(1024), 0, c->stream, Yc_dev, ldy, N, P, scal);
   {
     const int64_t nthr = (int64_t)Ppad * 2 * KS;
@@ -540,10 +594,15 @@ int launch_null_local_i8(cna_ctx* c, const double* Yc_dev, int ldy, int P, const
                        scal, Yq, Yt, ldt, colL1);
   }
   hipLaunchKernelGGL(k_y_finish, dim3(1), dim3(1024), 0, c->stream, colL1, P, scal);
-  hipLaunchKernelGGL(k_quant_x, dim3((unsigned)ntiles), dim3(256), (size_t)3 * KS * 64 * 16, c->stream, c->X, c->ldx, c->nx, N,
-                     KS, scal, inv_step, slack, Xq, rowinfo);
+  if (!c->xq_valid) {                                        // X did not come with its digit planes
+    hipLaunchKernelGGL(k_quant_x, dim3((unsigned)ntiles), dim3(256), 0, c->stream, c->X, c->ldx, c->nx, N, 32 * KS,
+                       (unsigned char*)c->xq, (double2*)c->xq_scale);
+    c->xq_valid = true;
+  }
+  hipLaunchKernelGGL(k_rowinfo, dim3((unsigned)((ntiles * 32 + 255) / 256)), dim3(256), 0, c->stream, (const double2*)c->xq_scale,
+                     c->nx, ntiles * 32, N, scal, inv_step, slack, rowinfo);
   const float bconst = (float)(1.0 - cut0 * inv_step);
-  CNA_TRY(kI8[KS - 1](c, grid, i8_lds(KS, T), Xq, rowinfo, ntiles, Yq, nstrips, nsplit, spp, T, bconst, slabs, queue, qcount, qcap, status));
+  CNA_TRY(kI8[KS - 1](c, grid, i8_lds(KS, T), Xq, rowinfo, ntiles, Yq, nstages, nsplit, spp, T, bconst, slabs, queue, qcount, qcap, status));
   hipLaunchKernelGGL(k_null_recheck, dim3(nrecheck), dim3(256), (size_t)4 * (T + 1), c->stream, c->X, c->ldx, N, Yt, ldt, queue,
                      qcount, qcap, cuts_dev, T, cut0, inv_step, slabs + (size_t)grid * (T + 1));
   hipLaunchKernelGGL(k_i8_reduce, dim3((unsigned)((T + 3) / 4)), dim3(256), 0, c->stream, slabs, nslabs, T, hist);

@@ -211,7 +211,11 @@ __global__ __launch_bounds__(256) void k_select_std(const double* __restrict__ n
                                                     int64_t nx, int Nx, int ldx, unsigned long long* nzero,
                                                     const double* __restrict__ y, double* __restrict__ nc,
                                                     unsigned long long* __restrict__ blockmax,
-                                                    const double* __restrict__ Wg, const double* __restrict__ Ctg, int rk) {
+                                                    const double* __restrict__ Wg, const double* __restrict__ Ctg, int rk,
+                                                    unsigned char* __restrict__ xq, double2* __restrict__ xscale, int Kp) {
+  // xq != null: the rows also leave as the 24-bit fixed-point digit planes of the integer local null
+  // (null_i8.hip: [row][digit][Kp] bytes, one scale per row, {max |x|, sum |q|} in xscale), so that pass
+  // does not have to read X again.
   // y != null: the rows leave this kernel final, so the neighbourhood coefficients
   // ncorrs = X.y/N (_association.py:77) and their max |.| are taken on the way out, as k_ncorrs would.
   // rk > 0: a projector M = I - C.W in factored form (W: rk x Nx, C^T: rk x Nx, see k_resid_lowrank) is
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(256) void k_select_std(const double* __restrict__ n
   constexpr int RPW = 4;
   extern __shared__ double lw[];
   __shared__ unsigned long long wmax[4];
+  __shared__ unsigned qstage[4][192];
   for (int i = threadIdx.x; i < 2 * rk * Nx; i += 256) lw[i] = i < rk * Nx ? Wg[i] : Ctg[i - rk * Nx];
   if (rk > 0) __syncthreads();
   const double* Wl = lw;
@@ -295,13 +300,47 @@ __global__ __launch_bounds__(256) void k_select_std(const double* __restrict__ n
         }
       }
       const double sd = sqrt(wave_sum(ss) / (n - 1.0));
-      double dot = 0.0;
+      double dot = 0.0, amax = 0.0;
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int col = lane + 64 * q;
         const double xs = col < Nx ? __ddiv_rn(x[r][q], sd) : 0.0;
         if (col < ldx) X[(base + r) * ldx + col] = xs;
         dot += yv[q] * xs;
+        x[r][q] = xs;
+        amax = fmax(amax, fabs(xs));                      // NaN rows (zero variance): fmax drops them, q = 0 below
+      }
+      if (xq) {
+        const double rmax = wave_max_d(amax);
+        const double inv = rmax > 0.0 ? I8_QMAX / rmax : 0.0;
+        // bytes of a row meet in LDS (one plane = 256 bytes per wave) and leave as dwords: three 4 Kp / 4-lane stores
+        // per row instead of twelve byte stores (partial-line writes: +0.6 ms at 2M x 200)
+        unsigned char* qb = (unsigned char*)qstage[wv];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          const int col = lane + 64 * q;
+          if (col < Kp) {
+            const double v = x[r][q] * inv;
+            const int qi = v == v ? (int)rint(v) : 0;
+            // balanced base-256 digits: the low byte of qi, of (qi + 128) >> 8 and of ((qi + 128) >> 8) + 128 >> 8
+            const int q1 = (qi + 128) >> 8;
+            qb[col] = (unsigned char)qi;
+            qb[256 + col] = (unsigned char)q1;
+            qb[512 + col] = (unsigned char)((q1 + 128) >> 8);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (4 * lane < Kp) {
+          unsigned* rq = (unsigned*)(xq + (size_t)(base + r) * 3 * Kp);
+          rq[lane] = qstage[wv][lane];
+          rq[Kp / 4 + lane] = qstage[wv][64 + lane];
+          rq[2 * (Kp / 4) + lane] = qstage[wv][128 + lane];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // sum |q| from above instead of a reduction: the row has sum x^2 = N - 1, so sum |x| < N and
+        // sum |q| <= N Q / max|x| + N / 2
+        const double l1 = rmax > 0.0 ? n * (I8_QMAX / rmax) + n : 0.0;
+        if (lane == 0) xscale[base + r] = make_double2(rmax, l1);
       }
       if (y) {
         const double v = wave_sum(dot) / n;
@@ -755,7 +794,8 @@ int launch_select_zv(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* 
 }
 
 int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev, const double* y_dev,
-                      unsigned long long* maxbits_dev, const double* W_dev, const double* Ct_dev, int rk) {
+                      unsigned long long* maxbits_dev, const double* W_dev, const double* Ct_dev, int rk,
+                      unsigned char* xq, void* xscale, int Kp) {
   // maxbits_dev (with y_dev): [0] = max |ncorrs| bits, [1 ..] per-workgroup partials (4097 words)
   HIP_TRY(hipMemsetAsync(nzero_dev, 0, sizeof(unsigned long long), c->stream));
   if (maxbits_dev) HIP_TRY(hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned long long), c->stream));
@@ -766,7 +806,7 @@ int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long*
   const size_t smem = sizeof(double) * 2 * (size_t)rk * c->Nx;
   if (smem > 128 * 1024) CNA_FAIL(CNA_EINVAL, "projector factors too large for LDS");
 #define SS_LAUNCH(Q) { static bool once = false; if (smem > 48 * 1024 && !once) { HIP_TRY(hipFuncSetAttribute((const void*)k_select_std<Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)); once = true; } \
-    hipLaunchKernelGGL(k_select_std<Q>, dim3(grid), dim3(256), smem, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev, y_dev, c->ncorrs, maxbits_dev ? maxbits_dev + 1 : nullptr, W_dev, Ct_dev, rk); }
+    hipLaunchKernelGGL(k_select_std<Q>, dim3(grid), dim3(256), smem, c->stream, c->nam, c->ld, c->keep_idx, colmap_dev, c->X, c->nx, c->Nx, c->ldx, nzero_dev, y_dev, c->ncorrs, maxbits_dev ? maxbits_dev + 1 : nullptr, W_dev, Ct_dev, rk, xq, (double2*)xscale, Kp); }
   switch ((c->ldx + 63) / 64) {
     case 1: SS_LAUNCH(1) break;
     case 2: SS_LAUNCH(2) break;

@@ -1,5 +1,6 @@
 """CPU checks of the host-side graph helpers of the C ABI (csrc/host_graph.c): content hash, cluster
 order, per-block source lists.  No device involved."""
+import pytest
 import numpy as np
 import scipy.sparse as sp
 
@@ -100,3 +101,15 @@ def test_permute_rows_equals_numpy_formulation():
             assert np.array_equal(ip, ref.indptr.astype(np.int64))
             assert np.array_equal(ix, _order.inverse(perm)[ref.indices]) and ix.dtype == np.int32
             assert np.array_equal(da, ref.data) and da.dtype == dt
+
+
+@pytest.mark.parametrize('n,threads', [(0, 4), (1, 4), (131071, 3), (3_000_001, 8), (2_000_000, 1)])
+def test_host_copy_is_a_memcpy_whatever_the_thread_count(n, threads):
+    """cna_host_copy (the per-cell result column into the caller's frame) on odd sizes and thread counts."""
+    from cna_amd import _ffi
+    lib = _ffi.load()
+    rs = np.random.RandomState(n % 97)
+    src = rs.randn(n)
+    dst = np.full(n + 2, -7.0)
+    assert lib.cna_host_copy(dst[1:1 + n].ctypes.data if n else None, src.ctypes.data if n else None, 8 * n, threads) == 0
+    assert np.array_equal(dst[1:1 + n], src) and dst[0] == -7.0 and dst[-1] == -7.0

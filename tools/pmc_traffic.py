@@ -13,7 +13,8 @@ import pandas as pd
 
 d = sys.argv[1]
 # device kernel -> bench kernel name (cna_prof_*), and how many bench launches one step makes
-NAMES = [('k_nam_first', 'nam_first'), ('k_nam_step', 'nam_step'), ('k_null', 'null_local'), ('k_hist_reduce', 'null_local'),
+NAMES = [('k_nam_first', 'nam_first'), ('k_nam_step', 'nam_step'), ('k_null', 'null_local'), ('k_hist_reduce', 'null_local'), ('k_quant_', 'null_local'), ('k_y_', 'null_local'),
+         ('k_i8_', 'null_local'),
          ('k_gram_reduce', 'gram_reduce'), ('k_gram', 'gram'), ('k_select_std', 'select'), ('k_select', 'select'),
          ('k_xb', 'resid_xb'), ('k_standardize', 'standardize'), ('k_ncorrs', 'ncorrs'), ('k_cond', 'condition'),
          ('k_gt_', 'global_test'), ('k_obs_counts', 'obs_counts'), ('k_percell', 'percell_fdr')]
