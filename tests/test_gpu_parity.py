@@ -264,6 +264,30 @@ def test_local_null_i8_sums_equal_f64_kernel(eng, n, N, P, heavy):
         assert np.array_equal(sums, tails[3:70].sum(axis=0))
 
 
+@pytest.mark.parametrize('name', ['c01_plain_f32', 'c03_covs_batches', 'c05_ks_f64', 'c12_batchy_qc'])
+def test_local_null_i8_on_the_planes_written_by_the_selection_pass(eng, name):
+    """After an analysis the working matrix, its fixed-point digit planes (written by the selection pass where
+    that pass produced X, by k_quant_x otherwise) and the conditioned phenotypes are resident: the integer
+    pass on them must return the f64 kernel's integers, and the FDR table of the analysis must be the one those
+    integers give."""
+    case = load_case(name)
+    res, err, _ = run_product(case, eng)
+    assert err is None
+    thr = res.fdrs.threshold.values
+    edges = thr ** 2 - 1e-8 - 1e-5 * thr ** 2
+    P = min(1000, int(case['call'].get('Nnull', 1000)))
+    tails = eng.null_local_resident(1, P, edges)
+    sums = eng.null_local_resident(1, P, edges, sums_only=True)
+    used, rechecked, fallback = eng.null_local_i8_stats()
+    assert used and not fallback
+    assert np.array_equal(sums, tails.sum(axis=0))
+    # the FDR table of the analysis is mean_p(tails / ranks): rebuild it from the f64 tails
+    ranks = np.array([(res.ncorrs.values ** 2 >= e).sum() for e in edges])
+    with np.errstate(all='ignore'):
+        want = (tails / ranks).mean(axis=0)
+    np.testing.assert_allclose(res.fdrs.fdr.values, want, rtol=1e-12, equal_nan=True)
+
+
 def test_local_null_i8_falls_back_when_the_queue_overflows(eng, monkeypatch):
     """A recheck queue too small for the outputs near a cut (forced here through CNA_I8_QCAP): the integer
     pass gives up on the device (status word) and the stand-by f64 kernel behind it produces the sums."""
