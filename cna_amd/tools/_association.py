@@ -20,7 +20,7 @@ import pandas as pd
 
 from .. import _ffi
 from ..engine import get_engine
-from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_plan, _resid_run, sample_codes_cached,
+from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_plan, _resid_run, sample_codes_cached, confirm_codes,
                    shard_of, global_samples,
                    _small_svd, _defer_pcs, host_blas_threads)
 from ._out import select_output
@@ -426,6 +426,14 @@ def _association_attempts(eng, rng_state, data, y, sid_name, batches, covs, dono
             except _StaleGraph:
                 if rng_state is not None:
                     np.random.set_state(rng_state)
+            except Exception:
+                # an error of the optimistic attempt counts only if its inputs were what the memos said
+                stale = not confirm_codes()
+                stale = (hasattr(eng, 'confirm_graph') and not eng.confirm_graph()) or stale
+                if attempt == 1 or not stale:
+                    raise
+                if rng_state is not None:
+                    np.random.set_state(rng_state)
             finally:
                 eng._defer_graph_check = False
         raise RuntimeError('the connectivities matrix keeps changing while it is being analysed')
@@ -448,8 +456,11 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
 
     # factorise the per-cell sample ids once; validation and NAM construction share the result
     _mark('enter')
-    codes, labels, counts, token = sample_codes_cached(data.obs[sid_name])
     sharded = shard_of(data) is not None
+    # one GPU: the content hash of the ids is checked on a helper thread, like the graph's (confirm_graph below)
+    defer_ids = (getattr(engine, '_defer_graph_check', False) and not sharded and getattr(engine, 'nranks', 1) == 1
+                 and not getattr(engine, '_has_comm', False))
+    codes, labels, counts, token = sample_codes_cached(data.obs[sid_name], defer=defer_ids)
     if sharded:      # this rank's cells only: agree with the other ranks on the samples and their sizes
         codes, labels, counts, token = global_samples(engine, codes, labels, counts, token)
     _mark('codes')
@@ -556,7 +567,8 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     previous = data.obs[key_added] if had_key else None
 
     def confirm_graph():
-        if hasattr(engine, 'confirm_graph') and not engine.confirm_graph():
+        ok = confirm_codes()
+        if (hasattr(engine, 'confirm_graph') and not engine.confirm_graph()) or not ok:
             raise _StaleGraph()
 
     fdr_key = f'{key_added}_fdr'

