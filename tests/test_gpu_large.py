@@ -119,7 +119,18 @@ def test_large_properties_and_renumbering(big, eng):
     p, k = res.p, res.k
     ks = list(res.ks)
     assert k in ks
-    del res
+    # the local null of that analysis ran on the integer matrix cores (csrc/null_i8.hip): on the state it left on
+    # the device, the f64 kernel must count the very same integers, threshold by threshold, at full size
+    edges = thr ** 2 - 1e-8 - 1e-5 * thr ** 2
+    tails = eng.null_local_resident(1, 1000, edges)
+    sums = eng.null_local_resident(1, 1000, edges, sums_only=True)
+    used, rechecked, fallback = eng.null_local_i8_stats()
+    assert used and not fallback and rechecked < 1e-3 * n * 1000
+    assert np.array_equal(sums, tails.sum(axis=0))
+    ranks = np.array([(np.nan_to_num(coef) ** 2 >= e).sum() for e in edges])
+    with np.errstate(all='ignore'):
+        np.testing.assert_allclose(fdr, (tails / ranks).mean(axis=0), rtol=1e-12, equal_nan=True)
+    del res, tails
 
     # the same analysis with the cells renumbered at random: the global p-value, the chosen k, the FDR
     # table and every cell's coefficient must not move
