@@ -288,6 +288,37 @@ def test_local_null_i8_on_the_planes_written_by_the_selection_pass(eng, name):
     np.testing.assert_allclose(res.fdrs.fdr.values, want, rtol=1e-12, equal_nan=True)
 
 
+@pytest.mark.parametrize('kind', ['irregular', 'many', 'near_zero', 'wide'])
+def test_local_null_sums_outside_the_integer_path(eng, kind):
+    """Passes the integer kernel does not take -- thresholds that are no arithmetic progression, more
+    thresholds than its LDS counters hold, a first cut within a step of zero, more than 256 samples -- go to
+    the f64 kernel and give the same sums as the per-permutation tails."""
+    rs = np.random.RandomState(11)
+    n, N, P = (1500, 40, 130) if kind != 'wide' else (300, 300, 70)
+    X = rs.randn(n, N)
+    X = (X - X.mean(axis=1, keepdims=True))
+    X /= X.std(axis=1, ddof=1)[:, None]
+    eng.upload_x(X)
+    nc, maxabs = eng.ncorrs(rs.randn(N), fetch=True)
+    Yc = rs.randn(N, P)
+    Yc /= Yc.std(axis=0, ddof=1)
+    if kind == 'irregular':
+        thr = np.sort(maxabs * (0.2 + 0.8 * rs.rand(120)))
+    elif kind == 'many':
+        thr = np.arange(maxabs / 4, maxabs, maxabs / 670)
+    elif kind == 'near_zero':
+        thr = np.arange(maxabs / 1000, maxabs, maxabs / 300)
+    else:
+        thr = np.arange(maxabs / 4, maxabs, maxabs / 400)
+    edges = thr ** 2 - 1e-8 - 1e-5 * thr ** 2
+    edges = edges[edges > 0]
+    tails = eng.null_local(Yc, edges)
+    sums = eng.null_local_resident(0, P, edges, sums_only=True)
+    used, rechecked, fallback = eng.null_local_i8_stats()
+    assert not used and rechecked == 0
+    assert np.array_equal(sums, tails.sum(axis=0))
+
+
 def test_local_null_i8_falls_back_when_the_queue_overflows(eng, monkeypatch):
     """A recheck queue too small for the outputs near a cut (forced here through CNA_I8_QCAP): the integer
     pass gives up on the device (status word) and the stand-by f64 kernel behind it produces the sums."""
