@@ -489,7 +489,16 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
 
     early = {}
 
+    import threading
+    walk_queued = threading.Event()
+    # many cells: the walk is long enough to hide the draw wherever it starts, and a helper thread that starts
+    # at once takes the interpreter from this thread's launches (0.2-0.3 ms later first kernel at 2M cells);
+    # few cells: the draw is on the critical path and starts at once (holding it back: 2.46 -> 3.0 ms at 200k)
+    hold_draw = _DRAW_THREAD and len(data.obs) >= _COEF_FIRST_CELLS
+
     def null_job():
+        if hold_draw:
+            walk_queued.wait(0.004)
         _mark('draw starts')
         out_ = _draw_null(yv, bv, dv,
                           Nnull=Nnull, force_permute_all=kwargs.get('force_permute_all', False),
@@ -529,6 +538,7 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
             null_future.run()
         return plan
 
+    engine._on_walk_queued = walk_queued.set
     try:
         kept, sample_index, colmap, batches, covs, donorids, filter_samples, plan = \
             compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
@@ -536,8 +546,12 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                                     nam_queued=nam_queued, y_std=y_std,
                                     fuse_null=min(1000, Nnull) if kwargs.get('local_test', True) and _FUSE else 0)
     except BaseException:
+        walk_queued.set()
         null_future.cancel() or null_future.exception()     # do not leave the helper thread running
         raise
+    finally:
+        engine._on_walk_queued = None
+        walk_queued.set()
 
     def cell_index():
         # names of the kept cells: only needed for the frames of a full result

@@ -283,6 +283,14 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
     """Reference ``_nam`` (_nam.py:44-76) with the state resident on the GPU.  On return the
     engine holds NAM = (s/C) (cells x samples); returns (labels, steps taken)."""
     out = select_output(show_progress)
+
+    def walk_queued():
+        # lets a caller hold back host work that competes for the interpreter (the permutation draw on its helper
+        # thread) until the first kernels are on the device
+        cb = getattr(engine, '_on_walk_queued', None)
+        if cb is not None:
+            engine._on_walk_queued = None
+            cb()
     _prepare_graph(engine, data, self_weight)
     token = None
     if codes_labels is not None and len(codes_labels) == 4:
@@ -305,6 +313,7 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
         sig = (token, nsteps, maxnsteps, float(self_weight))
         held = getattr(engine, '_nam_sig', None)
         if held is not None and held[0] == sig and held[1] == engine.nam_epoch:
+            walk_queued()
             return labels, held[2]
     C = counts.astype(np.float64)
     engine.set_samples(codes, N, C, token=token)
@@ -316,12 +325,14 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
     taken = 0
     if not need_kurt and 1 <= nsteps <= maxnsteps:
         engine.nam_steps(nsteps)                 # nothing to decide between steps: one call queues them all
+        walk_queued()
         engine._nam_sig = (sig, engine.nam_epoch, nsteps) if sig is not None else None
         return labels, nsteps
     for i in range(maxnsteps):
         last_for_sure = (nsteps is not None and i + 1 == nsteps) or (i + 1 == maxnsteps)
         may_stop = last_for_sure or show_progress or (nsteps is None and i + 1 >= 3)
         engine.nam_step(need_kurt, not last_for_sure, may_stop)
+        walk_queued()
         taken = i + 1
         if need_kurt:
             medkurt = engine.stat_median()
