@@ -44,6 +44,7 @@ def _background():
     return _pool
 
 
+_EARLY_WALK = os.environ.get('CNA_EARLY_WALK', '1') not in ('0', 'off', 'no')
 _EARLY_COEF = os.environ.get('CNA_EARLY_COEF', '1') not in ('0', 'off', 'no')     # ablation switches
 _DRAW_THREAD = os.environ.get('CNA_DRAW_THREAD', '1') not in ('0', 'off', 'no')
 _SWITCH_INTERVAL = float(os.environ.get('CNA_SWITCH_INTERVAL', '5e-5'))   # GIL hand-over between the helper thread and this one: 2.08 -> 1.86 ms per call at 200k cells (default interval: 5 ms)
@@ -464,10 +465,28 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     if sharded:      # this rank's cells only: agree with the other ranks on the samples and their sizes
         codes, labels, counts, token = global_samples(engine, codes, labels, counts, token)
     _mark('codes')
-    nam_queued = None
+    # The walk needs the graph and the sample ids only: it is queued before the (pandas) validation of the
+    # sample-level inputs, which then runs under it.  An error of the walk is held back until validation has
+    # had its say -- the order in which the reference would have raised; with progress output the reference's
+    # order of lines is kept instead (validation messages, then 'computing NAM').
+    import threading
+    walk_queued = threading.Event()
+    nam_queued = nam_error = None
+    if not show_progress and _EARLY_WALK:
+        engine._on_walk_queued = walk_queued.set
+        try:
+            nam_queued = _nam_device(engine, data, sid_name, nsteps=nsteps, show_progress=False,
+                                     codes_labels=(codes, labels, counts, token))
+        except Exception as exc:             # noqa: BLE001 - re-raised below, after validation
+            nam_error = exc
+        finally:
+            engine._on_walk_queued = None
+            walk_queued.set()
     used = counts > 0
     batches, filter_samples = check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size,
                                            sids_present=labels[used] if isinstance(y, pd.Series) or sharded else None)
+    if nam_error is not None:
+        raise nam_error
 
     # the permutation draw (numpy RNG + argsort, both outside the GIL) needs only sample-level
     # inputs: it starts on the helper thread right away and is collected just before the
@@ -489,8 +508,6 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
 
     early = {}
 
-    import threading
-    walk_queued = threading.Event()
     # many cells: the walk is long enough to hide the draw wherever it starts, and a helper thread that starts
     # at once takes the interpreter from this thread's launches (0.2-0.3 ms later first kernel at 2M cells);
     # few cells: the draw is on the critical path and starts at once (holding it back: 2.46 -> 3.0 ms at 200k)
