@@ -84,7 +84,7 @@ def _host_copy(dst, src):
         from .. import _ffi
         from .._order import usable_cpus
         lib = _ffi.load()
-        if lib.cna_host_copy(dst.ctypes.data, src.ctypes.data, dst.nbytes, min(8, usable_cpus(8))) == 0:
+        if lib.cna_host_copy(dst.ctypes.data, src.ctypes.data, dst.nbytes, min(4, usable_cpus(4))) == 0:   # 4: best on the box (thread start-up beyond)
             return
     except Exception:
         pass
