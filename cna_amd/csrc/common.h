@@ -297,10 +297,31 @@ __device__ __forceinline__ double dpp_add(double v, const int ctrl_sel) {
   }
   return v + __hiloint2double(hi2, lo2);
 }
+// the partner value of a DPP step (see dpp_add) without the addition
+__device__ __forceinline__ double dpp_partner(double v, const int ctrl_sel) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  int lo2, hi2;
+  switch (ctrl_sel) {
+    case 0: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;
+    case 1: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;
+    case 2: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break;
+    default: lo2 = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); hi2 = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break;
+  }
+  return __hiloint2double(hi2, lo2);
+}
+// max over the 64 lanes of a wave (non-negative inputs; NaN-free), in every lane: DPP steps inside the rows of 16,
+// scalar reads across them -- no LDS traffic (a __shfl_xor of a double is two ds_bpermute round trips per step)
 __device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-  return v;
+  v = fmax(v, dpp_partner(v, 0));
+  v = fmax(v, dpp_partner(v, 1));
+  v = fmax(v, dpp_partner(v, 2));
+  v = fmax(v, dpp_partner(v, 3));
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return fmax(fmax(r0, r1), fmax(r2, r3));
 }
 __device__ __forceinline__ double wave_sum(double v) {
   v = dpp_add(v, 0);
