@@ -145,8 +145,15 @@ def test_large_properties_and_renumbering(big, eng):
     assert res2.p == p and res2.k == k
     # sums over neighbours run in a different order: equal to rounding, counts identical
     np.testing.assert_allclose(data2.obs['coef'].values, coef[perm], rtol=1e-9, atol=1e-13)
-    assert np.array_equal(res2.fdrs.num_detected.values, num)
-    np.testing.assert_allclose(res2.fdrs.fdr.values, fdr, rtol=1e-9, equal_nan=True)
+    # thresholds = np.arange(m/4, m, m/400) has 300 or 301 entries depending on the last bit of m = max |coef|
+    # (numpy's ceil((stop - start) / step) at 300.0000...), which the order of the sums may move: compare the
+    # common ones
+    T2 = len(res2.fdrs)
+    assert abs(T2 - len(num)) <= 1
+    T = min(T2, len(num))
+    np.testing.assert_allclose(res2.fdrs.threshold.values[:T], thr[:T], rtol=1e-12)
+    assert np.array_equal(res2.fdrs.num_detected.values[:T], num[:T])
+    np.testing.assert_allclose(res2.fdrs.fdr.values[:T], fdr[:T], rtol=1e-9, equal_nan=True)
 
 
 def test_large_nam_slice_vs_oracle(big, eng, orc):
