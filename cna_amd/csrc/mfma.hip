@@ -319,10 +319,13 @@ __global__ __launch_bounds__(64 * NW) void k_gram_db(const double* __restrict__ 
 #pragma unroll 1
     for (int kq = 0; kq < SLAB / 4; ++kq) {
       const double* rowp = buf + (4 * kq + ak) * ldp + ai;
+      // consecutive tiles of a wave mostly share their row of the tile table (row-major upper triangle): the A
+      // fragment is read again only when it changes (uniform compare) -- 12 -> ~7.5 LDS reads per 6 MFMAs
+      double a = 0.0;
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
         if (live[t]) {
-          const double a = rowp[off_i[t]];
+          if (TPW < 5 || t == 0 || off_i[t] != off_i[t - 1]) a = rowp[off_i[t]];   // (short lists: the compare costs more than it saves -- 318 -> 565 us at N = 130)
           const double b = rowp[off_j[t]];
           acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
         }
