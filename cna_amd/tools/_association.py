@@ -607,6 +607,21 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     previous_fdr = data.obs[fdr_key] if had_fdr else None
     big = len(data.obs) >= _COEF_FIRST_CELLS
 
+    def roll_back():
+        # put data.obs back as it was: columns written early must not outlive a failed (or stale) attempt
+        if early_coef.pop('written', False):
+            if had_key:
+                data.obs[key_added] = previous
+            elif key_added in data.obs:
+                del data.obs[key_added]
+            if 'fdr_view' in early_coef or (big and fdr_key in data.obs and not had_fdr):
+                if had_fdr:
+                    data.obs[fdr_key] = previous_fdr
+                elif fdr_key in data.obs:
+                    del data.obs[fdr_key]
+            early_coef.pop('fdr_view', None)
+            early_coef.pop('values', None)
+
     def write_coef_early(coef):
         confirm_graph()                                   # nothing reaches data.obs from a stale graph
         early_coef['written'] = True
@@ -630,19 +645,14 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                                                  coef_first=len(data.obs) >= _COEF_FIRST_CELLS,
                                                  coef_launched=getattr(plan, 'coef_launched', False))
     except BaseException:
-        if early_coef.get('written'):
-            if had_key:
-                data.obs[key_added] = previous
-            elif key_added in data.obs:
-                del data.obs[key_added]
-            if 'fdr_view' in early_coef or (big and fdr_key in data.obs and not had_fdr):
-                if had_fdr:
-                    data.obs[fdr_key] = previous_fdr
-                elif fdr_key in data.obs:
-                    del data.obs[fdr_key]
+        roll_back()
         raise
     _mark('_association returned')
-    confirm_graph()
+    try:
+        confirm_graph()
+    except _StaleGraph:
+        roll_back()                                   # the retry starts from the frame as the caller left it
+        raise
     _defer_pcs(res, engine, U, svs, cell_index)
     res.kept = kept
 

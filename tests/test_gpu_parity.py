@@ -652,8 +652,11 @@ def test_ordered_fetch_on_device_equals_host_reorder(monkeypatch):
         np.testing.assert_array_equal(a, b)
 
 
-def test_failed_test_leaves_obs_untouched(eng, monkeypatch):
-    """data.obs[key_added] is written early (between the two halves of the F-test call, under the
+@pytest.mark.parametrize('big_path', [False, True])
+def test_failed_test_leaves_obs_untouched(eng, monkeypatch, big_path):
+    """(big_path: the schedule of large inputs -- coefficient column under the Gram kernels, the FDR column's
+    storage made early and filled in place at the end -- forced on this small dataset.)
+    data.obs[key_added] is written early (between the two halves of the F-test call, under the
     local-null kernel).  When the
     association test then fails, the column is put back -- absent if it was absent, the old values if
     it existed -- and the next call works: like upstream, an exception leaves data.obs alone."""
@@ -661,6 +664,8 @@ def test_failed_test_leaves_obs_untouched(eng, monkeypatch):
     from cna_amd import synth
     from cna_amd.tools import _association as A
     assert A._EARLY_COEF
+    if big_path:
+        monkeypatch.setattr(A, '_COEF_FIRST_CELLS', 0)
     data, meta = synth.make_dataset(5000, 24, k=15, seed=3)
     kw = dict(Nnull=100, seed=1, nsteps=3)
 
@@ -684,6 +689,7 @@ def test_failed_test_leaves_obs_untouched(eng, monkeypatch):
     with pytest.raises(FloatingPointError):
         cna.tl.association(data, y2, 'id', engine=eng, **kw)
     np.testing.assert_array_equal(data.obs['coef'].values, before)
+    np.testing.assert_array_equal(data.obs['coef_fdr'].values, before_fdr)
     monkeypatch.setattr(eng, 'global_test_fetch', real)
     assert cna.tl.association(data, meta['y'], 'id', engine=eng, **kw) == p1
     np.testing.assert_array_equal(data.obs['coef'].values, before)
