@@ -71,7 +71,7 @@ def algorithmic_work(kernel, n, nnz, N, P, T, wA):
     if kernel == 'null_local':
         return 'mfma', 2.0 * n * N * P
     if kernel == 'gram':
-        return 'mfma', 2.0 * n * N * N
+        return 'mfma', 1.0 * n * N * (N + 1)          # X^T X is symmetric: the upper triangle is all the algorithm needs
     if kernel in ('resid_xb', 'project_xb'):
         return 'mfma', 2.0 * n * N * N
     if kernel == 'colsum':
