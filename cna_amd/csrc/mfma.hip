@@ -9,6 +9,7 @@
 //   A[i][k]: i = lane & 15, k = lane >> 4        B[k][j]: k = lane >> 4, j = lane & 15
 //   D[r][j]: r = (lane >> 4) + 4*reg, j = lane & 15,  reg in 0..3
 #include "common.h"
+#include <algorithm>
 #include <array>
 #include <cstdlib>
 #include <utility>
@@ -254,6 +255,105 @@ __global__ __launch_bounds__(64 * NW) void k_gram(const double* __restrict__ X, 
     }
   }
 }
+// X^T X with the tiles of a wave arranged as a 3 x 3 block (three tile rows x three tile columns of the upper
+// triangle): per k step three A and three B fragments from LDS feed up to nine MFMAs -- 0.67-1 LDS reads per
+// MFMA against 1.25 (k_gram_db with the A reuse) or 2 (without).  On this chip an f64 MFMA does not hide the
+// LDS -> VGPR return of its operands (tools/micro/mfma_f64_rate.hip), so reads per MFMA set the pipe's duty.
+// One block per wave, sixteen waves: fits when the triangle has at most 16 blocks, i.e. 11 <= tiles per side
+// <= 15 (161 ... 240 samples); `blocks` holds per wave {i0, i1, i2, j0, j1, j2} (tile indices, -1: unused) in
+// an order that spreads the work over the four SIMDs; tixmap[i * nt + j] = index of tile (i, j) in the
+// upper-triangular table k_gram_reduce walks.
+template <int NW, int SLAB>
+__global__ __launch_bounds__(64 * NW) void k_gram_blk(const double* __restrict__ X, int64_t nx, int ldx, int nt,
+                                                  int ldp, int ntri, const int32_t* __restrict__ blocks,
+                                                  const int32_t* __restrict__ tixmap, double* __restrict__ partial) {
+  extern __shared__ double sm[];
+  constexpr int NT = 64 * NW, PF = 5;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ak = lane >> 4, ai = lane & 15;
+  int ri[3], cj[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    ri[r] = __builtin_amdgcn_readfirstlane(blocks[wv * 8 + r]);
+    cj[r] = __builtin_amdgcn_readfirstlane(blocks[wv * 8 + 3 + r]);
+  }
+  bool live[9];
+  v4d acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    live[t] = ri[t / 3] >= 0 && cj[t % 3] >= ri[t / 3];
+  }
+  for (int i = tid; i < 2 * SLAB * ldp; i += NT) sm[i] = 0.0;
+  const int64_t nslab = (nx + SLAB - 1) / SLAB;
+  const int slab2 = SLAB * ldx / 2;
+  int lrow[PF], lcol[PF];
+#pragma unroll
+  for (int u = 0; u < PF; ++u) {
+    const int i = 2 * (tid + u * NT);
+    lrow[u] = i / ldx;
+    lcol[u] = i - lrow[u] * ldx;
+  }
+  double2 v[PF];
+  auto gload = [&](int64_t slab) {
+    const int64_t r0 = slab * SLAB;
+    const int64_t rows = nx - r0 < SLAB ? nx - r0 : SLAB;
+    const int lim = (int)(rows * ldx / 2);
+    const double2* __restrict__ src = (const double2*)(X + r0 * ldx);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int i2 = tid + u * NT;
+      v[u] = i2 < lim ? src[i2] : make_double2(0.0, 0.0);
+    }
+  };
+  auto lstore = [&](double* buf) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u)
+      if (tid + u * NT < slab2) *(double2*)(buf + lrow[u] * ldp + lcol[u]) = v[u];
+  };
+  int64_t slab = blockIdx.x;
+  __syncthreads();
+  if (slab < nslab) { gload(slab); lstore(sm); }
+  __syncthreads();
+  int cur = 0;
+  const int oa0 = 16 * (ri[0] > 0 ? ri[0] : 0), oa1 = 16 * (ri[1] > 0 ? ri[1] : 0), oa2 = 16 * (ri[2] > 0 ? ri[2] : 0);
+  const int ob0 = 16 * (cj[0] > 0 ? cj[0] : 0), ob1 = 16 * (cj[1] > 0 ? cj[1] : 0), ob2 = 16 * (cj[2] > 0 ? cj[2] : 0);
+  for (; slab < nslab; slab += gridDim.x) {
+    const int64_t next = slab + gridDim.x;
+    if (next < nslab) gload(next);
+    const double* buf = sm + cur * SLAB * ldp;
+#pragma unroll 1
+    for (int kq = 0; kq < SLAB / 4; ++kq) {
+      const double* rowp = buf + (4 * kq + ak) * ldp + ai;
+      const double a0 = rowp[oa0], a1 = rowp[oa1], a2 = rowp[oa2];
+      const double b0 = rowp[ob0], b1 = rowp[ob1], b2 = rowp[ob2];
+      if (live[0]) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0], 0, 0, 0);
+      if (live[1]) acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[1], 0, 0, 0);
+      if (live[2]) acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b2, acc[2], 0, 0, 0);
+      if (live[3]) acc[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[3], 0, 0, 0);
+      if (live[4]) acc[4] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[4], 0, 0, 0);
+      if (live[5]) acc[5] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b2, acc[5], 0, 0, 0);
+      if (live[6]) acc[6] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b0, acc[6], 0, 0, 0);
+      if (live[7]) acc[7] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b1, acc[7], 0, 0, 0);
+      if (live[8]) acc[8] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[8], 0, 0, 0);
+    }
+    if (next < nslab) lstore(sm + (cur ^ 1) * SLAB * ldp);
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    if (live[t]) {
+      const int tix = tixmap[ri[t / 3] * nt + cj[t % 3]];
+      double* p = partial + ((size_t)blockIdx.x * ntri + tix) * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r * 64 + lane] = acc[t][r];
+    }
+  }
+}
+
 
 // The same with two LDS slabs: the next slab's global loads are issued before the MFMAs of the current one
 // and written to the other buffer after them -- one barrier per slab instead of two, and the load latency
@@ -934,16 +1034,67 @@ int launch_gram(cna_ctx* c, double* G_dev) {
   if (nblocks > blocks_1g) nblocks = (int)(blocks_1g > 1 ? blocks_1g : 1);
   CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, (int64_t)sizeof(double) * nblocks * ntri * 256));
   double* partial = (double*)c->scratch2;
-  if (c->gram_tiles_nt != nt) {                          // the tile table depends on nt only: upload once
+  // 3 x 3 blocks of tiles, one per wave (k_gram_blk), when the triangle has at most 16 of them and enough to
+  // keep 16 waves busy: 11 ... 15 tiles per side (161 ... 240 samples)
+  static const bool blk_on = !getenv("CNA_GRAM_NOBLK");
+  const int ng = (nt + 2) / 3;
+  const bool use_blk = blk_on && nt >= 11 && ng * (ng + 1) / 2 <= 16 && slab_rows == 32 &&
+                       2 * (size_t)32 * ldp * sizeof(double) <= 150 * 1024 && c->ldx <= 320;
+  std::vector<int32_t> extra(128 + (size_t)nt * nt, -1);   // [16 waves x 8] block table | tixmap
+  if (use_blk) {
+    struct Blk { int rg, cg, work; };
+    std::vector<Blk> bl;
+    for (int rg = 0; rg < ng; ++rg)
+      for (int cg = rg; cg < ng; ++cg) {
+        int w = 0;
+        for (int r = 0; r < 3; ++r)
+          for (int q = 0; q < 3; ++q) {
+            const int i = 3 * rg + r, j = 3 * cg + q;
+            w += i < nt && j < nt && j >= i;
+          }
+        bl.push_back({rg, cg, w});
+      }
+    std::stable_sort(bl.begin(), bl.end(), [](const Blk& a, const Blk& b) { return a.work > b.work; });
+    for (size_t p = 0; p < bl.size(); ++p) {               // snake over the four SIMDs (waves w, w+4, w+8, w+12 share one)
+      const int round = (int)p / 4, pos = (int)p % 4;
+      const int wave = 4 * round + ((round & 1) ? 3 - pos : pos);
+      for (int r = 0; r < 3; ++r) {
+        const int i = 3 * bl[p].rg + r, j = 3 * bl[p].cg + r;
+        extra[wave * 8 + r] = i < nt ? i : -1;
+        extra[wave * 8 + 3 + r] = j < nt ? j : -1;
+      }
+    }
+    for (int t = 0; t < ntri; ++t) extra[128 + (tiles[t] >> 16) * nt + (tiles[t] & 0xffff)] = t;
+  }
+  if (c->gram_tiles_nt != nt) {                          // the tables depend on nt only: upload once
     void* tp = c->gram_tiles_ptr;
-    CNA_TRY(dev_reserve(c, &tp, &c->gram_tiles_cap, (int64_t)sizeof(int32_t) * ntri));
+    CNA_TRY(dev_reserve(c, &tp, &c->gram_tiles_cap, (int64_t)sizeof(int32_t) * (ntri + extra.size())));
     c->gram_tiles_ptr = tp;
     HIP_TRY(hipMemcpyAsync(tp, tiles.data(), sizeof(int32_t) * ntri, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));            // tiles vector goes out of scope
+    HIP_TRY(hipMemcpyAsync((int32_t*)tp + ntri, extra.data(), sizeof(int32_t) * extra.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));            // the vectors go out of scope
     c->gram_tiles_nt = nt;
   }
   int32_t* tiles_dev = (int32_t*)c->gram_tiles_ptr;
   const size_t smem = sizeof(double) * slab_rows * ldp;
+  if (use_blk) {
+    {
+      ProfScope ps(c, CNA_K_GRAM);
+      static bool attr_blk = false;
+      if (!attr_blk) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_gram_blk<16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_blk = true;
+      }
+      hipLaunchKernelGGL((k_gram_blk<16, 32>), dim3(nblocks), dim3(1024), 2 * smem, c->stream, c->X, c->nx, c->ldx, nt, ldp, ntri,
+                         tiles_dev + ntri, tiles_dev + ntri + 128, partial);
+      HIP_TRY(hipGetLastError());
+    }
+    ProfScope ps(c, CNA_K_GRAM_REDUCE);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ntri * 4), dim3(64, 16), 0, c->stream, partial, nblocks, ntri,
+                       tiles_dev, Nx, G_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   {
     ProfScope ps(c, CNA_K_GRAM);
     int r;
