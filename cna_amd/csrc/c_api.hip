@@ -213,7 +213,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_flush(c);
   comm_destroy(c);
-  void* bufs[] = {c->i8_buf, c->xq, c->xq_scale, c->coef_dev, c->proj, c->sp_idx, c->sp_val, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+  void* bufs[] = {c->i8_buf, c->xq, c->xq_scale, c->coef_dev, c->proj, c->sp_pair, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
                   c->nam, c->X, c->X2, c->resid_f, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -381,10 +381,9 @@ static int ensure_sparse_state(cna_ctx* c) {
   if (!want) {
     if (c->sp_cnt) {
       HIP_TRY(hipStreamSynchronize(c->stream));
-      dev_free(c, c->sp_idx, 2 * 64 * (size_t)c->sp_rows);
-      dev_free(c, c->sp_val, 8 * 64 * (size_t)c->sp_rows);
+      dev_free(c, c->sp_pair, 16 * 64 * (size_t)c->sp_rows);
       dev_free(c, c->sp_cnt, (size_t)c->sp_rows);
-      c->sp_idx = c->sp_val = c->sp_cnt = nullptr;
+      c->sp_pair = c->sp_cnt = nullptr;
       c->sp_rows = 0;
     }
     return 0;
@@ -392,14 +391,12 @@ static int ensure_sparse_state(cna_ctx* c) {
   if (c->sp_cnt && c->sp_rows == c->n_pad) return 0;
   if (c->sp_cnt) {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    dev_free(c, c->sp_idx, 2 * 64 * (size_t)c->sp_rows);
-    dev_free(c, c->sp_val, 8 * 64 * (size_t)c->sp_rows);
+    dev_free(c, c->sp_pair, 16 * 64 * (size_t)c->sp_rows);
     dev_free(c, c->sp_cnt, (size_t)c->sp_rows);
-    c->sp_idx = c->sp_val = c->sp_cnt = nullptr;
+    c->sp_pair = c->sp_cnt = nullptr;
   }
   c->sp_rows = c->n_pad;
-  CNA_TRY(dev_alloc(c, &c->sp_idx, 2 * 64 * (size_t)c->sp_rows));
-  CNA_TRY(dev_alloc(c, &c->sp_val, 8 * 64 * (size_t)c->sp_rows));
+  CNA_TRY(dev_alloc(c, &c->sp_pair, 16 * 64 * (size_t)c->sp_rows));   // 64 = SP_CAP records of 16 bytes (diffuse.hip)
   CNA_TRY(dev_alloc(c, &c->sp_cnt, (size_t)c->sp_rows));
   return 0;
 }

@@ -162,8 +162,7 @@ struct cna_ctx {
   void* h_cell = nullptr;         // pinned: per-cell outputs of cna_percell_fdr_pinned (coef | fdr)
   int64_t h_cell_cap = 0;
   // compressed copy of the state after the first walk step (single GPU, wide sample axis)
-  void* sp_idx = nullptr;
-  void* sp_val = nullptr;
+  void* sp_pair = nullptr;
   void* sp_cnt = nullptr;
   int64_t sp_rows = 0;
   void* i8_buf = nullptr;         // digit planes, queue and slabs of the integer local-null path (null_i8.hip)

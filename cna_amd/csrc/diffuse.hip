@@ -50,10 +50,21 @@ struct StepArgs {
   int want_kurt, write_t, write_nam;
   int xcd_chunk;
   // compressed copy of the state after the first step (see k_nam_step_sparse); null = not kept
-  unsigned short* sp_idx;   // n x SP_CAP sample indices of the non-zeros of a row
-  double* sp_val;           // n x SP_CAP their values
+  struct SpPair* sp_pair;   // n x SP_CAP {value, sample index} records of the non-zeros of a row
   unsigned char* sp_cnt;    // n: how many (SP_DENSE: more than SP_CAP, use the dense row)
 };
+// One 16-byte record per non-zero: the second step then fetches an edge's whole neighbour row with ONE
+// global_load_dwordx4 (lane l = pair l).  With the indices and the values in two arrays the step issued two
+// gathers per edge: 4.59 -> 4.42 ms at 2M x 200.  What the step spends its time on is the scatter, not the
+// gather (tools/micro/lds_scatter_rate.hip: a ds_add_f64 of 35 lanes into random columns occupies the CU's LDS
+// for ~15 clk, 8 of them bank conflicts of the address pattern alone = 2.1 ms of the launch; with the pair
+// gathers replaced by constants the launch still takes 3.9 ms).
+struct SpPair {
+  double v;
+  int32_t col;
+  int32_t pad;
+};
+static_assert(sizeof(SpPair) == 16, "one dwordx4 per pair");
 constexpr int SP_CAP = 64;
 constexpr int SP_DENSE = 255;
 
@@ -196,10 +207,7 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
     const double t = col < a.width ? __ddiv_rn(s[q], cs) : 0.0;        // what finish_row stores in T
     const unsigned long long m = __ballot(t != 0.0);
     const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-    if (t != 0.0 && pos < SP_CAP) {
-      a.sp_idx[grow * SP_CAP + pos] = (unsigned short)col;
-      a.sp_val[grow * SP_CAP + pos] = t;
-    }
+    if (t != 0.0 && pos < SP_CAP) a.sp_pair[grow * SP_CAP + pos] = SpPair{t, col, 0};
     base += __popcll(m);
   }
   if (lane == 0) a.sp_cnt[grow] = (unsigned char)(base <= SP_CAP ? base : SP_DENSE);
@@ -420,6 +428,7 @@ __global__ __launch_bounds__(256) void k_nam_step_pair(StepArgs a) {
 // (tools/micro/lds_add_rounding.hip: 4M single adds and 260k chains of 40, no difference), so the
 // result is bit-identical to k_nam_step.  Rows that overflowed the compressed form (more than SP_CAP
 // distinct samples) are taken dense.
+// (a plain read - add - write of the wave's own row is legal too and slower in the kernel: 4.61 against 4.42 ms)
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 template <typename VT, int NQ2>
@@ -436,6 +445,7 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
   const int64_t grow = a.row0 + row;
   const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
   const double2* __restrict__ Tin = (const double2*)a.Tin;
+  const SpPair* __restrict__ pairs = a.sp_pair;
   const int ld2 = a.ld >> 1;
   auto dense_edge = [&](int j, double av) {
     const double2* __restrict__ rowp = Tin + (int64_t)j * ld2;
@@ -457,24 +467,20 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
     const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
     int l = 0;
     for (; l + U <= cnt; l += U) {
-      int si[U], cc[U];
-      double sv[U];
+      int cc[U];
+      SpPair sp[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int j = __builtin_amdgcn_readlane(jl, l + u);
         cc[u] = __builtin_amdgcn_readlane(cl, l + u);
-        si[u] = 0;
-        sv[u] = 0.0;
-        if (cc[u] != SP_DENSE && lane < cc[u]) {
-          si[u] = a.sp_idx[(int64_t)j * SP_CAP + lane];
-          sv[u] = a.sp_val[(int64_t)j * SP_CAP + lane];
-        }
+        sp[u] = SpPair{0.0, 0, 0};
+        if (cc[u] != SP_DENSE && lane < cc[u]) sp[u] = pairs[(int64_t)j * SP_CAP + lane];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const double av = readlane_d(al, l + u);
         if (cc[u] == SP_DENSE) dense_edge(__builtin_amdgcn_readlane(jl, l + u), av);
-        else if (lane < cc[u]) lds_add(&acc[si[u]], mul_rn(av, sv[u]));
+        else if (lane < cc[u]) lds_add(&acc[sp[u].col], mul_rn(av, sp[u].v));
       }
     }
     for (; l < cnt; ++l) {                       // ragged tail
@@ -482,8 +488,10 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
       const int c = __builtin_amdgcn_readlane(cl, l);
       const double av = readlane_d(al, l);
       if (c == SP_DENSE) dense_edge(j, av);
-      else if (lane < c)
-        lds_add(&acc[a.sp_idx[(int64_t)j * SP_CAP + lane]], mul_rn(av, a.sp_val[(int64_t)j * SP_CAP + lane]));
+      else if (lane < c) {
+        const SpPair p = pairs[(int64_t)j * SP_CAP + lane];
+        lds_add(&acc[p.col], mul_rn(av, p.v));
+      }
     }
   }
   // + w*s/colsums of the row itself, after the neighbours (the order of scipy's A.dot(s) + s): from its own
@@ -492,7 +500,10 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
   const int own_cnt = (int)a.sp_cnt[grow];
   if (own_cnt != SP_DENSE) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    if (lane < own_cnt) lds_add(&acc[a.sp_idx[grow * SP_CAP + lane]], mul_rn(a.w, a.sp_val[grow * SP_CAP + lane]));
+    if (lane < own_cnt) {
+      const SpPair p = pairs[grow * SP_CAP + lane];
+      lds_add(&acc[p.col], mul_rn(a.w, p.v));
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   double s[2 * NQ2];
@@ -853,8 +864,7 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
   a.write_nam = write_nam;
   // compressed state: written by the first step, read by the second (sample indicators only)
   const bool sp = c->sp_cnt && !dense && (first || c->steps_done == 1);
-  a.sp_idx = sp ? (unsigned short*)c->sp_idx : nullptr;
-  a.sp_val = sp ? (double*)c->sp_val : nullptr;
+  a.sp_pair = sp ? (SpPair*)c->sp_pair : nullptr;
   a.sp_cnt = sp ? (unsigned char*)c->sp_cnt : nullptr;
   return c->data_f64 ? launch_step_q<double>(c, first, a) : launch_step_q<float>(c, first, a);
 }
