@@ -324,7 +324,7 @@ __global__ __launch_bounds__(64 * NW) void k_gram_blk(const double* __restrict__
     const int64_t next = slab + gridDim.x;
     if (next < nslab) gload(next);
     const double* buf = sm + cur * SLAB * ldp;
-#pragma unroll 1
+#pragma unroll        // all eight k steps of a slab: the next fragments are read under the MFMAs (1965 -> 1908 us at 2M x 200)
     for (int kq = 0; kq < SLAB / 4; ++kq) {
       const double* rowp = buf + (4 * kq + ak) * ldp + ai;
       const double a0 = rowp[oa0], a1 = rowp[oa1], a2 = rowp[oa2];
@@ -1040,6 +1040,7 @@ int launch_gram(cna_ctx* c, double* G_dev) {
   const int ng = (nt + 2) / 3;
   const bool use_blk = blk_on && nt >= 11 && ng * (ng + 1) / 2 <= 16 && slab_rows == 32 &&
                        2 * (size_t)32 * ldp * sizeof(double) <= 150 * 1024 && c->ldx <= 320;
+  if (use_blk && nblocks > 256) nblocks = 256;             // one workgroup per CU, every slab after the first prefetched
   std::vector<int32_t> extra(128 + (size_t)nt * nt, -1);   // [16 waves x 8] block table | tixmap
   if (use_blk) {
     struct Blk { int rg, cg, work; };
