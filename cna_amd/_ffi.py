@@ -86,6 +86,8 @@ SIGNATURES = {
     'cna_reference_thresholds': (C.c_int, [C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
     'cna_percell_coef_launch': (C.c_int, [c_ctx]),
     'cna_percell_coef_wait': (C.c_int, [c_ctx, C.POINTER(C.c_void_p)]),
+    'cna_percell_fdr_copy_early': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_int)]),
+    'cna_percell_fdr_copied_early': (C.c_int, [c_ctx, C.POINTER(C.c_int)]),
     'cna_fetch_rows': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     'cna_project_keep': (C.c_int, [c_ctx, C.c_void_p, C.c_int]),
     'cna_stat_median': (C.c_int, [c_ctx, C.POINTER(C.c_double)]),

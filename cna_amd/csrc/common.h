@@ -159,6 +159,8 @@ struct cna_ctx {
   bool coef_early = false;        // h_cell[0, n_out) already holds the coefficients of the current ncorrs
   bool fdr_inline = false;        // ... and h_cell[n_out, 2 n_out) the per-cell FDRs of the last local-null pass
   double null_thr0 = 0, null_thr_step = 0;   // linear guess over the thresholds of the prepared pass
+  bool fdr_early_copied = false;  // cna_percell_fdr_copy_early took the FDR column of the pending pass ...
+  bool fdr_early_served = false;  // ... and cna_percell_fdr_pinned then returned that same column
   void* h_cell = nullptr;         // pinned: per-cell outputs of cna_percell_fdr_pinned (coef | fdr)
   int64_t h_cell_cap = 0;
   // compressed copy of the state after the first walk step (single GPU, wide sample axis)

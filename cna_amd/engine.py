@@ -619,6 +619,20 @@ class Engine(_order.CellOrder):
         check(self.lib.cna_percell_coef_wait(self.h, C.byref(cp)), 'cna_percell_coef_wait')
         return self._pinned_view(cp)
 
+    def percell_fdr_copy_early(self, dst, threads=4):
+        """Copy the FDR column of the pending local-null pass into `dst` (contiguous float64, all cells) once the
+        device has delivered it; for a helper thread.  False: not applicable, nothing copied."""
+        done = C.c_int(0)
+        check(self.lib.cna_percell_fdr_copy_early(self.h, dst.ctypes.data, dst.shape[0], int(threads), C.byref(done)),
+              'cna_percell_fdr_copy_early')
+        return bool(done.value)
+
+    def percell_fdr_copied_early(self):
+        """True when the FDR column percell() last returned is the one percell_fdr_copy_early() copied."""
+        yes = C.c_int(0)
+        check(self.lib.cna_percell_fdr_copied_early(self.h, C.byref(yes)), 'cna_percell_fdr_copied_early')
+        return bool(yes.value)
+
     def _pinned_view(self, p):
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), shape=(self.n,))
 

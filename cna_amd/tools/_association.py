@@ -46,6 +46,7 @@ def _background():
 
 _EARLY_WALK = os.environ.get('CNA_EARLY_WALK', '1') not in ('0', 'off', 'no')
 _EARLY_COEF = os.environ.get('CNA_EARLY_COEF', '1') not in ('0', 'off', 'no')     # ablation switches
+_EARLY_FDR = os.environ.get('CNA_EARLY_FDR', '1') not in ('0', 'off', 'no')
 _DRAW_THREAD = os.environ.get('CNA_DRAW_THREAD', '1') not in ('0', 'off', 'no')
 _SWITCH_INTERVAL = float(os.environ.get('CNA_SWITCH_INTERVAL', '5e-5'))   # GIL hand-over between the helper thread and this one: 2.08 -> 1.86 ms per call at 200k cells (default interval: 5 ms)
 
@@ -607,8 +608,18 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     previous_fdr = data.obs[fdr_key] if had_fdr else None
     big = len(data.obs) >= _COEF_FIRST_CELLS
 
+    def fdr_copied_early():
+        job = early_coef.pop('fdr_job', None)
+        if job is None:
+            return False
+        try:
+            return bool(job.result()) and engine.percell_fdr_copied_early()
+        except Exception:
+            return False
+
     def roll_back():
         # put data.obs back as it was: columns written early must not outlive a failed (or stale) attempt
+        fdr_copied_early()                                # the helper is done with the column's storage
         if early_coef.pop('written', False):
             if had_key:
                 data.obs[key_added] = previous
@@ -634,6 +645,12 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
             view = data.obs[fdr_key].values
             if view.dtype == np.float64 and view.flags.c_contiguous and view.flags.writeable:
                 early_coef['fdr_view'] = view
+                if _EARLY_FDR and hasattr(engine, 'percell_fdr_copy_early'):
+                    # the column follows the local null on the device and the host still has the SVD and the
+                    # F-tests in front of it: the helper thread waits for the column and fills the storage
+                    from .._order import usable_cpus
+                    early_coef['fdr_job'] = _background().submit(engine.percell_fdr_copy_early, view,
+                                                                  min(4, usable_cpus(4)))
         _mark('coef column written')
 
     try:
@@ -684,7 +701,10 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         # upstream dereferences res.fdrs here and dies when local_test=False (_association.py:235)
         raise AttributeError("'NoneType' object has no attribute 'loc'")
     view = early_coef.get('fdr_view')
-    if (view is not None and isinstance(fdr_all, np.ndarray) and fdr_all.dtype == np.float64 and fdr_all.flags.c_contiguous
+    early = fdr_copied_early()
+    if early and view is not None and fdr_key in data.obs and np.shares_memory(data.obs[fdr_key].values, view):
+        pass                                              # filled by the helper thread under the SVD
+    elif (view is not None and isinstance(fdr_all, np.ndarray) and fdr_all.dtype == np.float64 and fdr_all.flags.c_contiguous
             and fdr_all.shape == view.shape and fdr_key in data.obs and np.shares_memory(data.obs[fdr_key].values, view)):
         _host_copy(view, fdr_all)
     else:

@@ -277,6 +277,13 @@ int  cna_percell_fdr_pinned(cna_ctx* ctx, const double* thr, const double* runmi
  * delivers the FDR column only and returns the same coefficient pointer.  Single rank or local view. */
 int  cna_percell_coef_launch(cna_ctx* ctx);
 int  cna_percell_coef_wait(cna_ctx* ctx, double** coef_ptr);
+/* The FDR column of a pending local-null pass (cna_null_local_launch after cna_percell_coef_launch: the column
+ * follows the pass on the device) copied into dst[n] -- the storage of data.obs[key + '_fdr'],
+ * _association.py:236-237 -- as soon as it has reached the pinned block: callable from a helper thread while
+ * the main thread is inside the samples x samples SVD.  *done = 0: not applicable, nothing copied.
+ * cna_percell_fdr_copied_early: *yes = 1 when the column cna_percell_fdr_pinned last returned is that copy. */
+int  cna_percell_fdr_copy_early(cna_ctx* ctx, double* dst, int64_t n, int nthreads, int* done);
+int  cna_percell_fdr_copied_early(cna_ctx* ctx, int* yes);
 
 /* ---- device -> host for the lazily materialised result fields (a20) -------------------- */
 int  cna_matrix_shape(cna_ctx* ctx, int which, int64_t* n_rows_local, int* n_cols);

@@ -652,6 +652,38 @@ def test_ordered_fetch_on_device_equals_host_reorder(monkeypatch):
         np.testing.assert_array_equal(a, b)
 
 
+def test_fdr_column_copied_by_the_helper_thread_equals_the_late_copy(eng, monkeypatch):
+    """Large-input schedule: the FDR column follows the local null on the device and the helper thread copies it
+    into data.obs[key + '_fdr']'s storage while the main thread is in the SVD (cna_percell_fdr_copy_early).  Same
+    column, bit for bit, as with the copy at the end of the call; and the early path is really the one taken."""
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.tools import _association as A
+    monkeypatch.setattr(A, '_COEF_FIRST_CELLS', 0)
+    data, meta = synth.make_dataset(6000, 24, k=15, seed=5)
+    kw = dict(Nnull=200, seed=1, nsteps=3)
+    taken = []
+    real = eng.percell_fdr_copied_early
+    monkeypatch.setattr(eng, 'percell_fdr_copied_early', lambda: taken.append(real()) or taken[-1])
+    out = {}
+    for early in (True, False, True):
+        monkeypatch.setattr(A, '_EARLY_FDR', early)
+        for key in ('coef', 'coef_fdr'):
+            if key in data.obs:
+                del data.obs[key]
+        res = cna.tl.association(data, meta['y'], 'id', engine=eng, return_full=True, **kw)
+        out.setdefault(early, []).append((res.p, data.obs['coef'].values.copy(), data.obs['coef_fdr'].values.copy(),
+                                          res.fdrs.fdr.values.copy()))
+    assert taken == [True, True], taken                    # asked twice (the early runs), served from the helper's copy
+    p0, c0, f0, t0 = out[False][0]
+    assert (f0 < 1).any() and np.isfinite(f0).all()
+    for p1, c1, f1, t1 in out[True]:
+        assert p1 == p0
+        np.testing.assert_array_equal(c1, c0)
+        np.testing.assert_array_equal(f1, f0)
+        np.testing.assert_array_equal(t1, t0)
+
+
 @pytest.mark.parametrize('big_path', [False, True])
 def test_failed_test_leaves_obs_untouched(eng, monkeypatch, big_path):
     """(big_path: the schedule of large inputs -- coefficient column under the Gram kernels, the FDR column's
