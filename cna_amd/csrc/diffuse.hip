@@ -159,6 +159,40 @@ __device__ __forceinline__ int64_t my_row(int wv, int chunk) {
   return uniform64(blk * 4 + wv);
 }
 
+// what follows the neighbours of a row in the first step: the row's own term, the (sample, value) pairs of the
+// new state for the second step, the write-out
+template <int NQ>
+__device__ __forceinline__ void first_tail(const StepArgs& a, const double* accl, int64_t row, int64_t grow, int lane,
+                                           const CellInfo me, const double cs) {
+  const double self = __ddiv_rn(a.w, cs);        // (w*1)/colsums[i]
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  double s[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) s[q] = add_rn(accl[lane + 64 * q], (lane + 64 * q == me.sid) ? self : 0.0);
+  if (!a.sp_cnt) {
+    finish_row<NQ, ColStride1>(a, row, grow, lane, s);
+    return;
+  }
+  // after one step a row is non-zero only at the samples of the cell's neighbours: keep those
+  // (sample, value) pairs side by side so the second step gathers ~40 entries instead of N.  The dense row
+  // of the state is then dead weight -- the second step (k_nam_step_sparse) reads the pairs, its own row
+  // included -- and is written only for rows that overflow the SP_CAP pairs.
+  int base = 0;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int col = lane + 64 * q;
+    const double t = col < a.width ? __ddiv_rn(s[q], cs) : 0.0;        // what finish_row stores in T
+    const unsigned long long m = __ballot(t != 0.0);
+    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (t != 0.0 && pos < SP_CAP) a.sp_pair[grow * SP_CAP + pos] = SpPair{t, col, 0};
+    base += __popcll(m);
+  }
+  if (lane == 0) a.sp_cnt[grow] = (unsigned char)(base <= SP_CAP ? base : SP_DENSE);
+  StepArgs b = a;
+  b.write_t = a.write_t && base > SP_CAP;
+  finish_row<NQ, ColStride1>(b, row, grow, lane, s);
+}
+
 // First step: the input is the one-hot sample indicator, so neighbour j contributes
 // A[i,j] * (1/colsums[j]) to column sid[j] only.  One 16-byte record {1/colsums, sid} per cell
 // makes that a single gather per edge; every lane takes one edge and adds its term into the
@@ -185,35 +219,70 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
       if (ci.sid >= 0) unsafeAtomicAdd(&accl[ci.sid], mul_rn(al, ci.inv_colsum));
     }
   }
-  const CellInfo me = info[grow];
-  const double self = __ddiv_rn(a.w, a.colsum[grow]);        // (w*1)/colsums[i]
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  double s[NQ];
+  first_tail<NQ>(a, accl, row, grow, lane, info[grow], a.colsum[grow]);
+}
+
+// The same with TWO rows per wave, one after the other in every phase: the loads of a phase (row pointers,
+// edges, the neighbours' records, the row's own record and column sum) are four dependent round trips to memory
+// per row, and with one row per wave at full occupancy (8 waves per SIMD) part of the step is the latency of
+// that chain.  Both rows' loads of a phase are in flight together: 1002 -> 917-928 us at 2M x 200, 462 -> 399 at
+// 1M x 100, 77 -> 61 at 200k x 50; four rows per wave: 1120 / 418 / 62 (profiles/r02_kbench_first_rows.txt).
+template <typename VT, int NQ, int R>
+__global__ __launch_bounds__(256) void k_nam_first2(StepArgs a, const CellInfo* __restrict__ info) {
+  extern __shared__ double sm[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* accl[R];
+  int64_t row[R], start[R], end[R];
+  bool live[R];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) s[q] = add_rn(accl[lane + 64 * q], (lane + 64 * q == me.sid) ? self : 0.0);
-  if (!a.sp_cnt) {
-    finish_row<NQ, ColStride1>(a, row, grow, lane, s);
-    return;
-  }
-  // after one step a row is non-zero only at the samples of the cell's neighbours: keep those
-  // (sample, value) pairs side by side so the second step gathers ~40 entries instead of N.  The dense row
-  // of the state is then dead weight -- the second step (k_nam_step_sparse) reads the pairs, its own row
-  // included -- and is written only for rows that overflow the SP_CAP pairs.
-  const double cs = a.colsum[grow];
-  int base = 0;
+  for (int r = 0; r < R; ++r) {
+    accl[r] = sm + ((size_t)wv * R + r) * 64 * NQ;
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int col = lane + 64 * q;
-    const double t = col < a.width ? __ddiv_rn(s[q], cs) : 0.0;        // what finish_row stores in T
-    const unsigned long long m = __ballot(t != 0.0);
-    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-    if (t != 0.0 && pos < SP_CAP) a.sp_pair[grow * SP_CAP + pos] = SpPair{t, col, 0};
-    base += __popcll(m);
+    for (int q = 0; q < NQ; ++q) accl[r][lane + 64 * q] = 0.0;
+    const int64_t b = R * (int64_t)(blockIdx.x >> 3) + r, x = blockIdx.x & 7;       // my_row() of the two workgroups this one stands for
+    const int64_t blk = (b / a.xcd_chunk) * (8 * (int64_t)a.xcd_chunk) + x * a.xcd_chunk + (b % a.xcd_chunk);
+    row[r] = uniform64(blk * 4 + wv);
+    live[r] = row[r] < a.n_local;
+    start[r] = end[r] = 0;
   }
-  if (lane == 0) a.sp_cnt[grow] = (unsigned char)(base <= SP_CAP ? base : SP_DENSE);
-  StepArgs b = a;
-  b.write_t = a.write_t && base > SP_CAP;
-  finish_row<NQ, ColStride1>(b, row, grow, lane, s);
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (live[r]) { start[r] = uniform64(a.indptr[row[r]]); end[r] = uniform64(a.indptr[row[r] + 1]); }
+  int jl[R];
+  double al[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) { jl[r] = 0; al[r] = 0.0; if (live[r]) load_edges<VT>(a, start[r], end[r], lane, jl[r], al[r]); }
+  CellInfo ci[R], me[R];
+  double cs[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    ci[r] = CellInfo{0.0, -1, 0};
+    me[r] = CellInfo{0.0, -1, 0};
+    cs[r] = 1.0;
+    if (live[r]) {
+      if (start[r] + lane < end[r]) ci[r] = info[jl[r]];
+      me[r] = info[a.row0 + row[r]];
+      cs[r] = a.colsum[a.row0 + row[r]];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (!live[r]) continue;
+    if (start[r] + lane < end[r] && ci[r].sid >= 0) unsafeAtomicAdd(&accl[r][ci[r].sid], mul_rn(al[r], ci[r].inv_colsum));
+    for (int64_t base = start[r] + 64; base < end[r]; base += 64) {          // rows of more than 64 neighbours
+      int j2;
+      double a2;
+      load_edges<VT>(a, base, end[r], lane, j2, a2);
+      if (base + lane < end[r]) {
+        const CellInfo c2 = info[j2];
+        if (c2.sid >= 0) unsafeAtomicAdd(&accl[r][c2.sid], mul_rn(a2, c2.inv_colsum));
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+    if (live[r]) first_tail<NQ>(a, accl[r], row[r], a.row0 + row[r], lane, me[r], cs[r]);
 }
 
 // Steps >= 2: gather-accumulate over neighbour rows of the scaled state T.  Each lane owns two
@@ -705,6 +774,12 @@ __global__ void k_scale_rows(const double* __restrict__ s, const double* __restr
 
 template <typename VT, int NQ>
 int launch_first_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
+  static const bool one = getenv("CNA_FIRST_ONE_ROW") != nullptr;      // A/B switch
+  if (!one && (grid.x & 15) == 0) {       // an even number of workgroups per XCD: one workgroup takes two of them
+    hipLaunchKernelGGL((k_nam_first2<VT, NQ, 2>), dim3(grid.x / 2), dim3(256), sizeof(double) * 8 * 64 * NQ, c->stream, a,
+                       (const CellInfo*)c->cellinfo);
+    return 0;
+  }
   hipLaunchKernelGGL((k_nam_first<VT, NQ>), grid, dim3(256), sizeof(double) * 4 * 64 * NQ, c->stream, a,
                      (const CellInfo*)c->cellinfo);
   return 0;
