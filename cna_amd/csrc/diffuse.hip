@@ -500,9 +500,12 @@ __global__ __launch_bounds__(256) void k_nam_step_pair(StepArgs a) {
 // (a plain read - add - write of the wave's own row is legal too and slower in the kernel: 4.61 against 4.42 ms)
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
-template <typename VT, int NQ2>
+// U, the edges of a batch whose pairs are in flight together: 6 (us per launch at 2M x 200 / 1M x 100, from the
+// averages of profiles/r02_kbench_sparse_u.txt: U = 3: 4.41 / 2.12, 4: 4.20 / 2.03, 6: 4.10 / 1.95, 8: 4.37 / 2.10,
+// 12: 4.9 / 2.2, 16: 5.0 / 2.3; the ragged end of a row as one more, predicated batch instead of edge by edge:
+// slower at every U)
+template <typename VT, int NQ2, int U = 6>
 __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
-  constexpr int U = 8;
   extern __shared__ double sm[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
