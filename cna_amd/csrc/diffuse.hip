@@ -497,7 +497,9 @@ __global__ __launch_bounds__(256) void k_nam_step_pair(StepArgs a) {
 // (tools/micro/lds_add_rounding.hip: 4M single adds and 260k chains of 40, no difference), so the
 // result is bit-identical to k_nam_step.  Rows that overflowed the compressed form (more than SP_CAP
 // distinct samples) are taken dense.
-// (a plain read - add - write of the wave's own row is legal too and slower in the kernel: 4.61 against 4.42 ms)
+// (a plain read - add - write of the wave's own row is legal too and slower in the kernel: 4.61 against 4.42 ms;
+// two rows per wave side by side, as in k_nam_first2, is slower as well: 4.48 against 4.10 ms at 2M x 200,
+// 2.13 against 1.93 at 1M x 100 -- 65 VGPRs, seven waves per SIMD)
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
 // U, the edges of a batch whose pairs are in flight together: 6 (us per launch at 2M x 200 / 1M x 100, from the
