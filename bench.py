@@ -126,9 +126,29 @@ def self_spawn(args):
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # a rank that dies (an exception, a device fault) leaves the others blocked in their next collective: the
+    # first non-zero exit ends the job -- the remaining ranks are stopped and its code is passed on
+    import time
     rc = 0
-    for p in procs:
-        rc = p.wait() or rc
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                print('bench.py: a rank exited with status %d; stopping the other %d' % (code, len(live)), file=sys.stderr)
+                for q in live:
+                    q.terminate()
+                deadline = time.time() + 10
+                for q in live:
+                    try:
+                        q.wait(max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+        time.sleep(0.05)
     sys.exit(rc)
 
 
