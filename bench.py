@@ -346,7 +346,8 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         td.init_process_group(backend='gloo', rank=rank, world_size=world)
         from cna_amd import dist
-        dist.init(rank, world, device=0, shm=('cna_bench_%s' % os.environ['MASTER_PORT'], 64 << 20))
+        dist.init(rank, world, device=0, shm=('cna_bench_%s' % os.environ['MASTER_PORT'],
+                                                  (512 << 20) if WORKLOADS[args.workload][0] > 1_000_000 else (64 << 20)))   # a slot holds one rank's halo rows
     elif world > 1 or args.force_dist:
         import torch
         import torch.distributed as td
