@@ -78,6 +78,10 @@ SIGNATURES = {
     'cna_host_cluster_order': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'cna_host_block_sources': (C.c_int64, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
+    'cna_host_walk_blocks': (C.c_int64, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'cna_host_walk_tiles': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cna_host_set_threads': (None, [C.c_int]),
     'cna_host_argsort_gather': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'cna_global_test_launch': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),

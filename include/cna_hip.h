@@ -336,6 +336,30 @@ int64_t cna_host_cluster_order(int64_t n, const int64_t* indptr, const int32_t* 
  * int64[nblocks+1], src int32[>= nnz], slot uint16[nnz].  Returns the total length of the lists or -1. */
 int64_t cna_host_block_sources(int64_t n_local, int64_t n_cols, const int64_t* indptr, const int32_t* indices, int B,
                                int cap, int64_t* src_ptr, int32_t* src, uint16_t* slot);
+/* Blocks of the LDS-staged walk step (the neighbour rows one workgroup of csrc/walk_lds.hip stages in LDS for
+ * the sums of /root/reference/src/cna/tools/_nam.py:33): runs of consecutive device rows with at most `bmax`
+ * rows and at most `cap` distinct columns, never across a multiple of `super` rows; per block the distinct
+ * columns in ascending order, per edge its column's position in the block's list (0xFFFF: the one row of a
+ * block has more than `cap` distinct columns).  blk_row / src_ptr int64[<= n_local + 1] (closed by n_local and
+ * the total), src int32[<= nnz], slot uint16[nnz].  Threaded (result independent of the thread count);
+ * integer work only, no sum is reordered.  Returns the number of blocks or -1. */
+int64_t cna_host_walk_blocks(int64_t n_local, int64_t n_cols, const int64_t* indptr, const int32_t* indices, int bmax,
+                             int cap, int super, int nthreads, int64_t* blk_row, int64_t* src_ptr, int32_t* src,
+                             uint16_t* slot);
+
+/* Tile program of the LDS-tiled walk step (csrc/walk_lds.hip; the sums of _nam.py:33 with the neighbour rows of
+ * a block of nw * rpw destination rows staged tile by tile in LDS): the distinct columns of every block in
+ * ascending order of key[column] (the caller's index of a device column), cut into tiles of S, and the CSR
+ * entries of the block regrouped by (tile, wave, row) -- inside a row still in CSR order, which is the order of
+ * the tiles when the caller's rows list their columns in ascending order (scipy's canonical form).  Returns the
+ * number of tiles, -2 when a row is not sorted that way, -1 when out of memory.  With rec_pos == NULL only
+ * blk_tile int64[nb + 1] is filled (first tile of every block).  tile_src0 int64[ntiles + 1], tile_src
+ * int32[<= nnz], seg int64[ntiles * nw + 1] (first record of (tile, wave)), rec_pos int64[nnz] (record position of
+ * every CSR entry), rec_slot uint16[nnz] / rec_row uint8[nnz] (per record: source inside its tile, row inside its
+ * wave).  Threaded; integer work only. */
+int64_t cna_host_walk_tiles(int64_t n_local, const int64_t* indptr, const int32_t* indices, const int64_t* key, int nw,
+                            int rpw, int S, int nthreads, int64_t* blk_tile, int64_t* tile_src0, int32_t* tile_src,
+                            int64_t* seg, int64_t* rec_pos, uint16_t* rec_slot, uint8_t* rec_row);
 
 /* Rows [r0, r1) of the graph in the device order: out row i = caller's row perm[r0 + i], columns relabelled
  * through col_map and left in their original order; values (vbytes = 4 | 8) copied bit for bit.  Sizes from
