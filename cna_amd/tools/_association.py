@@ -22,7 +22,7 @@ from .. import _ffi
 from ..engine import get_engine
 from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_plan, _resid_run, sample_codes_cached, confirm_codes,
                    shard_of, global_samples,
-                   _small_svd, _defer_pcs, host_blas_threads)
+                   _small_svd, _defer_pcs, host_blas_threads, _top_pcs, GramPCs)
 from ._out import select_output
 from ._stats import conditional_permutation, grouplevel_permutation, default_ks, minp_stats
 
@@ -118,7 +118,7 @@ def _draw_null(y, batches, donorids, Nnull=1000, force_permute_all=False, seed=N
 
 def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_progress=False,
                  npcs=None, n_cells=None, conditioned=False, null_source=None, maxabs=None, on_coef=None,
-                 coef_first=False, coef_launched=False):
+                 coef_first=False, coef_launched=False, full=False):
     """Body of the reference's ``_association`` (_association.py:24-129) against the
     residualised NAM held by ``engine`` (cells x samples), whose Gram-matrix kernels have been
     queued.  ``res`` is the namespace from the residualisation (M, r), ``y`` / ``y_`` the
@@ -126,9 +126,11 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     when it is first needed, so that everything that only needs ``y`` runs while the permutations
     are still being drawn).
 
-    Ordering: the local-null kernel is started first and runs on the GPU while LAPACK's SVD of
-    G and the global F-tests run here; the values, warnings and progress text are those of the
-    reference's sequential order."""
+    Ordering: the local-null kernel is started first and runs on the GPU while the leading
+    eigenvectors of G are taken here (`_top_pcs`) and the global F-tests run on the second stream; the
+    sign-defining LAPACK SVD of G (_nam.py:105) runs on a worker thread when the caller wants the full
+    result (``full``) and otherwise only if a field that shows PC signs is read.  The values, warnings and
+    progress text are those of the reference's sequential order."""
     out = select_output(show_progress)
     M, r = res.M, res.r
     n = len(y)
@@ -189,16 +191,24 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         coef_first = coef_early and coef_first
         if coef_first:
             on_coef(engine.percell_coef_wait())
-        U, svs, _ = _small_svd(engine.gram_fetch())
+        G = engine.gram_fetch()
+        _mark('gram fetched')
+        pcs = GramPCs(G)
+        if full:
+            pcs.start()                                      # LAPACK's SVD beside the F-tests and the local null
+        Uk = _top_pcs(G, int(ks_arr.max()))
+        if Uk is None:
+            Uk = pcs.U[:, :int(ks_arr.max())]
+        _mark('pcs')
         if coef_early:
-            engine.global_test_launch(U, ks_arr, r)          # second stream
+            engine.global_test_launch(Uk, ks_arr, r)         # second stream
             try:
                 if not coef_first:
                     on_coef(engine.percell_coef_wait())
             finally:
                 best, pv, r2v = engine.global_test_fetch()
         else:
-            best, pv, r2v = engine.global_test(U, ks_arr, r)
+            best, pv, r2v = engine.global_test(Uk, ks_arr, r)
     finally:
         if pending:
             tail_sums, ranks, num_detected = engine.null_local_fetch()   # never leave a pass pending behind an exception
@@ -214,17 +224,21 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     # coefficients and r2 of the chosen model
     ycond_v = Mv.dot(y)
     ycond_v = ycond_v / ycond_v.std(ddof=1)
-    beta = U[:, :k].T.dot(ycond_v)
-    yhat = U[:, :k].dot(beta)
-    r2_perpc = (beta / np.sqrt(ycond_v.dot(ycond_v))) ** 2
+    beta_k = Uk[:, :k].T.dot(ycond_v)                   # up to the sign of every PC
+    yhat = Uk[:, :k].dot(beta_k)                         # sign free
+    r2_perpc = (beta_k / np.sqrt(ycond_v.dot(ycond_v))) ** 2
 
-    # sample-space frames of the result are only built when somebody reads them
+    # sample-space frames of the result are only built when somebody reads them; what shows the PC signs
+    # (U, beta) comes from LAPACK's SVD of G like upstream's (_nam.py:105, _association.py:70-72)
+    nU = len(G)
+
     def _names():
-        return ['PC' + str(i) for i in range(1, len(U) + 1)]
-    res._defer('namresid_sampleXpc', lambda: pd.DataFrame(U, index=M.index, columns=_names()))
-    res._defer('namresid_svs', lambda: pd.Series(svs, index=_names())[:npcs if npcs is not None else len(U)])
-    res._defer('namresid_varexp', lambda: pd.Series(svs, index=_names()) / len(U) / (n_cells() if callable(n_cells) else n_cells))
+        return ['PC' + str(i) for i in range(1, nU + 1)]
+    res._defer('namresid_sampleXpc', lambda: pd.DataFrame(pcs.U, index=M.index, columns=_names()))
+    res._defer('namresid_svs', lambda: pd.Series(pcs.svs, index=_names())[:npcs if npcs is not None else nU])
+    res._defer('namresid_varexp', lambda: pd.Series(pcs.svs, index=_names()) / nU / (n_cells() if callable(n_cells) else n_cells))
     res._defer('yresid', lambda: pd.Series(ycond_v, index=getattr(M, 'index', None)))
+    res._defer('beta', lambda: pcs.U[:, :k].T.dot(ycond_v))
 
     nullminps, nullr2s = pv[1:], r2v[1:]
     hits = (nullminps <= p + 1e-8).sum()
@@ -266,10 +280,10 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
 
     _mark('percell done')
     res.__dict__.update({'p': pfinal, 'nullminps': nullminps, 'k': k, 'fdr_5p_t': fdr_5p_t,
-                         'fdr_10p_t': fdr_10p_t, 'yresid_hat': yhat, 'ks': ks, 'beta': beta,
+                         'fdr_10p_t': fdr_10p_t, 'yresid_hat': yhat, 'ks': ks,
                          'r2': r2, 'r2_perpc': r2_perpc, 'nullr2_mean': nullr2s.mean(),
                          'nullr2_std': nullr2s.std()})
-    return coef_all, fdr_all, U, svs
+    return coef_all, fdr_all, pcs
 
 
 def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size, sids_present=None):
@@ -618,19 +632,21 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
             return False
 
     def roll_back():
-        # put data.obs back as it was: columns written early must not outlive a failed (or stale) attempt
+        # put data.obs back as it was: nothing written by this call -- early or late -- outlives an exception
+        # (or a stale attempt); like upstream, whose two assignments are the last statements that can fail
         fdr_copied_early()                                # the helper is done with the column's storage
         if early_coef.pop('written', False):
             if had_key:
                 data.obs[key_added] = previous
             elif key_added in data.obs:
                 del data.obs[key_added]
-            if 'fdr_view' in early_coef or (big and fdr_key in data.obs and not had_fdr):
+            if 'fdr_view' in early_coef or early_coef.get('fdr_touched') or (big and fdr_key in data.obs and not had_fdr):
                 if had_fdr:
                     data.obs[fdr_key] = previous_fdr
                 elif fdr_key in data.obs:
                     del data.obs[fdr_key]
             early_coef.pop('fdr_view', None)
+            early_coef.pop('fdr_touched', None)
             early_coef.pop('values', None)
 
     def write_coef_early(coef):
@@ -654,66 +670,67 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         _mark('coef column written')
 
     try:
-        coef_all, fdr_all, U, svs = _association(engine, res, y_std, None, ks=ks, Nnull=Nnull,
+        coef_all, fdr_all, pcs = _association(engine, res, y_std, None, ks=ks, Nnull=Nnull, full=return_full,
                                                  local_test=kwargs.get('local_test', True),
                                                  show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_global,
                                                  null_source=drawn,
                                                  maxabs=getattr(plan, 'maxabs', None), on_coef=write_coef_early,
                                                  coef_first=len(data.obs) >= _COEF_FIRST_CELLS,
                                                  coef_launched=getattr(plan, 'coef_launched', False))
+        _mark('_association returned')
+        confirm_graph()                               # (stale: the retry starts from the frame as the caller left it)
+        _defer_pcs(res, engine, pcs, cell_index)
+        res.kept = kept
+
+        def fetch_nam():
+            if engine.nam_epoch != nam_epoch:
+                raise RuntimeError('res.nam lives on the GPU and a later cna_amd call has replaced it; '
+                                   'read it (or call res.materialize()) before running the next analysis')
+            return pd.DataFrame(engine.nam_full(keep=kept, cols=colmap, transposed=True), index=sample_index,
+                                columns=cell_index(), copy=False)
+
+        res._defer('nam', fetch_nam)
+        _mark('lazies set')
+
+        if had_key:
+            warnings.warn(f"Key '{key_added}' already exists in data.obs. Overwriting.")
+        _mark('warned')
+        # coef_all / fdr_all may be views of the engine's pinned buffers: the DataFrame stores its own
+        # copy, and that copy (not the view) is what res.ncorrs is built from when somebody reads it
+        if 'values' in early_coef:
+            coef_kept = early_coef['values']                 # written while the null kernel was running
+        else:
+            early_coef['written'] = True                  # (roll_back undoes a late write as well)
+            data.obs[key_added] = coef_all
+            coef_kept = data.obs[key_added].values
+        if np.may_share_memory(coef_kept, coef_all):
+            coef_kept = np.array(coef_all)
+        res._defer('ncorrs', lambda: pd.Series(coef_kept if kept.all() else coef_kept[kept], index=cell_index()))
+        _mark('coef written')
+        view = early_coef.get('fdr_view')
+        early = fdr_copied_early()
+        if fdr_all is None:
+            pass                                              # local_test=False: see below
+        elif early and view is not None and fdr_key in data.obs and np.shares_memory(data.obs[fdr_key].values, view):
+            pass                                              # filled by the helper thread under the SVD
+        elif (view is not None and isinstance(fdr_all, np.ndarray) and fdr_all.dtype == np.float64 and fdr_all.flags.c_contiguous
+                and fdr_all.shape == view.shape and fdr_key in data.obs and np.shares_memory(data.obs[fdr_key].values, view)):
+            _host_copy(view, fdr_all)
+        else:
+            early_coef['written'] = early_coef['fdr_touched'] = True
+            data.obs[fdr_key] = fdr_all
+        _mark('obs written')
     except BaseException:
         roll_back()
         raise
-    _mark('_association returned')
-    try:
-        confirm_graph()
-    except _StaleGraph:
-        roll_back()                                   # the retry starts from the frame as the caller left it
-        raise
-    _defer_pcs(res, engine, U, svs, cell_index)
-    res.kept = kept
-
-    def fetch_nam():
-        if engine.nam_epoch != nam_epoch:
-            raise RuntimeError('res.nam lives on the GPU and a later cna_amd call has replaced it; '
-                               'read it (or call res.materialize()) before running the next analysis')
-        return pd.DataFrame(engine.nam_full(keep=kept, cols=colmap, transposed=True), index=sample_index,
-                            columns=cell_index(), copy=False)
-
-    res._defer('nam', fetch_nam)
-    _mark('lazies set')
-
-    if had_key:
-        warnings.warn(f"Key '{key_added}' already exists in data.obs. Overwriting.")
-    _mark('warned')
-    # coef_all / fdr_all may be views of the engine's pinned buffers: the DataFrame stores its own
-    # copy, and that copy (not the view) is what res.ncorrs is built from when somebody reads it
-    if 'values' in early_coef:
-        coef_kept = early_coef['values']                 # written while the null kernel was running
-    else:
-        data.obs[key_added] = coef_all
-        coef_kept = data.obs[key_added].values
-    if np.may_share_memory(coef_kept, coef_all):
-        coef_kept = np.array(coef_all)
-    res._defer('ncorrs', lambda: pd.Series(coef_kept if kept.all() else coef_kept[kept], index=cell_index()))
-    _mark('coef written')
     if fdr_all is None:
-        # upstream dereferences res.fdrs here and dies when local_test=False (_association.py:235)
+        # upstream has written data.obs[key_added] and then dereferences res.fdrs, which is None when
+        # local_test=False (_association.py:231,235): same state of data.obs, same exception
         raise AttributeError("'NoneType' object has no attribute 'loc'")
-    view = early_coef.get('fdr_view')
-    early = fdr_copied_early()
-    if early and view is not None and fdr_key in data.obs and np.shares_memory(data.obs[fdr_key].values, view):
-        pass                                              # filled by the helper thread under the SVD
-    elif (view is not None and isinstance(fdr_all, np.ndarray) and fdr_all.dtype == np.float64 and fdr_all.flags.c_contiguous
-            and fdr_all.shape == view.shape and fdr_key in data.obs and np.shares_memory(data.obs[fdr_key].values, view)):
-        _host_copy(view, fdr_all)
-    else:
-        data.obs[fdr_key] = fdr_all
-    _mark('obs written')
 
     if return_full:
         # everything but the three cells x samples frames is materialised now, like upstream
-        for name in ('ncorrs', 'fdrs', 'namresid_sampleXpc', 'namresid_svs', 'namresid_varexp', 'yresid'):
+        for name in ('ncorrs', 'fdrs', 'namresid_sampleXpc', 'namresid_svs', 'namresid_varexp', 'yresid', 'beta'):
             getattr(res, name)
         return res
     return res.p

@@ -56,6 +56,65 @@ def _small_svd(G):
     return np.linalg.svd(G)
 
 
+def _top_pcs(G, kmax):
+    """The kmax leading eigenvectors of the samples x samples Gram matrix (columns, leading first), for the global
+    F-tests.  Every statistic of _association.py:35-48 depends on the PCs only through squared projections -- not on
+    their signs -- so the tests need not wait for the sign-defining LAPACK SVD of _nam.py:105: LAPACK's dsyevr with
+    an index range (tridiagonalisation + the wanted eigenpairs) is ~3x shorter at 200 samples, and the SVD is left
+    to `GramPCs` (a worker thread, or whoever first reads a field that shows the signs).  Same subspaces to ~1e-13."""
+    n = len(G)
+    if kmax >= n or not np.isfinite(G).all():
+        return None                                 # degenerate input: the caller takes the SVD (and its errors)
+    from scipy.linalg import eigh
+    _, v = eigh(G, subset_by_index=[n - kmax, n - 1], driver='evr', check_finite=False, overwrite_a=False)
+    return np.ascontiguousarray(v[:, ::-1])
+
+
+_svd_workers = None
+
+
+class GramPCs:
+    """np.linalg.svd of the samples x samples Gram matrix (_nam.py:105; the LAPACK routine that defines the PC
+    signs of the reference), computed when `U` / `svs` are first read -- or from start() on a worker thread,
+    beside the local-null kernel."""
+
+    def __init__(self, G):
+        self._G, self._out, self._fut = G, None, None
+
+    def _run(self, limit):
+        if limit:
+            with host_blas_threads(1):
+                return _small_svd(self._G)
+        return _small_svd(self._G)
+
+    def start(self):
+        """Begin now on a worker thread (the caller holds host_blas_threads(1) until it has read the result)."""
+        global _svd_workers
+        if self._out is None and self._fut is None:
+            if _svd_workers is None:
+                from concurrent.futures import ThreadPoolExecutor
+                _svd_workers = ThreadPoolExecutor(max_workers=1, thread_name_prefix='cna-svd')
+            self._fut = _svd_workers.submit(self._run, False)
+        return self
+
+    def _get(self):
+        if self._out is None:
+            U, svs, _ = self._fut.result() if self._fut is not None else self._run(True)
+            self._out, self._fut, self._G = (U, svs), None, None
+        return self._out
+
+    @property
+    def U(self):
+        return self._get()[0]
+
+    @property
+    def svs(self):
+        return self._get()[1]
+
+    def __len__(self):
+        return len(self._G) if self._out is None else len(self._out[0])
+
+
 class LazyNamespace(Namespace):
     """Result namespace whose cells-sized fields are fetched from the device on first access
     (SURVEY.md §8f.1).  ``isinstance(res, argparse.Namespace)`` holds; a lazily provided
@@ -554,16 +613,17 @@ def _still_resident(engine, epoch):
                            'read it (or call res.materialize()) before running the next analysis')
 
 
-def _defer_pcs(res, engine, U, svs, cell_index):
-    """namresid_nbhdXpc: V = NAM^T U / sqrt(svs) (_nam.py:106), computed on the device when read."""
+def _defer_pcs(res, engine, pcs, cell_index):
+    """namresid_nbhdXpc: V = NAM^T U / sqrt(svs) (_nam.py:106), computed on the device when read.
+    pcs: GramPCs (U and svs are taken when the field is read)."""
     epoch = engine.x_epoch
     n_cells = engine.x_rows_total
-    names = _pc_names(len(U))
 
     def fetch_V():
         _still_resident(engine, epoch)
+        U, svs = pcs.U, pcs.svs
         with np.errstate(all='ignore'):
             V = engine.project_full(U / np.sqrt(svs))
-        return pd.DataFrame(V, index=_names(cell_index), columns=names)
+        return pd.DataFrame(V, index=_names(cell_index), columns=_pc_names(len(U)))
 
     res._defer('namresid_nbhdXpc', fetch_V)

@@ -84,7 +84,11 @@ def run_product(case, engine, **overrides):
 
 def assert_matches_golden(res, data, z, tol=1e-5, check_lazy=True):
     """Every result field of SURVEY.md §8a a20 against the reference's values.
-    ints / masks exact; floats within `tol` relative (BASELINE.json: 1e-5)."""
+    ints / masks exact; floats within `tol` relative (BASELINE.json: 1e-5) -- observed maxima over the 19
+    fixtures are 2e-8 ... 7e-7 (the reference's float32 first walk step on float32 graphs).  One exception, the
+    empirical FDRs: `fdr[t] = sum_p tails[p, t] / ranks[t] / P` is a ratio of COUNTS, and a null coefficient that sits
+    within that 1e-7 of a threshold moves a count by one (c14: 3.8e-5 relative on an entry with ~26 000 counted
+    outputs): 1e-4 there and on the per-cell FDR column that is looked up in the table."""
     import pytest
     assert int(res.k) == int(z['k'])
     assert np.array_equal(np.asarray(res.ks), z['ks'])
@@ -93,19 +97,19 @@ def assert_matches_golden(res, data, z, tol=1e-5, check_lazy=True):
     assert float(res.p) == pytest.approx(float(z['p']), rel=1e-12)
     assert relerr(res.ncorrs.values, z['ncorrs']) < tol
     assert relerr(res.M.values, z['M']) < tol
-    assert relerr(res.nullminps, z['nullminps']) < tol * 10
+    assert relerr(res.nullminps, z['nullminps']) < tol
     assert relerr(res.namresid_svs.values, z['svs']) < tol
     assert relerr(res.namresid_varexp.values, z['varexp']) < tol
     assert relerr(np.asarray(res.yresid), z['yresid']) < tol
-    assert float(res.r2) == pytest.approx(float(z['r2']), rel=tol * 10)
-    assert float(res.nullr2_mean) == pytest.approx(float(z['nullr2_mean']), rel=tol * 10)
-    assert float(res.nullr2_std) == pytest.approx(float(z['nullr2_std']), rel=tol * 10)
+    assert float(res.r2) == pytest.approx(float(z['r2']), rel=tol)
+    assert float(res.nullr2_mean) == pytest.approx(float(z['nullr2_mean']), rel=tol)
+    assert float(res.nullr2_std) == pytest.approx(float(z['nullr2_std']), rel=tol)
     kk = int(z['k'])
     U, Uref = sign_align(res.namresid_sampleXpc.values, z['U'], kk)
-    assert relerr(U, Uref) < 1e-4
-    assert relerr(np.abs(res.beta), np.abs(z['beta'])) < 1e-4
-    assert relerr(res.r2_perpc, z['r2_perpc']) < 1e-4
-    assert relerr(np.abs(res.yresid_hat), np.abs(z['yresid_hat'])) < 1e-4
+    assert relerr(U, Uref) < tol
+    assert relerr(np.abs(res.beta), np.abs(z['beta'])) < tol
+    assert relerr(res.r2_perpc, z['r2_perpc']) < tol
+    assert relerr(np.abs(res.yresid_hat), np.abs(z['yresid_hat'])) < tol
     np.testing.assert_allclose(data.obs['coef'].values, z['obs_coef'], rtol=0,
                                atol=tol * np.nanmax(np.abs(z['obs_coef'])), equal_nan=True)
     if 'fdr_fdr' in z:
@@ -114,7 +118,7 @@ def assert_matches_golden(res, data, z, tol=1e-5, check_lazy=True):
         assert abs(len(f) - len(z['fdr_threshold'])) <= 1 and T >= 300
         assert relerr(f.threshold.values[:T], z['fdr_threshold'][:T]) < tol
         assert np.array_equal(f.num_detected.values[:T], z['fdr_num_detected'][:T])
-        assert relerr(f.fdr.values[:T], z['fdr_fdr'][:T]) < tol * 10
+        assert relerr(f.fdr.values[:T], z['fdr_fdr'][:T]) < tol * 10                 # ratio of counts, see above
         for key in ('fdr_5p_t', 'fdr_10p_t'):
             ref = float(z[key])
             got = getattr(res, key)
@@ -128,7 +132,7 @@ def assert_matches_golden(res, data, z, tol=1e-5, check_lazy=True):
         assert relerr(res.nam.values, z['nam']) < tol
         assert relerr(res.namresid.values, z['namresid']) < tol
         V, Vref = sign_align(res.namresid_nbhdXpc.values, z['V'], kk)
-        assert relerr(V, Vref) < 1e-4
+        assert relerr(V, Vref) < tol
         assert res.nam.shape == z['nam'].shape and list(res.nam.columns) == list(data.obs.index[z['kept']])
 
 

@@ -130,7 +130,27 @@ def test_large_properties_and_renumbering(big, eng):
     ranks = np.array([(np.nan_to_num(coef) ** 2 >= e).sum() for e in edges])
     with np.errstate(all='ignore'):
         np.testing.assert_allclose(fdr, (tails / ranks).mean(axis=0), rtol=1e-12, equal_nan=True)
-    del res, tails
+    # ... and an INDEPENDENT count at full size (no HIP kernel on this side): the oracle's permutation draw
+    # (_stats.py:4-18, numpy's global RNG), its tail_counts (_stats.py:34-62) and numpy's GEMV on the fetched
+    # residualised NAM, for the first eight permutations -- against the f64 kernel's rows for those columns and
+    # against the integer pass restricted to them.  A value within an ulp of an edge may fall on either side
+    # of it (numpy adds the 200 products in another order): a handful of off-by-ones, as in
+    # test_local_null_counts_are_exact.
+    from oracle import cna_oracle as orc_
+    X = res.namresid.values                                            # samples x cells
+    yz = (y.values - y.values.mean()) / y.values.std()
+    np.random.seed(kw['seed'])
+    ynull = orc_.conditional_permutation(np.ones(N), yz, 1000)[:, :8]  # M = I: the conditioned phenotype is y_ / std
+    zc = ynull / ynull.std(axis=0, ddof=1)
+    znull = np.abs(zc.T.dot(X) / N).T                                  # cells x 8, _association.py:96-99
+    want = orc_.tail_counts(thr, znull)
+    diff = np.abs(tails[:8] - want)
+    assert diff.max() <= 1 and diff.sum() <= 8, (diff.max(), diff.sum())
+    sums8 = eng.null_local_resident(1, 8, edges, sums_only=True)
+    assert np.array_equal(sums8, tails[:8].sum(axis=0))
+    print('[%s] independent recount of 8 null columns at full size: %d of %d counts off by one' % (
+        name, int(diff.sum()), diff.size))
+    del res, tails, X, znull
 
     # the same analysis with the cells renumbered at random: the global p-value, the chosen k, the FDR
     # table and every cell's coefficient must not move

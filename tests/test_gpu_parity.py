@@ -685,6 +685,38 @@ def test_fdr_column_copied_by_the_helper_thread_equals_the_late_copy(eng, monkey
 
 
 @pytest.mark.parametrize('big_path', [False, True])
+def test_late_exception_leaves_obs_untouched(eng, monkeypatch, big_path):
+    """An exception AFTER the association test has returned -- here the 'already exists' warning of
+    _association.py:229 turned into an error (python -W error) -- finds data.obs as the caller left it: the
+    columns written early (coefficients under the null kernel; with big_path also the FDR column's storage, which
+    the helper thread may still be filling) are put back, and the helper is done with the storage."""
+    import warnings
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.tools import _association as A
+    if big_path:
+        monkeypatch.setattr(A, '_COEF_FIRST_CELLS', 0)
+    data, meta = synth.make_dataset(5000, 24, k=15, seed=3)
+    kw = dict(Nnull=100, seed=1, nsteps=3)
+    p1 = cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+    before = data.obs['coef'].values.copy()
+    before_fdr = data.obs['coef_fdr'].values.copy()
+    y2 = pd.Series(np.random.RandomState(2).randn(24), index=meta['y'].index)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        warnings.filterwarnings('error', message="Key '.*' already exists")
+        with pytest.raises(UserWarning, match='already exists'):
+            cna.tl.association(data, y2, 'id', engine=eng, **kw)
+    np.testing.assert_array_equal(data.obs['coef'].values, before)
+    np.testing.assert_array_equal(data.obs['coef_fdr'].values, before_fdr)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        assert cna.tl.association(data, meta['y'], 'id', engine=eng, **kw) == p1
+    np.testing.assert_array_equal(data.obs['coef'].values, before)
+    np.testing.assert_array_equal(data.obs['coef_fdr'].values, before_fdr)
+
+
+@pytest.mark.parametrize('big_path', [False, True])
 def test_failed_test_leaves_obs_untouched(eng, monkeypatch, big_path):
     """(big_path: the schedule of large inputs -- coefficient column under the Gram kernels, the FDR column's
     storage made early and filled in place at the end -- forced on this small dataset.)

@@ -44,19 +44,19 @@ def test_association_matches_reference(name, mode, tol):
     assert relerr(out['namresid'].T, z['namresid']) < tol
     assert relerr(out['M'], z['M']) < tol
     assert relerr(out['ncorrs'], z['ncorrs']) < tol
-    assert relerr(out['nullminps'], z['nullminps']) < tol * 10
+    assert relerr(out['nullminps'], z['nullminps']) < tol
     assert relerr(out['svs'], z['svs']) < tol
     assert relerr(out['varexp'], z['varexp']) < tol
     assert relerr(out['yresid'], z['yresid']) < tol
-    assert out['r2'] == pytest.approx(float(z['r2']), rel=tol * 10)
-    assert out['nullr2_mean'] == pytest.approx(float(z['nullr2_mean']), rel=tol * 10)
-    assert out['nullr2_std'] == pytest.approx(float(z['nullr2_std']), rel=tol * 10)
+    assert out['r2'] == pytest.approx(float(z['r2']), rel=tol)
+    assert out['nullr2_mean'] == pytest.approx(float(z['nullr2_mean']), rel=tol)
+    assert out['nullr2_std'] == pytest.approx(float(z['nullr2_std']), rel=tol)
     # PCs: up to sign, only well-separated ones
     kk = int(z['k'])
     U, Uref = sign_align(out['U'], z['U'], kk)
-    assert relerr(U, Uref) < 1e-4
-    assert relerr(np.abs(out['beta']), np.abs(z['beta'])) < 1e-4
-    assert relerr(out['r2_perpc'], z['r2_perpc']) < 1e-4
+    assert relerr(U, Uref) < tol                     # observed: 7e-14 in reference mode, 2e-7 in f64 mode
+    assert relerr(np.abs(out['beta']), np.abs(z['beta'])) < tol
+    assert relerr(out['r2_perpc'], z['r2_perpc']) < tol
     if 'fdr_fdr' in z:
         f = out['fdrs']
         # np.arange(maxcorr/4, maxcorr, maxcorr/400) (_association.py:102) yields 300 or 301

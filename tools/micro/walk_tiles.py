@@ -47,6 +47,29 @@ def main():
     tp['tile_src0'].tofile(d + '/tilesrc0.bin')
     tp['tile_src'].tofile(d + '/tilesrc.bin')
     tp['seg'].tofile(d + '/seg.bin')
+    # producer / consumer variant: one self-describing blob of BLOB bytes per tile -- nw + 1 uint16 record offsets
+    # (the waves' segments inside the tile), then the tile's records
+    BLOB, HDR = 4096, 64
+    seg = tp['seg']
+    t0 = seg[0:nt * nw:nw]
+    cnt = np.diff(np.append(t0, seg[nt * nw]))
+    cap = (BLOB - HDR) // 8
+    print('records per tile: mean %.1f max %d (blob holds %d)' % (cnt.mean(), cnt.max(), cap), flush=True)
+    assert cnt.max() <= cap and nw + 1 <= HDR // 2
+    blob = np.zeros((nt, BLOB), dtype=np.uint8)
+    offs = (seg[:nt * nw].reshape(nt, nw) - t0[:, None]).astype(np.uint16)
+    hdr = np.zeros((nt, HDR // 2), dtype=np.uint16)
+    hdr[:, :nw] = offs
+    hdr[:, nw] = cnt.astype(np.uint16)
+    blob[:, :HDR] = hdr.view(np.uint8).reshape(nt, HDR)
+    recb = rec.view(np.uint8).reshape(-1, 8)
+    tile_of = np.repeat(np.arange(nt), cnt)
+    pos_in = np.arange(len(indices)) - np.repeat(t0, cnt)
+    flat = blob.reshape(-1)
+    base = tile_of * BLOB + HDR + pos_in * 8
+    for k in range(8):
+        flat[base + k] = recb[:, k]
+    blob.tofile(d + '/blob.bin')
 
 
 if __name__ == '__main__':
