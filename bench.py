@@ -16,7 +16,8 @@ largest configuration -- it fits one MI355X (~20 GB of 288 GB).  With N > 1 rank
 by torch.distributed.run, or self-spawned when `--gpus N` is given to a plain `python bench.py`) the
 SAME 2M x 200 problem is sharded over the ranks by row blocks of cells (strong scaling, BASELINE.json's
 "sharded over 8 x MI355X"); `--scaling weak` keeps the per-GPU block fixed instead.  At N = 1 two more
-lines ride along in the same JSON object: configs[2] ("C3", 1M x 100) and configs[1] ("C2", 200k x 50).
+lines ride along in the same JSON object (`other_configs`): configs[4] ("C5": C4 + 5 covariates, Nnull = 10000),
+configs[2] ("C3", 1M x 100) and configs[1] ("C2", 200k x 50).
 
 Prints ONE JSON line on rank 0 (see the repo's bench contract) with two extra objects:
   roofline     for the kernel that dominates the timed region (HIP-event timed in this run)
@@ -43,7 +44,7 @@ I8_MFMA_PEAK_TOPS = 5033.0   # dense i8 matrix: 2x the bf16 rate (guide: >= 4404
 # profiles/*_pmc_traffic.json: bytes = 2 * FETCH_SIZE KB + WRITE_SIZE KB; the factor 2 on FETCH_SIZE is the
 # guide's gfx950 correction, re-calibrated on k_ncorrs, which streams the matrix once).  Counted at the L2's
 # fabric side, i.e. Infinity-Cache hits included.  Only valid for the profiled workload on one GPU.
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
 
 WORKLOADS = {
     # name: (cells, samples, kNN k, nsteps, Nnull, covariates)
@@ -64,7 +65,7 @@ def usable_cpus():
 def algorithmic_work(kernel, n, nnz, N, P, T, wA):
     """Algorithmic bytes / flops of ONE launch (DESIGN.md 'Kernels')."""
     ld = (N + 3) // 4 * 4
-    if kernel == 'nam_step':
+    if kernel in ('nam_step', 'nam_step_sparse'):      # the dense gather / the second step on the compressed state: same algorithmic bytes
         return 'hbm', nnz * (4 + wA) + 8 * (n + 1) + 8 * n + 2 * 8 * n * N
     if kernel == 'nam_first':
         return 'hbm', nnz * (4 + wA) + 8 * (n + 1) + n * (4 + 8) + 8 * n * N
@@ -85,32 +86,28 @@ def algorithmic_work(kernel, n, nnz, N, P, T, wA):
     return 'hbm', 8 * n
 
 
-def load_or_make_dataset(synth, n, N, k, rank, world, td, n_covs=0):
-    """One synthetic dataset for the whole job: rank 0 generates it (the kNN search is the slow,
-    CPU-only part) and the other ranks of this node read it from /dev/shm."""
+def load_or_make_dataset(synth, n, N, k, rank, world, n_covs=0):
+    """One synthetic dataset for the whole job: rank 0 generates it (graph construction) and the other ranks of
+    this node read it from /dev/shm.  No collective is involved (the ranks that wait must not sit in the
+    communicator's set-up meanwhile): rank 0 publishes the file by an atomic rename, the others poll for it; the
+    caller removes it after the job's first barrier."""
     if world == 1:
-        return synth.make_dataset(n, N, k=k, seed=0, n_covs=n_covs)
+        return synth.make_dataset(n, N, k=k, seed=0, n_covs=n_covs), None
     import pickle
-    path = '/dev/shm/cna_bench_%s_%d_%d.pkl' % (os.environ.get('MASTER_PORT', '0'), n, N)
+    path = '/dev/shm/cna_bench_%s_%s_%d_%d.pkl' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'x'), n, N)
     if rank == 0:
         out = synth.make_dataset(n, N, k=k, seed=0, n_covs=n_covs)
-        try:
-            with open(path + '.tmp', 'wb') as f:
-                pickle.dump(out, f, protocol=pickle.HIGHEST_PROTOCOL)
-            os.replace(path + '.tmp', path)
-        except OSError:                      # no room in /dev/shm: the other ranks generate their own copy
-            pass
-    td.barrier()
-    if rank != 0:
-        if os.path.exists(path):
-            with open(path, 'rb') as f:
-                out = pickle.load(f)
-        else:
-            out = synth.make_dataset(n, N, k=k, seed=0, n_covs=n_covs)
-    td.barrier()
-    if rank == 0 and os.path.exists(path):
-        os.remove(path)
-    return out
+        with open(path + '.tmp', 'wb') as f:
+            pickle.dump(out, f, protocol=pickle.HIGHEST_PROTOCOL)
+        os.replace(path + '.tmp', path)
+        return out, path
+    deadline = time.time() + 1800
+    while not os.path.exists(path):
+        if time.time() > deadline:
+            sys.exit('bench.py: rank %d saw no dataset from rank 0' % rank)
+        time.sleep(0.05)
+    with open(path, 'rb') as f:
+        return pickle.load(f), path
 
 
 def self_spawn(args):
@@ -152,7 +149,26 @@ def self_spawn(args):
     sys.exit(rc)
 
 
-def time_workload(name, args, rank, world, td, on_gpu_group, steps, warmup, want_kernels=True):
+class stdout_to_stderr:
+    """fd 1 -> fd 2 while a library that writes to C stdout starts up (RCCL prints a version banner when the first
+    communicator is created): rank 0's stdout carries the JSON line and nothing else."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
     """Generate the dataset of `name`, run the cold call, warm up, time `steps` calls.  Returns a dict of
     raw measurements (rank 0 fills the JSON from it)."""
     import warnings
@@ -164,7 +180,7 @@ def time_workload(name, args, rank, world, td, on_gpu_group, steps, warmup, want
     n_total, N, k, nsteps, Nnull, n_covs = WORKLOADS[name]
     n = n_total * world if args.scaling == 'weak' else n_total
     t0 = time.time()
-    data, meta = load_or_make_dataset(synth, n, N, k, rank, world, td, n_covs=n_covs)
+    (data, meta), shared_file = load_or_make_dataset(synth, n, N, k, rank, world, n_covs=n_covs)
     t_gen = time.time() - t0
     A = get_connectivity(data)
     nnz = int(A.nnz)
@@ -176,22 +192,26 @@ def time_workload(name, args, rank, world, td, on_gpu_group, steps, warmup, want
         data = dist.shard(data, rank, world)     # from here on this rank knows its own cells only
         del A
     y = meta['y']
-    eng = get_engine()
+    with stdout_to_stderr():
+        eng = get_engine()                       # (with a communicator: collective set-up, RCCL's banner)
     eng.reuse_nam = False           # every timed step recomputes the NAM (no result caching across steps)
     eng.pin_graph(get_connectivity(data))        # the bench never edits the graph in place (see module docstring)
     kw = dict(nsteps=nsteps, Nnull=Nnull, seed=0)
     if meta.get('covs') is not None:
         kw['covs'] = meta['covs']
 
+    from cna_amd import dist
+
     def sync():
+        # device idle on every rank, then a barrier through the library's own communicator, then idle again
         eng.sync()
-        if on_gpu_group:
-            import torch
-            torch.cuda.synchronize()
-            td.barrier()
-            torch.cuda.synchronize()
-        elif td is not None:
-            td.barrier()
+        if world > 1 or args.force_dist:
+            dist.barrier()
+            eng.sync()
+
+    sync()
+    if shared_file and rank == 0 and os.path.exists(shared_file):
+        os.remove(shared_file)                    # every rank has loaded it
 
     # cold call: graph preparation (cell order, block lists), H2D over PCIe, first analysis
     sync()
@@ -212,11 +232,8 @@ def time_workload(name, args, rank, world, td, on_gpu_group, steps, warmup, want
     dt = time.perf_counter() - t0
     eng.prof_enable(False)
     prof = eng.prof()
-    if td is not None:
-        import torch
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda' if on_gpu_group else 'cpu')
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = float(t[0])
+    if world > 1 or args.force_dist:
+        dt = dist.max_over_ranks(dt)               # the slowest rank's clock
     assert p_first == p_last
 
     if args.profile_host and rank == 0:
@@ -317,7 +334,7 @@ def main():
     ap.add_argument('--scaling', default='strong', choices=['strong', 'weak'],
                     help='N>1: strong = the same total problem sharded over the ranks (default, BASELINE configs[3]); '
                          'weak = the workload size PER GPU')
-    ap.add_argument('--no-extra', action='store_true', help='N=1: skip the additional C3 and C2 lines')
+    ap.add_argument('--no-extra', action='store_true', help='N=1: skip the additional C5, C3 and C2 lines')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-cells', type=int, default=150_000)
     ap.add_argument('--profile-host', default=None, help='write a cProfile of 3 extra steps to this file')
@@ -329,7 +346,7 @@ def main():
                          '(cna_amd.dist.shard) and gets per-cell results for that block; replicated: every rank '
                          'holds the whole dataset and the whole result, like a replicated AnnData')
     ap.add_argument('--force-dist', action='store_true',
-                    help='take the torch.distributed + RCCL code path even with one rank (plumbing check)')
+                    help='take the communicator (RCCL) code path even with one rank (plumbing check)')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'RANK' not in os.environ:
@@ -339,24 +356,19 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         sys.exit('bench.py --gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    td = None
-    if args.comm == 'shm' and world > 1:
-        import torch.distributed as td
+    if world > 1 or args.force_dist:
+        # The launcher (torch.distributed.run, or self_spawn above) only provides RANK / LOCAL_RANK / WORLD_SIZE /
+        # MASTER_PORT.  torch.distributed is NOT initialised: the job's one communicator is the library's own RCCL
+        # communicator, whose id travels over a Unix-domain socket (cna_amd.dist.init_from_env); barriers and the
+        # max over ranks of the timing go through it as well.
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
-        td.init_process_group(backend='gloo', rank=rank, world_size=world)
         from cna_amd import dist
-        dist.init(rank, world, device=0, shm=('cna_bench_%s' % os.environ['MASTER_PORT'],
-                                                  (512 << 20) if WORKLOADS[args.workload][0] > 1_000_000 else (64 << 20)))   # a slot holds one rank's halo rows
-    elif world > 1 or args.force_dist:
-        import torch
-        import torch.distributed as td
-        torch.cuda.set_device(local_rank)
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29533')
-        td.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank), rank=rank, world_size=world)
-        from cna_amd import dist
-        dist.init_from_torch(device=local_rank, always_comm=args.force_dist)
+        if args.comm == 'shm':
+            dist.init_from_env(shm=('cna_bench_%s' % os.environ['MASTER_PORT'],
+                                    (512 << 20) if WORKLOADS[args.workload][0] > 1_000_000 else (64 << 20)))   # a slot holds one rank's halo rows
+        else:
+            dist.init_from_env(always_comm=args.force_dist)
 
     import warnings
     # every repeated call warns that data.obs['coef'] exists (as the reference does); keep the
@@ -368,14 +380,13 @@ def main():
     from cna_amd import synth
     cna.tune_host_allocator()       # host-side: no mmap/munmap churn for per-cell numpy temporaries
     from cna_amd.engine import get_engine
-    on_gpu_group = td is not None and args.comm != 'shm'
 
     steps = args.steps if args.steps is not None else DEFAULT_STEPS[args.workload][0]
     warmup = args.warmup if args.warmup is not None else DEFAULT_STEPS[args.workload][1]
-    m = time_workload(args.workload, args, rank, world, td, on_gpu_group, steps, warmup)
+    m = time_workload(args.workload, args, rank, world, steps, warmup)
     eng = get_engine()
 
-    if td is not None:
+    if world > 1 or args.force_dist:
         # every rank pushes out what its runtime libraries buffered (RCCL's version banner) before
         # rank 0 goes on to print the result line: nothing from another rank can land after it
         sys.stderr.flush()
@@ -385,10 +396,9 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        td.barrier()
+        from cna_amd import dist
+        dist.barrier()
     if rank != 0:
-        if td is not None:
-            td.destroy_process_group()
         return
 
     main_sum = summary(m, world, steps)
@@ -417,6 +427,13 @@ def main():
                    mode='reference-cost', seconds=round(t_cpu, 2), host_cpus=os.cpu_count(), p_value=float(ref['p']),
                    stages_s={k_: round(v, 2) for k_, v in st.items()},
                    value_without_percell_apply=round(ns * Pc / max(t_cpu - st.get('percell_apply', 0.0), 1e-9), 1),
+                   # every stage of the reference's cost profile is linear in the cell count at fixed samples and Nnull
+                   # (the null loop's per-permutation cost does not depend on the cells, the rest is per cell):
+                   # the sample's stage times scaled to the workload's cells
+                   extrapolated_to_workload=dict(
+                       cells=m['n'], seconds=round(sum((v if k_ == 'global_test' else v * m['n'] / ns) for k_, v in st.items()), 1),
+                       stages_s={k_: round(v if k_ == 'global_test' else v * m['n'] / ns, 1) for k_, v in st.items()},
+                       value=round(m['n'] * Pc / max(sum((v if k_ == 'global_test' else v * m['n'] / ns) for k_, v in st.items()), 1e-9), 1)),
                    sample='oracle/reference_cost.py (the reference\'s own sequence of library calls: pandas frames, '
                           'scipy csr.dot + st.kurtosis per step, a Python loop over the permutations with st.f.sf, the '
                           'materialised cells x Nnull null matrix, np.histogram per null column, per-cell Series.apply; '
@@ -427,10 +444,10 @@ def main():
 
     extra = {}
     if world == 1 and not args.no_extra and args.workload == 'C4':
-        for name in ('C3', 'C2'):
+        for name in ('C5', 'C3', 'C2'):
             st_, wu_ = DEFAULT_STEPS[name]
             try:
-                mm = time_workload(name, args, rank, world, td, on_gpu_group, st_, wu_)
+                mm = time_workload(name, args, rank, world, st_, wu_)
                 s_ = summary(mm, world, st_)
                 extra[name] = dict(workload=workload_text(mm, world, args), steps=st_, warmup=wu_, **s_)
                 del mm
@@ -461,6 +478,7 @@ def main():
         'host_ms_per_step': main_sum['host_ms_per_step'],
         'cold_first_call': main_sum['cold_first_call'],
         'first_call_ms_incl_graph_h2d': main_sum['cold_first_call']['ms'],
+        'value_cold': main_sum['cold_first_call']['value'],      # the same metric on the first call (graph preparation + H2D included)
         'dataset_gen_s': main_sum['dataset_gen_s'],
         'kernels': main_sum['kernels'],
         'other_configs': extra,
@@ -471,8 +489,6 @@ def main():
         eng.close()
     except Exception:
         pass
-    if td is not None:
-        td.destroy_process_group()
     sys.stderr.flush()
     try:
         import ctypes

@@ -111,7 +111,7 @@ SIGNATURES = {
 MAT_NAM, MAT_X, MAT_PROJ = 0, 1, 2
 KERNELS = ['colsum', 'nam_first', 'nam_step', 'batch_kurtosis', 'zero_variance', 'select', 'resid_xb',
            'standardize', 'gram', 'gram_reduce', 'ncorrs', 'null_local', 'obs_counts', 'percell_fdr',
-           'project_xb', 'transpose', 'rccl', 'condition', 'global_test']
+           'project_xb', 'transpose', 'rccl', 'condition', 'global_test', 'nam_step_sparse']
 
 _lib = None
 

@@ -99,7 +99,7 @@ static void prof_flush(cna_ctx* c) {
 static const char* kKernelNames[CNA_K_COUNT] = {
     "colsum", "nam_first", "nam_step", "batch_kurtosis", "zero_variance", "select", "resid_xb",
     "standardize", "gram", "gram_reduce", "ncorrs", "null_local", "obs_counts", "percell_fdr",
-    "project_xb", "transpose", "rccl", "condition", "global_test"};
+    "project_xb", "transpose", "rccl", "condition", "global_test", "nam_step_sparse"};
 
 #define CHECK_CTX(c)                                        \
   do {                                                      \

@@ -921,7 +921,8 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
     HIP_TRY(hipGetLastError());
     c->cellinfo_valid = true;
   }
-  ProfScope ps(c, first ? CNA_K_NAM_FIRST : CNA_K_NAM_STEP);
+  const bool sparse_step = !first && !dense && c->sp_cnt && c->steps_done == 1;       // launch_step_q takes k_nam_step_sparse then
+  ProfScope ps(c, first ? CNA_K_NAM_FIRST : (sparse_step ? CNA_K_NAM_STEP_SPARSE : CNA_K_NAM_STEP));
   StepArgs a;
   a.indptr = c->indptr;
   a.idx = c->indices;

@@ -2,8 +2,10 @@
 
 The data path uses RCCL directly from libcna_hip.so (cna_comm_init).  RCCL needs one
 out-of-band exchange -- rank 0's 128-byte unique id -- which any host channel can carry.
-``init_from_torch`` uses an already-initialised ``torch.distributed`` group for that single
-broadcast (this is what bench.py does under torchrun); ``init`` takes the id directly.
+``init_from_env`` carries it over an abstract Unix-domain socket between the ranks of a node (what
+bench.py does under `torch.distributed.run` -- the launcher only provides RANK / WORLD_SIZE /
+MASTER_PORT; torch.distributed itself is not used); ``init_from_torch`` uses an already-initialised
+``torch.distributed`` group for that single broadcast; ``init`` takes the id directly.
 """
 import os
 
@@ -47,6 +49,81 @@ def init_from_torch(device=None, always_comm=False):
         uid = box[0]
     init(rank, nranks, uid, device)
     return rank, nranks
+
+
+def _exchange_id(rank, nranks, key, make, timeout=600.0):
+    """Rank 0's 128-byte RCCL id to every rank of this node, without torch: rank 0 listens on an abstract Unix-domain
+    socket named after the job (`key`: MASTER_PORT of the launcher, unique per job on a node; no file is left
+    behind and a stale name cannot exist -- the kernel drops it with the last descriptor) and hands the id to the
+    nranks - 1 processes that connect."""
+    import socket
+    import time
+    name = b'\0cna_amd_rdzv_' + str(key).encode()
+    if rank == 0:
+        uid = make()
+        srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        srv.bind(name)
+        srv.listen(max(nranks, 1))
+        srv.settimeout(timeout)
+        try:
+            for _ in range(nranks - 1):
+                conn, _ = srv.accept()
+                with conn:
+                    conn.sendall(uid)
+        finally:
+            srv.close()
+        return uid
+    deadline = time.time() + timeout
+    while True:
+        cli = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        try:
+            cli.connect(name)
+            buf = b''
+            while len(buf) < 128:
+                part = cli.recv(128 - len(buf))
+                if not part:
+                    raise ConnectionError('rank 0 closed the rendezvous socket early')
+                buf += part
+            return buf
+        except (FileNotFoundError, ConnectionRefusedError):
+            if time.time() > deadline:
+                raise TimeoutError('no RCCL id from rank 0 (rendezvous %r)' % name)
+            time.sleep(0.02)
+        finally:
+            cli.close()
+
+
+def init_from_env(always_comm=False, shm=None):
+    """One process per GPU started by a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT
+    (`python -m torch.distributed.run`, `torchrun`, bench.py's own spawner): rank 0 makes the RCCL id and the
+    other ranks of the node fetch it through `_exchange_id` -- torch.distributed is neither imported nor
+    initialised, so the job holds ONE RCCL communicator, the library's.  shm=(name, slot bytes): the host-staged
+    test communicator instead (ranks may share a GPU; no id needed)."""
+    rank = int(os.environ.get('RANK', '0'))
+    nranks = int(os.environ.get('WORLD_SIZE', '1'))
+    device = int(os.environ.get('LOCAL_RANK', rank))
+    if shm is not None:
+        init(rank, nranks, None, 0, shm=tuple(shm))          # the test communicator: every rank on GPU 0
+        return rank, nranks
+    uid = None
+    if nranks > 1 or always_comm:
+        key = os.environ.get('MASTER_PORT', '29533') + '_' + os.environ.get('TORCHELASTIC_RUN_ID', 'none')
+        uid = _exchange_id(rank, nranks, key, new_unique_id) if nranks > 1 else new_unique_id()
+    init(rank, nranks, uid, device)
+    return rank, nranks
+
+
+def barrier():
+    """All ranks of the job (a small collective through the library's own communicator)."""
+    from .engine import get_engine
+    get_engine().allgather_fixed([0])
+
+
+def max_over_ranks(x):
+    """max of a host float over the ranks (timings): gathered as integers, exact to a nanosecond for seconds."""
+    from .engine import get_engine
+    got = get_engine().allgather_fixed([int(round(float(x) * 1e9))])
+    return float(got.max()) * 1e-9
 
 
 def block(n_cells, rank, nranks):

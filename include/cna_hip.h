@@ -48,7 +48,9 @@ enum {
   CNA_K_COLSUM = 0, CNA_K_NAM_FIRST, CNA_K_NAM_STEP, CNA_K_BATCH_KURT, CNA_K_ZEROVAR,
   CNA_K_SELECT, CNA_K_RESID, CNA_K_STANDARDIZE, CNA_K_GRAM, CNA_K_GRAM_REDUCE, CNA_K_NCORRS,
   CNA_K_NULL_LOCAL, CNA_K_OBS_COUNTS, CNA_K_PERCELL_FDR, CNA_K_PROJECT, CNA_K_TRANSPOSE,
-  CNA_K_ALLGATHER, CNA_K_CONDITION, CNA_K_GLOBAL_TEST, CNA_K_COUNT
+  CNA_K_ALLGATHER, CNA_K_CONDITION, CNA_K_GLOBAL_TEST,
+  CNA_K_NAM_STEP_SPARSE,        /* the second walk step on the compressed state (k_nam_step_sparse); CNA_K_NAM_STEP is the dense gather */
+  CNA_K_COUNT
 };
 
 /* ---- library / context ------------------------------------------------------------- */
