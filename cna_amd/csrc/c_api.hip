@@ -859,9 +859,22 @@ int cna_select_checked(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, cons
   return 0;
 }
 
+static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
+                                    int64_t* n_zero_out, const double* y, double* max_abs_out, bool* gram_too);
+
 int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
                             int64_t* n_zero_out, const double* y, double* max_abs_out) {
+  return select_standardized_impl(c, keep_idx, n_keep, colmap, n_sel, n_zero_out, y, max_abs_out, nullptr);
+}
+
+// gram_too != nullptr: the caller will want the Gram matrix of the result next.  When the selection is "all cells,
+// samples in place, no projector" and the shape suits it, selection and Gram kernels are ONE launch
+// (mfma.hip:k_selgram_blk) and *gram_too comes back true: the matrix is in c->gram_buf, summed over the ranks, as
+// after cna_gram_launch (meaningless, like X, when *n_zero_out != 0).
+static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
+                                    int64_t* n_zero_out, const double* y, double* max_abs_out, bool* gram_too) {
   CHECK_CTX(c);
+  if (gram_too) *gram_too = false;
   if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
   const int64_t nx = keep_idx ? n_keep : c->n_local;
   const int Nx = colmap ? n_sel : c->N;
@@ -900,9 +913,20 @@ int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep,
   const bool with_q = y != nullptr && Nx <= 256 && nx > 0 && null_i8_enabled();
   const int KSq = (Nx + 31) / 32;
   if (with_q) CNA_TRY(ensure_xq(c, KSq));
-  CNA_TRY(launch_select_std(c, colmap ? cm : nullptr, nz, y ? yd : nullptr, y ? mb : nullptr, c->resid_f,
-                            c->resid_f ? c->resid_f + (size_t)rk * Nx : nullptr, rk,
-                            with_q ? (unsigned char*)c->xq : nullptr, with_q ? c->xq_scale : nullptr, 32 * KSq));
+  bool in_place = colmap == nullptr || n_sel == c->N;
+  for (int i = 0; colmap && in_place && i < n_sel; ++i) in_place = colmap[i] == i;
+  const bool fused = gram_too && y && !keep_idx && in_place && rk == 0 && gram_fused_ok(c, Nx, c->ldx, 32 * KSq);
+  if (fused) {
+    void* g = c->gram_buf;
+    CNA_TRY(dev_reserve(c, &g, &c->gram_cap, (int64_t)sizeof(double) * Nx * Nx));
+    c->gram_buf = (double*)g;
+    CNA_TRY(launch_selgram(c, c->gram_buf, nz, yd, mb, with_q ? (unsigned char*)c->xq : nullptr,
+                           with_q ? c->xq_scale : nullptr, 32 * KSq));
+  } else {
+    CNA_TRY(launch_select_std(c, colmap ? cm : nullptr, nz, y ? yd : nullptr, y ? mb : nullptr, c->resid_f,
+                              c->resid_f ? c->resid_f + (size_t)rk * Nx : nullptr, rk,
+                              with_q ? (unsigned char*)c->xq : nullptr, with_q ? c->xq_scale : nullptr, 32 * KSq));
+  }
   c->resid_rk = 0;
   CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)nz, 1));
   if (y) CNA_TRY(comm_allreduce_f64_max(c, (double*)mb, 1));
@@ -919,6 +943,12 @@ int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep,
   c->xq_valid = with_q;
   c->coef_early = false;
   c->fdr_inline = false;
+  if (fused) {                                   // what cna_gram_launch does after its kernels
+    CNA_TRY(comm_allreduce_f64_sum(c, c->gram_buf, (size_t)Nx * Nx));
+    HIP_TRY(hipEventRecord(c->gram_done, c->stream));
+    c->gram_n = Nx;
+    *gram_too = true;
+  }
   return 0;
 }
 
@@ -962,7 +992,8 @@ int cna_select_standardized_fused(cna_ctx* c, const int64_t* keep_idx, int64_t n
   if (coef_queued) *coef_queued = 0;
   int64_t nz = 0;
   double m = 0.0;
-  CNA_TRY(cna_select_standardized(c, keep_idx, n_keep, colmap, n_sel, &nz, y, &m));
+  bool gram_done = false;
+  CNA_TRY(select_standardized_impl(c, keep_idx, n_keep, colmap, n_sel, &nz, y, &m, &gram_done));
   if (n_zero_out) *n_zero_out = nz;
   if (max_abs_out) *max_abs_out = m;
   if (nz != 0 || !y) return 0;
@@ -976,7 +1007,7 @@ int cna_select_standardized_fused(cna_ctx* c, const int64_t* keep_idx, int64_t n
     CNA_TRY(cna_percell_coef_launch(c));
     *coef_queued = 1;
   }
-  CNA_TRY(cna_gram_launch(c));
+  if (!gram_done) CNA_TRY(cna_gram_launch(c));
   if (gram_queued) *gram_queued = 1;
   if (T < 1) return 0;
   CNA_TRY(null_local_prepare(c, null_P, edges, T, 0, thr_out));

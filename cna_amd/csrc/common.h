@@ -240,6 +240,7 @@ int launch_gather_rows(cna_ctx* c, const double* src, int ld, const int64_t* row
                        const int32_t* cols_dev, int n_cols, double* dst, int transposed);
 int launch_digit_hist(cna_ctx* c, const double* v, int64_t n, unsigned long long prefix, int shift,
                       unsigned long long* hist_dev);
+int launch_max_fold(cna_ctx* c, const unsigned long long* blockmax, int nblocks, unsigned long long* out);
 int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev, const double* y_dev,
                       unsigned long long* maxbits_dev, const double* W_dev, const double* Ct_dev, int rk,
                       unsigned char* xq = nullptr, void* xscale = nullptr, int Kp = 0);
@@ -263,6 +264,11 @@ int launch_transpose(cna_ctx* c, const double* in, int64_t rows, int cols, int l
 // mfma.hip
 int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, double* out, int ld_out);
 int launch_gram(cna_ctx* c, double* G_dev);
+// selection (all cells, samples in place, no projector) + standardisation + coefficients + digit planes + Gram in one
+// kernel (k_selgram_blk); gram_fused_ok: the shapes it covers (c->nx, c->ld set)
+bool gram_fused_ok(const cna_ctx* c, int Nx, int ldx, int Kp);
+int launch_selgram(cna_ctx* c, double* G_dev, unsigned long long* nzero, const double* y, unsigned long long* maxbits,
+                   unsigned char* xq, void* xscale, int Kp);
 int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* cuts_dev, int T,
                       double cut0, double inv_step, double eps, unsigned long long* hist_dev, const int* guard = nullptr);
 // null_i8.hip

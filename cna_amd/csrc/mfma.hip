@@ -355,6 +355,287 @@ __global__ __launch_bounds__(64 * NW) void k_gram_blk(const double* __restrict__
 }
 
 
+// ---- selection pass and Gram matrix in ONE kernel (round 3; 161 ... 240 samples, all cells, samples in place).
+// The standardisation of the NAM rows is row-local (_nam.py:122,159), so a Gram workgroup can standardise its own
+// 32-cell slab: the raw NAM rows of the NEXT slab arrive by LDS-DMA (inline assembly: hipcc neither counts nor
+// serialises these copies) while the 3 x 3 tile blocks of k_gram_blk run on the current one; then the eight waves --
+// sixteen lanes per cell, four cells per wave, the arithmetic of rows.hip:k_select_std16 statement by statement --
+// standardise the slab from LDS into the MFMA buffer and write X, the digit planes of the integer local null, the
+// neighbourhood coefficients (X.y/N, _association.py:77) and the zero-variance count on the way.  X is read by
+// nobody before the local null any more: 3.2 GB less traffic and one launch less at 2M x 200.  Same slabs per
+// workgroup, same order of the MFMAs and of k_gram_reduce: G is bit-identical to k_select_std16 + k_gram_blk.
+__device__ __forceinline__ double sg_row16_sum(double v) {
+  v = dpp_add(v, 0);
+  v = dpp_add(v, 1);
+  v = dpp_add(v, 2);
+  return dpp_add(v, 3);
+}
+__device__ __forceinline__ double sg_row16_max(double v) {
+  v = fmax(v, dpp_partner(v, 0));
+  v = fmax(v, dpp_partner(v, 1));
+  v = fmax(v, dpp_partner(v, 2));
+  return fmax(v, dpp_partner(v, 3));
+}
+__device__ __forceinline__ void sg_dma16(const void* gsrc, unsigned lds_base) {      // 16 bytes per lane, LDS = base + 16 lane
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_base) : "memory");
+}
+
+#ifndef SG_UNROLL
+#define SG_UNROLL 1     // deeper unrolling spills out of the 256 registers (18 accumulator tiles are live)
+#endif
+template <int G>
+__global__ __launch_bounds__(512) void k_selgram_blk(const double* __restrict__ nam, int ld, double* __restrict__ X,
+                                                     int64_t nx, int Nx, int ldx, unsigned long long* nzero,
+                                                     const double* __restrict__ y, double* __restrict__ nc,
+                                                     unsigned long long* __restrict__ blockmax,
+                                                     unsigned char* __restrict__ xq, double2* __restrict__ xscale, int Kp,
+                                                     int nt, int ldp, int ntri, const int32_t* __restrict__ blocks,
+                                                     const int32_t* __restrict__ tixmap, double* __restrict__ partial) {
+  // EIGHT waves (two per SIMD, 256 registers each): a wave carries the two 3 x 3 tile blocks that waves w and w + 8 of
+  // k_gram_blk carry (the same four blocks per SIMD) -- 18 accumulator tiles -- and still has registers for the
+  // standardisation of four cells, in which all eight waves take part (32 cells per slab).
+  extern __shared__ double sm[];
+  constexpr int NW = 8, SLAB = 32, NT = 64 * NW;
+  double* buf = sm;                                   // SLAB x ldp: the standardised slab (MFMA operands)
+  double* raw = sm + SLAB * ldp;                      // SLAB x ld : raw NAM rows of the next slab
+  double* ysh = raw + SLAB * ld;                      // 64 G: the phenotype, zero beyond Nx
+  unsigned long long* wmax = (unsigned long long*)(ysh + 64 * G);   // 8: per-wave max |coefficient|
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ak = lane >> 4, ai = lane & 15;
+  int ri[2][3], cj[2][3];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      ri[h][r] = __builtin_amdgcn_readfirstlane(blocks[(wv + 8 * h) * 8 + r]);
+      cj[h][r] = __builtin_amdgcn_readfirstlane(blocks[(wv + 8 * h) * 8 + 3 + r]);
+    }
+  bool live_t[2][9];
+  v4d acc[2][9];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      acc[h][t] = (v4d){0.0, 0.0, 0.0, 0.0};
+      live_t[h][t] = ri[h][t / 3] >= 0 && cj[h][t % 3] >= ri[h][t / 3];
+    }
+  for (int i = tid; i < SLAB * ldp; i += NT) buf[i] = 0.0;
+  for (int i = tid; i < 64 * G; i += NT) ysh[i] = (y && i < Nx) ? y[i] : 0.0;
+  const int64_t nslab = (nx + SLAB - 1) / SLAB;
+  const unsigned raw_lds = (unsigned)(size_t)raw;
+  const int slab_bytes = SLAB * ld * 8;
+  const int64_t nam_bytes = nx * (int64_t)ld * 8;
+  auto dma_raw = [&](int64_t slab) {                  // rows [32 slab, 32 slab + 32) x ld doubles are contiguous in the NAM
+    const int64_t b0 = slab * (int64_t)slab_bytes;
+    for (int pc = wv; pc * 1024 < slab_bytes; pc += NW) {
+      int64_t off = b0 + pc * 1024 + lane * 16;
+      if (off > nam_bytes - 16) off = nam_bytes - 16;  // past the last row: any valid address (those rows are not live)
+      sg_dma16((const char*)nam + off, raw_lds + (unsigned)(pc * 1024));
+    }
+  };
+  const int r4 = lane >> 4, l16 = lane & 15;
+  const double n = (double)Nx;
+  double vmax = 0.0;
+  bool any_nan = false;
+  // waves 0-7: rows 4 wv + r4 of the slab from `raw` into `buf` (and out to memory)
+  // Registers are scarce here (nine accumulator tiles per lane stay live): every pass over the row re-reads its four
+  // columns per group from LDS instead of keeping the row in registers -- the same values, the same operations in
+  // the same order as rows.hip:k_select_std16.
+  auto standardize = [&](int64_t slab) {
+    const int srow = 4 * wv + r4;
+    const int64_t row = slab * SLAB + srow;
+    const bool live = row < nx;
+    const double* rrow = raw + srow * ld;
+    auto rawval = [&](int col) -> double { return (live && col < Nx) ? rrow[col] : 0.0; };
+    double sum = 0.0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sum += rawval(64 * g + 4 * l16 + j);
+    const double avg0 = sg_row16_sum(sum) / n;
+    bool flat = true;
+    double s2 = 0.0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = 64 * g + 4 * l16 + j;
+        double xv = rawval(col);
+        if (col < Nx) {
+          flat = flat && (avg0 - xv == 0.0);
+          xv -= avg0;
+        }
+        s2 += xv;
+      }
+    {
+      const unsigned long long bal = __ballot(flat);
+      const unsigned long long rowmask = 0xffffull << (16 * r4);
+      if (live && l16 == 0 && (bal & rowmask) == rowmask) atomicAdd(nzero, 1ull);
+    }
+    const double avg = sg_row16_sum(s2) / n;
+    double ss = 0.0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = 64 * g + 4 * l16 + j;
+        if (col < Nx) {
+          double xv = rawval(col);
+          xv -= avg0;
+          const double d = avg - xv;
+          ss += d * d;
+        }
+      }
+    const double sd = sqrt(sg_row16_sum(ss) / (n - 1.0));
+    double dot = 0.0, amax = 0.0;
+    double* __restrict__ dst = X + row * ldx;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int c0 = 64 * g + 4 * l16;
+      double xs4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = c0 + j;
+        double xv = rawval(col);
+        if (col < Nx) xv -= avg0;
+        const double xs = col < Nx ? __ddiv_rn(xv, sd) : 0.0;
+        xs4[j] = xs;
+        dot += ysh[col] * xs;
+        amax = fmax(amax, fabs(xs));
+      }
+      if (live) {
+        if (c0 + 3 < ldx && (ldx & 1) == 0) {
+          *(double2*)(dst + c0) = make_double2(xs4[0], xs4[1]);
+          *(double2*)(dst + c0 + 2) = make_double2(xs4[2], xs4[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (c0 + j < ldx) dst[c0 + j] = xs4[j];
+        }
+      }
+      if (c0 + 3 < ldp) {                              // the slab for the MFMAs (rows past the end: zero)
+        *(double2*)(buf + srow * ldp + c0) = live ? make_double2(xs4[0], xs4[1]) : make_double2(0.0, 0.0);
+        *(double2*)(buf + srow * ldp + c0 + 2) = live ? make_double2(xs4[2], xs4[3]) : make_double2(0.0, 0.0);
+      }
+    }
+    if (xq) {
+      const double rmax = sg_row16_max(amax);
+      const double inv = rmax > 0.0 ? I8_QMAX / rmax : 0.0;
+      unsigned* rq = (unsigned*)(xq + (size_t)row * 3 * Kp);
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int c0 = 64 * g + 4 * l16;
+        unsigned w0 = 0, w1 = 0, w2 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          double xv = rawval(c0 + j);                  // the standardised value again (the slab may be narrower than Kp)
+          if (c0 + j < Nx) xv -= avg0;
+          const double xs = c0 + j < Nx ? __ddiv_rn(xv, sd) : 0.0;
+          const double v = xs * inv;
+          const int qi = v == v ? (int)rint(v) : 0;
+          const int q1 = (qi + 128) >> 8;
+          w0 |= ((unsigned)qi & 255u) << (8 * j);
+          w1 |= ((unsigned)q1 & 255u) << (8 * j);
+          w2 |= ((unsigned)((q1 + 128) >> 8) & 255u) << (8 * j);
+        }
+        if (live && c0 < Kp) {
+          rq[c0 >> 2] = w0;
+          rq[(Kp + c0) >> 2] = w1;
+          rq[(2 * Kp + c0) >> 2] = w2;
+        }
+      }
+      const double l1 = rmax > 0.0 ? n * (I8_QMAX / rmax) + n : 0.0;
+      if (live && l16 == 0) xscale[row] = make_double2(rmax, l1);
+    }
+    if (y) {
+      const double v = sg_row16_sum(dot) / n;
+      if (live) {
+        if (l16 == 0) nc[row] = v;
+        const double av = fabs(v);
+        if (av > vmax) vmax = av;
+        any_nan = any_nan || (v != v);
+      }
+    }
+  };
+  auto lds_barrier = [&]() {                          // LDS traffic only: the global stores of X need not have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  int64_t slab = blockIdx.x;
+  __syncthreads();
+  if (slab < nslab) {
+    dma_raw(slab);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    standardize(slab);
+    lds_barrier();
+  }
+  int oa[2][3], ob[2][3];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      oa[h][r] = 16 * (ri[h][r] > 0 ? ri[h][r] : 0);
+      ob[h][r] = 16 * (cj[h][r] > 0 ? cj[h][r] : 0);
+    }
+  for (; slab < nslab; slab += gridDim.x) {
+    const int64_t next = slab + gridDim.x;
+    if (next < nslab) dma_raw(next);
+#pragma unroll SG_UNROLL
+    for (int kq = 0; kq < SLAB / 4; ++kq) {
+      const double* rowp = buf + (4 * kq + ak) * ldp + ai;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double a0 = rowp[oa[h][0]], a1 = rowp[oa[h][1]], a2 = rowp[oa[h][2]];
+        const double b0 = rowp[ob[h][0]], b1 = rowp[ob[h][1]], b2 = rowp[ob[h][2]];
+        if (live_t[h][0]) acc[h][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[h][0], 0, 0, 0);
+        if (live_t[h][1]) acc[h][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[h][1], 0, 0, 0);
+        if (live_t[h][2]) acc[h][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b2, acc[h][2], 0, 0, 0);
+        if (live_t[h][3]) acc[h][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[h][3], 0, 0, 0);
+        if (live_t[h][4]) acc[h][4] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[h][4], 0, 0, 0);
+        if (live_t[h][5]) acc[h][5] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b2, acc[h][5], 0, 0, 0);
+        if (live_t[h][6]) acc[h][6] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b0, acc[h][6], 0, 0, 0);
+        if (live_t[h][7]) acc[h][7] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b1, acc[h][7], 0, 0, 0);
+        if (live_t[h][8]) acc[h][8] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc[h][8], 0, 0, 0);
+      }
+    }
+    if (next < nslab) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next slab's raw rows
+      lds_barrier();                                        // everybody's; and all MFMAs have read `buf`
+      standardize(next);
+      lds_barrier();
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (live_t[h][t]) {
+        const int tix = tixmap[ri[h][t / 3] * nt + cj[h][t % 3]];
+        double* p = partial + ((size_t)blockIdx.x * ntri + tix) * 256;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r * 64 + lane] = acc[h][t][r];
+      }
+    }
+  if (y) {
+    {
+      const bool wn = __any(any_nan);
+      const double wm = wave_max_d(vmax);
+      if (lane == 0) wmax[wv] = wn ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(wm);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long m = wmax[0];
+      for (int i = 1; i < 8; ++i) m = wmax[i] > m ? wmax[i] : m;
+      blockmax[blockIdx.x] = m;
+    }
+  }
+}
+
 // The same with two LDS slabs: the next slab's global loads are issued before the MFMAs of the current one
 // and written to the other buffer after them -- one barrier per slab instead of two, and the load latency
 // (~2 us per 53 KB slab at N = 200) disappears behind 48 MFMAs per wave.
@@ -1013,7 +1294,35 @@ int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, 
   return fn(c, grid, smem, B_dev, ldb, center ? 1 : 0, out, ld_out, 0, nullptr, 0);
 }
 
-int launch_gram(cna_ctx* c, double* G_dev) {
+// selgram != nullptr: the fused selection + Gram kernel (k_selgram_blk) instead of the Gram kernel on X -- the caller
+// has made sure the selection is "all cells, samples in place, no projector" and that gram_fused_ok() holds.
+struct SelGramArgs {
+  unsigned long long* nzero; const double* y; unsigned long long* maxbits; unsigned char* xq; void* xscale; int Kp;
+};
+bool gram_fused_ok(const cna_ctx* c, int Nx, int ldx, int Kp) {
+  const int nt = (Nx + 15) / 16, ng = (nt + 2) / 3;
+  const int ldp = 16 * nt + ((nt & 1) ? 0 : 16);
+  // OFF by default: measured at 2M x 200 the fused kernel takes 5.05 ms against 1.63 + 1.75 ms for the two kernels.
+  // The standardisation is ~700 vector instructions per wave and slab (sixteen f64 divisions per lane expand to ~35
+  // instructions each) and on this chip nothing overlaps an f64 MFMA on the same SIMD: the vector work of the selection
+  // pass (about a millisecond of whole-chip issue) ADDS to the 1.75 ms of matrix work instead of hiding under it, and
+  // with 18 accumulator tiles per wave the standardisation runs out of spilled registers.  Kept for the parity test and
+  // as the measured answer to "fuse selection and Gram" (DESIGN 8); CNA_SELGRAM=1 selects it (read per call).
+  const bool on = getenv("CNA_SELGRAM") && !getenv("CNA_GRAM_NOBLK");
+  const int cols = ldx > Kp ? ldx : Kp;
+  const size_t lds = sizeof(double) * ((size_t)32 * ldp + (size_t)32 * c->ld + 64 * ((cols + 63) / 64) + 8);
+  return on && nt >= 11 && ng * (ng + 1) / 2 <= 16 && ldx <= 320 && (c->ld & 1) == 0 && cols <= 256 &&
+         lds <= 158 * 1024 && c->nx >= 32;
+}
+static int launch_gram_impl(cna_ctx* c, double* G_dev, const SelGramArgs* selgram);
+int launch_gram(cna_ctx* c, double* G_dev) { return launch_gram_impl(c, G_dev, nullptr); }
+int launch_selgram(cna_ctx* c, double* G_dev, unsigned long long* nzero, const double* y, unsigned long long* maxbits,
+                   unsigned char* xq, void* xscale, int Kp) {
+  const SelGramArgs a{nzero, y, maxbits, xq, xscale, Kp};
+  return launch_gram_impl(c, G_dev, &a);
+}
+
+static int launch_gram_impl(cna_ctx* c, double* G_dev, const SelGramArgs* selgram) {
   const int Nx = c->Nx;
   const int nt = (Nx + 15) / 16;
   const int ntri = nt * (nt + 1) / 2;
@@ -1078,6 +1387,31 @@ int launch_gram(cna_ctx* c, double* G_dev) {
   }
   int32_t* tiles_dev = (int32_t*)c->gram_tiles_ptr;
   const size_t smem = sizeof(double) * slab_rows * ldp;
+  if (selgram) {
+    if (!use_blk) CNA_FAIL(CNA_ESTATE, "launch_selgram: shape outside the fused kernel's range");
+    HIP_TRY(hipMemsetAsync(selgram->nzero, 0, sizeof(unsigned long long), c->stream));
+    if (selgram->maxbits) HIP_TRY(hipMemsetAsync(selgram->maxbits, 0, sizeof(unsigned long long), c->stream));
+    const int cols = c->ldx > selgram->Kp ? c->ldx : selgram->Kp;
+    const int G = (cols + 63) / 64;
+    const size_t lds = sizeof(double) * ((size_t)32 * ldp + (size_t)32 * c->ld + 64 * G + 8);
+    {
+      ProfScope ps(c, CNA_K_GRAM);
+#define SG_LAUNCH(GG) { static bool once = false; if (!once) { HIP_TRY(hipFuncSetAttribute((const void*)k_selgram_blk<GG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); once = true; } \
+      hipLaunchKernelGGL(k_selgram_blk<GG>, dim3(nblocks), dim3(512), lds, c->stream, c->nam, c->ld, c->X, c->nx, c->Nx, c->ldx, selgram->nzero, selgram->y, c->ncorrs, selgram->maxbits ? selgram->maxbits + 1 : nullptr, selgram->xq, (double2*)selgram->xscale, selgram->Kp, nt, ldp, ntri, tiles_dev + ntri, tiles_dev + ntri + 128, partial); }
+      switch (G) {
+        case 3: SG_LAUNCH(3) break;
+        default: SG_LAUNCH(4) break;
+      }
+#undef SG_LAUNCH
+      HIP_TRY(hipGetLastError());
+    }
+    if (selgram->y) launch_max_fold(c, selgram->maxbits + 1, nblocks, selgram->maxbits);
+    ProfScope ps(c, CNA_K_GRAM_REDUCE);
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ntri * 4), dim3(64, 16), 0, c->stream, partial, nblocks, ntri,
+                       tiles_dev, Nx, G_dev);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   if (use_blk) {
     {
       ProfScope ps(c, CNA_K_GRAM);

@@ -1043,6 +1043,12 @@ int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long*
   return 0;
 }
 
+int launch_max_fold(cna_ctx* c, const unsigned long long* blockmax, int nblocks, unsigned long long* out) {
+  hipLaunchKernelGGL(k_max_fold, dim3(1), dim3(256), 0, c->stream, blockmax, nblocks, out);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
 int launch_digit_hist(cna_ctx* c, const double* v, int64_t n, unsigned long long prefix, int shift,
                       unsigned long long* hist_dev) {
   HIP_TRY(hipMemsetAsync(hist_dev, 0, sizeof(unsigned long long) * 257, c->stream));

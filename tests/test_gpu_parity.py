@@ -799,6 +799,40 @@ def test_fused_selection_call_equals_separate_calls(eng, monkeypatch):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize('n,N', [(20011, 200), (5000, 170), (9999, 233), (40, 180)])
+def test_selection_and_gram_in_one_kernel(eng, monkeypatch, n, N):
+    """161 ... 240 samples, all cells kept, samples in place, nothing regressed out: the selection pass
+    (_nam.py:122,159: centre, / std; the coefficients of _association.py:77; the digit planes of the integer local
+    null) and the Gram matrix (_nam.py:105) can be ONE kernel (mfma.hip:k_selgram_blk, CNA_SELGRAM=1; off by default:
+    slower than the two kernels, see the note at gram_fused_ok).  Everything it leaves behind -- X, the coefficients, the
+    Gram matrix, and through them every result field -- equals the separate kernels bit for bit; odd cell counts
+    exercise the partial last slab, 40 cells (most samples empty, so the selection is not "in place") the fall-back."""
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd._ffi import MAT_X
+    data, meta = synth.make_dataset(n, N, k=15, seed=11)
+    out = {}
+    for fused in (True, False):
+        if fused:
+            monkeypatch.setenv('CNA_SELGRAM', '1')
+        else:
+            monkeypatch.delenv('CNA_SELGRAM', raising=False)
+        eng.prof_reset(); eng.prof_enable(True)
+        res = cna.tl.association(data, meta['y'], 'id', Nnull=200, seed=5, nsteps=3, return_full=True, engine=eng)
+        eng.sync(); eng.prof_enable(False)
+        prof = eng.prof()
+        out[fused] = (res.p, int(res.k), res.ncorrs.values.copy(), res.fdrs.values.copy(), data.obs['coef'].values.copy(),
+                      data.obs['coef_fdr'].values.copy(), res.namresid_sampleXpc.values.copy(), res.namresid.values.copy(),
+                      eng.gram_fetch().copy(), res.nullminps.copy())
+        out[fused, 'select launches'] = prof.get('select', (0, 0))[1]
+    assert out[False, 'select launches'] == 1
+    in_place = data.obs['id'].nunique() == N          # (with 40 cells most samples are empty: the selection drops them)
+    assert out[True, 'select launches'] == (0 if n >= 32 and in_place else 1)      # the fused kernel is booked under 'gram'
+    assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
+    for a, b in zip(out[True][2:], out[False][2:]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_nam_cache_on_device(eng):
     """A second phenotype on the same dataset reuses the resident NAM (no diffusion kernels) and gives
     the results of a from-scratch run."""
