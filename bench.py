@@ -47,13 +47,18 @@ I8_MFMA_PEAK_TOPS = 5033.0   # dense i8 matrix: 2x the bf16 rate (guide: >= 4404
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
 
 WORKLOADS = {
-    # name: (cells, samples, kNN k, nsteps, Nnull, covariates)
+    # name: (cells, samples, kNN k, nsteps, Nnull, covariates[, batches])
     'C2': (200_000, 50, 30, 3, 1000, 0),
     'C3': (1_000_000, 100, 30, 3, 1000, 0),
     'C4': (2_000_000, 200, 30, 3, 1000, 0),     # BASELINE config 4
     'C5': (2_000_000, 200, 30, 3, 10000, 5),    # BASELINE config 5: + 5 covariates, Nnull = 10000
+    # the reference's own call shapes at the size of configs[2]: its default walk rule (nsteps=None,
+    # _association.py:194, _nam.py:64-68) and the demo's call with covariates AND batches (demo/demo.ipynb:149)
+    'C3_default_nsteps': (1_000_000, 100, 30, None, 1000, 0),
+    'C3_covs_batches': (1_000_000, 100, 30, 3, 1000, 2, 5),
 }
-DEFAULT_STEPS = {'C2': (100, 60), 'C3': (20, 5), 'C4': (20, 5), 'C5': (20, 5)}
+DEFAULT_STEPS = {'C2': (100, 60), 'C3': (20, 5), 'C4': (20, 5), 'C5': (20, 5), 'C3_default_nsteps': (10, 3),
+                 'C3_covs_batches': (10, 3)}
 
 
 def usable_cpus():
@@ -86,17 +91,17 @@ def algorithmic_work(kernel, n, nnz, N, P, T, wA):
     return 'hbm', 8 * n
 
 
-def load_or_make_dataset(synth, n, N, k, rank, world, n_covs=0):
+def load_or_make_dataset(synth, n, N, k, rank, world, n_covs=0, n_batches=0):
     """One synthetic dataset for the whole job: rank 0 generates it (graph construction) and the other ranks of
     this node read it from /dev/shm.  No collective is involved (the ranks that wait must not sit in the
     communicator's set-up meanwhile): rank 0 publishes the file by an atomic rename, the others poll for it; the
     caller removes it after the job's first barrier."""
     if world == 1:
-        return synth.make_dataset(n, N, k=k, seed=0, n_covs=n_covs), None
+        return synth.make_dataset(n, N, k=k, seed=0, n_covs=n_covs, n_batches=n_batches), None
     import pickle
     path = '/dev/shm/cna_bench_%s_%s_%d_%d.pkl' % (os.environ.get('MASTER_PORT', '0'), os.environ.get('TORCHELASTIC_RUN_ID', 'x'), n, N)
     if rank == 0:
-        out = synth.make_dataset(n, N, k=k, seed=0, n_covs=n_covs)
+        out = synth.make_dataset(n, N, k=k, seed=0, n_covs=n_covs, n_batches=n_batches)
         with open(path + '.tmp', 'wb') as f:
             pickle.dump(out, f, protocol=pickle.HIGHEST_PROTOCOL)
         os.replace(path + '.tmp', path)
@@ -177,10 +182,11 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
     from cna_amd.engine import get_engine
     from cna_amd.tools._nam import get_connectivity
 
-    n_total, N, k, nsteps, Nnull, n_covs = WORKLOADS[name]
+    n_total, N, k, nsteps, Nnull, n_covs = WORKLOADS[name][:6]
+    n_batches = WORKLOADS[name][6] if len(WORKLOADS[name]) > 6 else 0
     n = n_total * world if args.scaling == 'weak' else n_total
     t0 = time.time()
-    (data, meta), shared_file = load_or_make_dataset(synth, n, N, k, rank, world, n_covs=n_covs)
+    (data, meta), shared_file = load_or_make_dataset(synth, n, N, k, rank, world, n_covs=n_covs, n_batches=n_batches)
     t_gen = time.time() - t0
     A = get_connectivity(data)
     nnz = int(A.nnz)
@@ -199,6 +205,8 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
     kw = dict(nsteps=nsteps, Nnull=Nnull, seed=0)
     if meta.get('covs') is not None:
         kw['covs'] = meta['covs']
+    if meta.get('batches') is not None:
+        kw['batches'] = meta['batches']
 
     from cna_amd import dist
 
@@ -260,7 +268,7 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
         i8 = eng.null_local_i8_stats()
     except Exception:
         i8 = (False, 0, False)
-    return dict(name=name, n=n, N=N, k=k, nsteps=nsteps, Nnull=Nnull, n_covs=n_covs, nnz=nnz, wA=wA, dt=dt, t_cold=t_cold, i8=i8,
+    return dict(name=name, n=n, N=N, k=k, nsteps=nsteps, Nnull=Nnull, n_covs=n_covs, n_batches=n_batches, nnz=nnz, wA=wA, dt=dt, t_cold=t_cold, i8=i8,
                 t_gen=t_gen, prof=prof, p=p_last, n_loc=n_loc, nnz_loc=nnz_loc, halo=getattr(eng, 'halo', None),
                 sharded_inputs=sharded_inputs, data=data, meta=meta, kw=kw, steps=steps, warmup=warmup, comm=eng.comm_info())
 
@@ -318,11 +326,12 @@ def summary(m, world, steps):
 
 
 def workload_text(m, world, args):
-    return ('%s: %d cells (%d per GPU) x %d samples, k=%d kNN (%.1f nnz/row, float32 CSR), nsteps=%d, Nnull=%d%s, '
+    return ('%s: %d cells (%d per GPU) x %d samples, k=%d kNN (%.1f nnz/row, float32 CSR), nsteps=%s, Nnull=%d%s%s, '
             'local FDR pass on; graph + device cell order + sample codes resident (graph pinned: engine.pin_graph), '
             'NAM recomputed every step (NAM cache off)' % (
-                m['name'], m['n'], -(-m['n'] // world), m['N'], m['k'], m['nnz'] / m['n'], m['nsteps'], m['Nnull'],
-                ', %d covariates' % m['n_covs'] if m['n_covs'] else ''))
+                m['name'], m['n'], -(-m['n'] // world), m['N'], m['k'], m['nnz'] / m['n'],
+                'None (the reference\'s stop rule)' if m['nsteps'] is None else str(m['nsteps']), m['Nnull'],
+                ', %d covariates' % m['n_covs'] if m['n_covs'] else '', ', %d batches' % m['n_batches'] if m.get('n_batches') else ''))
 
 
 def main():
@@ -444,7 +453,7 @@ def main():
 
     extra = {}
     if world == 1 and not args.no_extra and args.workload == 'C4':
-        for name in ('C5', 'C3', 'C2'):
+        for name in ('C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches'):
             st_, wu_ = DEFAULT_STEPS[name]
             try:
                 mm = time_workload(name, args, rank, world, st_, wu_)

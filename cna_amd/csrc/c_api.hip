@@ -107,6 +107,12 @@ static const char* kKernelNames[CNA_K_COUNT] = {
     HIP_TRY(hipSetDevice((c)->device));                     \
   } while (0)
 
+// entry points that read or replace the NAM collect a pending walk's verdict first
+#define AUTO_FINISH(c)                                                   \
+  do {                                                                   \
+    if ((c)->auto_pending) CNA_TRY(cna_nam_auto_finish((c), nullptr, nullptr)); \
+  } while (0)
+
 // scratch layout helper: carve 256-byte aligned pieces out of c->scratch
 struct Carver {
   char* base;
@@ -208,6 +214,7 @@ int cna_ctx_create(int device, cna_ctx** out) {
 }
 
 int cna_ctx_destroy(cna_ctx* c) {
+  if (c && c->auto_state) { (void)hipFree(c->auto_state); c->auto_state = nullptr; }
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
@@ -236,6 +243,7 @@ int cna_ctx_destroy(cna_ctx* c) {
 
 int cna_ctx_sync(cna_ctx* c) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   HIP_TRY(hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -250,6 +258,7 @@ int cna_ctx_device_bytes(cna_ctx* c, int64_t* bytes) {
 int cna_graph_upload(cna_ctx* c, int64_t n_global, int64_t row0, int64_t n_local, const int64_t* indptr,
                      const int32_t* indices, const void* data, int data_is_f64) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   if (n_global <= 0 || n_local < 0 || row0 < 0 || row0 + n_local > n_global || !indptr)
     CNA_FAIL(CNA_EINVAL, "cna_graph_upload: bad shape");
   const int64_t rpr = (n_global + c->nranks - 1) / c->nranks;
@@ -404,6 +413,7 @@ static int ensure_sparse_state(cna_ctx* c) {
 // -------------------------------------------------------------------------------- NAM
 int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const double* counts) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   if (!c->indptr) CNA_FAIL(CNA_ESTATE, "cna_set_samples before cna_graph_upload");
   if (n_samples < 1 || n_samples > 1024) CNA_FAIL(CNA_EINVAL, "n_samples must be in [1, 1024]");
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -441,6 +451,7 @@ int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const doubl
 
 int cna_restart_nam(cna_ctx* c) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   if (!c->sid || !c->counts) CNA_FAIL(CNA_ESTATE, "cna_restart_nam needs cna_set_samples first");
   HIP_TRY(hipStreamSynchronize(c->stream));
   CNA_TRY(ensure_T(c, c->ld));
@@ -541,13 +552,86 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
 }
 
 int cna_nam_steps(cna_ctx* c, int nsteps) {
+  CHECK_CTX(c);
+  AUTO_FINISH(c);
   if (nsteps < 1) CNA_FAIL(CNA_EINVAL, "nsteps < 1");
   for (int i = 0; i < nsteps; ++i) CNA_TRY(cna_nam_step(c, 0, i + 1 < nsteps, i + 1 == nsteps));
   return 0;
 }
 
+// The walk of _nam.py:57-70 with nsteps=None: steps until the median kurtosis stops falling by 3 or more (checked from
+// the third step on, at most maxnsteps).  Steps, medians and the rule are queued without waiting for a verdict --
+// four steps by cna_nam_auto_launch, which returns at once, then two at a time by cna_nam_auto_finish, which reads
+// one word per batch; the steps queued behind the one that met the rule return at once (StepArgs::stop).  The first
+// step's kurtosis is never looked at by the rule (_nam.py:65: i + 1 >= 3 compares steps 2 and 3) and is not
+// computed.  Same steps, same NAM as cna_nam_step + cna_stat_median in a host loop.
+static int auto_queue(cna_ctx* c, int upto) {
+  const size_t sb = (auto_state_bytes() + 255) & ~(size_t)255;
+  unsigned long long* hist = (unsigned long long*)((char*)c->auto_state + sb);
+  struct Guard { cna_ctx* c; ~Guard() { c->auto_stop = nullptr; } } guard{c};
+  c->auto_stop = (const int*)((const char*)c->auto_state + auto_state_stopped_offset());
+  for (int i = c->auto_queued; i < upto; ++i) {
+    const bool last = i + 1 == c->auto_max;
+    CNA_TRY(cna_nam_step(c, i >= 1, !last, last || i + 1 >= 3));
+    if (i >= 1) CNA_TRY(launch_auto_median(c, c->stat, c->n_global, c->auto_state, hist, i, 3));
+    c->auto_queued = i + 1;
+  }
+  return 0;
+}
+
+int cna_nam_auto_launch(cna_ctx* c, int maxnsteps) {
+  CHECK_CTX(c);
+  if (maxnsteps < 1 || maxnsteps > 16) CNA_FAIL(CNA_EINVAL, "cna_nam_auto: 1 <= maxnsteps <= 16");
+  if (c->steps_done != 0) CNA_FAIL(CNA_ESTATE, "cna_nam_auto starts a walk: call cna_set_samples / cna_restart_nam first");
+  const size_t sb = (auto_state_bytes() + 255) & ~(size_t)255;
+  if (!c->auto_state) HIP_TRY(hipMalloc(&c->auto_state, sb + 8 * 2 * 257));
+  HIP_TRY(hipMemsetAsync(c->auto_state, 0, sb, c->stream));
+  c->auto_max = maxnsteps;
+  c->auto_queued = 0;
+  c->auto_pending = true;
+  const int rc = auto_queue(c, std::min(4, maxnsteps));
+  if (rc) c->auto_pending = false;
+  return rc;
+}
+
+int cna_nam_auto_finish(cna_ctx* c, int* steps_out, double* medkurt_out) {
+  CHECK_CTX(c);
+  if (!c->auto_pending) CNA_FAIL(CNA_ESTATE, "cna_nam_auto_finish without cna_nam_auto_launch");
+  c->auto_pending = false;
+  const size_t sb = (auto_state_bytes() + 255) & ~(size_t)255;
+  std::vector<char> host(sb);
+  int taken = 0;
+  for (;;) {
+    HIP_TRY(hipMemcpyAsync(host.data(), c->auto_state, sb, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int stopped;
+    std::memcpy(&stopped, host.data() + auto_state_stopped_offset(), 4);
+    taken = stopped ? stopped : c->auto_queued;
+    if (stopped || c->auto_queued >= c->auto_max) break;
+    CNA_TRY(auto_queue(c, std::min(c->auto_queued + 2, c->auto_max)));
+  }
+  // the steps queued behind the last one taken did nothing: the NAM on the device is that of step `taken`
+  c->steps_done = taken;
+  c->nam_valid = true;
+  c->t_valid = false;
+  c->stat_space = CNA_MAT_NAM;
+  if (steps_out) *steps_out = taken;
+  if (medkurt_out) {
+    const size_t off = 2 * 8 + 2 * 8 + 2 * 8;             // AutoState: prefix[2], k[2], n_tot, n_nan, then med[16]
+    std::memcpy(medkurt_out, host.data() + off, 8 * (size_t)taken);
+    medkurt_out[0] = __builtin_nan("");                    // (not computed: the rule never reads it)
+  }
+  return 0;
+}
+
+int cna_nam_auto(cna_ctx* c, int maxnsteps, int* steps_out, double* medkurt_out) {
+  CNA_TRY(cna_nam_auto_launch(c, maxnsteps));
+  return cna_nam_auto_finish(c, steps_out, medkurt_out);
+}
+
 int cna_fetch_cell_stat(cna_ctx* c, double* out, int64_t n_expected) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   if (c->stat_space == CNA_MAT_NAM && c->local_view) {
     if (n_expected != c->n_local) CNA_FAIL(CNA_EINVAL, "cna_fetch_cell_stat: expected n_local entries");
     HIP_TRY(hipMemcpyAsync(out, c->stat + c->row0, sizeof(double) * c->n_local, hipMemcpyDeviceToHost, c->stream));
@@ -608,6 +692,7 @@ static int stat_select(cna_ctx* c, const double* v, int64_t n_loc, bool sharded,
 
 int cna_stat_median(cna_ctx* c, double* median_out) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   if (!median_out) CNA_FAIL(CNA_EINVAL, "cna_stat_median: null output");
   const double* v = c->stat;
   int64_t n_loc;
@@ -630,6 +715,7 @@ int cna_stat_median(cna_ctx* c, double* median_out) {
 // --------------------------------------------------------------------- dense diffusion
 int cna_dense_load(cna_ctx* c, const double* s_local, int m) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   if (!c->have_colsum) CNA_FAIL(CNA_ESTATE, "cna_dense_load needs cna_colsums");
   if (m < 1 || m > 1024) CNA_FAIL(CNA_EINVAL, "dense state must have 1..1024 columns");
   const int ld = round_up(m, 4);
@@ -673,6 +759,7 @@ int cna_dense_fetch(cna_ctx* c, double* out) {
 // ------------------------------------------------------------------------ QC / select
 int cna_batch_kurtosis(cna_ctx* c, int which, const int32_t* batch_codes, int n_batches) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   const double* mat;
   int64_t rows;
   int ncols, ld;
@@ -711,6 +798,7 @@ int cna_batch_kurtosis(cna_ctx* c, int which, const int32_t* batch_codes, int n_
 
 int cna_zero_variance(cna_ctx* c, const int32_t* colmap, int n_sel, uint8_t* flags_out, int64_t* n_zero_out) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
   if (!colmap) n_sel = c->N;
   if (n_sel < 1) CNA_FAIL(CNA_EINVAL, "no samples selected");
@@ -757,6 +845,7 @@ static int x_ld(int Nx) {
 
 int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
   const int64_t nx = keep_idx ? n_keep : c->n_local;
   const int Nx = colmap ? n_sel : c->N;
@@ -820,6 +909,7 @@ int cna_set_resid_factors(cna_ctx* c, const double* C, const double* W, int r, i
 int cna_select_checked(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
                        int64_t* n_zero_out) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
   const int64_t nx = keep_idx ? n_keep : c->n_local;
   const int Nx = colmap ? n_sel : c->N;
@@ -874,6 +964,7 @@ int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep,
 static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
                                     int64_t* n_zero_out, const double* y, double* max_abs_out, bool* gram_too) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   if (gram_too) *gram_too = false;
   if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
   const int64_t nx = keep_idx ? n_keep : c->n_local;
@@ -1789,6 +1880,7 @@ int cna_percell_fdr(cna_ctx* c, const double* thr, const double* runmin_fdr, int
 // -------------------------------------------------------------------------------- D2H
 int cna_matrix_shape(cna_ctx* c, int which, int64_t* n_rows_local, int* n_cols) {
   if (!c) CNA_FAIL(CNA_EINVAL, "null context");
+  if (which == CNA_MAT_NAM) AUTO_FINISH(c);
   if (which == CNA_MAT_NAM) {
     if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
     *n_rows_local = c->n_local; *n_cols = c->N;
@@ -1803,6 +1895,7 @@ int cna_matrix_shape(cna_ctx* c, int which, int64_t* n_rows_local, int* n_cols) 
 
 int cna_fetch_matrix(cna_ctx* c, int which, double* out, int transposed) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   int64_t rows;
   int cols;
   CNA_TRY(cna_matrix_shape(c, which, &rows, &cols));
@@ -1828,6 +1921,7 @@ int cna_fetch_matrix(cna_ctx* c, int which, double* out, int transposed) {
 int cna_fetch_rows(cna_ctx* c, int which, const int64_t* rows, int64_t n_out, const int32_t* cols, int n_cols,
                    double* out, int transposed) {
   CHECK_CTX(c);
+  AUTO_FINISH(c);
   const double* src;
   int ld, width;
   int64_t have;

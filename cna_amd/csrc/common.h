@@ -125,6 +125,12 @@ struct cna_ctx {
   // ---- per-cell vectors
   double* stat = nullptr;  // n_pad
   int stat_space = -1;     // CNA_MAT_NAM / CNA_MAT_X
+  // walk with the stop rule on the device (cna_nam_auto): bookkeeping block (rows.hip:AutoState) and, while such a
+  // walk is being queued, the address of its `stopped_at` word for the step kernels
+  void* auto_state = nullptr;
+  const int* auto_stop = nullptr;
+  bool auto_pending = false;   // cna_nam_auto_launch has queued steps whose verdict nobody has read yet
+  int auto_max = 0, auto_queued = 0;
   double* ncorrs = nullptr;
   int64_t ncorrs_cap = 0;
   bool ncorrs_valid = false;
@@ -241,6 +247,11 @@ int launch_gather_rows(cna_ctx* c, const double* src, int ld, const int64_t* row
 int launch_digit_hist(cna_ctx* c, const double* v, int64_t n, unsigned long long prefix, int shift,
                       unsigned long long* hist_dev);
 int launch_max_fold(cna_ctx* c, const unsigned long long* blockmax, int nblocks, unsigned long long* out);
+// exact median of v[0..n) (np.median semantics) on the device, then the walk's stop rule for step `step` (0-based):
+// nothing returns to the host; `state` is the AutoState block of the walk, `hist` 2 x 257 words of scratch
+int launch_auto_median(cna_ctx* c, const double* v, int64_t n, void* state, unsigned long long* hist, int step, int min_steps);
+size_t auto_state_bytes();
+int auto_state_stopped_offset();
 int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev, const double* y_dev,
                       unsigned long long* maxbits_dev, const double* W_dev, const double* Ct_dev, int rk,
                       unsigned char* xq = nullptr, void* xscale = nullptr, int Kp = 0);

@@ -52,7 +52,11 @@ struct StepArgs {
   // compressed copy of the state after the first step (see k_nam_step_sparse); null = not kept
   struct SpPair* sp_pair;   // n x SP_CAP {value, sample index} records of the non-zeros of a row
   unsigned char* sp_cnt;    // n: how many (SP_DENSE: more than SP_CAP, use the dense row)
+  // walk with the stop rule on the device (cna_nam_auto): steps queued behind the one that met the rule find this
+  // word non-zero and return at once; null = unconditional step
+  const int* stop;
 };
+#define STEP_STOPPED(a) ((a).stop != nullptr && __builtin_nontemporal_load((a).stop) != 0)
 // One 16-byte record per non-zero: the second step then fetches an edge's whole neighbour row with ONE
 // global_load_dwordx4 (lane l = pair l).  With the indices and the values in two arrays the step issued two
 // gathers per edge: 4.59 -> 4.42 ms at 2M x 200.  What the step spends its time on is the scatter, not the
@@ -201,6 +205,7 @@ __device__ __forceinline__ void first_tail(const StepArgs& a, const double* accl
 template <typename VT, int NQ>
 __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* __restrict__ info) {
   extern __shared__ double sm[];
+  if (STEP_STOPPED(a)) return;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* accl = sm + (size_t)wv * 64 * NQ;
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
 template <typename VT, int NQ, int R>
 __global__ __launch_bounds__(256) void k_nam_first2(StepArgs a, const CellInfo* __restrict__ info) {
   extern __shared__ double sm[];
+  if (STEP_STOPPED(a)) return;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* accl[R];
@@ -293,6 +299,7 @@ __global__ __launch_bounds__(256) void k_nam_first2(StepArgs a, const CellInfo* 
 // products / sums are unfused and in CSR order (scipy's csr_matvecs rounding sequence).
 template <typename VT, int NQ2, int U = 8>       // U: neighbour rows in flight per wave (8 beats 16 and 32; 4 beyond 512 columns: registers)
 __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
+  if (STEP_STOPPED(a)) return;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t row = my_row(wv, a.xcd_chunk);
@@ -386,6 +393,7 @@ __device__ __forceinline__ double half_sum(double v, int h) {
 
 template <typename VT>
 __global__ __launch_bounds__(256) void k_nam_step_pair(StepArgs a) {
+  if (STEP_STOPPED(a)) return;
   constexpr int U = 4;                          // neighbour rows in flight per half-wave (8: +2 % time, 16: +16 %)
   __shared__ EdgeRec recs[4][2][32];
   const int lane = threadIdx.x & 63, hl = lane & 31, h = lane >> 5;
@@ -508,6 +516,7 @@ __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p
 // slower at every U)
 template <typename VT, int NQ2, int U = 6>
 __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
+  if (STEP_STOPPED(a)) return;
   extern __shared__ double sm[];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -943,6 +952,7 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
   a.want_kurt = want_kurt;
   a.write_t = write_t;
   a.write_nam = write_nam;
+  a.stop = c->auto_stop;
   // compressed state: written by the first step, read by the second (sample indicators only)
   const bool sp = c->sp_cnt && !dense && (first || c->steps_done == 1);
   a.sp_pair = sp ? (SpPair*)c->sp_pair : nullptr;

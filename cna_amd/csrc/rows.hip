@@ -3,6 +3,7 @@
 // All matrices are cell-major (one row per cell), so every statistic "over samples" is a
 // reduction inside one row: one wave per row, lanes across the sample axis.
 #include "common.h"
+#include <cstddef>
 
 namespace {
 
@@ -748,6 +749,86 @@ __global__ __launch_bounds__(256) void k_digit_hist(const double* __restrict__ v
     if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
+// ---- the walk's stop rule without the host (cna_nam_auto; _nam.py:59,64-68).  After every step the median over the
+// cells of the per-cell kurtosis decides whether the walk goes on: medkurt = np.median(kurtosis), stop at the first
+// step i + 1 >= 3 with prevmedkurt - medkurt < 3.  Exact radix select as cna_stat_median does it -- eight 8-bit
+// digits of the order-preserving key, both middle order statistics at once -- but with the digit choice on the
+// device too, so that the next steps can be queued before this one's verdict: a step kernel that finds
+// `stopped_at` set returns at once.
+struct AutoState {
+  unsigned long long prefix[2];       // key prefix of the lower / upper middle element so far
+  long long k[2];                     // their rank among the entries that share the prefix
+  long long n_tot, n_nan;
+  double med[16];                     // medkurt of every step taken
+  int stopped_at;                     // 0: still walking; else the number of steps after which the rule was met
+  int pad;
+};
+__global__ __launch_bounds__(256) void k_digit_hist2(const double* __restrict__ v, int64_t n,
+                                                     const AutoState* __restrict__ st, int shift,
+                                                     unsigned long long* __restrict__ hist) {
+  if (st->stopped_at) return;
+  __shared__ unsigned int h[2][257];
+  for (int i = threadIdx.x; i < 2 * 257; i += 256) (&h[0][0])[i] = 0u;
+  __syncthreads();
+  const unsigned long long p0 = st->prefix[0], p1 = st->prefix[1];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const double x = v[i];
+    if (x != x) {
+      if (shift == 56) atomicAdd(&h[0][256], 1u);            // NaNs are counted once, in the first pass
+      continue;
+    }
+    const unsigned long long k = order_key(x);
+    const unsigned d = (unsigned)(k >> shift) & 255u;
+    if (shift == 56) { atomicAdd(&h[0][d], 1u); continue; }  // (the second histogram of the first pass is the first)
+    const unsigned long long hi = k >> (shift + 8);
+    if (hi == p0) atomicAdd(&h[0][d], 1u);
+    if (hi == p1) atomicAdd(&h[1][d], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * 257; i += 256) {
+    const unsigned c = (&h[0][0])[i];
+    if (c) atomicAdd(&hist[i], (unsigned long long)c);
+  }
+}
+// one thread per order statistic: pick the digit, descend; zero the histograms for the next pass; after the last
+// pass (decide >= 0) the median and the stop rule
+__global__ void k_auto_pick(unsigned long long* __restrict__ hist, AutoState* __restrict__ st, int pass, int step,
+                            int min_steps) {
+  if (st->stopped_at) return;
+  __shared__ unsigned long long val[2];
+  const int w = threadIdx.x;
+  if (w < 2) {
+    const unsigned long long* h = hist + (pass == 0 ? 0 : 257 * w);
+    long long k;
+    if (pass == 0) {
+      long long tot = 0;
+      for (int d = 0; d < 256; ++d) tot += (long long)h[d];
+      if (w == 0) { st->n_tot = tot + (long long)h[256]; st->n_nan = (long long)h[256]; }
+      k = w == 0 ? (tot - 1) / 2 : tot / 2;
+      if (k >= tot) k = tot - 1;
+      if (k < 0) k = 0;
+    } else {
+      k = st->k[w];
+    }
+    int d = 0;
+    long long before = 0;
+    while (d < 255 && before + (long long)h[d] <= k) before += (long long)h[d++];
+    st->k[w] = k - before;
+    const unsigned long long prefix = ((pass == 0 ? 0ull : st->prefix[w]) << 8) | (unsigned long long)d;
+    st->prefix[w] = prefix;
+    val[w] = (prefix >> 63) ? (prefix & 0x7fffffffffffffffull) : ~prefix;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * 257; i += blockDim.x) hist[i] = 0ull;
+  if (pass == 7 && threadIdx.x == 0) {
+    const double lo = __longlong_as_double((long long)val[0]), hi = __longlong_as_double((long long)val[1]);
+    const long long tot = st->n_tot;
+    const double med = (tot == 0 || st->n_nan > 0) ? __builtin_nan("") : ((tot & 1) ? lo : (lo + hi) / 2.0);
+    st->med[step] = med;
+    if (step + 1 >= min_steps && step >= 1 && (st->med[step - 1] - med < 3.0)) st->stopped_at = step + 1;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_max_fold(const unsigned long long* __restrict__ blockmax, int nblocks,
                                                   unsigned long long* __restrict__ out) {
   __shared__ unsigned long long sm[256];
@@ -1039,6 +1120,20 @@ int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long*
   }
 #undef SS_LAUNCH
   if (y_dev) hipLaunchKernelGGL(k_max_fold, dim3(1), dim3(256), 0, c->stream, maxbits_dev + 1, (int)grid, maxbits_dev);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+size_t auto_state_bytes() { return sizeof(AutoState); }
+int auto_state_stopped_offset() { return (int)offsetof(AutoState, stopped_at); }
+int launch_auto_median(cna_ctx* c, const double* v, int64_t n, void* state, unsigned long long* hist, int step, int min_steps) {
+  const int64_t want = (n + 1023) / 1024;
+  const unsigned grid = (unsigned)(want < 1 ? 1 : (want < 1024 ? want : 1024));
+  HIP_TRY(hipMemsetAsync(hist, 0, sizeof(unsigned long long) * 2 * 257, c->stream));
+  for (int pass = 0; pass < 8; ++pass) {
+    hipLaunchKernelGGL(k_digit_hist2, dim3(grid), dim3(256), 0, c->stream, v, n, (const AutoState*)state, 56 - 8 * pass, hist);
+    hipLaunchKernelGGL(k_auto_pick, dim3(1), dim3(256), 0, c->stream, hist, (AutoState*)state, pass, step, min_steps);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }

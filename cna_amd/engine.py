@@ -294,6 +294,26 @@ class Engine(_order.CellOrder):
         """nsteps walk steps in one call (fixed step count, nothing for the host to decide in between)."""
         check(self.lib.cna_nam_steps(self.h, int(nsteps)), 'cna_nam_steps')
 
+    def nam_auto(self, maxnsteps=15):
+        """The walk with the reference's stop rule (nsteps=None, _nam.py:64-68) in one call, medians and rule on
+        the device; returns (steps taken, median kurtosis after every step)."""
+        taken = C.c_int(0)
+        med = np.empty(int(maxnsteps))
+        check(self.lib.cna_nam_auto(self.h, int(maxnsteps), C.byref(taken), ptr(med)), 'cna_nam_auto')
+        return taken.value, med[:taken.value]
+
+    def nam_auto_launch(self, maxnsteps=15):
+        """First half of nam_auto(): queue the walk and return at once.  The verdict is collected by
+        nam_auto_finish() or by whatever engine call next reads the NAM."""
+        check(self.lib.cna_nam_auto_launch(self.h, int(maxnsteps)), 'cna_nam_auto_launch')
+        self._auto_max = int(maxnsteps)
+
+    def nam_auto_finish(self):
+        taken = C.c_int(0)
+        med = np.empty(self._auto_max)
+        check(self.lib.cna_nam_auto_finish(self.h, C.byref(taken), ptr(med)), 'cna_nam_auto_finish')
+        return taken.value, med[:taken.value]
+
     def stat_median(self):
         """np.median of the per-cell statistic of the last kernel that made one, over all cells (or all
         kept cells, all ranks): exact radix select on the device, no cells-sized transfer."""

@@ -16,6 +16,7 @@ return types, progress text); the cells-sized arithmetic is done by libcna_hip.s
 Device matrices are cells x samples; DataFrames handed back to the caller are transposed to
 the reference's samples x cells on the way out.
 """
+import os
 import warnings
 from argparse import Namespace
 
@@ -387,6 +388,15 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
         walk_queued()
         engine._nam_sig = (sig, engine.nam_epoch, nsteps) if sig is not None else None
         return labels, nsteps
+    if (nsteps is None and not show_progress and 1 <= maxnsteps <= 16 and hasattr(engine, 'nam_auto_launch')
+            and os.environ.get('CNA_AUTO_HOST', '0') in ('0', '', 'off', 'no')):
+        # the reference's default: walk until the median kurtosis stops falling (_nam.py:64-68).  Medians and rule are
+        # evaluated on the device and the steps are queued ahead of the verdict: no host round trip per step
+        # (the call returns once the first steps are queued; whoever reads the NAM next collects the verdict)
+        engine.nam_auto_launch(maxnsteps)
+        walk_queued()
+        engine._nam_sig = (sig, engine.nam_epoch, None) if sig is not None else None
+        return labels, None
     for i in range(maxnsteps):
         last_for_sure = (nsteps is not None and i + 1 == nsteps) or (i + 1 == maxnsteps)
         may_stop = last_for_sure or show_progress or (nsteps is None and i + 1 >= 3)

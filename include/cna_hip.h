@@ -128,6 +128,19 @@ int  cna_nam_step(cna_ctx* ctx, int want_kurt, int may_continue, int may_stop);
 int  cna_nam_steps(cna_ctx* ctx, int nsteps);
 /* per-cell statistic of the last kernel that produced one (kurtosis / batch kurtosis),
  * gathered over ranks: out has n_global entries (CNA_MAT_NAM rows) or n_x_total (CNA_MAT_X) */
+/* The whole walk of _nam.py:57-70 with nsteps=None in one call: steps are taken until the median over the cells of
+ * the per-cell kurtosis (np.median, _nam.py:59) falls by less than 3 from one step to the next (checked from the
+ * third step on, _nam.py:64-68), at most maxnsteps (<= 16).  The medians and the rule are evaluated on the device
+ * and steps are queued ahead of the verdict (those behind the last step return at once); the host reads one word
+ * per batch of steps.  *steps_out: steps taken; medkurt_out (maxnsteps doubles, may be NULL): the median after
+ * every step taken.  Leaves the NAM of the last step on the device, like cna_nam_step(.., may_stop=1). */
+int  cna_nam_auto(cna_ctx* ctx, int maxnsteps, int* steps_out, double* medkurt_out);
+/* The same in two halves: _launch queues the first four steps with their medians and the rule and returns at once (the
+ * host goes on with its own work); _finish reads the verdict, queues two more steps at a time while the rule is not met,
+ * and leaves the context as cna_nam_auto does.  Every entry point that reads or replaces the NAM finishes a pending
+ * walk itself, so calling _finish is only needed for its outputs. */
+int  cna_nam_auto_launch(cna_ctx* ctx, int maxnsteps);
+int  cna_nam_auto_finish(cna_ctx* ctx, int* steps_out, double* medkurt_out);
 int  cna_fetch_cell_stat(cna_ctx* ctx, double* out, int64_t n_expected);
 /* np.median of that statistic over all cells (or all kept cells, all ranks), computed on the device
  * by an exact radix select: NaN if any entry is NaN, mean of the two middle values for an even count

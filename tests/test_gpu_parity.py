@@ -833,6 +833,56 @@ def test_selection_and_gram_in_one_kernel(eng, monkeypatch, n, N):
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize('n,N,seed', [(30000, 40, 3), (8000, 120, 4), (50001, 24, 5)])
+def test_walk_with_the_stop_rule_on_the_device(eng, monkeypatch, n, N, seed):
+    """nsteps=None (the reference's default, _nam.py:64-68): cna_nam_auto queues steps ahead of the verdict and
+    evaluates np.median(kurtosis) and the rule on the device.  Same number of steps, the same medians and the same
+    NAM, bit for bit, as the host loop over cna_nam_step + cna_stat_median (CNA_AUTO_HOST=1) -- also when the rule
+    is met before the steps already queued (four are queued at once) and when maxnsteps ends the walk."""
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.tools._nam import _nam_device, sample_codes
+    data, meta = synth.make_dataset(n, N, k=15, seed=seed)
+    codes, labels = sample_codes(data.obs['id'])
+    counts = np.bincount(codes, minlength=len(labels))
+    out = {}
+    for host in (False, True):
+        monkeypatch.setenv('CNA_AUTO_HOST', '1' if host else '0')
+        for maxn in (15, 3, 2):
+            _, taken = _nam_device(eng, data, 'id', nsteps=None, maxnsteps=maxn, codes_labels=(codes, labels, counts))
+            if taken is None:                     # queued, verdict pending: read the step count (nam_full would collect it too)
+                taken, _ = eng.nam_auto_finish()
+            out[host, maxn] = (taken, eng.nam_full().copy())
+    for maxn in (15, 3, 2):
+        assert out[False, maxn][0] == out[True, maxn][0], maxn
+        np.testing.assert_array_equal(out[False, maxn][1], out[True, maxn][1])
+    assert 3 <= out[True, 15][0] <= 15 and out[True, 2][0] == 2
+    # the medians themselves
+    monkeypatch.setenv('CNA_AUTO_HOST', '0')
+    eng.set_samples(codes, len(labels), counts.astype(float))
+    taken, med = eng.nam_auto(15)
+    eng.set_samples(codes, len(labels), counts.astype(float))
+    want = []
+    for i in range(taken):
+        eng.nam_step(True, True, True)
+        want.append(eng.stat_median())
+    assert np.isnan(med[0])                        # the rule never reads the first step's median: not computed
+    np.testing.assert_array_equal(med[1:], want[1:])
+    # a pending walk is finished by whatever reads the NAM next
+    eng.set_samples(codes, len(labels), counts.astype(float))
+    eng.nam_auto_launch(15)
+    np.testing.assert_array_equal(eng.nam_full(), out[True, 15][1])
+    # and through the public call
+    res = {}
+    for host in ('0', '1'):
+        monkeypatch.setenv('CNA_AUTO_HOST', host)
+        r = cna.tl.association(data, meta['y'], 'id', Nnull=100, seed=1, return_full=True, engine=eng)
+        res[host] = (r.p, int(r.k), r.ncorrs.values.copy(), r.nam.values.copy())
+    assert res['0'][:2] == res['1'][:2]
+    np.testing.assert_array_equal(res['0'][2], res['1'][2])
+    np.testing.assert_array_equal(res['0'][3], res['1'][3])
+
+
 def test_nam_cache_on_device(eng):
     """A second phenotype on the same dataset reuses the resident NAM (no diffusion kernels) and gives
     the results of a from-scratch run."""
