@@ -42,6 +42,7 @@ SIGNATURES = {
     'cna_nam_auto': (C.c_int, [c_ctx, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     'cna_nam_auto_launch': (C.c_int, [c_ctx, C.c_int]),
     'cna_nam_auto_finish': (C.c_int, [c_ctx, C.POINTER(C.c_int), C.c_void_p]),
+    'cna_stat_qc': (C.c_int, [c_ctx, c_f64p, c_f64p, c_i64p]),
     'cna_fetch_cell_stat': (C.c_int, [c_ctx, C.c_void_p, C.c_int64]),
     'cna_dense_load': (C.c_int, [c_ctx, C.c_void_p, C.c_int]),
     'cna_dense_step': (C.c_int, [c_ctx]),
@@ -56,6 +57,7 @@ SIGNATURES = {
     'cna_upload_x': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_int]),
     'cna_resid_apply': (C.c_int, [c_ctx, C.c_void_p, C.c_int]),
     'cna_resid_lowrank': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, c_f64p]),
+    'cna_resid_lowrank_bk': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, c_f64p, C.c_void_p, C.c_int, c_f64p]),
     'cna_standardize': (C.c_int, [c_ctx, C.c_int]),
     'cna_gram': (C.c_int, [c_ctx, C.c_void_p]),
     'cna_gram_launch': (C.c_int, [c_ctx]),

@@ -565,6 +565,7 @@ int cna_nam_steps(cna_ctx* c, int nsteps) {
 // one word per batch; the steps queued behind the one that met the rule return at once (StepArgs::stop).  The first
 // step's kurtosis is never looked at by the rule (_nam.py:65: i + 1 >= 3 compares steps 2 and 3) and is not
 // computed.  Same steps, same NAM as cna_nam_step + cna_stat_median in a host loop.
+static int ensure_auto_state(cna_ctx* c, unsigned long long** hist);
 static int auto_queue(cna_ctx* c, int upto) {
   const size_t sb = (auto_state_bytes() + 255) & ~(size_t)255;
   unsigned long long* hist = (unsigned long long*)((char*)c->auto_state + sb);
@@ -584,7 +585,7 @@ int cna_nam_auto_launch(cna_ctx* c, int maxnsteps) {
   if (maxnsteps < 1 || maxnsteps > 16) CNA_FAIL(CNA_EINVAL, "cna_nam_auto: 1 <= maxnsteps <= 16");
   if (c->steps_done != 0) CNA_FAIL(CNA_ESTATE, "cna_nam_auto starts a walk: call cna_set_samples / cna_restart_nam first");
   const size_t sb = (auto_state_bytes() + 255) & ~(size_t)255;
-  if (!c->auto_state) HIP_TRY(hipMalloc(&c->auto_state, sb + 8 * 2 * 257));
+  CNA_TRY(ensure_auto_state(c, nullptr));
   HIP_TRY(hipMemsetAsync(c->auto_state, 0, sb, c->stream));
   c->auto_max = maxnsteps;
   c->auto_queued = 0;
@@ -690,25 +691,82 @@ static int stat_select(cna_ctx* c, const double* v, int64_t n_loc, bool sharded,
   return 0;
 }
 
-int cna_stat_median(cna_ctx* c, double* median_out) {
-  CHECK_CTX(c);
-  AUTO_FINISH(c);
-  if (!median_out) CNA_FAIL(CNA_EINVAL, "cna_stat_median: null output");
+// the device-side bookkeeping block of the medians (rows.hip:AutoState) + 2 x 257 histogram words behind it
+static int ensure_auto_state(cna_ctx* c, unsigned long long** hist) {
+  const size_t sb = (auto_state_bytes() + 255) & ~(size_t)255;
+  if (!c->auto_state) HIP_TRY(hipMalloc(&c->auto_state, sb + 8 * 2 * 257));
+  if (hist) *hist = (unsigned long long*)((char*)c->auto_state + sb);
+  return 0;
+}
+
+// median (and, with qc, threshold and count of _qc_nam) of the current per-cell statistic; everything is queued, the
+// host waits once.  out3 = {median, threshold, count}
+static int stat_median_device(cna_ctx* c, bool qc, double* out3) {
   const double* v = c->stat;
   int64_t n_loc;
   bool sharded;
   if (c->stat_space == CNA_MAT_NAM) { n_loc = c->n_global; sharded = false; }
   else if (c->stat_space == CNA_MAT_X) { n_loc = c->nx; sharded = c->nranks > 1 || comm_active(c); }
   else CNA_FAIL(CNA_ESTATE, "no per-cell statistic available");
-  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, 8 * 257 + 64));   // main-stream scratch (not c->gt:
-  unsigned long long* hist = (unsigned long long*)c->scratch;            // the helper thread may be conditioning)
-  double lo = 0.0, hi = 0.0;
-  int64_t n_nan = 0, n_tot = 0;
-  CNA_TRY(stat_select(c, v, n_loc, sharded, -1, hist, &lo, &n_nan, &n_tot));
-  if (n_tot == 0 || n_nan > 0) { *median_out = __builtin_nan(""); return 0; }
-  if (n_tot & 1) { *median_out = lo; return 0; }
-  CNA_TRY(stat_select(c, v, n_loc, sharded, n_tot / 2, hist, &hi, &n_nan, &n_tot));
-  *median_out = (lo + hi) / 2.0;
+  unsigned long long* hist = nullptr;
+  CNA_TRY(ensure_auto_state(c, &hist));
+  const size_t sb = (auto_state_bytes() + 255) & ~(size_t)255;
+  HIP_TRY(hipMemsetAsync(c->auto_state, 0, sb, c->stream));
+  CNA_TRY(launch_auto_median(c, v, n_loc, c->auto_state, hist, -1, 0, sharded));
+  if (qc) {
+    CNA_TRY(launch_qc_count(c, v, n_loc, c->auto_state));
+    if (sharded) CNA_FAIL(CNA_ESTATE, "cna_stat_qc is for the NAM-space statistic");
+  }
+  struct { double median, threshold; unsigned long long count; } res;
+  HIP_TRY(hipMemcpyAsync(&res, (const char*)c->auto_state + auto_state_result_offset(), sizeof(res), hipMemcpyDeviceToHost,
+                         c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  out3[0] = res.median;
+  out3[1] = res.threshold;
+  out3[2] = (double)res.count;
+  return 0;
+}
+
+int cna_stat_median(cna_ctx* c, double* median_out) {
+  CHECK_CTX(c);
+  AUTO_FINISH(c);
+  if (!median_out) CNA_FAIL(CNA_EINVAL, "cna_stat_median: null output");
+  if (getenv("CNA_MEDIAN_HOST")) {            // the first implementation: digit choice on the host, 16 round trips
+    const double* v = c->stat;
+    int64_t n_loc;
+    bool sharded;
+    if (c->stat_space == CNA_MAT_NAM) { n_loc = c->n_global; sharded = false; }
+    else if (c->stat_space == CNA_MAT_X) { n_loc = c->nx; sharded = c->nranks > 1 || comm_active(c); }
+    else CNA_FAIL(CNA_ESTATE, "no per-cell statistic available");
+    CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, 8 * 257 + 64));   // main-stream scratch (not c->gt:
+    unsigned long long* hist = (unsigned long long*)c->scratch;            // the helper thread may be conditioning)
+    double lo = 0.0, hi = 0.0;
+    int64_t n_nan = 0, n_tot = 0;
+    CNA_TRY(stat_select(c, v, n_loc, sharded, -1, hist, &lo, &n_nan, &n_tot));
+    if (n_tot == 0 || n_nan > 0) { *median_out = __builtin_nan(""); return 0; }
+    if (n_tot & 1) { *median_out = lo; return 0; }
+    CNA_TRY(stat_select(c, v, n_loc, sharded, n_tot / 2, hist, &hi, &n_nan, &n_tot));
+    *median_out = (lo + hi) / 2.0;
+    return 0;
+  }
+  double out3[3];
+  CNA_TRY(stat_median_device(c, false, out3));
+  *median_out = out3[0];
+  return 0;
+}
+
+// _qc_nam's decision (_nam.py:94-96) on the batch kurtosis left by cna_batch_kurtosis(CNA_MAT_NAM, ..): the median,
+// threshold = max(6, 2 median) and the number of cells that fail `kurtosis < threshold` -- zero means "every cell
+// stays", and then nothing cells-sized has to travel to the host (cna_fetch_cell_stat otherwise).  One wait.
+int cna_stat_qc(cna_ctx* c, double* median_out, double* threshold_out, int64_t* n_dropped_out) {
+  CHECK_CTX(c);
+  AUTO_FINISH(c);
+  if (c->stat_space != CNA_MAT_NAM) CNA_FAIL(CNA_ESTATE, "cna_stat_qc needs the NAM-space statistic of cna_batch_kurtosis");
+  double out3[3];
+  CNA_TRY(stat_median_device(c, true, out3));
+  if (median_out) *median_out = out3[0];
+  if (threshold_out) *threshold_out = out3[1];
+  if (n_dropped_out) *n_dropped_out = (int64_t)out3[2];
   return 0;
 }
 
@@ -1187,6 +1245,73 @@ int cna_resid_lowrank(cna_ctx* c, const double* C, const double* W, int r, int c
   HIP_TRY(hipStreamSynchronize(c->stream));        // Ct is a local
   if (max_abs_out) *max_abs_out = m;
   c->ncorrs_valid = y != nullptr;
+  c->xq_valid = false;
+  c->coef_early = false;
+  c->fdr_inline = false;
+  return 0;
+}
+
+// One ridge of the schedule of _nam.py:142-156 in ONE pass over X and one wait: X <- (X - mean).M^T for M = I - C.W, the
+// batch kurtosis of the result (_nam.py:150: its median decides whether the schedule ends here), then -- optimistically --
+// the division by the std (_nam.py:159) and the coefficients X.y/N (_association.py:77).  *median_out: np.median of the
+// batch kurtosis (formed on the device).  When it is <= 6 the schedule is over and X is final; otherwise the caller
+// restores X (selection from the NAM) and continues with cna_resid_lowrank + cna_batch_kurtosis ridge by ridge.
+int cna_resid_lowrank_bk(cna_ctx* c, const double* C, const double* W, int r, const double* y, double* max_abs_out,
+                         const int32_t* batch_codes, int n_batches, double* median_out) {
+  CHECK_CTX(c);
+  if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  if (r < 0 || (r > 0 && (!C || !W)) || !y || !batch_codes || n_batches < 1 || n_batches > 256 || !median_out)
+    CNA_FAIL(CNA_EINVAL, "cna_resid_lowrank_bk: bad arguments");
+  if (c->nx > c->n_pad) CNA_FAIL(CNA_EINVAL, "X larger than the stat buffer");
+  const int Nx = c->Nx;
+  std::vector<int32_t> order, boff(n_batches + 1, 0);
+  for (int s = 0; s < Nx; ++s)
+    if (batch_codes[s] >= 0 && batch_codes[s] < n_batches) boff[batch_codes[s] + 1]++;
+  for (int b = 0; b < n_batches; ++b) boff[b + 1] += boff[b];
+  order.resize(std::max(boff[n_batches], 1));
+  std::vector<int32_t> cur(boff.begin(), boff.end() - 1);
+  for (int s = 0; s < Nx; ++s)
+    if (batch_codes[s] >= 0 && batch_codes[s] < n_batches) order[cur[batch_codes[s]]++] = s;
+  const int64_t rn = 8 * (int64_t)std::max(r, 1) * Nx;
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap,
+                      carve_bytes({rn, rn, 8 * (int64_t)Nx, 8 * 2049, 4 * (int64_t)order.size(), 4 * (n_batches + 1)})));
+  Carver cv(c->scratch);
+  double* Wd = cv.take<double>((int64_t)std::max(r, 1) * Nx);
+  double* Ctd = cv.take<double>((int64_t)std::max(r, 1) * Nx);
+  double* yd = cv.take<double>(Nx);
+  unsigned long long* mb = cv.take<unsigned long long>(2049);
+  int32_t* order_dev = cv.take<int32_t>(order.size());
+  int32_t* boff_dev = cv.take<int32_t>(n_batches + 1);
+  std::vector<double> Ct((size_t)std::max(r, 1) * Nx, 0.0);
+  for (int i = 0; i < Nx; ++i)
+    for (int k = 0; k < r; ++k) Ct[(size_t)k * Nx + i] = C[(size_t)i * r + k];
+  if (r > 0) {
+    HIP_TRY(hipMemcpyAsync(Wd, W, 8 * (size_t)r * Nx, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(Ctd, Ct.data(), 8 * (size_t)r * Nx, hipMemcpyHostToDevice, c->stream));
+  }
+  void* np = c->ncorrs;
+  CNA_TRY(dev_reserve(c, &np, &c->ncorrs_cap, 8 * std::max<int64_t>(c->nx, 1)));
+  c->ncorrs = (double*)np;
+  HIP_TRY(hipMemcpyAsync(yd, y, 8 * Nx, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(order_dev, order.data(), 4 * order.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(boff_dev, boff.data(), 4 * (n_batches + 1), hipMemcpyHostToDevice, c->stream));
+  CNA_TRY(launch_resid_lowrank(c, Wd, Ctd, r, 1, 1, yd, mb, order_dev, boff_dev, n_batches, c->stat));
+  c->stat_space = CNA_MAT_X;
+  CNA_TRY(comm_allreduce_f64_max(c, (double*)mb, 1));
+  // the median of the batch kurtosis, on the device; its result and max |coefficient| come back with one wait
+  const bool sharded = c->nranks > 1 || comm_active(c);
+  unsigned long long* hist = nullptr;
+  CNA_TRY(ensure_auto_state(c, &hist));
+  const size_t sb = (auto_state_bytes() + 255) & ~(size_t)255;
+  HIP_TRY(hipMemsetAsync(c->auto_state, 0, sb, c->stream));
+  CNA_TRY(launch_auto_median(c, c->stat, c->nx, c->auto_state, hist, -1, 0, sharded));
+  double m = 0.0, med = 0.0;
+  HIP_TRY(hipMemcpyAsync(&m, mb, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&med, (const char*)c->auto_state + auto_state_result_offset(), 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));        // (Ct, order, boff are locals)
+  if (max_abs_out) *max_abs_out = m;
+  *median_out = med;
+  c->ncorrs_valid = true;
   c->xq_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;

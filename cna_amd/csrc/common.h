@@ -249,7 +249,10 @@ int launch_digit_hist(cna_ctx* c, const double* v, int64_t n, unsigned long long
 int launch_max_fold(cna_ctx* c, const unsigned long long* blockmax, int nblocks, unsigned long long* out);
 // exact median of v[0..n) (np.median semantics) on the device, then the walk's stop rule for step `step` (0-based):
 // nothing returns to the host; `state` is the AutoState block of the walk, `hist` 2 x 257 words of scratch
-int launch_auto_median(cna_ctx* c, const double* v, int64_t n, void* state, unsigned long long* hist, int step, int min_steps);
+int launch_auto_median(cna_ctx* c, const double* v, int64_t n, void* state, unsigned long long* hist, int step, int min_steps,
+                       bool sum_over_ranks = false);
+int launch_qc_count(cna_ctx* c, const double* v, int64_t n, void* state);   // threshold max(6, 2 median) and the entries not below it
+int auto_state_result_offset();                                             // {median, threshold, count} in the state block
 size_t auto_state_bytes();
 int auto_state_stopped_offset();
 int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long* nzero_dev, const double* y_dev,
@@ -258,7 +261,8 @@ int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long*
 int launch_standardize(cna_ctx* c, int center);
 int launch_ncorrs(cna_ctx* c, const double* y_dev, unsigned long long* maxbits_dev);
 int launch_resid_lowrank(cna_ctx* c, const double* W_dev, const double* Ct_dev, int r, int center, int standardize,
-                         const double* y_dev, unsigned long long* maxbits_dev);
+                         const double* y_dev, unsigned long long* maxbits_dev, const int32_t* bk_order = nullptr,
+                         const int32_t* bk_boff = nullptr, int nb = 0, double* bk_out = nullptr);
 int launch_obs_counts(cna_ctx* c, const double* edges_dev, const double* thr_dev, int T, double thr0,
                       double inv_step, unsigned long long* hist_dev /* 2*T */);
 int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, int64_t* tails);

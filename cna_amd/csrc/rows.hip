@@ -15,6 +15,93 @@ __device__ __forceinline__ int64_t uniform64(int64_t v) {
 
 constexpr int MAXQ = 16;  // up to 1024 columns per row
 
+// ---- batch kurtosis of a row held in registers (lane owns columns lane + 64 q), up to BK_FAST batches:
+// per batch one masked partial per lane and one wave reduction (six DPP steps) -- every lane takes part, where the
+// sum "in sample order" of k_batch_kurtosis keeps nb lanes busy with a chain of dependent LDS reads (0.84 ms for the
+// 0.16 ms of traffic of a 1M x 100 matrix).  The batch sums add in another order than there (lane partials, then
+// the reduction tree): equal to rounding (1e-16), and likewise deterministic.
+constexpr int BK_FAST = 16;
+template <int NQ>
+__device__ __forceinline__ double batch_kurt_regs(const double (&x)[NQ], const int (&code)[NQ], int nb,
+                                                  const double* __restrict__ inv_cnt) {
+  double bm[BK_FAST];
+  double sum = 0.0;
+#pragma unroll
+  for (int b = 0; b < BK_FAST; ++b) {
+    bm[b] = 0.0;
+    if (b < nb) {
+      double part = 0.0;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) part += code[q] == b ? x[q] : 0.0;
+      bm[b] = wave_sum(part) * inv_cnt[b];
+      sum += bm[b];
+    }
+  }
+  const double n = (double)nb;
+  const double mean = sum / n;
+  double d2s = 0.0, d4s = 0.0;
+#pragma unroll
+  for (int b = 0; b < BK_FAST; ++b) {
+    if (b < nb) {
+      const double d = bm[b] - mean;
+      const double d2 = d * d;
+      d2s += d2;
+      d4s += d2 * d2;
+    }
+  }
+  const double m2 = d2s / n, m4 = d4s / n;
+  const double em = 2.220446049250313e-16 * mean;
+  const double k = (m2 <= em * em) ? __builtin_nan("") : m4 / (m2 * m2);
+  return (k - 3.0) + 3.0;                                  // Fisher, then "+ 3" as the reference writes it
+}
+// codes of the columns a lane owns and 1 / (samples of batch b), from the grouped lists k_batch_kurtosis takes
+template <int NQ>
+__device__ __forceinline__ void batch_codes_of(const int32_t* __restrict__ order, const int32_t* __restrict__ boff, int nb,
+                                               int ncols, int lane, int (&code)[NQ], double* inv_cnt_lds) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) code[q] = -1;
+  for (int b = 0; b < nb; ++b) {
+    const int s0 = boff[b], s1 = boff[b + 1];
+    for (int m = s0; m < s1; ++m) {
+      const int col = order[m];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (col == lane + 64 * q) code[q] = b;
+    }
+    if (threadIdx.x == 0) inv_cnt_lds[b] = 1.0 / (double)(s1 - s0);
+  }
+  (void)ncols;
+}
+template <int NQ>
+__global__ __launch_bounds__(256) void k_batch_kurtosis_fast(const double* __restrict__ mat, int64_t rows, int ncols,
+                                                             int ld, const int32_t* __restrict__ order,
+                                                             const int32_t* __restrict__ boff, int nb,
+                                                             double* __restrict__ out) {
+  __shared__ double inv_cnt[BK_FAST];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int code[NQ];
+  batch_codes_of<NQ>(order, boff, nb, ncols, lane, code, inv_cnt);
+  __syncthreads();
+  // four rows in flight per wave: one row at a time leaves the pass bound by the latency of its 800-byte loads
+  constexpr int RPW = NQ <= 4 ? 4 : 2;
+  const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wv) * RPW; base < rows; base += stride) {
+    double x[RPW][NQ];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        x[r][q] = (base + r < rows && lane + 64 * q < ncols) ? mat[(base + r) * ld + lane + 64 * q] : 0.0;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      if (base + r >= rows) break;
+      const double k = batch_kurt_regs<NQ>(x[r], code, nb, inv_cnt);
+      if (lane == 0) out[base + r] = k;
+    }
+  }
+}
+
 // ---- _batch_kurtosis (_nam.py:78-82) -------------------------------------------------
 // order[] lists the sample columns grouped by batch (stable), boff[b]..boff[b+1] is batch b.
 // Lane b sums its batch's entries in sample order (the order numpy's mean walks them).
@@ -579,29 +666,51 @@ __global__ __launch_bounds__(256) void k_resid_lowrank(double* __restrict__ X, i
                                                        const double* __restrict__ Wg, const double* __restrict__ Ctg,
                                                        int r, int center, int standardize,
                                                        const double* __restrict__ y, double* __restrict__ nc,
-                                                       unsigned long long* __restrict__ blockmax) {
-  extern __shared__ double lw[];               // W (r x Nx) | C^T (r x Nx)
+                                                       unsigned long long* __restrict__ blockmax,
+                                                       const int32_t* __restrict__ bk_order,
+                                                       const int32_t* __restrict__ bk_boff, int nb,
+                                                       double* __restrict__ bk_out) {
+  // bk_out != null: the batch kurtosis of the residualised row (_nam.py:150, before the division by the std) leaves
+  // with it -- k_batch_kurtosis's arithmetic on the row staged in LDS (lane b sums batch b in sample order) -- so
+  // the ridge schedule's check needs no pass of its own
+  extern __shared__ double lw[];               // W (r x Nx) | C^T (r x Nx) | [4 x ldx: one row per wave]
   __shared__ unsigned long long wmax[4];
   double* W = lw;
   double* Ct = lw + (size_t)r * Nx;
+  double* xr = lw + 2 * (size_t)r * Nx + (size_t)(threadIdx.x >> 6) * ldx;
+  __shared__ double inv_cnt[BK_FAST];
+  int bcode[NQ];
+  if (bk_out && nb <= BK_FAST) batch_codes_of<NQ>(bk_order, bk_boff, nb, Nx, threadIdx.x & 63, bcode, inv_cnt);
   for (int i = threadIdx.x; i < 2 * r * Nx; i += 256) lw[i] = i < r * Nx ? Wg[i] : Ctg[i - r * Nx];
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t stride = (int64_t)gridDim.x * 4;
+  // two rows in flight per wave (the loads of the second are issued before the first is worked on): one at a time the
+  // pass is bound by the latency of its row loads (0.71 ms for 1.6 GB at 1M x 100)
+  constexpr int RPW = NQ <= 4 ? 2 : 1;
+  const int64_t stride = (int64_t)gridDim.x * 4 * RPW;
   const double n = (double)Nx;
   double yv[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) yv[q] = (y && lane + 64 * q < Nx) ? y[lane + 64 * q] : 0.0;
   double vmax = 0.0;
   bool any_nan = false;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < nx; row += stride) {
+  for (int64_t base = ((int64_t)blockIdx.x * 4 + wv) * RPW; base < nx; base += stride) {
+   double xin[RPW][NQ];
+#pragma unroll
+   for (int rr = 0; rr < RPW; ++rr)
+#pragma unroll
+     for (int q = 0; q < NQ; ++q)
+       xin[rr][q] = (base + rr < nx && lane + 64 * q < Nx) ? X[(base + rr) * ldx + lane + 64 * q] : 0.0;
+#pragma unroll
+   for (int rr = 0; rr < RPW; ++rr) {
+    const int64_t row = base + rr;
+    if (row >= nx) break;
     double x[NQ];
     double s = 0.0;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int col = lane + 64 * q;
-      x[q] = col < Nx ? X[row * ldx + col] : 0.0;
+      x[q] = xin[rr][q];
       s += x[q];
     }
     if (center) {
@@ -634,6 +743,46 @@ __global__ __launch_bounds__(256) void k_resid_lowrank(double* __restrict__ X, i
       x[q] -= corr[q];
       s2 += x[q];
     }
+    if (bk_out && nb <= BK_FAST) {
+      const double kk = batch_kurt_regs<NQ>(x, bcode, nb, inv_cnt);
+      if (lane == 0) bk_out[row] = kk;
+    } else if (bk_out) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (lane + 64 * q < Nx) xr[lane + 64 * q] = x[q];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      double bm[4];
+      double bsum = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int b = lane + 64 * q;
+        bm[q] = 0.0;
+        if (b < nb) {
+          const int s0 = bk_boff[b], s1 = bk_boff[b + 1];
+          double sb = 0.0;
+          for (int m = s0; m < s1; ++m) sb += xr[bk_order[m]];
+          bm[q] = sb / (double)(s1 - s0);
+          bsum += bm[q];
+        }
+      }
+      const double nbd = (double)nb;
+      const double bmean = wave_sum(bsum) / nbd;
+      double d2s = 0.0, d4s = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (lane + 64 * q < nb) {
+          const double d = bm[q] - bmean;
+          const double d2 = d * d;
+          d2s += d2;
+          d4s += d2 * d2;
+        }
+      }
+      const double m2 = wave_sum(d2s) / nbd, m4 = wave_sum(d4s) / nbd;
+      const double em = 2.220446049250313e-16 * bmean;
+      const double kk = (m2 <= em * em) ? __builtin_nan("") : m4 / (m2 * m2);
+      if (lane == 0) bk_out[row] = (kk - 3.0) + 3.0;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     double sd = 1.0;
     if (standardize) {                          // pandas std: avg = sum/N ; sqrt(sum((avg-x)^2)/(N-1))
       const double avg = wave_sum(s2) / n;
@@ -662,6 +811,7 @@ __global__ __launch_bounds__(256) void k_resid_lowrank(double* __restrict__ X, i
       if (av > vmax) vmax = av;
       any_nan = any_nan || (v != v);
     }
+   }
   }
   if (y) {
     if (lane == 0)
@@ -762,6 +912,9 @@ struct AutoState {
   double med[16];                     // medkurt of every step taken
   int stopped_at;                     // 0: still walking; else the number of steps after which the rule was met
   int pad;
+  double median;                      // of the last select (launch_device_median)
+  double threshold;                   // launch_qc_count: max(6, 2 median) (_nam.py:94)
+  unsigned long long n_not_below;     // launch_qc_count: entries that are not < threshold (NaN included)
 };
 __global__ __launch_bounds__(256) void k_digit_hist2(const double* __restrict__ v, int64_t n,
                                                      const AutoState* __restrict__ st, int shift,
@@ -824,9 +977,24 @@ __global__ void k_auto_pick(unsigned long long* __restrict__ hist, AutoState* __
     const double lo = __longlong_as_double((long long)val[0]), hi = __longlong_as_double((long long)val[1]);
     const long long tot = st->n_tot;
     const double med = (tot == 0 || st->n_nan > 0) ? __builtin_nan("") : ((tot & 1) ? lo : (lo + hi) / 2.0);
-    st->med[step] = med;
-    if (step + 1 >= min_steps && step >= 1 && (st->med[step - 1] - med < 3.0)) st->stopped_at = step + 1;
+    st->median = med;
+    if (step >= 0) {                                        // the walk's rule (_nam.py:64-68)
+      st->med[step] = med;
+      if (step + 1 >= min_steps && step >= 1 && (st->med[step - 1] - med < 3.0)) st->stopped_at = step + 1;
+    }
   }
+}
+// _qc_nam (_nam.py:94-96) without the vector leaving the device: threshold = max(6, 2 median), and how many entries
+// fail `kurtosis < threshold` (NaN fails).  Zero -- the usual outcome: with up to seven batches the kurtosis of the batch
+// means cannot reach 6 -- means "keep every cell" and nothing cells-sized has to reach the host.
+__global__ __launch_bounds__(256) void k_qc_count(const double* __restrict__ v, int64_t n, AutoState* __restrict__ st) {
+  const double med = st->median;
+  const double thr = fmax(6.0, 2.0 * med);                  // (NaN median: fmax gives 6, as Python's max(6, nan) does)
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->threshold = thr;
+  unsigned long long cnt = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) cnt += !(v[i] < thr);
+  cnt = (unsigned long long)wave_sum((double)cnt);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&st->n_not_below, cnt);
 }
 
 __global__ __launch_bounds__(256) void k_max_fold(const unsigned long long* __restrict__ blockmax, int nblocks,
@@ -1040,6 +1208,20 @@ int launch_batch_kurtosis(cna_ctx* c, const double* mat, int64_t rows, int ncols
   if (rows == 0) return 0;
   if (n_batches > 256) CNA_FAIL(CNA_EINVAL, "more than 256 batches are not supported");
   ProfScope ps(c, CNA_K_BATCH_KURT);
+  if (n_batches <= BK_FAST && ncols <= 64 * MAXQ && !getenv("CNA_BK_SERIAL")) {
+#define BKF(Q) hipLaunchKernelGGL(k_batch_kurtosis_fast<Q>, dim3(wave_grid(rows)), dim3(256), 0, c->stream, mat, rows, ncols, ld, order_dev, boff_dev, n_batches, out)
+    switch ((ncols + 63) / 64) {
+      case 1: BKF(1); break;
+      case 2: BKF(2); break;
+      case 3: BKF(3); break;
+      case 4: BKF(4); break;
+      case 5: case 6: case 7: case 8: BKF(8); break;
+      default: BKF(MAXQ); break;
+    }
+#undef BKF
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(k_batch_kurtosis, dim3(wave_grid(rows)), dim3(256), sizeof(double) * 4 * ld, c->stream,
                      mat, rows, ncols, ld, order_dev, boff_dev, n_batches, out);
   HIP_TRY(hipGetLastError());
@@ -1126,14 +1308,27 @@ int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long*
 
 size_t auto_state_bytes() { return sizeof(AutoState); }
 int auto_state_stopped_offset() { return (int)offsetof(AutoState, stopped_at); }
-int launch_auto_median(cna_ctx* c, const double* v, int64_t n, void* state, unsigned long long* hist, int step, int min_steps) {
+int auto_state_result_offset() { return (int)offsetof(AutoState, median); }
+// step >= 0: the walk's bookkeeping (med[step], the stop rule); step < 0: the median alone (AutoState::median).
+// sum_over_ranks: the values are this rank's share of a vector spread over the ranks (X-space statistics): the digit
+// histograms are summed over the ranks between counting and picking -- still no host round trip.
+int launch_auto_median(cna_ctx* c, const double* v, int64_t n, void* state, unsigned long long* hist, int step, int min_steps,
+                       bool sum_over_ranks) {
   const int64_t want = (n + 1023) / 1024;
   const unsigned grid = (unsigned)(want < 1 ? 1 : (want < 1024 ? want : 1024));
   HIP_TRY(hipMemsetAsync(hist, 0, sizeof(unsigned long long) * 2 * 257, c->stream));
   for (int pass = 0; pass < 8; ++pass) {
     hipLaunchKernelGGL(k_digit_hist2, dim3(grid), dim3(256), 0, c->stream, v, n, (const AutoState*)state, 56 - 8 * pass, hist);
+    if (sum_over_ranks) CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, 2 * 257));
     hipLaunchKernelGGL(k_auto_pick, dim3(1), dim3(256), 0, c->stream, hist, (AutoState*)state, pass, step, min_steps);
   }
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int launch_qc_count(cna_ctx* c, const double* v, int64_t n, void* state) {
+  const int64_t want = (n + 1023) / 1024;
+  const unsigned grid = (unsigned)(want < 1 ? 1 : (want < 1024 ? want : 1024));
+  hipLaunchKernelGGL(k_qc_count, dim3(grid), dim3(256), 0, c->stream, v, n, (AutoState*)state);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1174,17 +1369,19 @@ int launch_standardize(cna_ctx* c, int center) {
 
 // W_dev: r x Nx, Ct_dev: r x Nx (C transposed); maxbits_dev as in launch_ncorrs (only with y_dev)
 int launch_resid_lowrank(cna_ctx* c, const double* W_dev, const double* Ct_dev, int r, int center, int standardize,
-                         const double* y_dev, unsigned long long* maxbits_dev) {
+                         const double* y_dev, unsigned long long* maxbits_dev, const int32_t* bk_order,
+                         const int32_t* bk_boff, int nb, double* bk_out) {
   if (y_dev) HIP_TRY(hipMemsetAsync(maxbits_dev, 0, sizeof(unsigned long long), c->stream));
   if (c->nx == 0) return 0;
   if (c->Nx > 64 * MAXQ) CNA_FAIL(CNA_EINVAL, "more than 1024 samples are not supported");
-  const size_t smem = sizeof(double) * 2 * (size_t)r * c->Nx;
+  if (bk_out && nb > 256) CNA_FAIL(CNA_EINVAL, "more than 256 batches are not supported");
+  const size_t smem = sizeof(double) * (2 * (size_t)r * c->Nx + (bk_out ? 4 * (size_t)c->ldx : 0));
   if (smem > 128 * 1024) CNA_FAIL(CNA_EINVAL, "cna_resid_lowrank: r x N too large for LDS");
   ProfScope ps(c, CNA_K_RESID);
   const int64_t want = (c->nx + 15) / 16;
   const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
 #define LR_CASE(Q) { static bool once = false; if (!once) { HIP_TRY(hipFuncSetAttribute((const void*)k_resid_lowrank<Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)); once = true; } \
-    hipLaunchKernelGGL(k_resid_lowrank<Q>, dim3(grid), dim3(256), smem, c->stream, c->X, c->nx, c->Nx, c->ldx, W_dev, Ct_dev, r, center, standardize, y_dev, c->ncorrs, y_dev ? maxbits_dev + 1 : nullptr); }
+    hipLaunchKernelGGL(k_resid_lowrank<Q>, dim3(grid), dim3(256), smem, c->stream, c->X, c->nx, c->Nx, c->ldx, W_dev, Ct_dev, r, center, standardize, y_dev, c->ncorrs, y_dev ? maxbits_dev + 1 : nullptr, bk_order, bk_boff, nb, bk_out); }
   switch ((c->Nx + 63) / 64) {
     case 1: LR_CASE(1) break;
     case 2: LR_CASE(2) break;

@@ -321,6 +321,13 @@ class Engine(_order.CellOrder):
         check(self.lib.cna_stat_median(self.h, C.byref(m)), 'cna_stat_median')
         return m.value
 
+    def stat_qc(self):
+        """(median, threshold = max(6, 2 median), cells failing `kurtosis < threshold`) of the NAM's batch kurtosis
+        (_nam.py:94-96), decided on the device; a count of zero means every cell is kept."""
+        m, t, nd = C.c_double(0.0), C.c_double(0.0), C.c_int64(0)
+        check(self.lib.cna_stat_qc(self.h, C.byref(m), C.byref(t), C.byref(nd)), 'cna_stat_qc')
+        return m.value, t.value, nd.value
+
     def cell_stat(self, n_expected, nam_space=True):
         """Per-cell statistic of the last kernel that made one: over all cells in the caller's
         order (nam_space) or over the rows of X in device order (see x_stat())."""
@@ -460,6 +467,18 @@ class Engine(_order.CellOrder):
         check(self.lib.cna_resid_lowrank(self.h, ptr(Cmat), ptr(W), int(r), int(bool(center)), int(bool(standardize)),
                                          ptr(yv), C.byref(m)), 'cna_resid_lowrank')
         return m.value if y is not None else None
+
+    def resid_lowrank_bk(self, Cmat, W, y, batch_codes, n_batches):
+        """One ridge in one pass: X <- (X - mean).M^T for M = I - Cmat.W, its batch kurtosis and the median of that
+        (on the device), then / std and the coefficients X.y/N.  Returns (max |ncorrs|, median batch kurtosis); when
+        the median is > 6 the caller must restore X before going on with the next ridge."""
+        Cmat, W, yv = _f64(Cmat), _f64(W), _f64(y)
+        r = Cmat.shape[1]
+        bc = np.ascontiguousarray(batch_codes, dtype=np.int32)
+        m, med = C.c_double(0.0), C.c_double(0.0)
+        check(self.lib.cna_resid_lowrank_bk(self.h, ptr(Cmat), ptr(W), int(r), ptr(yv), C.byref(m), ptr(bc), int(n_batches),
+                                            C.byref(med)), 'cna_resid_lowrank_bk')
+        return m.value, med.value
 
     def standardize(self, center=False):
         check(self.lib.cna_standardize(self.h, int(bool(center))), 'cna_standardize')

@@ -358,8 +358,7 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     else:
         labels, _ = _nam_device(engine, data, sid_name, nsteps=nsteps, show_progress=show_progress,
                                 codes_labels=codes_labels, **nam_kwargs)
-    kept = _qc_device(engine, labels, batches, show_progress=show_progress)
-
+    batches_qc = batches
     # NAM.reindex(y.index)[filter_samples]: boolean-Series indexing aligns on the index
     positions = pd.Series(np.arange(len(y)), index=y.index)[filter_samples].values
     sample_index = y.index[positions]
@@ -372,7 +371,10 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     donorids = donorids.reindex(y.index) if donorids is not None else None
     filter_samples = filter_samples.reindex(y.index)
     sample_index = pd.Index(sample_index, name=sid_name)
+    # the host-only planning (projector, one-hot batches: pandas work) first: it needs nothing from the device and
+    # runs while the walk does; the QC below waits for the walk (its batch-kurtosis pass and one read-back)
     extra = overlap(sample_index, batches, covs, donorids, filter_samples) if overlap is not None else None
+    kept = _qc_device(engine, labels, batches_qc, show_progress=show_progress)
 
     plan = extra if hasattr(extra, 'kind') else None
     nzero = -1
@@ -394,6 +396,9 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     if nzero != 0 and hasattr(engine, 'select_checked'):
         # something is regressed out: plain selection, with the zero-variance count taken in the same pass
         nzero = engine.select_checked(None if kept.all() else kept, colmap)
+        if nzero == 0 and plan is not None:
+            # (the one-pass first ridge of _resid_run overwrites X optimistically; this puts it back)
+            plan.reselect = lambda: engine.select_checked(None if kept.all() else kept, colmap)
     if nzero != 0:
         zero_var, nzero = engine.zero_variance(colmap)
         if nzero:

@@ -446,6 +446,12 @@ def _qc_device(engine, labels, batches, show_progress=False):
         return np.repeat(True, engine.n)
     codes, nb = _batch_codes(batches, labels)
     engine.batch_kurtosis(_ffi.MAT_NAM, codes, nb)
+    if not show_progress and hasattr(engine, 'stat_qc'):
+        # median, threshold and the count of failing cells are formed on the device: when nobody fails (always, with
+        # up to seven batches: the kurtosis of so few batch means cannot reach 6) the vector stays where it is
+        _, _, n_dropped = engine.stat_qc()
+        if n_dropped == 0:
+            return np.repeat(True, engine.n)
     threshold = max(6, 2 * engine.stat_median())
     kurtoses = engine.cell_stat(engine.n)
     print('throwing out neighborhoods with batch kurtosis >=', threshold, file=out)
@@ -535,8 +541,20 @@ def _resid_plan(sample_index, covs, batches, ridges=None):
         plan.C = pd.concat([plan.B, covs], axis=1)
         plan.ridges = DEFAULT_RIDGES if ridges is None else ridges
         plan.bcodes, plan.nb = _batch_codes(batches, sample_index)
+        # the first ridge's factors now (under the walk): with up to seven batches the schedule always ends there
+        if len(plan.ridges):
+            plan.first_ridge = _ridge_factors(plan.C, len(plan.B.T), plan.ridges[0], N)
     plan.r = len(plan.C.T)
     return plan
+
+
+def _ridge_factors(C, n_batch_cols, ridge, N):
+    """W = (C^T C + ridge N L)^-1 C^T and M = I - C W of one ridge of the schedule (_nam.py:143-146)."""
+    L = np.diag([1] * n_batch_cols + [0] * (len(C.T) - n_batch_cols))
+    W = np.linalg.solve(C.T.dot(C) + ridge * len(C) * L, C.T)
+    M = np.eye(N) - C.dot(W)
+    M.columns = M.index
+    return W, M
 
 
 def _lowrank_ok(engine, plan):
@@ -575,11 +593,26 @@ def _resid_run(engine, plan, cell_index, show_progress=False):
         B = plan.B
         first = True
         M = None
-        for ridge in plan.ridges:
-            L = np.diag([1] * len(B.T) + [0] * (len(C.T) - len(B.T)))
-            W = np.linalg.solve(C.T.dot(C) + ridge * len(C) * L, C.T)
-            M = np.eye(N) - C.dot(W)
-            M.columns = M.index
+        y_std = getattr(plan, 'y_std', None)
+        done = False
+        if (len(plan.ridges) and y_std is not None and _lowrank_ok(engine, plan) and hasattr(engine, 'resid_lowrank_bk')
+                and getattr(plan, 'reselect', None) is not None and os.environ.get('CNA_RIDGE_ONEPASS', '1') not in ('0', 'off', 'no')):
+            # The first ridge in ONE pass, optimistically: residualise, batch kurtosis (median taken on the device),
+            # and -- assuming the schedule ends here, as it always does with up to seven batches -- the division by the
+            # std and the coefficients.  Should the median say otherwise, X is selected again and the schedule runs
+            # ridge by ridge as below.
+            W, M = plan.first_ridge
+            m, med = engine.resid_lowrank_bk(np.asarray(C.values, dtype=np.float64), np.asarray(W, dtype=np.float64), y_std,
+                                             plan.bcodes, plan.nb)
+            if med <= 6:
+                print('\twith ridge', plan.ridges[0], 'median batch kurtosis = ', med, file=out)
+                plan.maxabs = m
+                first = False
+                done = True
+            else:
+                plan.reselect()
+        for i, ridge in enumerate(() if done else plan.ridges):
+            W, M = plan.first_ridge if i == 0 and hasattr(plan, 'first_ridge') else _ridge_factors(C, len(B.T), ridge, N)
             if _lowrank_ok(engine, plan):
                 engine.resid_lowrank(np.asarray(C.values, dtype=np.float64), np.asarray(W, dtype=np.float64), center=first)
             else:
@@ -592,7 +625,14 @@ def _resid_run(engine, plan, cell_index, show_progress=False):
                 break
         if first:   # empty ridge list: only centring applies
             engine.resid_apply(None, center=True)
-        engine.standardize(center=False)
+        if done:
+            pass
+        elif y_std is not None and not first and _lowrank_ok(engine, plan):
+            # division by the std (_nam.py:159) and the coefficients X.y/N (_association.py:77) in one row-local pass
+            # (the projector part of that kernel with no factors)
+            plan.maxabs = engine.resid_lowrank(np.zeros((N, 0)), np.zeros((0, N)), center=False, standardize=True, y=y_std)
+        else:
+            engine.standardize(center=False)
 
     # the caller's coefficient column, when the coefficients came with the residualisation pass: queued in front
     # of the Gram kernels so that the host can write it into the frame while those run

@@ -141,6 +141,11 @@ int  cna_nam_auto(cna_ctx* ctx, int maxnsteps, int* steps_out, double* medkurt_o
  * walk itself, so calling _finish is only needed for its outputs. */
 int  cna_nam_auto_launch(cna_ctx* ctx, int maxnsteps);
 int  cna_nam_auto_finish(cna_ctx* ctx, int* steps_out, double* medkurt_out);
+/* _qc_nam's decision (_nam.py:94-96) on the statistic left by cna_batch_kurtosis(CNA_MAT_NAM, ...): np.median of it,
+ * threshold = max(6, 2 median), and the number of cells that fail `kurtosis < threshold` (NaN fails) -- 0 means every
+ * cell is kept and the per-cell vector need not be fetched (cna_fetch_cell_stat).  Median, threshold and count are
+ * formed on the device; one wait. */
+int  cna_stat_qc(cna_ctx* ctx, double* median_out, double* threshold_out, int64_t* n_dropped_out);
 int  cna_fetch_cell_stat(cna_ctx* ctx, double* out, int64_t n_expected);
 /* np.median of that statistic over all cells (or all kept cells, all ranks), computed on the device
  * by an exact radix select: NaN if any entry is NaN, mean of the two middle values for an even count
@@ -207,6 +212,13 @@ int  cna_resid_apply(cna_ctx* ctx, const double* M, int center);
  * coefficients X.y/N with their max |.| (_association.py:77,101): one pass over X instead of three */
 int  cna_resid_lowrank(cna_ctx* ctx, const double* C, const double* W, int r, int center, int standardize,
                        const double* y, double* max_abs_out);
+/* One ridge of the schedule of _nam.py:142-156 in one pass over X and one wait: centre, apply M = I - C.W (factors as
+ * above), take the batch kurtosis of the result (_nam.py:150; batch_codes: batch of every sample of X, -1 = none) and
+ * its np.median (on the device, *median_out), and -- optimistically -- divide by the std (_nam.py:159) and take the
+ * coefficients X.y/N (_association.py:77; *max_abs_out = max |coefficient|).  median <= 6: the schedule is over and X is
+ * final.  Otherwise X has to be restored by the caller (cna_select_checked from the NAM) before the next ridge. */
+int  cna_resid_lowrank_bk(cna_ctx* ctx, const double* C, const double* W, int r, const double* y, double* max_abs_out,
+                          const int32_t* batch_codes, int n_batches, double* median_out);
 int  cna_standardize(cna_ctx* ctx, int center);
 /* G = X^T X over all cells of all ranks (NAM.dot(NAM.T), _nam.py:105), n_cols x n_cols row-major */
 int  cna_gram(cna_ctx* ctx, double* G_out);

@@ -883,6 +883,34 @@ def test_walk_with_the_stop_rule_on_the_device(eng, monkeypatch, n, N, seed):
     np.testing.assert_array_equal(res['0'][3], res['1'][3])
 
 
+@pytest.mark.parametrize('n,N,nb,nc', [(20000, 40, 5, 2), (9000, 100, 4, 0), (15000, 64, 12, 1)])
+def test_covariates_and_batches_fast_path(eng, monkeypatch, n, N, nb, nc):
+    """The demo's call shape (covariates AND batches, demo/demo.ipynb:149; _nam.py:85-99,136-156): the QC decision
+    (median, threshold, count of failing cells) is taken on the device, and the first ridge of the schedule is one
+    pass (residualise + batch kurtosis + device median + / std + coefficients).  Same results as the step-by-step
+    path -- QC vector fetched and compared on the host, ridge by ridge with separate kurtosis / median / std /
+    coefficient passes."""
+    import cna_amd as cna
+    from cna_amd import synth
+    data, meta = synth.make_dataset(n, N, k=15, seed=21, n_covs=nc, n_batches=nb)
+    kw = dict(covs=meta['covs'], batches=meta['batches'], Nnull=200, seed=3, nsteps=3, return_full=True, engine=eng)
+    fast = cna.tl.association(data, meta['y'], 'id', **kw)
+    f = (fast.p, int(fast.k), fast.ncorrs.values.copy(), fast.kept.copy(), fast.namresid.values.copy(),
+         fast.fdrs.values.copy(), data.obs['coef_fdr'].values.copy(), fast.M.values.copy())
+    monkeypatch.setenv('CNA_RIDGE_ONEPASS', '0')
+    monkeypatch.setenv('CNA_MEDIAN_HOST', '1')
+    monkeypatch.delattr(type(eng), 'stat_qc')
+    slow = cna.tl.association(data, meta['y'], 'id', **kw)
+    assert f[0] == slow.p and f[1] == int(slow.k)
+    assert np.array_equal(f[3], slow.kept)
+    np.testing.assert_allclose(f[2], slow.ncorrs.values, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(f[4], slow.namresid.values, rtol=1e-12, atol=1e-14)
+    np.testing.assert_array_equal(f[5][:, 2], slow.fdrs.values[:, 2])             # num_detected
+    np.testing.assert_allclose(f[5], slow.fdrs.values, rtol=1e-9)
+    np.testing.assert_allclose(f[6], data.obs['coef_fdr'].values, rtol=1e-9)
+    np.testing.assert_array_equal(f[7], slow.M.values)
+
+
 def test_nam_cache_on_device(eng):
     """A second phenotype on the same dataset reuses the resident NAM (no diffusion kernels) and gives
     the results of a from-scratch run."""

@@ -10,9 +10,12 @@ from cna_amd import synth
 from cna_amd.engine import get_engine, Engine
 n, N = int(sys.argv[1]) if len(sys.argv) > 1 else 200000, int(sys.argv[2]) if len(sys.argv) > 2 else 50
 ncov = int(os.environ.get('TRACE_COVS', '0'))
-data, meta = synth.make_dataset(n, N, k=30, seed=0, n_covs=ncov)
+nbat = int(os.environ.get('TRACE_BATCHES', '0'))
+data, meta = synth.make_dataset(n, N, k=30, seed=0, n_covs=ncov, n_batches=nbat)
 eng = get_engine(); eng.reuse_nam = False; kw = dict(nsteps=3, Nnull=int(os.environ.get('TRACE_NNULL', '1000')), seed=0)
 if ncov: kw['covs'] = meta['covs']
+if nbat: kw['batches'] = meta['batches']
+if os.environ.get('TRACE_NSTEPS') == 'None': kw['nsteps'] = None
 if os.environ.get('TRACE_PIN'): eng.pin_graph(data.obsp['connectivities'])
 for _ in range(4): cna.tl.association(data, meta['y'], 'id', **kw)
 ev = []
