@@ -380,13 +380,18 @@ static int ensure_T(cna_ctx* c, int ld) {
 }
 
 // The second walk step can gather a compressed copy of the state (diffuse.hip: k_nam_step_sparse).
-// Worth it when rows are mostly zeros after one step, i.e. many more samples than neighbours; kept
-// to the single-GPU path (the exchange between ranks carries dense rows).  CNA_SPARSE_MIN_N moves
-// the switch-over (0 = never).
+// Worth it when rows are mostly zeros after one step, i.e. many more samples than neighbours.  Sharded over
+// ranks (round 3): the exchange between ranks still carries dense rows -- the first step then writes the dense row
+// of every cell as well, and the rows that arrive from other ranks are marked "dense" in sp_cnt once (this rank's
+// steps only ever write the marks of its own rows), so the second step takes its local neighbours -- nine in ten
+// at eight ranks -- from their pairs and the others from the dense rows the halo exchange delivered, exactly as it
+// does for a row that overflowed its pairs.  Needs the halo exchange (with the all-gather fallback every row would
+// be foreign).  CNA_SPARSE_MIN_N moves the switch-over (0 = never).
 static int ensure_sparse_state(cna_ctx* c) {
   int min_n = 96;
   if (const char* e = getenv("CNA_SPARSE_MIN_N")) min_n = atoi(e);
-  const bool want = min_n > 0 && c->N >= min_n && c->nranks == 1 && !comm_active(c);
+  const bool multi = c->nranks > 1 || comm_active(c);
+  const bool want = min_n > 0 && c->N >= min_n && (!multi || (c->halo_on && !getenv("CNA_SPARSE_ONE_GPU_ONLY")));
   if (!want) {
     if (c->sp_cnt) {
       HIP_TRY(hipStreamSynchronize(c->stream));
@@ -407,6 +412,8 @@ static int ensure_sparse_state(cna_ctx* c) {
   c->sp_rows = c->n_pad;
   CNA_TRY(dev_alloc(c, &c->sp_pair, 16 * 64 * (size_t)c->sp_rows));   // 64 = SP_CAP records of 16 bytes (diffuse.hip)
   CNA_TRY(dev_alloc(c, &c->sp_cnt, (size_t)c->sp_rows));
+  // every row "dense" (255 = SP_DENSE) until a first step of this rank says otherwise: rows of other ranks stay so
+  HIP_TRY(hipMemsetAsync(c->sp_cnt, 0xff, (size_t)c->sp_rows, c->stream));
   return 0;
 }
 

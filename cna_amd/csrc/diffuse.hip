@@ -55,6 +55,7 @@ struct StepArgs {
   // walk with the stop rule on the device (cna_nam_auto): steps queued behind the one that met the rule find this
   // word non-zero and return at once; null = unconditional step
   const int* stop;
+  int sp_keep_dense;        // sharded: the first step writes the dense row of every cell besides its pairs (halo exchange)
 };
 #define STEP_STOPPED(a) ((a).stop != nullptr && __builtin_nontemporal_load((a).stop) != 0)
 // One 16-byte record per non-zero: the second step then fetches an edge's whole neighbour row with ONE
@@ -193,7 +194,7 @@ __device__ __forceinline__ void first_tail(const StepArgs& a, const double* accl
   }
   if (lane == 0) a.sp_cnt[grow] = (unsigned char)(base <= SP_CAP ? base : SP_DENSE);
   StepArgs b = a;
-  b.write_t = a.write_t && base > SP_CAP;
+  b.write_t = a.write_t && (base > SP_CAP || a.sp_keep_dense);
   finish_row<NQ, ColStride1>(b, row, grow, lane, s);
 }
 
@@ -953,6 +954,7 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
   a.write_t = write_t;
   a.write_nam = write_nam;
   a.stop = c->auto_stop;
+  a.sp_keep_dense = (c->nranks > 1 || c->halo_on) ? 1 : 0;
   // compressed state: written by the first step, read by the second (sample indicators only)
   const bool sp = c->sp_cnt && !dense && (first || c->steps_done == 1);
   a.sp_pair = sp ? (SpPair*)c->sp_pair : nullptr;

@@ -147,28 +147,31 @@ int cna_host_copy(void* dst, const void* src, int64_t nbytes, int nthreads) {
 int64_t cna_host_cluster_order(int64_t n, const int64_t* indptr, const int32_t* indices, int B, int64_t* order_out) {
   if (n <= 0) return 0;
   if (B < 1) B = 1;
-  unsigned char* placed = (unsigned char*)calloc((size_t)n, 1);
-  int32_t* links = (int32_t*)calloc((size_t)n, 4);            /* edges from the growing cluster into a candidate */
+  /* state[j]: -1 = placed, else the number of edges from the growing cluster into j (one random access per edge;
+   * with `placed` and `links` as two arrays the pass took 0.59 s at 2M cells, three quarters of a cold call) */
+  int32_t* state = (int32_t*)calloc((size_t)n, 4);
   int32_t* touched = (int32_t*)malloc(4 * (size_t)n);         /* candidates of the current cluster */
   int32_t* fifo = (int32_t*)malloc(4 * (size_t)n);            /* seeds-to-be: every cell enters at most once */
   unsigned char* queued = (unsigned char*)calloc((size_t)n, 1);
   int64_t* shorts = (int64_t*)malloc(8 * (size_t)n);          /* members of short clusters */
   int32_t* members = (int32_t*)malloc(4 * (size_t)B);
-  /* lazy bucket queue: level[c] holds cells whose link count was c when pushed; stale entries are
-   * skipped when popped.  Pushes per cluster <= edges of its members. */
+  /* lazy bucket queue: level[c] holds cells whose link count was c when pushed; stale entries are skipped when
+   * popped.  Pushes per cluster <= edges of its members.  A link count can exceed B when a row lists a column
+   * more than once (non-canonical CSR): counts are filed under min(count, B + 1). */
   int32_t** level = (int32_t**)calloc((size_t)B + 2, sizeof(int32_t*));
   int64_t* lsize = (int64_t*)calloc((size_t)B + 2, 8);
   int64_t* lcap = (int64_t*)calloc((size_t)B + 2, 8);
-  if (!placed || !links || !touched || !fifo || !queued || !shorts || !members || !level || !lsize || !lcap) return -1;
   int64_t n_full = 0, n_short = 0, fifo_head = 0, fifo_tail = 0, next_index = 0;
+  int64_t rc = -1;
+  if (!state || !touched || !fifo || !queued || !shorts || !members || !level || !lsize || !lcap) goto done;
   for (;;) {
     int64_t seed = -1;
     while (fifo_head < fifo_tail) {
       const int32_t c = fifo[fifo_head++];
-      if (!placed[c]) { seed = c; break; }
+      if (state[c] >= 0) { seed = c; break; }
     }
     if (seed < 0) {
-      while (next_index < n && placed[next_index]) ++next_index;
+      while (next_index < n && state[next_index] < 0) ++next_index;
       if (next_index >= n) break;
       seed = next_index;
     }
@@ -176,18 +179,23 @@ int64_t cna_host_cluster_order(int64_t n, const int64_t* indptr, const int32_t* 
     int64_t ntouched = 0;
     int32_t cur = (int32_t)seed;
     for (;;) {
-      placed[cur] = 1;
+      if (state[cur] == 0) touched[ntouched++] = cur;         /* (a seed nobody linked to: reset below like the others) */
+      state[cur] = -1;
       members[m++] = cur;
       if (m == B) break;
       for (int64_t e = indptr[cur]; e < indptr[cur + 1]; ++e) {
         const int32_t j = indices[e];
-        if (j < 0 || j >= n || placed[j]) continue;
-        if (links[j] == 0) touched[ntouched++] = j;
-        const int c = ++links[j];                             /* <= m <= B */
+        if (j < 0 || j >= n) continue;
+        const int32_t sj = state[j];
+        if (sj < 0) continue;
+        if (sj == 0) touched[ntouched++] = j;
+        state[j] = sj + 1;
+        const int c = sj + 1 > B + 1 ? B + 1 : sj + 1;
         if (lsize[c] == lcap[c]) {
           lcap[c] = lcap[c] ? 2 * lcap[c] : 256;
-          level[c] = (int32_t*)realloc(level[c], 4 * (size_t)lcap[c]);
-          if (!level[c]) return -1;
+          int32_t* grown = (int32_t*)realloc(level[c], 4 * (size_t)lcap[c]);
+          if (!grown) goto done;
+          level[c] = grown;
         }
         level[c][lsize[c]++] = j;
         if (c > top) top = c;
@@ -196,16 +204,19 @@ int64_t cna_host_cluster_order(int64_t n, const int64_t* indptr, const int32_t* 
       while (top > 0) {
         if (lsize[top] == 0) { --top; continue; }
         const int32_t j = level[top][--lsize[top]];
-        if (!placed[j] && links[j] == top) { pick = j; break; }
+        const int32_t sj = state[j];
+        if (sj >= 0 && (sj > B + 1 ? B + 1 : sj) == top) { pick = j; break; }
       }
       if (pick < 0) break;                                    /* no candidate left: a short cluster */
       cur = pick;
     }
-    for (int c = 0; c <= B; ++c) lsize[c] = 0;
+    for (int c = 0; c <= B + 1; ++c) lsize[c] = 0;
     for (int64_t t = 0; t < ntouched; ++t) {
       const int32_t j = touched[t];
-      links[j] = 0;
-      if (!placed[j] && !queued[j]) { queued[j] = 1; fifo[fifo_tail++] = j; }
+      if (state[j] >= 0) {
+        state[j] = 0;
+        if (!queued[j]) { queued[j] = 1; fifo[fifo_tail++] = j; }
+      }
     }
     if (m == B) {
       for (int i = 0; i < m; ++i) order_out[n_full + i] = members[i];
@@ -216,10 +227,12 @@ int64_t cna_host_cluster_order(int64_t n, const int64_t* indptr, const int32_t* 
     }
   }
   for (int64_t i = 0; i < n_short; ++i) order_out[n_full + i] = shorts[i];
-  for (int c = 0; c <= B + 1; ++c) free(level[c]);
-  free(level); free(lsize); free(lcap); free(placed); free(links); free(touched); free(fifo); free(queued);
+  rc = n_full;
+done:
+  if (level) for (int c = 0; c <= B + 1; ++c) free(level[c]);
+  free(level); free(lsize); free(lcap); free(state); free(touched); free(fifo); free(queued);
   free(shorts); free(members);
-  return n_full;
+  return rc;
 }
 
 /* Per block of B consecutive local rows: the distinct columns its rows reference ("sources", in order of

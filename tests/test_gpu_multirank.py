@@ -173,6 +173,68 @@ def test_sharded_random_configurations_equal_single_gpu(seed, world):
         np.testing.assert_allclose(g['coef_fdr'], one['coef_fdr'], rtol=1e-9, atol=1e-13)
 
 
+def _sparse_worker(rank, world, seg, q):
+    sys.path.insert(0, ROOT)
+    import warnings
+    warnings.simplefilter('ignore')
+    try:
+        import cna_amd as cna
+        from cna_amd import synth
+        from cna_amd.engine import Engine
+        data, meta = synth.make_dataset(9000, 120, k=15, seed=31)
+        eng = Engine(device=0, rank=rank, nranks=world, shm=(seg, 32 << 20)) if world > 1 else Engine(device=0)
+        eng.prof_enable(True)
+        res = cna.tl.association(data, meta['y'], 'id', nsteps=3, Nnull=100, seed=2, return_full=True, engine=eng)
+        eng.sync()
+        prof = eng.prof()
+        out = dict(p=res.p, k=int(res.k), nam=res.nam.values, ncorrs=res.ncorrs.values, halo=getattr(eng, 'halo', None),
+                   sparse=prof.get('nam_step_sparse', (0, 0))[1], dense=prof.get('nam_step', (0, 0))[1])
+        eng.close()
+        q.put((rank, out))
+    except BaseException as e:
+        import traceback
+        q.put((rank, 'ERROR %r\n%s' % (e, traceback.format_exc())))
+        os._exit(1)
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_compressed_second_step_across_ranks(world):
+    """120 samples: the second walk step gathers (sample, value) pairs instead of dense rows (k_nam_step_sparse).
+    Sharded, a rank has the pairs of its own rows only; the rows the halo exchange brings arrive dense and are
+    marked so -- the step then runs on every rank (one sparse and one dense step, as on one GPU) and the NAM is
+    bit for bit the single-GPU NAM."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    results = {}
+    for w in (1, world):
+        q = ctx.Queue()
+        seg = 'cna_sp_%d_%d' % (os.getpid(), w)
+        procs = [ctx.Process(target=_sparse_worker, args=(r, w, seg, q)) for r in range(w)]
+        for p in procs:
+            p.start()
+        got = {}
+        try:
+            for _ in range(w):
+                r, out = q.get(timeout=240)
+                assert not isinstance(out, str), out
+                got[r] = out
+        finally:
+            for p in procs:
+                p.join(timeout=30)
+                if p.is_alive():
+                    p.kill()
+        results[w] = got
+    one = results[1][0]
+    assert one['sparse'] == 1 and one['dense'] == 1
+    for r in range(world):
+        g = results[world][r]
+        assert g['halo'] is not None and g['halo'][1] > 0          # rows do arrive from other ranks
+        assert g['sparse'] == 1 and g['dense'] == 1, (g['sparse'], g['dense'])
+        np.testing.assert_array_equal(g['nam'], one['nam'])
+        assert g['k'] == one['k'] and g['p'] == pytest.approx(one['p'], rel=1e-12)
+        np.testing.assert_allclose(g['ncorrs'], one['ncorrs'], rtol=1e-9, atol=1e-13)
+
+
 def _shard_worker(rank, world, seg, name, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
