@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """From the rocprofv3 --pmc CSVs of tools/profile_round2.sh: per-kernel counter means (pmc_summary_<W>.txt) and
-profiles-style HBM-side traffic per bench kernel launch (r02_pmc_traffic.json):
+profiles-style HBM-side traffic per bench kernel launch (r03_pmc_traffic.json):
     bytes = 2 * FETCH_SIZE [KB] * 1e3 + WRITE_SIZE [KB] * 1e3   (MI355X_MICROARCH.md: FETCH_SIZE reads half)
 summed over the device kernels behind one bench kernel name, per launch of that name."""
 import glob
@@ -13,12 +13,12 @@ import pandas as pd
 
 d = sys.argv[1]
 # device kernel -> bench kernel name (cna_prof_*), and how many bench launches one step makes
-NAMES = [('k_nam_first', 'nam_first'), ('k_nam_step', 'nam_step'), ('k_null', 'null_local'), ('k_hist_reduce', 'null_local'), ('k_quant_', 'null_local'), ('k_y_', 'null_local'),
+NAMES = [('k_nam_first', 'nam_first'), ('k_nam_step_sparse', 'nam_step_sparse'), ('k_nam_step', 'nam_step'), ('k_null', 'null_local'), ('k_hist_reduce', 'null_local'), ('k_quant_', 'null_local'), ('k_y_', 'null_local'),
          ('k_i8_', 'null_local'),
          ('k_gram_reduce', 'gram_reduce'), ('k_gram', 'gram'), ('k_select_std', 'select'), ('k_select', 'select'),
          ('k_xb', 'resid_xb'), ('k_standardize', 'standardize'), ('k_ncorrs', 'ncorrs'), ('k_cond', 'condition'),
          ('k_gt_', 'global_test'), ('k_obs_counts', 'obs_counts'), ('k_percell', 'percell_fdr')]
-PER_STEP = {'nam_step': 2, 'percell_fdr': 2}
+PER_STEP = {'percell_fdr': 2}        # (round 3: the dense and the compressed walk step are separate bench kernels)
 
 
 def bench_name(k):
@@ -63,6 +63,6 @@ for W in ('C4', 'C3', 'C2', 'C5'):
         w = sums.loc[k, 'WRITE_SIZE'] / steps_w if steps_w else 0.0
         traffic[name] = traffic.get(name, 0.0) + (2.0 * f + w) * 1e3
     out[W] = {name: round(v / PER_STEP.get(name, 1), 0) for name, v in traffic.items()}
-with open(os.path.join(d, 'r02_pmc_traffic.json'), 'w') as fh:
+with open(os.path.join(d, 'r03_pmc_traffic.json'), 'w') as fh:
     json.dump(out, fh, indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
