@@ -42,6 +42,61 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 }
 
 // ---- reference: wave per row (the production kernel's shape, U rows in flight)
+// the same on a column slice: row stride ld2 (double2), columns [c2, c2 + w2) of every row
+template <int NQ2, int U>
+__global__ __launch_bounds__(256) void k_row_slice(const long* __restrict__ indptr, const int* __restrict__ idx,
+                                                   const float* __restrict__ val, const double2* __restrict__ T, int ld2,
+                                                   int c2, int w2, long n, double2* __restrict__ out, int chunk) {
+  const int lane = threadIdx.x & 63;
+  const long b = blockIdx.x >> 3, x = blockIdx.x & 7;
+  const long blk = (b / chunk) * (8 * (long)chunk) + x * chunk + (b % chunk);
+  const long row = blk * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const long start = indptr[row], end = indptr[row + 1];
+  double2 acc[NQ2];
+#pragma unroll
+  for (int q = 0; q < NQ2; ++q) acc[q] = make_double2(0, 0);
+  for (long base = start; base < end; base += 64) {
+    const bool ok = base + lane < end;
+    const int jl = ok ? idx[base + lane] : 0;
+    const double al = ok ? (double)val[base + lane] : 0.0;
+    const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+    int l = 0;
+    for (; l + U <= cnt; l += U) {
+      double2 t[U][NQ2];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = __builtin_amdgcn_readlane(jl, l + u);
+        const double2* rp = T + (long)j * ld2 + c2;
+#pragma unroll
+        for (int q = 0; q < NQ2; ++q) t[u][q] = (lane + 64 * q < w2) ? rp[lane + 64 * q] : make_double2(0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double av = readlane_d(al, l + u);
+#pragma unroll
+        for (int q = 0; q < NQ2; ++q) { acc[q].x = acc[q].x + av * t[u][q].x; acc[q].y = acc[q].y + av * t[u][q].y; }
+      }
+    }
+    for (; l < cnt; ++l) {
+      const int j = __builtin_amdgcn_readlane(jl, l);
+      const double av = readlane_d(al, l);
+      const double2* rp = T + (long)j * ld2 + c2;
+#pragma unroll
+      for (int q = 0; q < NQ2; ++q) {
+        const double2 t = (lane + 64 * q < w2) ? rp[lane + 64 * q] : make_double2(0, 0);
+        acc[q].x = acc[q].x + av * t.x; acc[q].y = acc[q].y + av * t.y;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ2; ++q)
+    if (lane + 64 * q < w2) {
+      const double2 own = T[row * ld2 + c2 + lane + 64 * q];
+      out[row * ld2 + c2 + lane + 64 * q] = make_double2(acc[q].x + own.x, acc[q].y + own.y);
+    }
+}
+
 template <int NQ2, int U>
 __global__ __launch_bounds__(256) void k_row(const long* __restrict__ indptr, const int* __restrict__ idx,
                                              const float* __restrict__ val, const double2* __restrict__ T, int ld2,
@@ -600,6 +655,24 @@ int main(int argc, char** argv) {
     unsigned long long h; (void)hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost);
     printf("      %s: %llu of %ld outputs differ from the wave-per-row result\n", what, h, n * (long)N);
   };
+  if (ld > 128) {
+    // the wave-per-row gather in column slices (one launch per slice): does a smaller L2 footprint per cluster pay?
+    for (int slices : {2, 4}) {
+      for (int chunk : {128, 512, 2048}) {
+        const long grid = ((n + 3) / 4 + 8 * chunk - 1) / (8 * chunk) * (8 * chunk);
+        const int ld2 = ld / 2, w = (ld2 + slices - 1) / slices;
+        (void)hipMemset(O2, 0, rm * 8);
+        const float ms = time_it([&] {
+          for (int sidx = 0; sidx < slices; ++sidx) {
+            const int c2 = sidx * w, w2 = (c2 + w <= ld2) ? w : ld2 - c2;
+            hipLaunchKernelGGL((k_row_slice<1, 10>), dim3((unsigned)grid), dim3(256), 0, 0, d_indptr, d_idx, d_val, (const double2*)T, ld2, c2, w2, n, (double2*)O2, chunk);
+          }
+        });
+        printf("  wave-per-row in %d column slices (xcd chunk %4d)  %8.1f us  (%.2f TB/s gathered)\n", slices, chunk, ms * 1e3, gathered / (ms * 1e-3) / 1e12);
+        if (chunk == 128) check("sliced");
+      }
+    }
+  }
 #define RUNSET(NQ2, R_, NW_, NI_)                                                  \
   for (int xc : {4, 1, 16, 32, 64, 256}) {                                         \
     a.xcd_chunk = xc;                                                              \
