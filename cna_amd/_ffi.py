@@ -81,6 +81,7 @@ SIGNATURES = {
     'cna_host_permute_rows': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     'cna_host_cluster_order': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    'cna_host_cluster_order_mt': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'cna_host_block_sources': (C.c_int64, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
     'cna_host_walk_blocks': (C.c_int64, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -235,6 +235,259 @@ done:
   return rc;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * The same order on several threads (round 3: the sequential pass was three quarters of a cold call at 2M cells).
+ *   1. the cells are split into P regions by a multi-source breadth-first search from P evenly spaced seeds: a cell
+ *      joins the region that reaches it first, the lowest-numbered one among those that reach it in the same round
+ *      (level-synchronous rounds, atomic minimum) -- connected, compact regions whatever the caller's numbering;
+ *      cells no seed reaches (other components) are dealt to the regions by index;
+ *   2. every region is ordered by the greedy cluster growth above, edges that leave the region ignored -- regions are
+ *      independent, so they run in parallel;
+ *   3. layout: the full clusters of region 0, 1, ..., then the short clusters of all regions.
+ * P depends on n only (n / 65536, at most 64; one region below 131072 cells = the sequential order): the result
+ * does not depend on the number of threads.  Returns the number of cells in full clusters, -1: out of memory. */
+struct co_shared {
+  int64_t n; const int64_t* indptr; const int32_t* indices; int B, P, nthreads;
+  int32_t* region; int32_t* cand;
+  int32_t* frontier; int64_t nfront;             /* current round */
+  int32_t** next; int64_t* nnext; int64_t* capnext;   /* per thread */
+  pthread_barrier_t bar;
+  /* phase 2 */
+  int64_t* rstart; int32_t* members;             /* cells of region p: members[rstart[p] .. rstart[p+1]) ascending */
+  int32_t* state; unsigned char* queued;
+  int64_t* out_full; int64_t* n_full; int64_t* out_short; int64_t* n_short;   /* per region, written at rstart[p] */
+  volatile int failed; volatile int64_t next_region;
+};
+struct co_job { struct co_shared* sh; int tid; };
+
+static int co_grow(struct co_shared* sh, int p) {
+  const int B = sh->B;
+  const int64_t r0 = sh->rstart[p], cnt = sh->rstart[p + 1] - r0;
+  if (cnt == 0) { sh->n_full[p] = sh->n_short[p] = 0; return 0; }
+  const int32_t* mem = sh->members + r0;
+  int32_t* state = sh->state;
+  const int32_t* region = sh->region;
+  int32_t* touched = (int32_t*)malloc(4 * (size_t)cnt);
+  int32_t* fifo = (int32_t*)malloc(4 * (size_t)cnt);
+  int32_t* cl = (int32_t*)malloc(4 * (size_t)B);
+  int32_t** level = (int32_t**)calloc((size_t)B + 2, sizeof(int32_t*));
+  int64_t* lsize = (int64_t*)calloc((size_t)B + 2, 8);
+  int64_t* lcap = (int64_t*)calloc((size_t)B + 2, 8);
+  int64_t* full = sh->out_full + r0;
+  int64_t* shorts = sh->out_short + r0;
+  int64_t n_full = 0, n_short = 0, fifo_head = 0, fifo_tail = 0, next_i = 0;
+  int rc = -1;
+  if (!touched || !fifo || !cl || !level || !lsize || !lcap) goto done;
+  for (;;) {
+    int64_t seed = -1;
+    while (fifo_head < fifo_tail) {
+      const int32_t c = fifo[fifo_head++];
+      if (state[c] >= 0) { seed = c; break; }
+    }
+    if (seed < 0) {
+      while (next_i < cnt && state[mem[next_i]] < 0) ++next_i;
+      if (next_i >= cnt) break;
+      seed = mem[next_i];
+    }
+    int m = 0, top = 0;
+    int64_t ntouched = 0;
+    int32_t cur = (int32_t)seed;
+    for (;;) {
+      if (state[cur] == 0) touched[ntouched++] = cur;
+      state[cur] = -1;
+      cl[m++] = cur;
+      if (m == B) break;
+      for (int64_t e = sh->indptr[cur]; e < sh->indptr[cur + 1]; ++e) {
+        const int32_t j = sh->indices[e];
+        if (j < 0 || j >= sh->n || region[j] != p) continue;
+        const int32_t sj = state[j];
+        if (sj < 0) continue;
+        if (sj == 0) touched[ntouched++] = j;
+        state[j] = sj + 1;
+        const int c = sj + 1 > B + 1 ? B + 1 : sj + 1;
+        if (lsize[c] == lcap[c]) {
+          lcap[c] = lcap[c] ? 2 * lcap[c] : 256;
+          int32_t* grown = (int32_t*)realloc(level[c], 4 * (size_t)lcap[c]);
+          if (!grown) goto done;
+          level[c] = grown;
+        }
+        level[c][lsize[c]++] = j;
+        if (c > top) top = c;
+      }
+      int32_t pick = -1;
+      while (top > 0) {
+        if (lsize[top] == 0) { --top; continue; }
+        const int32_t j = level[top][--lsize[top]];
+        const int32_t sj = state[j];
+        if (sj >= 0 && (sj > B + 1 ? B + 1 : sj) == top) { pick = j; break; }
+      }
+      if (pick < 0) break;
+      cur = pick;
+    }
+    for (int c = 0; c <= B + 1; ++c) lsize[c] = 0;
+    for (int64_t t = 0; t < ntouched; ++t) {
+      const int32_t j = touched[t];
+      if (state[j] >= 0) {
+        state[j] = 0;
+        if (!sh->queued[j]) { sh->queued[j] = 1; fifo[fifo_tail++] = j; }
+      }
+    }
+    if (m == B) { for (int i = 0; i < m; ++i) full[n_full + i] = cl[i]; n_full += m; }
+    else { for (int i = 0; i < m; ++i) shorts[n_short + i] = cl[i]; n_short += m; }
+  }
+  sh->n_full[p] = n_full;
+  sh->n_short[p] = n_short;
+  rc = 0;
+done:
+  if (level) for (int c = 0; c <= B + 1; ++c) free(level[c]);
+  free(level); free(lsize); free(lcap); free(touched); free(fifo); free(cl);
+  return rc;
+}
+
+static void* co_worker(void* arg) {
+  struct co_job* jb = (struct co_job*)arg;
+  struct co_shared* sh = jb->sh;
+  const int t = jb->tid, T = sh->nthreads;
+  /* ---- 1. regions: level-synchronous multi-source BFS */
+  for (;;) {
+    const int64_t nf = sh->nfront;
+    if (nf == 0) break;
+    const int64_t a = nf * t / T, b = nf * (t + 1) / T;
+    for (int64_t i = a; i < b; ++i) {                       /* candidates: the lowest region that reaches a cell */
+      const int32_t u = sh->frontier[i], ru = sh->region[u];
+      for (int64_t e = sh->indptr[u]; e < sh->indptr[u + 1]; ++e) {
+        const int32_t v = sh->indices[e];
+        if (v < 0 || v >= sh->n || __atomic_load_n(&sh->region[v], __ATOMIC_RELAXED) >= 0) continue;
+        int32_t c = __atomic_load_n(&sh->cand[v], __ATOMIC_RELAXED);
+        while (ru < c && !__atomic_compare_exchange_n(&sh->cand[v], &c, ru, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+      }
+    }
+    pthread_barrier_wait(&sh->bar);
+    sh->nnext[t] = 0;
+    for (int64_t i = a; i < b && !sh->failed; ++i) {        /* claim: exactly one thread appends a reached cell */
+      const int32_t u = sh->frontier[i];
+      for (int64_t e = sh->indptr[u]; e < sh->indptr[u + 1]; ++e) {
+        const int32_t v = sh->indices[e];
+        if (v < 0 || v >= sh->n) continue;
+        int32_t expect = -1;
+        const int32_t c = sh->cand[v];
+        if (c == 0x7fffffff) continue;
+        if (__atomic_compare_exchange_n(&sh->region[v], &expect, c, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+          if (sh->nnext[t] == sh->capnext[t]) {
+            sh->capnext[t] = sh->capnext[t] ? 2 * sh->capnext[t] : 4096;
+            int32_t* g = (int32_t*)realloc(sh->next[t], 4 * (size_t)sh->capnext[t]);
+            if (!g) { sh->failed = 1; break; }
+            sh->next[t] = g;
+          }
+          sh->next[t][sh->nnext[t]++] = v;
+        }
+      }
+    }
+    pthread_barrier_wait(&sh->bar);
+    if (t == 0) {                                           /* the next round's frontier (its order does not matter) */
+      int64_t tot = 0;
+      for (int k = 0; k < T; ++k) { memcpy(sh->frontier + tot, sh->next[k], 4 * (size_t)sh->nnext[k]); tot += sh->nnext[k]; }
+      sh->nfront = sh->failed ? 0 : tot;
+    }
+    pthread_barrier_wait(&sh->bar);
+  }
+  pthread_barrier_wait(&sh->bar);
+  if (t == 0 && !sh->failed) {                              /* leftovers by index; members of every region, ascending */
+    const int64_t n = sh->n;
+    for (int64_t i = 0; i < n; ++i) if (sh->region[i] < 0) sh->region[i] = (int32_t)(i * sh->P / n);
+    for (int p = 0; p <= sh->P; ++p) sh->rstart[p] = 0;
+    for (int64_t i = 0; i < n; ++i) sh->rstart[sh->region[i] + 1]++;
+    for (int p = 0; p < sh->P; ++p) sh->rstart[p + 1] += sh->rstart[p];
+    int64_t* cur = (int64_t*)malloc(8 * (size_t)sh->P);
+    if (!cur) sh->failed = 1;
+    else {
+      memcpy(cur, sh->rstart, 8 * (size_t)sh->P);
+      for (int64_t i = 0; i < n; ++i) sh->members[cur[sh->region[i]]++] = (int32_t)i;
+      free(cur);
+    }
+  }
+  pthread_barrier_wait(&sh->bar);
+  /* ---- 2. greedy cluster growth, region by region (largest first would balance better; regions are similar) */
+  while (!sh->failed) {
+    const int64_t p = __atomic_fetch_add(&sh->next_region, 1, __ATOMIC_RELAXED);
+    if (p >= sh->P) break;
+    if (co_grow(sh, (int)p) != 0) sh->failed = 1;
+  }
+  return NULL;
+}
+
+int64_t cna_host_cluster_order_mt(int64_t n, const int64_t* indptr, const int32_t* indices, int B, int nthreads,
+                                  int64_t* order_out) {
+  if (n <= 0) return 0;
+  int P = (int)(n / 65536);
+  if (P > 64) P = 64;
+  if (P < 2 || nthreads < 1) return cna_host_cluster_order(n, indptr, indices, B, order_out);
+  if (B < 1) B = 1;
+  if (nthreads > 64) nthreads = 64;
+  struct co_shared sh;
+  memset(&sh, 0, sizeof(sh));
+  sh.n = n; sh.indptr = indptr; sh.indices = indices; sh.B = B; sh.P = P; sh.nthreads = nthreads;
+  sh.region = (int32_t*)malloc(4 * (size_t)n);
+  sh.cand = (int32_t*)malloc(4 * (size_t)n);
+  sh.frontier = (int32_t*)malloc(4 * (size_t)n);
+  sh.next = (int32_t**)calloc((size_t)nthreads, sizeof(int32_t*));
+  sh.nnext = (int64_t*)calloc((size_t)nthreads, 8);
+  sh.capnext = (int64_t*)calloc((size_t)nthreads, 8);
+  sh.rstart = (int64_t*)calloc((size_t)P + 1, 8);
+  sh.members = (int32_t*)malloc(4 * (size_t)n);
+  sh.state = (int32_t*)calloc((size_t)n, 4);
+  sh.queued = (unsigned char*)calloc((size_t)n, 1);
+  sh.out_full = (int64_t*)malloc(8 * (size_t)n);
+  sh.out_short = (int64_t*)malloc(8 * (size_t)n);
+  sh.n_full = (int64_t*)calloc((size_t)P, 8);
+  sh.n_short = (int64_t*)calloc((size_t)P, 8);
+  int64_t rc = -1;
+  pthread_t th[64];
+  struct co_job jobs[64];
+  int started = 0, bar_ok = 0;
+  if (!sh.region || !sh.cand || !sh.frontier || !sh.next || !sh.nnext || !sh.capnext || !sh.rstart || !sh.members ||
+      !sh.state || !sh.queued || !sh.out_full || !sh.out_short || !sh.n_full || !sh.n_short) goto done;
+  for (int64_t i = 0; i < n; ++i) { sh.region[i] = -1; sh.cand[i] = 0x7fffffff; }
+  for (int p = 0; p < P; ++p) {                              /* seeds: evenly spaced indices (distinct since n >= 65536 P) */
+    const int64_t sidx = (int64_t)p * n / P;
+    sh.region[sidx] = p;
+    sh.frontier[p] = (int32_t)sidx;
+  }
+  sh.nfront = P;
+  if (pthread_barrier_init(&sh.bar, NULL, (unsigned)nthreads) != 0) goto done;
+  bar_ok = 1;
+  for (int t = 0; t < nthreads; ++t) { jobs[t].sh = &sh; jobs[t].tid = t; }
+  for (int t = 1; t < nthreads; ++t) {
+    if (pthread_create(&th[t], NULL, co_worker, &jobs[t]) != 0) {
+      /* cannot run with fewer participants than the barrier counts: give up on threads */
+      sh.failed = 1;
+      for (int k = 1; k < t; ++k) pthread_cancel(th[k]);
+      for (int k = 1; k < t; ++k) pthread_join(th[k], NULL);
+      started = 0;
+      goto done;
+    }
+    started = t;
+  }
+  co_worker(&jobs[0]);
+  for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
+  started = 0;
+  if (sh.failed) goto done;
+  {
+    int64_t pos = 0, nf = 0;
+    for (int p = 0; p < P; ++p) { memcpy(order_out + pos, sh.out_full + sh.rstart[p], 8 * (size_t)sh.n_full[p]); pos += sh.n_full[p]; }
+    nf = pos;
+    for (int p = 0; p < P; ++p) { memcpy(order_out + pos, sh.out_short + sh.rstart[p], 8 * (size_t)sh.n_short[p]); pos += sh.n_short[p]; }
+    rc = pos == n ? nf : -1;
+  }
+done:
+  if (bar_ok) pthread_barrier_destroy(&sh.bar);
+  if (sh.next) for (int t = 0; t < nthreads; ++t) free(sh.next[t]);
+  free(sh.next); free(sh.nnext); free(sh.capnext); free(sh.region); free(sh.cand); free(sh.frontier); free(sh.rstart);
+  free(sh.members); free(sh.state); free(sh.queued); free(sh.out_full); free(sh.out_short); free(sh.n_full); free(sh.n_short);
+  if (rc < 0 && !sh.failed) return cna_host_cluster_order(n, indptr, indices, B, order_out);
+  return rc;
+}
+
 /* Per block of B consecutive local rows: the distinct columns its rows reference ("sources", in order of
  * first appearance, at most `cap` per block) and, per edge, the position of its column in that list
  * (0xFFFF: the block's list was full -- the kernel fetches such a neighbour row from memory instead).

@@ -51,6 +51,39 @@ _DRAW_THREAD = os.environ.get('CNA_DRAW_THREAD', '1') not in ('0', 'off', 'no')
 _SWITCH_INTERVAL = float(os.environ.get('CNA_SWITCH_INTERVAL', '5e-5'))   # GIL hand-over between the helper thread and this one: 2.08 -> 1.86 ms per call at 200k cells (default interval: 5 ms)
 
 
+import threading as _threading
+
+_switch_lock = _threading.Lock()
+_switch_users = 0
+_switch_saved = None
+
+
+def _switch_interval_enter():
+    """The interpreter's switch interval is process-wide: calls running at the same time share one change (the
+    first sets it, the last puts the caller's value back), so that overlapping calls cannot leave it shortened."""
+    global _switch_users, _switch_saved
+    if _SWITCH_INTERVAL <= 0:
+        return
+    import sys
+    with _switch_lock:
+        if _switch_users == 0:
+            _switch_saved = sys.getswitchinterval()
+            sys.setswitchinterval(_SWITCH_INTERVAL)
+        _switch_users += 1
+
+
+def _switch_interval_exit():
+    global _switch_users, _switch_saved
+    if _SWITCH_INTERVAL <= 0:
+        return
+    import sys
+    with _switch_lock:
+        _switch_users -= 1
+        if _switch_users == 0 and _switch_saved is not None:
+            sys.setswitchinterval(_switch_saved)
+            _switch_saved = None
+
+
 class _InlineJob:
     """Future-like wrapper of a job that runs on the calling thread, at most once."""
 
@@ -286,15 +319,20 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     return coef_all, fdr_all, pcs
 
 
-def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size, sids_present=None):
-    """Input validation and the sample filter (reference _association.py:131-173): same
-    exception types, messages and printed warnings.  ``sids_present``: the distinct sample ids
-    of the cells if the caller already has them (one hash pass over the cells instead of three)."""
+def check_types(y, batches, covs, donorids):
+    """The type checks that open the reference's check_inputs (_association.py:132-139)."""
     for name, val, kind, label in (('y', y, pd.Series, 'Series'), ('batches', batches, pd.Series, 'Series'),
                                    ('covs', covs, pd.DataFrame, 'DataFrame'),
                                    ('donorids', donorids, pd.Series, 'Series')):
         if (name == 'y' or val is not None) and not isinstance(val, kind):
             raise TypeError(f"'{name}' must be a pandas {label}, but got {type(val)}")
+
+
+def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_size, sids_present=None):
+    """Input validation and the sample filter (reference _association.py:131-173): same
+    exception types, messages and printed warnings.  ``sids_present``: the distinct sample ids
+    of the cells if the caller already has them (one hash pass over the cells instead of three)."""
+    check_types(y, batches, covs, donorids)
     if sids_present is None:
         sids_present = pd.unique(data.obs[sid_name])
     if isinstance(sids_present, pd.Index) and len(sids_present) == len(y.index) and sids_present.equals(y.index):
@@ -424,21 +462,18 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
         # the outcome is collected, and if the matrix was edited in place the call starts over on a fresh
         # upload, with numpy's global RNG put back where it was.
         rng_state = np.random.get_state() if kwargs.get('seed') is None else None
-        import sys
-        interval = sys.getswitchinterval()
-        if _SWITCH_INTERVAL > 0:
-            sys.setswitchinterval(_SWITCH_INTERVAL)       # helper thread and this one hand the GIL over promptly
+        _switch_interval_enter()                          # helper thread and this one hand the GIL over promptly
         try:
             return _association_attempts(eng, rng_state, data, y, sid_name, batches, covs, donorids, ks, key_added,
                                          max_frac_pcs, nsteps, show_progress, allow_low_sample_size, return_full, ridges,
                                          kwargs)
         finally:
-            sys.setswitchinterval(interval)
+            _switch_interval_exit()
 
 
 def _association_attempts(eng, rng_state, data, y, sid_name, batches, covs, donorids, ks, key_added, max_frac_pcs, nsteps,
                           show_progress, allow_low_sample_size, return_full, ridges, kwargs):
-    if True:
+    for _once in (0,):
         for attempt in (0, 1):
             eng._defer_graph_check = attempt == 0 and hasattr(eng, 'confirm_graph')
             try:
@@ -492,6 +527,9 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     import threading
     walk_queued = threading.Event()
     nam_queued = nam_error = None
+    # (the checks that need no look at the data come first: a call with an argument of the wrong type neither starts a
+    # walk nor replaces the NAM an earlier result still reads lazily)
+    check_types(y, batches, covs, donorids)
     if not show_progress and _EARLY_WALK:
         engine._on_walk_queued = walk_queued.set
         try:

@@ -358,6 +358,11 @@ int  cna_host_copy(void* dst, const void* src, int64_t nbytes, int nthreads);
  * in full clusters, -1 when out of memory.  Only the numbering changes: every row keeps its neighbours in
  * the caller's CSR order, so no sum is reordered (_nam.py:33). */
 int64_t cna_host_cluster_order(int64_t n, const int64_t* indptr, const int32_t* indices, int B, int64_t* order_out);
+/* The same on several threads: the cells are first split into n / 65536 (<= 64) connected regions by a multi-source
+ * breadth-first search, every region is ordered as above on its own (in parallel), full clusters of all regions first.
+ * The result depends on n and the graph only, not on nthreads.  Below 131072 cells: the sequential order. */
+int64_t cna_host_cluster_order_mt(int64_t n, const int64_t* indptr, const int32_t* indices, int B, int nthreads,
+                                  int64_t* order_out);
 /* Per block of B consecutive rows: the distinct columns referenced (<= cap per block, in order of first
  * appearance) and, per edge, its column's position in the block's list (0xFFFF: not listed).  src_ptr
  * int64[nblocks+1], src int32[>= nnz], slot uint16[nnz].  Returns the total length of the lists or -1. */
