@@ -39,6 +39,7 @@ SIGNATURES = {
     'cna_set_samples': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p]),
     'cna_restart_nam': (C.c_int, [c_ctx]),
     'cna_nam_step': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int]),
+    'cna_nam_select_hint': (C.c_int, [c_ctx, C.c_void_p, C.c_int]),
     'cna_nam_auto': (C.c_int, [c_ctx, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     'cna_nam_auto_launch': (C.c_int, [c_ctx, C.c_int]),
     'cna_nam_auto_finish': (C.c_int, [c_ctx, C.POINTER(C.c_int), C.c_void_p]),

@@ -215,6 +215,7 @@ int cna_ctx_create(int device, cna_ctx** out) {
 
 int cna_ctx_destroy(cna_ctx* c) {
   if (c && c->auto_state) { (void)hipFree(c->auto_state); c->auto_state = nullptr; }
+  if (c && c->byp_buf) { (void)hipFree(c->byp_buf); c->byp_buf = nullptr; }
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
@@ -300,11 +301,11 @@ int cna_graph_upload(cna_ctx* c, int64_t n_global, int64_t row0, int64_t n_local
   c->have_colsum = false;
   c->cellinfo_valid = false;
   c->t_valid = false;
-  c->nam_valid = false;
+  c->nam_valid = false; c->nam_lazy = false;
   c->x_valid = false;
-  c->xq_valid = false;
+  c->xq_valid = false; c->byp_valid = false;
   c->ncorrs_valid = false;
-  c->xq_valid = false;
+  c->xq_valid = false; c->byp_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   c->steps_done = 0;
@@ -449,9 +450,9 @@ int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const doubl
   c->t_cur = 0;
   c->steps_done = 0;
   c->t_valid = false;
-  c->nam_valid = false;
+  c->nam_valid = false; c->nam_lazy = false;
   c->x_valid = false;
-  c->xq_valid = false;
+  c->xq_valid = false; c->byp_valid = false;
   CNA_TRY(ensure_sparse_state(c));
   return 0;
 }
@@ -467,9 +468,9 @@ int cna_restart_nam(cna_ctx* c) {
   c->t_cur = 0;
   c->steps_done = 0;
   c->t_valid = false;
-  c->nam_valid = false;
+  c->nam_valid = false; c->nam_lazy = false;
   c->x_valid = false;
-  c->xq_valid = false;
+  c->xq_valid = false; c->byp_valid = false;
   return 0;
 }
 
@@ -537,19 +538,99 @@ static int exchange_stat(cna_ctx* c) {
   return comm_allgather_bytes(c, (char*)c->stat + block * c->rank, c->stat, block);
 }
 
+// y: the standardised phenotype the analysis will pass to cna_select_standardized[_fused] (n = number of samples);
+// the next walk step that is the last of its walk then also leaves that call's results (see common.h: byp_*).
+// y = NULL clears.  A hint, never a promise: a selection call that asks for anything else runs its own pass.
+int cna_nam_select_hint(cna_ctx* c, const double* y, int n) {
+  CHECK_CTX(c);
+  c->byp_hint.clear();
+  if (!y || n < 2 || n > 1024) return 0;
+  if (!c->byp_buf) HIP_TRY(hipMalloc(&c->byp_buf, 16 + 8 * 1024));
+  // on the copy stream: the main stream is busy with the first steps of the walk and this call must not wait for them
+  // (the kernel that reads y is launched after this call has returned)
+  HIP_TRY(hipMemcpyAsync((char*)c->byp_buf + 16, y, 8 * (size_t)n, hipMemcpyHostToDevice, c->copy_stream));
+  HIP_TRY(hipStreamSynchronize(c->copy_stream));
+  c->byp_hint.assign(y, y + n);
+  return 0;
+}
+
+static int x_ld(int Nx);
+// The NAM on the device, for whoever reads it.  A last step that left the selection pass's results instead (see
+// cna_nam_select_hint) is run once more, now for the NAM: its input state is still in T[t_cur] (a step that ends a walk
+// writes no state), so are the pairs of a two-step walk; same kernel, same inputs, same bits as a first run would give.
+static int need_nam(cna_ctx* c) {
+  if (!c->nam_valid && c->nam_lazy) {
+    const int done = c->steps_done;
+    c->steps_done = c->lazy_steps_before;                 // launch_nam_step picks the compressed second step by it
+    const int rc = launch_nam_step(c, false, false, false, true, false);
+    c->steps_done = done;
+    CNA_TRY(rc);
+    c->nam_valid = true;
+    c->nam_lazy = false;
+  }
+  if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+  return 0;
+}
+// 1: the launch that follows is to produce the by-product (buffers sized, y and counters on the device); 0: no
+static int arm_select_byproduct(cna_ctx* c) {
+  const char* sw = getenv("CNA_WALK_SELECT");              // A/B switch, read at every walk (tests flip it)
+  const bool off = sw && atoi(sw) == 0;
+  std::vector<double> y;
+  y.swap(c->byp_hint);                                  // one-shot
+  if (off || (int)y.size() != c->N || c->t_ld != c->ld || c->t_ld <= 64 || c->N < 2 || c->n_local < 1) return 0;
+  const int64_t nx = c->n_local;
+  const int Nx = c->N;
+  void* xp = c->X;
+  if (dev_reserve(c, &xp, &c->x_cap, (int64_t)sizeof(double) * nx * x_ld(Nx))) return 0;
+  c->X = (double*)xp;
+  void* np = c->ncorrs;
+  if (dev_reserve(c, &np, &c->ncorrs_cap, 8 * nx)) return 0;
+  c->ncorrs = (double*)np;
+  c->nx = nx;
+  c->Nx = Nx;
+  c->ldx = x_ld(Nx);
+  c->keep_idx = nullptr;
+  c->x_valid = false;
+  c->ncorrs_valid = false;
+  c->xq_valid = false;
+  c->coef_early = false;
+  c->fdr_inline = false;
+  c->byp_with_q = Nx <= 256 && null_i8_enabled();
+  if (c->byp_with_q && ensure_xq(c, (Nx + 31) / 32)) return 0;
+  if (!c->byp_buf) return 0;
+  c->byp_y.swap(y);
+  if (hipMemsetAsync(c->byp_buf, 0, 16, c->stream) != hipSuccess) return 0;
+  return 1;
+}
+
 int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
   CHECK_CTX(c);
   if (!c->sid || !c->have_colsum) CNA_FAIL(CNA_ESTATE, "cna_nam_step needs cna_colsums and cna_set_samples");
   if (c->t_ld != c->ld) CNA_FAIL(CNA_ESTATE, "state buffers hold a dense diffusion; call cna_set_samples again");
   const bool first = c->steps_done == 0;
   if (!first && !c->t_valid) CNA_FAIL(CNA_ESTATE, "previous step did not keep its state (may_continue=0)");
-  CNA_TRY(launch_nam_step(c, first, want_kurt != 0, may_continue != 0, may_stop != 0, false));
+  c->byp_valid = false;
+  c->nam_lazy = false;
+  const bool arm = !first && !may_continue && may_stop && !c->auto_stop && arm_select_byproduct(c) == 1;
+  // ... and then the NAM itself is not written: the analysis reads X, and whoever does ask for the NAM (res.nam, a later
+  // call with other covariates) gets it from a second run of this step (need_nam), whose input state stays where it is
+  const char* keep = getenv("CNA_WALK_SELECT_KEEP_NAM");
+  const bool skip_nam = arm && !(keep && atoi(keep) != 0);
+  c->byp_arm = arm;
+  c->byp_skip_nam = skip_nam;
+  const int rc_step = launch_nam_step(c, first, want_kurt != 0, may_continue != 0, may_stop != 0, false);
+  c->byp_arm = false;
+  c->byp_skip_nam = false;
+  CNA_TRY(rc_step);
+  c->byp_valid = arm;
+  c->lazy_steps_before = c->steps_done;
   if (may_continue) {
     CNA_TRY(exchange_state(c, c->T[c->t_cur ^ 1]));
     c->t_cur ^= 1;
   }
   c->t_valid = may_continue != 0;
-  c->nam_valid = may_stop != 0;
+  c->nam_valid = may_stop != 0 && !skip_nam;
+  c->nam_lazy = skip_nam;
   c->steps_done += 1;
   if (want_kurt) {
     c->stat_space = CNA_MAT_NAM;
@@ -797,7 +878,7 @@ int cna_dense_load(cna_ctx* c, const double* s_local, int m) {
   CNA_TRY(exchange_state(c, c->T[0]));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->t_valid = true;
-  c->nam_valid = false;
+  c->nam_valid = false; c->nam_lazy = false;
   c->steps_done = 1;  // never take the one-hot path
   return 0;
 }
@@ -830,7 +911,7 @@ int cna_batch_kurtosis(cna_ctx* c, int which, const int32_t* batch_codes, int n_
   int ncols, ld;
   double* out;
   if (which == CNA_MAT_NAM) {
-    if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+    CNA_TRY(need_nam(c));
     mat = c->nam; rows = c->n_local; ncols = c->N; ld = c->ld; out = c->stat + c->row0;
   } else if (which == CNA_MAT_X) {
     if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
@@ -864,7 +945,7 @@ int cna_batch_kurtosis(cna_ctx* c, int which, const int32_t* batch_codes, int n_
 int cna_zero_variance(cna_ctx* c, const int32_t* colmap, int n_sel, uint8_t* flags_out, int64_t* n_zero_out) {
   CHECK_CTX(c);
   AUTO_FINISH(c);
-  if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+  CNA_TRY(need_nam(c));
   if (!colmap) n_sel = c->N;
   if (n_sel < 1) CNA_FAIL(CNA_EINVAL, "no samples selected");
   CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({4 * (int64_t)n_sel, c->n_pad, 8})));
@@ -911,7 +992,7 @@ static int x_ld(int Nx) {
 int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel) {
   CHECK_CTX(c);
   AUTO_FINISH(c);
-  if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+  CNA_TRY(need_nam(c));
   const int64_t nx = keep_idx ? n_keep : c->n_local;
   const int Nx = colmap ? n_sel : c->N;
   if (nx < 0 || nx > c->n_local || Nx < 1) CNA_FAIL(CNA_EINVAL, "cna_select: bad sizes");
@@ -939,7 +1020,7 @@ int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_
   c->x_valid = true;
   c->x_from_nam = true;
   c->ncorrs_valid = false;
-  c->xq_valid = false;
+  c->xq_valid = false; c->byp_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -975,7 +1056,7 @@ int cna_select_checked(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, cons
                        int64_t* n_zero_out) {
   CHECK_CTX(c);
   AUTO_FINISH(c);
-  if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+  CNA_TRY(need_nam(c));
   const int64_t nx = keep_idx ? n_keep : c->n_local;
   const int Nx = colmap ? n_sel : c->N;
   if (nx < 0 || nx > c->n_local || Nx < 1) CNA_FAIL(CNA_EINVAL, "cna_select_checked: bad sizes");
@@ -1008,7 +1089,7 @@ int cna_select_checked(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, cons
   c->x_valid = true;
   c->x_from_nam = true;
   c->ncorrs_valid = false;
-  c->xq_valid = false;
+  c->xq_valid = false; c->byp_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1031,7 +1112,9 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
   CHECK_CTX(c);
   AUTO_FINISH(c);
   if (gram_too) *gram_too = false;
-  if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+  if (!c->nam_valid && !c->nam_lazy) CNA_FAIL(CNA_ESTATE, "NAM not available");
+  const bool byp_was = c->byp_valid;
+  c->byp_valid = false;
   const int64_t nx = keep_idx ? n_keep : c->n_local;
   const int Nx = colmap ? n_sel : c->N;
   if (nx < 0 || nx > c->n_local || Nx < 2) CNA_FAIL(CNA_EINVAL, "cna_select_standardized: bad sizes");
@@ -1065,14 +1148,24 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
   }
   const int rk = (c->resid_rk > 0 && c->resid_n == Nx) ? c->resid_rk : 0;     // one-shot: cna_set_resid_factors
   // the rows leave this pass final: their fixed-point digit planes for the integer local null go out with them
-  c->xq_valid = false;
+  c->xq_valid = false; c->byp_valid = false;
   const bool with_q = y != nullptr && Nx <= 256 && nx > 0 && null_i8_enabled();
   const int KSq = (Nx + 31) / 32;
   if (with_q) CNA_TRY(ensure_xq(c, KSq));
   bool in_place = colmap == nullptr || n_sel == c->N;
   for (int i = 0; colmap && in_place && i < n_sel; ++i) in_place = colmap[i] == i;
-  const bool fused = gram_too && y && !keep_idx && in_place && rk == 0 && gram_fused_ok(c, Nx, c->ldx, 32 * KSq);
-  if (fused) {
+  // the walk's last step may have done this pass already (cna_nam_select_hint): same cells, samples in place, nothing
+  // regressed out, the same phenotype bit for bit -- then X, planes, coefficients and the two counters are there
+  const bool byp = byp_was && y && !keep_idx && in_place && rk == 0 && Nx == c->N && nx == c->n_local &&
+                   with_q == c->byp_with_q && (int)c->byp_y.size() == Nx && std::memcmp(y, c->byp_y.data(), 8 * (size_t)Nx) == 0;
+  if (byp) {
+    nz = (unsigned long long*)c->byp_buf;
+    mb = nz + 1;
+  }
+  if (!byp) CNA_TRY(need_nam(c));           // (a last step that left X instead of the NAM is run again for the NAM)
+  const bool fused = !byp && gram_too && y && !keep_idx && in_place && rk == 0 && gram_fused_ok(c, Nx, c->ldx, 32 * KSq);
+  if (byp) {
+  } else if (fused) {
     void* g = c->gram_buf;
     CNA_TRY(dev_reserve(c, &g, &c->gram_cap, (int64_t)sizeof(double) * Nx * Nx));
     c->gram_buf = (double*)g;
@@ -1189,7 +1282,7 @@ int cna_upload_x(cna_ctx* c, const double* x_local, int64_t n_rows, int n_cols) 
   c->x_valid = true;
   c->x_from_nam = false;
   c->ncorrs_valid = false;
-  c->xq_valid = false;
+  c->xq_valid = false; c->byp_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1209,7 +1302,7 @@ int cna_resid_apply(cna_ctx* c, const double* M, int center) {
   CNA_TRY(launch_xb(c, (const double*)c->scratch, ldb, Nx, center != 0, c->X, ldx));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->ncorrs_valid = false;
-  c->xq_valid = false;
+  c->xq_valid = false; c->byp_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1252,7 +1345,7 @@ int cna_resid_lowrank(cna_ctx* c, const double* C, const double* W, int r, int c
   HIP_TRY(hipStreamSynchronize(c->stream));        // Ct is a local
   if (max_abs_out) *max_abs_out = m;
   c->ncorrs_valid = y != nullptr;
-  c->xq_valid = false;
+  c->xq_valid = false; c->byp_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1319,7 +1412,7 @@ int cna_resid_lowrank_bk(cna_ctx* c, const double* C, const double* W, int r, co
   if (max_abs_out) *max_abs_out = m;
   *median_out = med;
   c->ncorrs_valid = true;
-  c->xq_valid = false;
+  c->xq_valid = false; c->byp_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1330,7 +1423,7 @@ int cna_standardize(cna_ctx* c, int center) {
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
   CNA_TRY(launch_standardize(c, center));
   c->ncorrs_valid = false;
-  c->xq_valid = false;
+  c->xq_valid = false; c->byp_valid = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -2014,7 +2107,7 @@ int cna_matrix_shape(cna_ctx* c, int which, int64_t* n_rows_local, int* n_cols) 
   if (!c) CNA_FAIL(CNA_EINVAL, "null context");
   if (which == CNA_MAT_NAM) AUTO_FINISH(c);
   if (which == CNA_MAT_NAM) {
-    if (!c->nam_valid) CNA_FAIL(CNA_ESTATE, "NAM not available");
+    CNA_TRY(need_nam(c));
     *n_rows_local = c->n_local; *n_cols = c->N;
   } else if (which == CNA_MAT_X) {
     if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");

@@ -121,6 +121,20 @@ struct cna_ctx {
   int64_t* keep_store = nullptr;  // allocation behind keep_idx
   int64_t keep_cap = 0;
   bool x_valid = false, x_from_nam = false;
+  // The selection pass as a by-product of the walk's last step (cna_nam_select_hint): when the caller says which
+  // standardised phenotype the analysis will use and nothing will be filtered or regressed out, the last step's
+  // write-out also leaves X = centred / standardised NAM, its digit planes, the coefficients X.y/N and the
+  // zero-variance count -- what cna_select_standardized(all cells, samples in place, y) would produce from the NAM
+  // it has just written -- and that call then finds its work done (the 1.5 ms pass at 2M x 200 leaves the path).
+  std::vector<double> byp_hint;    // y of a pending hint (consumed by the next last step)
+  std::vector<double> byp_y;       // y the by-product on the device was made for
+  bool byp_valid = false;          // X / planes / coefficients on the device are that by-product
+  bool byp_with_q = false;
+  bool byp_skip_nam = false;       // ... and it does not write the NAM (nam_lazy afterwards)
+  bool nam_lazy = false;           // the NAM is one more run of the last step away (c_api.hip:need_nam)
+  int lazy_steps_before = 0;       // steps_done when that step was launched
+  bool byp_arm = false;            // the launch being issued is that last step (launch_nam_step reads it)
+  void* byp_buf = nullptr;         // device: [0] zero-variance rows, [1] max |coef| bits, then y (1024 doubles)
 
   // ---- per-cell vectors
   double* stat = nullptr;  // n_pad

@@ -14,6 +14,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 
 // The walk's products and sums are meant to round like scipy's csr_matvecs (a multiply, then an add).
 // hipcc contracts a*b+c into an fma by default -- also through __dmul_rn / __dadd_rn, which are plain
@@ -23,6 +24,26 @@
 #pragma clang fp contract(off)
 __device__ __forceinline__ double mul_rn(double a, double b) { return a * b; }
 __device__ __forceinline__ double add_rn(double a, double b) { return a + b; }
+
+// Stores of the write-out, by cache policy (StepArgs::store_mode; experiments): 0 plain, 1 sc1 (written through, the
+// line is not kept in this XCD's L2 -- nothing in the launch reads it again), 2 nt
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_f64(double* p, double v, int mode) {
+  if (mode == 1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else if (mode == 2) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+__device__ __forceinline__ void st_f64x2(double* p, double a, double b, int mode) {
+  d2v v = {a, b};
+  if (mode == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else if (mode == 2) __builtin_nontemporal_store(v, (d2v*)p);
+  else *(d2v*)p = v;
+}
+__device__ __forceinline__ void st_u32(unsigned* p, unsigned v, int mode) {
+  if (mode == 1) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+  else if (mode == 2) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
 
 namespace {
 
@@ -56,6 +77,15 @@ struct StepArgs {
   // word non-zero and return at once; null = unconditional step
   const int* stop;
   int sp_keep_dense;        // sharded: the first step writes the dense row of every cell besides its pairs (halo exchange)
+  // the selection pass as a by-product of the last step (select_tail below); sel_X == null: not wanted
+  double* sel_X;
+  const double* sel_y;
+  double* sel_nc;
+  unsigned char* sel_xq;    // digit planes of X for the integer local null; null: none
+  double2* sel_xscale;
+  unsigned long long* sel_nz;   // [0] rows of zero variance, [1] bits of max |coefficient| (NaN pattern if any is NaN)
+  int sel_ldx, sel_Kp;
+  int store_mode;           // cache policy of the write-out stores (st_f64); bit 2: the NAM itself is not stored
 };
 #define STEP_STOPPED(a) ((a).stop != nullptr && __builtin_nontemporal_load((a).stop) != 0)
 // One 16-byte record per non-zero: the second step then fetches an edge's whole neighbour row with ONE
@@ -95,6 +125,92 @@ struct ColPair {      // double2 per lane: cols 2*(lane + 64*(k/2)) + (k&1)
   __device__ static int col(int lane, int k) { return 2 * (lane + 64 * (k >> 1)) + (k & 1); }
 };
 
+// What rows.hip:k_select_std16 makes of a NAM row when every cell and every sample stays and nothing is regressed out
+// (_association.py:182 zero-variance count, _nam.py:122 centring, :159 division by the std with ddof = 1,
+// _association.py:77 coefficient X.y/N, the 24-bit digit planes of null_i8.hip), done by the wave that has just
+// formed the row: x[] holds s/C in the ColPair layout (lane l: columns 2l, 2l+1, 128+2l, ...).  Same statements as
+// that kernel; its sums run over 16 lanes x 4 columns, these over 64 lanes x 2, so the results agree to rounding.
+template <int NV>
+__device__ __forceinline__ void select_tail(const StepArgs& a, int64_t row, int lane, double (&x)[NV]) {
+  const double n = (double)a.width;
+  double sum = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) sum += x[k];
+  const double avg0 = wave_sum(sum) / n;
+  bool flat = true;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (ColPair::col(lane, k) < a.width) flat = flat && (avg0 - x[k] == 0.0);
+  if (__all(flat) && lane == 0) atomicAdd(a.sel_nz, 1ull);
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (ColPair::col(lane, k) < a.width) x[k] -= avg0;
+  double s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) s2 += x[k];
+  const double avg = wave_sum(s2) / n;
+  double ss = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (ColPair::col(lane, k) < a.width) {
+      const double d = avg - x[k];
+      ss += d * d;
+    }
+  }
+  const double sd = sqrt(wave_sum(ss) / (n - 1.0));
+  double dot = 0.0, amax = 0.0;
+  double* __restrict__ dst = a.sel_X + row * a.sel_ldx;
+#pragma unroll
+  for (int k = 0; k < NV; k += 2) {
+    const int c0 = ColPair::col(lane, k);
+    const double x0 = c0 < a.width ? __ddiv_rn(x[k], sd) : 0.0;
+    const double x1 = c0 + 1 < a.width ? __ddiv_rn(x[k + 1], sd) : 0.0;
+    x[k] = x0;
+    x[k + 1] = x1;
+    if (c0 < a.width) dot += a.sel_y[c0] * x0;
+    if (c0 + 1 < a.width) dot += a.sel_y[c0 + 1] * x1;
+    amax = fmax(amax, fmax(fabs(x0), fabs(x1)));          // NaN rows (zero variance): fmax drops them, q = 0 below
+    if (c0 + 1 < a.sel_ldx) st_f64x2(dst + c0, x0, x1, a.store_mode & 3);
+  }
+  if (a.sel_xq) {
+    const double rmax = wave_max_d(amax);
+    const double inv = rmax > 0.0 ? I8_QMAX / rmax : 0.0;
+    unsigned char* rq = a.sel_xq + (size_t)row * 3 * a.sel_Kp;
+#pragma unroll
+    for (int k = 0; k < NV; k += 2) {
+      unsigned h0 = 0, h1 = 0, h2 = 0;                      // this lane's two bytes of each plane
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const double v = x[k + j] * inv;
+        const int qi = v == v ? (int)rint(v) : 0;
+        const int q1 = (qi + 128) >> 8;
+        h0 |= ((unsigned)qi & 255u) << (8 * j);
+        h1 |= ((unsigned)q1 & 255u) << (8 * j);
+        h2 |= ((unsigned)((q1 + 128) >> 8) & 255u) << (8 * j);
+      }
+      // even lanes store dwords: their own half and the odd neighbour's
+      const unsigned p01 = h0 | (h1 << 16);
+      const unsigned o01 = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (lane + 1), (int)p01);
+      const unsigned o2 = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (lane + 1), (int)h2);
+      const int c0 = ColPair::col(lane, k);
+      if ((lane & 1) == 0 && c0 < a.sel_Kp) {
+        st_u32((unsigned*)(rq + c0), (p01 & 0xffffu) | (o01 << 16), a.store_mode & 3);
+        st_u32((unsigned*)(rq + a.sel_Kp + c0), (p01 >> 16) | (o01 & 0xffff0000u), a.store_mode & 3);
+        st_u32((unsigned*)(rq + 2 * a.sel_Kp + c0), (h2 & 0xffffu) | (o2 << 16), a.store_mode & 3);
+      }
+    }
+    const double l1 = rmax > 0.0 ? n * (I8_QMAX / rmax) + n : 0.0;
+    if (lane == 0) a.sel_xscale[row] = make_double2(rmax, l1);
+  }
+  const double v = wave_sum(dot) / n;
+  if (lane == 0) {
+    a.sel_nc[row] = v;
+    const unsigned long long bits = v != v ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(fabs(v));
+    // the maximum over all rows: most waves find the word already above their value and skip the atomic
+    if (bits > __builtin_nontemporal_load(a.sel_nz + 1)) atomicMax(a.sel_nz + 1, bits);
+  }
+}
+
 template <int NV, typename CM>
 __device__ __forceinline__ void finish_row(const StepArgs& a, int64_t row, int64_t grow, int lane,
                                            const double (&s)[NV]) {
@@ -104,7 +220,7 @@ __device__ __forceinline__ void finish_row(const StepArgs& a, int64_t row, int64
     const int col = CM::col(lane, k);
     if (col < a.ld) {
       const bool in = col < a.width;
-      if (a.write_t) a.Tout[grow * a.ld + col] = in ? __ddiv_rn(s[k], cs) : 0.0;
+      if (a.write_t) st_f64(&a.Tout[grow * a.ld + col], in ? __ddiv_rn(s[k], cs) : 0.0, a.store_mode & 3);
       if (a.dense_out) a.dense_out[row * a.ld + col] = in ? s[k] : 0.0;
     }
   }
@@ -116,7 +232,7 @@ __device__ __forceinline__ void finish_row(const StepArgs& a, int64_t row, int64
       const int col = CM::col(lane, k);
       const bool in = col < a.width;
       x[k] = in ? __ddiv_rn(s[k], a.counts[col]) : 0.0;     // s / C   (_nam.py:59,73)
-      if (a.write_nam && col < a.ld) a.nam[row * a.ld + col] = x[k];
+      if (a.write_nam && col < a.ld && !(a.store_mode & 4)) st_f64(&a.nam[row * a.ld + col], x[k], a.store_mode & 3);
       sum += x[k];
     }
     if (a.want_kurt) {
@@ -138,6 +254,9 @@ __device__ __forceinline__ void finish_row(const StepArgs& a, int64_t row, int64
       const double em = 2.220446049250313e-16 * mean;
       const double k4 = (m2 <= em * em) ? __builtin_nan("") : m4 / (m2 * m2);
       if (lane == 0) a.stat[grow] = k4 - 3.0;
+    }
+    if constexpr (std::is_same<CM, ColPair>::value) {
+      if (a.sel_X) select_tail<NV>(a, row, lane, x);
     }
   }
 }
@@ -959,6 +1078,28 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
   const bool sp = c->sp_cnt && !dense && (first || c->steps_done == 1);
   a.sp_pair = sp ? (SpPair*)c->sp_pair : nullptr;
   a.sp_cnt = sp ? (unsigned char*)c->sp_cnt : nullptr;
+  a.sel_X = nullptr;
+  a.sel_y = nullptr;
+  a.sel_nc = nullptr;
+  a.sel_xq = nullptr;
+  a.sel_xscale = nullptr;
+  a.sel_nz = nullptr;
+  a.sel_ldx = a.sel_Kp = 0;
+  a.store_mode = 0;
+  if (const char* e = getenv("CNA_STEP_STORE")) a.store_mode = atoi(e) & 3;      // experiments
+  if (c->byp_arm && c->byp_skip_nam) a.store_mode |= 4;
+  if (c->byp_arm) {            // c_api.hip:arm_select_byproduct has sized X / planes / coefficients for this launch
+    a.sel_X = c->X;
+    a.sel_ldx = c->ldx;
+    a.sel_nz = (unsigned long long*)c->byp_buf;
+    a.sel_y = (const double*)((const char*)c->byp_buf + 16);
+    a.sel_nc = c->ncorrs;
+    if (c->byp_with_q) {
+      a.sel_xq = (unsigned char*)c->xq;
+      a.sel_xscale = (double2*)c->xq_scale;
+      a.sel_Kp = 32 * ((c->N + 31) / 32);
+    }
+  }
   return c->data_f64 ? launch_step_q<double>(c, first, a) : launch_step_q<float>(c, first, a);
 }
 

@@ -294,6 +294,12 @@ class Engine(_order.CellOrder):
         """nsteps walk steps in one call (fixed step count, nothing for the host to decide in between)."""
         check(self.lib.cna_nam_steps(self.h, int(nsteps)), 'cna_nam_steps')
 
+    def nam_select_hint(self, y_std):
+        """Tell the walk in progress which standardised phenotype select_standardized() will be called with (all
+        cells, samples in place, nothing regressed out): its last step then does that pass on its way out."""
+        yv = None if y_std is None else _f64(y_std)
+        check(self.lib.cna_nam_select_hint(self.h, ptr(yv), 0 if yv is None else len(yv)), 'cna_nam_select_hint')
+
     def nam_auto(self, maxnsteps=15):
         """The walk with the reference's stop rule (nsteps=None, _nam.py:64-68) in one call, medians and rule on
         the device; returns (steps taken, median kurtosis after every step)."""

@@ -530,11 +530,25 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     # (the checks that need no look at the data come first: a call with an argument of the wrong type neither starts a
     # walk nor replaces the NAM an earlier result still reads lazily)
     check_types(y, batches, covs, donorids)
+    def select_hint(labels_):
+        # What select_standardized() will be asked for if validation finds nothing to filter: every sample present,
+        # phenotype complete, no covariates or batches.  Same arithmetic as y_std below on the same values, so the
+        # library recognises the phenotype bit for bit; anything else and the selection runs its own pass.
+        if covs is not None or batches is not None or not isinstance(y, pd.Series) or len(y) != len(labels_):
+            return None
+        yv_ = y.values
+        if yv_.dtype.kind != 'f' or not (counts > 0).all() or np.isnan(yv_).any():
+            return None
+        if not (y.index is labels_ or y.index.equals(labels_)):
+            return None
+        with np.errstate(all='ignore'):
+            return (yv_ - yv_.mean()) / yv_.std()
     if not show_progress and _EARLY_WALK:
         engine._on_walk_queued = walk_queued.set
         try:
             nam_queued = _nam_device(engine, data, sid_name, nsteps=nsteps, show_progress=False,
-                                     codes_labels=(codes, labels, counts, token))
+                                     codes_labels=(codes, labels, counts, token),
+                                     select_hint=select_hint if kwargs.get('local_test', True) else None)
         except Exception as exc:             # noqa: BLE001 - re-raised below, after validation
             nam_error = exc
         finally:

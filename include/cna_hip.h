@@ -126,6 +126,14 @@ int  cna_nam_step(cna_ctx* ctx, int want_kurt, int may_continue, int may_stop);
 /* nsteps steps with a fixed step count and no per-step host decision (nsteps given, no progress
  * output): cna_nam_step(0, more, last) x nsteps in one call */
 int  cna_nam_steps(cna_ctx* ctx, int nsteps);
+/* A hint for the walk in progress: y[0..n_samples) is the standardised phenotype that the analysis will hand to
+ * cna_select_standardized[_fused] with every cell and every sample kept and nothing to regress out
+ * (_association.py:182,77; _nam.py:122,159).  The next cna_nam_step that ends its walk (may_continue = 0) then leaves,
+ * besides the NAM, what that call computes from it -- X, its digit planes, the coefficients X.y/N, the zero-variance
+ * count -- and the call finds its pass done (its results agree with the separate pass to rounding: the row sums run
+ * over the lanes in another order).  Wide sample axes only (more than 64 samples); y = NULL clears; a selection call
+ * that asks for anything else simply runs its own pass from the NAM. */
+int  cna_nam_select_hint(cna_ctx* ctx, const double* y, int n_samples);
 /* per-cell statistic of the last kernel that produced one (kurtosis / batch kurtosis),
  * gathered over ranks: out has n_global entries (CNA_MAT_NAM rows) or n_x_total (CNA_MAT_X) */
 /* The whole walk of _nam.py:57-70 with nsteps=None in one call: steps are taken until the median over the cells of
