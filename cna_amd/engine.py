@@ -395,6 +395,9 @@ class Engine(_order.CellOrder):
         check(self.lib.cna_set_resid_factors(self.h, ptr(Cmat), ptr(W), int(Cmat.shape[1]), int(Cmat.shape[0])),
               'cna_set_resid_factors')
 
+    def clear_resid_factors(self):
+        check(self.lib.cna_set_resid_factors(self.h, None, None, 0, max(int(self.N), 1)), 'cna_set_resid_factors')
+
     def select_checked(self, keep_global, colmap):
         """select() and, in the same pass, the number of selected cells with zero variance over the
         selected samples (non-zero: redo with zero_variance() + select())."""

@@ -110,6 +110,10 @@ _TRACE = None      # list of (label, perf_counter) when tools/host_trace.py swit
 
 
 _COEF_FIRST_CELLS = int(os.environ.get('CNA_COEF_FIRST_CELLS', '500000'))
+# From this many cells on (and three or more steps) the walk's last step is queued after validation and planning, which
+# run under the first steps; it then knows what the selection pass will be asked for and does it on its way out
+# (compute_nam_and_reindex).  Below, the first steps are too short to hide the host work.
+_DEFER_LAST_CELLS = int(os.environ.get('CNA_DEFER_LAST_CELLS', '300000'))
 
 
 def _host_copy(dst, src):
@@ -391,8 +395,10 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     out = select_output(show_progress)
     nam_kwargs = {k: v for k, v in kwargs.items() if k in ('self_weight',)}
     print('computing NAM', file=out)
+    finish_walk = None
     if nam_queued is not None:
-        labels, _ = nam_queued
+        labels = nam_queued[0]
+        finish_walk = nam_queued[2] if len(nam_queued) > 2 else None        # the last step is still to be queued
     else:
         labels, _ = _nam_device(engine, data, sid_name, nsteps=nsteps, show_progress=show_progress,
                                 codes_labels=codes_labels, **nam_kwargs)
@@ -412,13 +418,26 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     # the host-only planning (projector, one-hot batches: pandas work) first: it needs nothing from the device and
     # runs while the walk does; the QC below waits for the walk (its batch-kurtosis pass and one read-back)
     extra = overlap(sample_index, batches, covs, donorids, filter_samples) if overlap is not None else None
-    kept = _qc_device(engine, labels, batches_qc, show_progress=show_progress)
-
     plan = extra if hasattr(extra, 'kind') else None
-    nzero = -1
     from ._nam import _lowrank_ok
     single = (plan is not None and plan.kind == 'single' and hasattr(engine, 'set_resid_factors') and _lowrank_ok(engine, plan)
               and os.environ.get('CNA_RESID_IN_SELECT', '1') not in ('0', 'off', 'no'))
+    if finish_walk is not None:
+        # The walk's last step is queued here, with the selection pass's arguments when they are "every cell, the
+        # samples in place, nothing to regress out" -- what the call below then asks for: that step leaves X, its
+        # coefficients and the zero-variance count itself (diffuse.hip:select_tail).  (With covariates the projector
+        # would ride along in factored form: measured at 2M x 200 with five of them, 10.4 ms against 7.7 + 2.4 for the
+        # two kernels -- the factors through LDS, the projections' wave sums overlapped -- so that case keeps its pass.)
+        hint = None
+        if (plan is not None and plan.kind == 'identity' and y_std is not None and len(y_std) == len(colmap)
+                and len(colmap) == len(labels) and np.array_equal(colmap, np.arange(len(colmap)))
+                and len(np.unique(batches_qc)) == 1):
+            engine.clear_resid_factors()
+            hint = y_std
+        finish_walk(hint)
+    kept = _qc_device(engine, labels, batches_qc, show_progress=show_progress)
+
+    nzero = -1
     if plan is not None and (plan.kind == 'identity' or single):
         # nothing to regress out, or a projector that the selection pass applies in factored form
         # (covariates without batches): select + centre [+ M] + /std in one pass over the NAM
@@ -530,25 +549,13 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     # (the checks that need no look at the data come first: a call with an argument of the wrong type neither starts a
     # walk nor replaces the NAM an earlier result still reads lazily)
     check_types(y, batches, covs, donorids)
-    def select_hint(labels_):
-        # What select_standardized() will be asked for if validation finds nothing to filter: every sample present,
-        # phenotype complete, no covariates or batches.  Same arithmetic as y_std below on the same values, so the
-        # library recognises the phenotype bit for bit; anything else and the selection runs its own pass.
-        if covs is not None or batches is not None or not isinstance(y, pd.Series) or len(y) != len(labels_):
-            return None
-        yv_ = y.values
-        if yv_.dtype.kind != 'f' or not (counts > 0).all() or np.isnan(yv_).any():
-            return None
-        if not (y.index is labels_ or y.index.equals(labels_)):
-            return None
-        with np.errstate(all='ignore'):
-            return (yv_ - yv_.mean()) / yv_.std()
     if not show_progress and _EARLY_WALK:
         engine._on_walk_queued = walk_queued.set
         try:
             nam_queued = _nam_device(engine, data, sid_name, nsteps=nsteps, show_progress=False,
                                      codes_labels=(codes, labels, counts, token),
-                                     select_hint=select_hint if kwargs.get('local_test', True) else None)
+                                     defer_last=(nsteps is not None and nsteps >= 3 and kwargs.get('local_test', True)
+                                                 and len(data.obs) >= _DEFER_LAST_CELLS))
         except Exception as exc:             # noqa: BLE001 - re-raised below, after validation
             nam_error = exc
         finally:

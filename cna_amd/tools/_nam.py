@@ -339,7 +339,7 @@ def diffuse(data, s, nsteps, show_progress=False, self_weight=1, engine=None):
 
 # --------------------------------------------------------------------------- NAM on device
 def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1, show_progress=False,
-                codes_labels=None, select_hint=None):
+                codes_labels=None, defer_last=False):
     """Reference ``_nam`` (_nam.py:44-76) with the state resident on the GPU.  On return the
     engine holds NAM = (s/C) (cells x samples); returns (labels, steps taken)."""
     out = select_output(show_progress)
@@ -384,24 +384,23 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
     old = None
     taken = 0
     if not need_kurt and 1 <= nsteps <= maxnsteps:
-        hint = select_hint if (nsteps >= 2 and N > 64 and hasattr(engine, 'nam_select_hint')) else None
-        if hint is None:
-            engine.nam_steps(nsteps)             # nothing to decide between steps: one call queues them all
-            walk_queued()
-        else:
-            # ``select_hint(labels)``: the standardised phenotype in label order if the caller expects to select every
-            # cell and every sample with nothing to regress out, else None.  It is evaluated while the first steps
-            # run; the last step then leaves the selection pass's results as well (cna_nam_select_hint).
+        if defer_last and nsteps >= 2 and N > 64 and hasattr(engine, 'nam_select_hint'):
+            # All steps but the last are queued now; the caller queues the last one -- finish(y_std or None) -- once it
+            # knows what the selection pass will be asked for (validation and the residualisation plan run while the
+            # first steps do): with a phenotype the last step does that pass on its way out (cna_nam_select_hint).
             for _ in range(nsteps - 1):
                 engine.nam_step(False, True, False)
             walk_queued()
-            try:
-                y_hint = hint(labels)
-            except Exception:                    # noqa: BLE001 - a hint only: validation reports what is wrong, later
-                y_hint = None
-            if y_hint is not None:
-                engine.nam_select_hint(y_hint)
-            engine.nam_step(False, False, True)
+            engine._nam_sig = None
+
+            def finish(y_hint=None):
+                if y_hint is not None:
+                    engine.nam_select_hint(y_hint)
+                engine.nam_step(False, False, True)
+                engine._nam_sig = (sig, engine.nam_epoch, nsteps) if sig is not None else None
+            return labels, nsteps, finish
+        engine.nam_steps(nsteps)                 # nothing to decide between steps: one call queues them all
+        walk_queued()
         engine._nam_sig = (sig, engine.nam_epoch, nsteps) if sig is not None else None
         return labels, nsteps
     if (nsteps is None and not show_progress and 1 <= maxnsteps <= 16 and hasattr(engine, 'nam_auto_launch')

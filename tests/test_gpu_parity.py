@@ -799,31 +799,36 @@ def test_fused_selection_call_equals_separate_calls(eng, monkeypatch):
         np.testing.assert_array_equal(a, b)
 
 
-@pytest.mark.parametrize('n,N,nsteps', [(20011, 200, 3), (5000, 100, 3), (9999, 233, 2), (3001, 66, 4), (2500, 300, 3),
-                                        (40, 180, 3), (4000, 64, 3)])
-def test_selection_as_a_by_product_of_the_last_walk_step(eng, monkeypatch, n, N, nsteps):
+@pytest.mark.parametrize('n,N,nsteps,ncov', [(20011, 200, 3, 0), (5000, 100, 3, 0), (9999, 233, 2, 0), (3001, 66, 4, 0),
+                                             (2500, 300, 3, 0), (40, 180, 3, 0), (4000, 64, 3, 0), (7001, 200, 3, 5),
+                                             (3000, 90, 5, 2)])
+def test_selection_as_a_by_product_of_the_last_walk_step(eng, monkeypatch, n, N, nsteps, ncov):
     """More than 64 samples, every cell and sample kept, nothing regressed out: the last step of the walk also does the
     selection pass (_association.py:182 zero-variance count, _nam.py:122,159 centre and / std, _association.py:77
     coefficients, the digit planes of the integer local null) on the row it has just formed -- diffuse.hip:select_tail,
     armed by cna_nam_select_hint -- and cna_select_standardized finds its work done.  The NAM is the same bit for bit;
     everything downstream agrees with the separate pass to rounding (the row sums run over the lanes in another order)
-    and the integer results are identical.  40 cells (empty samples: the selection is not "in place") and 64 samples
-    (two rows per wave: no by-product) exercise the fall-back to the separate pass."""
+    and the integer results are identical.  With covariates the selection keeps its own pass (it applies the projector).
+    40 cells (fewer than 65 samples have any), 64 samples (two rows per wave:
+    no by-product) and a two-step walk (the last step is not held back) exercise the separate pass."""
     import cna_amd as cna
     from cna_amd import synth
-    data, meta = synth.make_dataset(n, N, k=15, seed=21)
+    from cna_amd.tools import _association as A
+    monkeypatch.setattr(A, '_DEFER_LAST_CELLS', 0)         # (the schedule of large inputs)
+    data, meta = synth.make_dataset(n, N, k=15, seed=21, n_covs=ncov)
     out = {}
     for byp in (True, False):
         monkeypatch.setenv('CNA_WALK_SELECT', '1' if byp else '0')
         eng.prof_reset(); eng.prof_enable(True)
-        res = cna.tl.association(data, meta['y'], 'id', Nnull=200, seed=5, nsteps=nsteps, return_full=True, engine=eng)
+        res = cna.tl.association(data, meta['y'], 'id', covs=meta['covs'] if ncov else None, Nnull=200, seed=5,
+                                 nsteps=nsteps, return_full=True, engine=eng)
         eng.sync(); eng.prof_enable(False)
         out[byp] = (res.p, int(res.k), res.nam.values.copy(), res.kept.copy(), res.fdrs.num_detected.values.copy(),
                     res.ncorrs.values.copy(), res.namresid.values.copy(), res.fdrs.fdr.values.copy(),
                     data.obs['coef'].values.copy(), data.obs['coef_fdr'].values.copy(), res.nullminps.copy(),
                     eng.gram_fetch().copy())
         out[byp, 'select launches'] = eng.prof().get('select', (0, 0))[1]
-    expect = data.obs['id'].nunique() == N and N > 64
+    expect = data.obs['id'].nunique() > 64 and nsteps >= 3 and not ncov      # (samples without cells are not part of the NAM)
     assert out[False, 'select launches'] == 1 and out[True, 'select launches'] == (0 if expect else 1)
     assert out[True][1] == out[False][1]
     # (np.arange(m/4, m, m/400) has 300 or 301 entries depending on the last bits of m: compare the common prefix)
