@@ -633,7 +633,12 @@ __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p
 // U, the edges of a batch whose pairs are in flight together: 6 (us per launch at 2M x 200 / 1M x 100, from the
 // averages of profiles/r02_kbench_sparse_u.txt: U = 3: 4.41 / 2.12, 4: 4.20 / 2.03, 6: 4.10 / 1.95, 8: 4.37 / 2.10,
 // 12: 4.9 / 2.2, 16: 5.0 / 2.3; the ragged end of a row as one more, predicated batch instead of edge by edge:
-// slower at every U)
+// slower at every U).  Round 3: the bank conflicts of the scatter are NOT what the step waits for -- with every lane
+// adding into its own column (conflict-free, wrong sums: a timing experiment) the launch goes from 4.45 to 4.25 ms at
+// 2M x 200, 1.86 -> 1.78 at 1M x 100; a pair order that spreads a row's columns over the banks
+// (tools/micro/lds_scatter_pattern.hip: 14.3 -> 11.7 clk per ds_add_f64, floor 7.4) is therefore not worth its
+// bookkeeping.  Counters (profiles/r03_pmc_summary_C4.txt): VALU 42 % and LDS 49 % of the cycles, 61 % of the wave
+// cycles waiting, 12.5 vector instructions per edge: no single unit is the limit.
 template <typename VT, int NQ2, int U = 6>
 __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
   if (STEP_STOPPED(a)) return;
