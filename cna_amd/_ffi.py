@@ -78,6 +78,7 @@ SIGNATURES = {
     'cna_knn_graph': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, c_i64p]),
     'cna_host_hash64': (C.c_uint64, [C.c_void_p, C.c_int64, C.c_int]),
     'cna_host_copy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    'cna_host_expand_u16': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
     'cna_host_permuted_nnz': (C.c_int64, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     'cna_host_permute_rows': (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

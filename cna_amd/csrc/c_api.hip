@@ -1,5 +1,6 @@
 // extern "C" entry points of libcna_hip.so (see include/cna_hip.h for the contract).
 #include "common.h"
+#include <sched.h>
 #include <cmath>
 #include <cstring>
 
@@ -204,6 +205,7 @@ int cna_ctx_create(int device, cna_ctx** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->stage_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->coef_copied, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->null_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->bins_copied, hipEventDisableTiming);
   if (e != hipSuccess) {
     delete c;
     cna_set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
@@ -236,6 +238,9 @@ int cna_ctx_destroy(cna_ctx* c) {
   if (c->h_gt) (void)hipHostFree(c->h_gt);
   if (c->coef_copied) (void)hipEventDestroy(c->coef_copied);
   if (c->null_done) (void)hipEventDestroy(c->null_done);
+  if (c->bins_copied) (void)hipEventDestroy(c->bins_copied);
+  if (c->h_bins) (void)hipHostFree(c->h_bins);
+  if (c->h_tab) (void)hipHostFree(c->h_tab);
   if (c->h_res) (void)hipHostFree(c->h_res);
   if (c->h_cell) (void)hipHostFree(c->h_cell);
   delete c;
@@ -1606,6 +1611,10 @@ static int ensure_zc(cna_ctx* c, int N, int P, hipStream_t st) {
 // the pinned buffer h_res ([T sums][P*T tails if requested][2T observed counts]) and null_done fires
 // when they are there.  Nothing else may use c->scratch between the two.
 static int null_local_prepare(cna_ctx* c, int P, const double* edges, int T, int want_tails, const double* thr) {
+  if (c->bins_pending) {          // the per-cell counts of the previous pass read its thresholds out of c->scratch (coef_stream)
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->bins_copied, 0));
+    c->bins_pending = false;
+  }
   if (P < 1 || T < 1) CNA_FAIL(CNA_EINVAL, "cna_null_local: P and T must be positive");
   if (c->null_pending) CNA_FAIL(CNA_ESTATE, "a local-null pass is still pending: fetch it first");
   for (int t = 1; t < T; ++t)
@@ -1715,20 +1724,38 @@ static int null_local_go(cna_ctx* c, int col0) {
     double* fdr_local = c->coef_dev + 2 * c->n_pad;
     double* fdr_u = c->coef_dev + 3 * c->n_pad;
     double* tab = c->coef_dev + 4 * c->n_pad;
+    (void)fdr_local; (void)fdr_u;
+    // Behind the null only the FDR table is formed and sent (2.4 KB).  The per-cell half of the lookup -- how many
+    // thresholds lie at or below |coef_i| -- needs nothing from the null: it runs on the coefficient stream now and its
+    // 2 bytes per cell cross PCIe under the null kernel; the host puts table and counts together.  (Round 2 stored
+    // the finished 8-byte column from a kernel behind the null: 16 MB over PCIe on the critical path at 2M cells.)
     CNA_TRY(launch_fdr_table(c, sums, otails, T, P, tab, tab + 512));
-    CNA_TRY(launch_percell_lookup(c, coef_local, otd, tab + 512, T, c->null_thr0, c->null_thr_step, fdr_local));
-    const double* src = fdr_local;
-    if (c->orig_idx) {
-      CNA_TRY(launch_unpermute2(c, fdr_local, nullptr, c->orig_idx, c->n_local, fdr_u, nullptr));
-      src = fdr_u;
+    if (!c->h_tab) HIP_TRY(hipHostMalloc((void**)&c->h_tab, 8 * 512, hipHostMallocDefault));
+    HIP_TRY(hipMemcpyAsync(c->h_tab, tab + 512, 8 * (size_t)T, hipMemcpyDeviceToHost, c->stream));
+    {
+      void* bp = c->bins_dev;
+      CNA_TRY(dev_reserve(c, &bp, &c->bins_cap, 2 * std::max<int64_t>(std::max(c->n_pad, n_out), 1)));
+      c->bins_dev = (unsigned short*)bp;
+      if (2 * n_out > c->h_bins_cap) {
+        if (c->h_bins) HIP_TRY(hipHostFree(c->h_bins));
+        c->h_bins = nullptr;
+        HIP_TRY(hipHostMalloc((void**)&c->h_bins, (size_t)std::max<int64_t>(2 * n_out, 64), hipHostMallocDefault));
+        c->h_bins_cap = 2 * n_out;
+      }
+      hipStream_t cs = c->coef_stream;
+      HIP_TRY(hipStreamWaitEvent(cs, c->stage_done, 0));        // thresholds uploaded, coefficients formed (c->stream order)
+      CNA_TRY(launch_percell_bins(c, cs, coef_local, otd, T, c->null_thr0, c->null_thr_step, c->bins_dev));
+      if (n_out > 0) HIP_TRY(hipMemcpyAsync(c->h_bins, c->bins_dev, 2 * (size_t)n_out, hipMemcpyDeviceToHost, cs));
+      HIP_TRY(hipEventRecord(c->bins_copied, cs));
+      c->bins_pending = true;
     }
-    CNA_TRY(launch_store_host(c, src, n_out, (double*)c->h_cell + n_out));   // not a memcpy: see k_store_host
     c->fdr_inline = true;
   }
   if (c->null_has_tails)
     HIP_TRY(hipMemcpyAsync((char*)c->h_res + 8 * (size_t)T, tails, 8 * (size_t)P * T, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipEventRecord(c->null_done, c->stream));
   c->fdr_early_copied = false;
+  c->fdr_early_dst = nullptr;
   c->fdr_early_served = false;
   c->null_pending = 1;
   return 0;
@@ -2000,9 +2027,13 @@ int cna_percell_fdr_copy_early(cna_ctx* c, double* dst, int64_t n, int nthreads,
   *done = 0;
   const int64_t n_out = c->local_view ? c->n_local : c->n_global;
   if (!c->coef_early || !c->fdr_inline || !c->null_pending || !c->h_cell || n != n_out) return 0;
+  // (the main thread's cna_percell_fdr_pinned waits while this one is at work instead of doing the same work again)
+  struct Flight { std::atomic<int>& f; Flight(std::atomic<int>& f_) : f(f_) { f.store(1); } ~Flight() { f.store(0); } } flight(c->fdr_early_inflight);
+  HIP_TRY(hipEventSynchronize(c->bins_copied));
   HIP_TRY(hipEventSynchronize(c->null_done));
-  if (cna_host_copy(dst, (const double*)c->h_cell + n_out, 8 * n, nthreads) != 0)
-    std::memcpy(dst, (const double*)c->h_cell + n_out, 8 * (size_t)n);
+  if (cna_host_expand_u16(dst, c->h_bins, n, c->h_tab, c->null_T, nthreads) != 0)
+    CNA_FAIL(CNA_ESTATE, "cna_percell_fdr_copy_early: expansion failed");
+  c->fdr_early_dst = dst;
   c->fdr_early_copied = true;
   *done = 1;
   return 0;
@@ -2026,10 +2057,20 @@ int cna_percell_fdr_pinned(cna_ctx* c, const double* thr, const double* runmin_f
   const bool want_fdr = fdr_ptr && thr && runmin_fdr && T > 0;
   if (c->coef_early) HIP_TRY(hipEventSynchronize(c->coef_copied));     // coefficients already on the host
   if (c->coef_early && c->fdr_inline && want_fdr && T == c->null_T && !c->null_pending) {
-    // both columns are in the pinned block already (the FDR one was queued behind the local null)
+    // the coefficient column is in the pinned block; the FDR column is the table that followed the local null looked
+    // up with the per-cell counts that left before it -- already put together in the caller's own storage by
+    // cna_percell_fdr_copy_early (then that is what *fdr_ptr names), else put together here
+    HIP_TRY(hipEventSynchronize(c->bins_copied));
     HIP_TRY(hipEventSynchronize(c->null_done));
+    while (c->fdr_early_inflight.load()) sched_yield();
     *coef_ptr = hc;
-    *fdr_ptr = hc + n_out;
+    if (c->fdr_early_copied && c->fdr_early_dst) {
+      *fdr_ptr = c->fdr_early_dst;
+    } else {
+      if (cna_host_expand_u16(hc + n_out, c->h_bins, n_out, c->h_tab, T, 4) != 0)
+        CNA_FAIL(CNA_ESTATE, "cna_percell_fdr_pinned: expansion failed");
+      *fdr_ptr = hc + n_out;
+    }
     c->fdr_early_served = true;
     return 0;
   }

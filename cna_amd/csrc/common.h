@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <string>
 #include <mutex>
+#include <atomic>
 #include <vector>
 #include "../../include/cna_hip.h"
 
@@ -181,6 +182,18 @@ struct cna_ctx {
   double null_thr0 = 0, null_thr_step = 0;   // linear guess over the thresholds of the prepared pass
   bool fdr_early_copied = false;  // cna_percell_fdr_copy_early took the FDR column of the pending pass ...
   bool fdr_early_served = false;  // ... and cna_percell_fdr_pinned then returned that same column
+  // the FDR column behind a local-null pass that was launched with the coefficient column already out (fdr_inline):
+  // the per-cell threshold counts (16 bits, caller's order) cross PCIe while the null runs, the FDR table follows it,
+  // and the host puts the two together (cna_percell_fdr_copy_early / cna_percell_fdr_pinned)
+  unsigned short* bins_dev = nullptr;
+  int64_t bins_cap = 0;
+  unsigned short* h_bins = nullptr;   // pinned
+  int64_t h_bins_cap = 0;
+  double* h_tab = nullptr;            // pinned: running minimum of the FDR table (512 doubles)
+  hipEvent_t bins_copied = nullptr;
+  bool bins_pending = false;          // the copy on coef_stream may still read the thresholds in c->scratch
+  double* fdr_early_dst = nullptr;    // where cna_percell_fdr_copy_early put the column
+  std::atomic<int> fdr_early_inflight{0};   // a helper thread is inside cna_percell_fdr_copy_early
   void* h_cell = nullptr;         // pinned: per-cell outputs of cna_percell_fdr_pinned (coef | fdr)
   int64_t h_cell_cap = 0;
   // compressed copy of the state after the first walk step (single GPU, wide sample axis)
@@ -283,6 +296,9 @@ int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, 
 int launch_tail_sums(cna_ctx* c, const int64_t* tails, int P, int T, int64_t* sums);
 int launch_store_host(cna_ctx* c, const double* src, int64_t n, double* dst_host);
 int launch_fdr_table(cna_ctx* c, const int64_t* sums, const int64_t* ranks, int T, int P, double* fdr, double* runmin);
+int launch_percell_bins(cna_ctx* c, hipStream_t st, const double* coef_local, const double* thr_dev, int T, double thr0,
+                        double inv_step, unsigned short* bins);
+extern "C" int cna_host_expand_u16(double* dst, const uint16_t* bins, int64_t n, const double* runmin, int T, int nthreads);
 int launch_percell_lookup(cna_ctx* c, const double* coef_local, const double* thr_dev, const double* runmin_dev, int T,
                           double thr0, double inv_step, double* fdr_local);
 int launch_unpermute2(cna_ctx* c, const double* a, const double* b, const int64_t* idx, int64_t n, double* oa,

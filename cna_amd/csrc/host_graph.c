@@ -125,6 +125,47 @@ int cna_host_copy(void* dst, const void* src, int64_t nbytes, int nthreads) {
   return 0;
 }
 
+/* dst[i] = bins[i] > 0 ? runmin[bins[i] - 1] : 1.0 on several threads: the per-cell FDR column (_association.py:234-237)
+ * from the per-cell threshold counts, which leave the device while the local null still runs, and the FDR table,
+ * which follows it (2 bytes per cell cross PCIe instead of 8, and none of them after the null) */
+struct expand_job { double* d; const uint16_t* b; size_t n; const double* tab; int T; };
+/* branch-free: a 1024-entry table t2[h] = 1 for h = 0 (and beyond T), runmin[h - 1] otherwise */
+__attribute__((target_clones("avx2", "default")))
+static void expand_span(double* d, const uint16_t* b, size_t n, const double* t2) {
+  for (size_t i = 0; i < n; ++i) d[i] = t2[b[i] & 1023u];
+}
+static void* expand_worker(void* a) {
+  struct expand_job* j = (struct expand_job*)a;
+  expand_span(j->d, j->b, j->n, j->tab);
+  return NULL;
+}
+int cna_host_expand_u16(double* dst, const uint16_t* bins, int64_t n, const double* runmin, int T, int nthreads) {
+  if (n <= 0) return 0;
+  if (!dst || !bins || !runmin) return 1;
+  if (nthreads > 16) nthreads = 16;
+  if ((int64_t)nthreads > n / (1 << 17)) nthreads = (int)(n / (1 << 17));
+  if (nthreads < 1) nthreads = 1;
+  struct expand_job jobs[16];
+  pthread_t th[16];
+  int started[16];
+  double t2[1024];
+  for (int h = 0; h < 1024; ++h) t2[h] = (h > 0 && h <= T && h <= 512) ? runmin[h - 1] : 1.0;
+  const size_t part = (((size_t)n / nthreads) + 63) & ~(size_t)63;
+  for (int t = 0; t < nthreads; ++t) {
+    const size_t b = (size_t)t * part;
+    jobs[t].d = dst + b; jobs[t].b = bins + b; jobs[t].tab = t2; jobs[t].T = T;
+    jobs[t].n = b >= (size_t)n ? 0 : ((size_t)n - b < part || t == nthreads - 1 ? (size_t)n - b : part);
+    started[t] = 0;
+  }
+  for (int t = 1; t < nthreads; ++t) started[t] = pthread_create(&th[t], NULL, expand_worker, &jobs[t]) == 0;
+  expand_worker(&jobs[0]);
+  for (int t = 1; t < nthreads; ++t) {
+    if (started[t]) pthread_join(th[t], NULL);
+    else expand_worker(&jobs[t]);
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Cell order of the device copy: clusters of `B` cells that share neighbours.
  *

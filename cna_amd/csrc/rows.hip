@@ -1145,6 +1145,19 @@ __global__ void k_percell_fdr(const double* __restrict__ coef, int64_t n, const 
   fdr[i] = h > 0 ? runmin[h - 1] : 1.0;
 }
 
+// h_i = #{t : thr_t <= |coef_i|}, the count k_percell_fdr looks its FDR up with, as 16 bits per cell in the caller's
+// cell order (orig null: identity): it depends on the observed coefficients and the thresholds only, so it can leave
+// the device while the local null runs; the host finishes fdr_i = h_i > 0 ? runmin[h_i - 1] : 1 when the table arrives
+__global__ void k_percell_bins(const double* __restrict__ coef, int64_t n, const double* __restrict__ thr, int T,
+                               double thr0, double inv_step, const int64_t* __restrict__ orig,
+                               unsigned short* __restrict__ bins) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double z = fabs(coef[i]);
+  const int h = count_le(thr, T, z, linear_guess(z, thr0, inv_step, T));
+  bins[orig ? orig[i] : i] = (unsigned short)h;
+}
+
 // dst[i][j] = src[rows[i]][cols[j]] (rows / cols null = identity), written row-major (n_out x n_cols)
 // or transposed (n_cols x n_out): the matrices handed back to the caller leave the device already in
 // the caller's cell order and orientation.
@@ -1505,6 +1518,16 @@ int launch_store_host(cna_ctx* c, const double* src, int64_t n, double* dst_host
 
 int launch_fdr_table(cna_ctx* c, const int64_t* sums, const int64_t* ranks, int T, int P, double* fdr, double* runmin) {
   hipLaunchKernelGGL(k_fdr_table, dim3(1), dim3(512), 0, c->stream, sums, ranks, T, P, fdr, runmin);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_percell_bins(cna_ctx* c, hipStream_t st, const double* coef_local, const double* thr_dev, int T, double thr0,
+                        double inv_step, unsigned short* bins) {
+  const int64_t n = c->n_local;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_percell_bins, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, coef_local, n, thr_dev, T, thr0,
+                     inv_step, c->orig_idx, bins);
   HIP_TRY(hipGetLastError());
   return 0;
 }

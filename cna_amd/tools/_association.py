@@ -730,7 +730,7 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                     # F-tests in front of it: the helper thread waits for the column and fills the storage
                     from .._order import usable_cpus
                     early_coef['fdr_job'] = _background().submit(engine.percell_fdr_copy_early, view,
-                                                                  min(4, usable_cpus(4)))
+                                                                  min(8, usable_cpus(8)))
         _mark('coef column written')
 
     try:

@@ -359,6 +359,9 @@ uint64_t cna_host_hash64(const void* p, int64_t nbytes, int nthreads);
 /* memcpy on up to nthreads threads (the per-cell result columns into the caller's frame,
  * _association.py:230-237 of the reference assigns them to data.obs) */
 int  cna_host_copy(void* dst, const void* src, int64_t nbytes, int nthreads);
+/* dst[i] = bins[i] > 0 ? runmin[bins[i] - 1] : 1.0 on nthreads threads: the per-cell FDR column (_association.py:234-237)
+ * from the per-cell threshold counts #{t : thr_t <= |coef_i|} and the running minimum of the FDR table */
+int  cna_host_expand_u16(double* dst, const uint16_t* bins, int64_t n, const double* runmin, int T, int nthreads);
 /* Device cell order: clusters of B cells grown greedily by "most edges into the cluster" so that the
  * rows of one block share neighbours (edges / distinct neighbour rows of a block: 3.0 at B = 64 against
  * 2.0 for reverse Cuthill-McKee).  indptr int64[n+1], indices int32 of the rows' columns (columns outside
