@@ -223,7 +223,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_flush(c);
   comm_destroy(c);
-  void* bufs[] = {c->i8_buf, c->xq, c->xq_scale, c->coef_dev, c->proj, c->sp_pair, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+  void* bufs[] = {c->i8_buf, c->xq, c->xq_scale, c->coef_dev, c->proj, c->sp_pair, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_rows_b, c->halo_rows_i, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
                   c->nam, c->X, c->X2, c->resid_f, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -239,6 +239,9 @@ int cna_ctx_destroy(cna_ctx* c) {
   if (c->coef_copied) (void)hipEventDestroy(c->coef_copied);
   if (c->null_done) (void)hipEventDestroy(c->null_done);
   if (c->bins_copied) (void)hipEventDestroy(c->bins_copied);
+  if (c->halo_stream) (void)hipStreamDestroy(c->halo_stream);
+  if (c->halo_e1) (void)hipEventDestroy(c->halo_e1);
+  if (c->halo_e2) (void)hipEventDestroy(c->halo_e2);
   if (c->h_bins) (void)hipHostFree(c->h_bins);
   if (c->h_tab) (void)hipHostFree(c->h_tab);
   if (c->h_res) (void)hipHostFree(c->h_res);
@@ -485,6 +488,10 @@ static void halo_clear(cna_ctx* c) {
   c->halo_send_idx = c->halo_recv_idx = nullptr;
   c->halo_ns = c->halo_nr = 0;
   c->halo_on = false;
+  if (c->halo_rows_b) dev_free(c, c->halo_rows_b, sizeof(int32_t) * std::max<int64_t>(c->halo_nb, 1));
+  if (c->halo_rows_i) dev_free(c, c->halo_rows_i, sizeof(int32_t) * std::max<int64_t>(c->halo_ni, 1));
+  c->halo_rows_b = c->halo_rows_i = nullptr;
+  c->halo_nb = c->halo_ni = 0;
 }
 
 int cna_set_halo(cna_ctx* c, const int64_t* send_rows, const int64_t* send_counts, const int64_t* recv_rows,
@@ -515,6 +522,25 @@ int cna_set_halo(cna_ctx* c, const int64_t* send_rows, const int64_t* send_count
   c->halo_send_cnt.assign(send_counts, send_counts + c->nranks);
   c->halo_recv_cnt.assign(recv_counts, recv_counts + c->nranks);
   c->halo_on = true;
+  // the block's rows in two lists -- those some other rank has asked for, and the rest: a step that is followed by an
+  // exchange walks the first list, hands its rows to the exchange and walks the second meanwhile (cna_nam_step)
+  {
+    std::vector<char> wanted((size_t)std::max<int64_t>(c->n_local, 1), 0);
+    for (int64_t k = 0; k < ns; ++k) wanted[(size_t)send_rows[k]] = 1;
+    std::vector<int32_t> rb, ri;
+    for (int64_t r = 0; r < c->n_local; ++r) (wanted[(size_t)r] ? rb : ri).push_back((int32_t)r);
+    c->halo_nb = (int64_t)rb.size();
+    c->halo_ni = (int64_t)ri.size();
+    CNA_TRY(dev_alloc(c, (void**)&c->halo_rows_b, sizeof(int32_t) * std::max<int64_t>(c->halo_nb, 1)));
+    CNA_TRY(dev_alloc(c, (void**)&c->halo_rows_i, sizeof(int32_t) * std::max<int64_t>(c->halo_ni, 1)));
+    if (c->halo_nb) HIP_TRY(hipMemcpy(c->halo_rows_b, rb.data(), sizeof(int32_t) * c->halo_nb, hipMemcpyHostToDevice));
+    if (c->halo_ni) HIP_TRY(hipMemcpy(c->halo_rows_i, ri.data(), sizeof(int32_t) * c->halo_ni, hipMemcpyHostToDevice));
+    if (!c->halo_stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&c->halo_e1, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c->halo_e2, hipEventDisableTiming));
+    }
+  }
   return 0;
 }
 
@@ -522,15 +548,15 @@ int cna_set_halo(cna_ctx* c, const int64_t* send_rows, const int64_t* send_count
 // all-gather of the row blocks (every rank ends up with everything).  With cna_set_halo: pack the
 // rows other ranks asked for, one grouped send/recv per peer, scatter what arrives -- with a banded
 // cell order that is a few per cent of the all-gather volume.
-static int exchange_state(cna_ctx* c, double* T) {
+static int exchange_state(cna_ctx* c, double* T, hipStream_t st = nullptr) {
   if (c->halo_on) {
     const int ld = c->t_ld;
     CNA_TRY(dev_reserve(c, &c->halo_sbuf, &c->halo_sbuf_cap, 8 * std::max<int64_t>(c->halo_ns, 1) * ld));
     CNA_TRY(dev_reserve(c, &c->halo_rbuf, &c->halo_rbuf_cap, 8 * std::max<int64_t>(c->halo_nr, 1) * ld));
-    CNA_TRY(launch_pack_rows(c, T + c->row0 * ld, c->halo_send_idx, c->halo_ns, ld, (double*)c->halo_sbuf));
+    CNA_TRY(launch_pack_rows(c, T + c->row0 * ld, c->halo_send_idx, c->halo_ns, ld, (double*)c->halo_sbuf, st));
     if (c->halo_ns + c->halo_nr > 0)
-      CNA_TRY(comm_halo_exchange(c, (const double*)c->halo_sbuf, (double*)c->halo_rbuf, ld));
-    CNA_TRY(launch_unpack_rows(c, (const double*)c->halo_rbuf, c->halo_recv_idx, c->halo_nr, ld, T));
+      CNA_TRY(comm_halo_exchange(c, (const double*)c->halo_sbuf, (double*)c->halo_rbuf, ld, st));
+    CNA_TRY(launch_unpack_rows(c, (const double*)c->halo_rbuf, c->halo_recv_idx, c->halo_nr, ld, T, st));
     return 0;
   }
   if (c->nranks == 1) return 0;
@@ -623,15 +649,38 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
   const bool skip_nam = arm && !(keep && atoi(keep) != 0);
   c->byp_arm = arm;
   c->byp_skip_nam = skip_nam;
-  const int rc_step = launch_nam_step(c, first, want_kurt != 0, may_continue != 0, may_stop != 0, false);
-  c->byp_arm = false;
-  c->byp_skip_nam = false;
-  CNA_TRY(rc_step);
-  c->byp_valid = arm;
-  c->lazy_steps_before = c->steps_done;
-  if (may_continue) {
-    CNA_TRY(exchange_state(c, c->T[c->t_cur ^ 1]));
+  // A step whose state other ranks need (halo exchange): the rows they asked for first, their exchange on its own
+  // stream while the rest of the block is walked; the next step waits for both.  (The buffers are sized before anything
+  // is queued: a reallocation would wait for the device.)
+  const char* ov = getenv("CNA_HALO_OVERLAP");
+  const bool overlap = may_continue && c->halo_on && c->halo_stream && c->halo_nb > 0 && c->halo_ni > 0 && !(ov && atoi(ov) == 0);
+  if (overlap) {
+    c->byp_arm = false;
+    c->byp_skip_nam = false;
+    const int ld = c->t_ld;
+    double* Tn = c->T[c->t_cur ^ 1];
+    CNA_TRY(dev_reserve(c, &c->halo_sbuf, &c->halo_sbuf_cap, 8 * std::max<int64_t>(c->halo_ns, 1) * ld));
+    CNA_TRY(dev_reserve(c, &c->halo_rbuf, &c->halo_rbuf_cap, 8 * std::max<int64_t>(c->halo_nr, 1) * ld));
+    CNA_TRY(launch_nam_step(c, first, want_kurt != 0, true, may_stop != 0, false, c->halo_rows_b, c->halo_nb));
+    HIP_TRY(hipEventRecord(c->halo_e1, c->stream));
+    CNA_TRY(launch_nam_step(c, first, want_kurt != 0, true, may_stop != 0, false, c->halo_rows_i, c->halo_ni));
+    HIP_TRY(hipStreamWaitEvent(c->halo_stream, c->halo_e1, 0));
+    CNA_TRY(exchange_state(c, Tn, c->halo_stream));
+    HIP_TRY(hipEventRecord(c->halo_e2, c->halo_stream));
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->halo_e2, 0));
     c->t_cur ^= 1;
+    c->lazy_steps_before = c->steps_done;
+  } else {
+    const int rc_step = launch_nam_step(c, first, want_kurt != 0, may_continue != 0, may_stop != 0, false);
+    c->byp_arm = false;
+    c->byp_skip_nam = false;
+    CNA_TRY(rc_step);
+    c->byp_valid = arm;
+    c->lazy_steps_before = c->steps_done;
+    if (may_continue) {
+      CNA_TRY(exchange_state(c, c->T[c->t_cur ^ 1]));
+      c->t_cur ^= 1;
+    }
   }
   c->t_valid = may_continue != 0;
   c->nam_valid = may_stop != 0 && !skip_nam;

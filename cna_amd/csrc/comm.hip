@@ -135,14 +135,14 @@ int shm_allgather(cna_ctx* c, const void* send, void* recv, size_t bytes_per_ran
 }
 
 // slot of rank r: [nranks counts (int64, rows for each destination)] [rows for rank 0][rows for rank 1]...
-int shm_halo(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t dpr) {
+int shm_halo(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t dpr, hipStream_t st) {
   ShmComm* s = (ShmComm*)c->shm;
   const int64_t ns = c->halo_ns;
   const size_t head = sizeof(int64_t) * c->nranks;
   if ((int64_t)(head + (size_t)ns * dpr * 8) > s->slot_bytes) CNA_FAIL(CNA_EINVAL, "shm communicator: halo larger than a slot");
   std::memcpy(s->slot(c->rank), c->halo_send_cnt.data(), head);
-  if (ns > 0) HIP_TRY(hipMemcpyAsync(s->slot(c->rank) + head, sendbuf, (size_t)ns * dpr * 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (ns > 0) HIP_TRY(hipMemcpyAsync(s->slot(c->rank) + head, sendbuf, (size_t)ns * dpr * 8, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   shm_barrier(c);
   int64_t ro = 0;
   for (int p = 0; p < c->nranks; ++p) {
@@ -152,10 +152,10 @@ int shm_halo(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t dpr) {
     for (int q = 0; q < c->rank; ++q) so += cnt[q];
     if (cnt[c->rank] > 0)
       HIP_TRY(hipMemcpyAsync(recvbuf + ro * dpr, s->slot(p) + head + (size_t)so * dpr * 8, (size_t)cnt[c->rank] * dpr * 8,
-                             hipMemcpyHostToDevice, c->stream));
+                             hipMemcpyHostToDevice, st));
     ro += cnt[c->rank];
   }
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipStreamSynchronize(st));
   shm_barrier(c);
   return 0;
 }
@@ -296,10 +296,11 @@ int comm_allgather_bytes(cna_ctx* c, const void* send, void* recv, size_t bytes_
 
 // Point-to-point exchange of packed state rows: rank p receives halo_send_cnt[p] rows from us and
 // sends us halo_recv_cnt[p]; one grouped launch, so the xGMI links to all peers run concurrently.
-int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t doubles_per_row) {
-  if (c->shm) return shm_halo(c, sendbuf, recvbuf, doubles_per_row);
+int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t doubles_per_row, hipStream_t st) {
+  if (!st) st = c->stream;
+  if (c->shm) return shm_halo(c, sendbuf, recvbuf, doubles_per_row, st);
   if (!c->comm) CNA_FAIL(CNA_ESTATE, "halo exchange without cna_comm_init");
-  ProfScope ps(c, CNA_K_ALLGATHER);
+  ProfScope ps(c, CNA_K_ALLGATHER, st);
   NCCL_TRY(g_rccl.GroupStart());
   int64_t so = 0, ro = 0;
   ncclResult_t bad = ncclSuccess;
@@ -307,10 +308,10 @@ int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64
     const int64_t ns = c->halo_send_cnt[p], nr = c->halo_recv_cnt[p];
     if (ns > 0 && bad == ncclSuccess)
       bad = g_rccl.Send(sendbuf + so * doubles_per_row, (size_t)(ns * doubles_per_row), ncclFloat64, p,
-                        (ncclComm_t)c->comm, c->stream);
+                        (ncclComm_t)c->comm, st);
     if (nr > 0 && bad == ncclSuccess)
       bad = g_rccl.Recv(recvbuf + ro * doubles_per_row, (size_t)(nr * doubles_per_row), ncclFloat64, p,
-                        (ncclComm_t)c->comm, c->stream);
+                        (ncclComm_t)c->comm, st);
     so += ns;
     ro += nr;
   }

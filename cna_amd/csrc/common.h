@@ -69,6 +69,13 @@ struct cna_ctx {
   int64_t* halo_recv_idx = nullptr;   // device: global rows received, grouped by source rank
   std::vector<int64_t> halo_send_cnt, halo_recv_cnt;
   int64_t halo_ns = 0, halo_nr = 0;
+  // overlap of the exchange with the step that produces it: the rows other ranks wait for are walked first, their
+  // exchange runs on halo_stream while the rest of the block is walked (cna_nam_step)
+  int32_t* halo_rows_b = nullptr;     // device: local rows some other rank asked for (ascending, each once)
+  int32_t* halo_rows_i = nullptr;     // device: the other local rows (ascending)
+  int64_t halo_nb = 0, halo_ni = 0;
+  hipStream_t halo_stream = nullptr;
+  hipEvent_t halo_e1 = nullptr, halo_e2 = nullptr;
   void* halo_sbuf = nullptr;
   void* halo_rbuf = nullptr;
   int64_t halo_sbuf_cap = 0, halo_rbuf_cap = 0;
@@ -248,9 +255,9 @@ int dev_reserve(cna_ctx* c, void** p, int64_t* cap_bytes, int64_t need_bytes);
 
 // ---- collectives (comm.hip)
 inline bool comm_active(const cna_ctx* c) { return c->comm != nullptr || c->shm != nullptr; }
-int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t doubles_per_row);
-int launch_pack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst);
-int launch_unpack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst);
+int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t doubles_per_row, hipStream_t st = nullptr);
+int launch_pack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst, hipStream_t st = nullptr);
+int launch_unpack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst, hipStream_t st = nullptr);
 int comm_allreduce_f64_sum(cna_ctx* c, double* buf, size_t count);
 int comm_allreduce_f64_max(cna_ctx* c, double* buf, size_t count);
 int comm_allreduce_i64_sum(cna_ctx* c, int64_t* buf, size_t count);
@@ -260,7 +267,8 @@ int comm_allgather_bytes(cna_ctx* c, const void* send, void* recv, size_t bytes_
 // diffuse.hip
 int launch_colsum(cna_ctx* c);
 int launch_add_scalar(cna_ctx* c, double* v, int64_t n, double s);
-int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool write_nam, bool dense);
+int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool write_nam, bool dense,
+                    const int32_t* rows = nullptr, int64_t n_rows = 0);      // rows: this launch's rows of the block (null: all)
 int launch_scale_rows(cna_ctx* c, const double* s_local, double* t_global, int m, int ld);
 // rows.hip
 int launch_batch_kurtosis(cna_ctx* c, const double* mat, int64_t rows, int ncols, int ld,

@@ -66,6 +66,9 @@ struct StepArgs {
   double* stat;
   double* dense_out;
   int64_t n_local, row0;
+  // this launch covers rows[0 .. n_local) of the block (halo overlap: the rows other ranks wait for first, then the
+  // rest); null: all rows 0 .. n_local in order
+  const int32_t* rows;
   int width, ld;
   double w;
   int want_kurt, write_t, write_nam;
@@ -331,8 +334,9 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
   double* accl = sm + (size_t)wv * 64 * NQ;
 #pragma unroll
   for (int q = 0; q < NQ; ++q) accl[lane + 64 * q] = 0.0;
-  const int64_t row = my_row(wv, a.xcd_chunk);
+  int64_t row = my_row(wv, a.xcd_chunk);
   if (row >= a.n_local) return;
+  if (a.rows) row = uniform64(a.rows[row]);
   const int64_t grow = a.row0 + row;
   const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
   for (int64_t base = start; base < end; base += 64) {
@@ -370,6 +374,7 @@ __global__ __launch_bounds__(256) void k_nam_first2(StepArgs a, const CellInfo* 
     const int64_t blk = (b / a.xcd_chunk) * (8 * (int64_t)a.xcd_chunk) + x * a.xcd_chunk + (b % a.xcd_chunk);
     row[r] = uniform64(blk * 4 + wv);
     live[r] = row[r] < a.n_local;
+    if (live[r] && a.rows) row[r] = uniform64(a.rows[row[r]]);
     start[r] = end[r] = 0;
   }
 #pragma unroll
@@ -422,8 +427,9 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
   if (STEP_STOPPED(a)) return;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row = my_row(wv, a.xcd_chunk);
+  int64_t row = my_row(wv, a.xcd_chunk);
   if (row >= a.n_local) return;
+  if (a.rows) row = uniform64(a.rows[row]);
   const int64_t grow = a.row0 + row;
   const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
   const double2* __restrict__ Tin = (const double2*)a.Tin;
@@ -521,7 +527,7 @@ __global__ __launch_bounds__(256) void k_nam_step_pair(StepArgs a) {
   const int64_t row_a = my_row(wv, a.xcd_chunk) * 2;          // this wave: rows row_a, row_a + 1
   if (row_a >= a.n_local) return;
   const bool have = row_a + h < a.n_local;                    // odd n_local: the last wave's upper half idles
-  const int64_t row = have ? row_a + h : row_a;
+  const int64_t row = a.rows ? (int64_t)a.rows[have ? row_a + h : row_a] : (have ? row_a + h : row_a);
   const int64_t grow = a.row0 + row;
   const int64_t start = a.indptr[row];
   const int deg = have ? (int)(a.indptr[row + 1] - start) : 0;
@@ -648,8 +654,9 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
   double* acc = sm + (size_t)wv * 128 * NQ2;
 #pragma unroll
   for (int q = 0; q < 2 * NQ2; ++q) acc[lane + 64 * q] = 0.0;
-  const int64_t row = my_row(wv, a.xcd_chunk);
+  int64_t row = my_row(wv, a.xcd_chunk);
   if (row >= a.n_local) return;
+  if (a.rows) row = uniform64(a.rows[row]);
   const int64_t grow = a.row0 + row;
   const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
   const double2* __restrict__ Tin = (const double2*)a.Tin;
@@ -941,7 +948,7 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
   // two rows per wave when a row fits a half-wave and byte offsets into the state fit 32 bits
   const bool pair = !first && !a.sp_cnt && a.ld <= 64 && c->n_pad * (int64_t)a.ld * 8 < (int64_t)4 << 30 &&
                     !getenv("CNA_STEP_WIDE");
-  const int64_t nblk = pair ? (c->n_local + 7) / 8 : (c->n_local + 3) / 4;
+  const int64_t nblk = pair ? (a.n_local + 7) / 8 : (a.n_local + 3) / 4;
   int64_t cpx = (nblk + 7) / 8;
   // measured (tools/kbench.py): one contiguous eighth per XCD is best at 200k x 50 (+4 % over
   // round-robin) and within 2 % of every chunk size at 1M x 100
@@ -1044,8 +1051,9 @@ int launch_add_scalar(cna_ctx* c, double* v, int64_t n, double s) {
   return 0;
 }
 
-int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool write_nam, bool dense) {
-  if (c->n_local == 0) return 0;
+int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool write_nam, bool dense, const int32_t* rows,
+                    int64_t n_rows) {
+  if (c->n_local == 0 || (rows && n_rows == 0)) return 0;
   if (first && !c->cellinfo_valid) {
     void* p = c->cellinfo;
     CNA_TRY(dev_reserve(c, &p, &c->cellinfo_cap, (int64_t)sizeof(CellInfo) * c->n_global));
@@ -1069,7 +1077,8 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
   a.nam = c->nam;
   a.stat = c->stat;
   a.dense_out = dense ? c->dense_s : nullptr;
-  a.n_local = c->n_local;
+  a.n_local = rows ? n_rows : c->n_local;
+  a.rows = rows;
   a.row0 = c->row0;
   a.width = c->t_width;
   a.ld = c->t_ld;

@@ -1551,18 +1551,18 @@ int launch_unpermute2(cna_ctx* c, const double* a, const double* b, const int64_
   return 0;
 }
 
-int launch_pack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst) {
+int launch_pack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst, hipStream_t st) {
   if (nrows == 0) return 0;
   const int64_t work = nrows * (ld / 2);
-  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, c->stream, (const double2*)src,
+  hipLaunchKernelGGL(k_pack_rows, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st ? st : c->stream, (const double2*)src,
                      idx, nrows, ld / 2, (double2*)dst);
   HIP_TRY(hipGetLastError());
   return 0;
 }
-int launch_unpack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst) {
+int launch_unpack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst, hipStream_t st) {
   if (nrows == 0) return 0;
   const int64_t work = nrows * (ld / 2);
-  hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, c->stream,
+  hipLaunchKernelGGL(k_unpack_rows, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st ? st : c->stream,
                      (const double2*)src, idx, nrows, ld / 2, (double2*)dst);
   HIP_TRY(hipGetLastError());
   return 0;

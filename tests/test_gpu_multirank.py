@@ -202,7 +202,8 @@ def test_compressed_second_step_across_ranks(world):
     """120 samples: the second walk step gathers (sample, value) pairs instead of dense rows (k_nam_step_sparse).
     Sharded, a rank has the pairs of its own rows only; the rows the halo exchange brings arrive dense and are
     marked so -- the step then runs on every rank (one sparse and one dense step, as on one GPU) and the NAM is
-    bit for bit the single-GPU NAM."""
+    bit for bit the single-GPU NAM.  The sparse step is followed by an exchange, so it walks the rows other ranks have
+    asked for first and the rest while they travel (cna_nam_step: two launches)."""
     import multiprocessing as mp
     ctx = mp.get_context('spawn')
     results = {}
@@ -229,7 +230,8 @@ def test_compressed_second_step_across_ranks(world):
     for r in range(world):
         g = results[world][r]
         assert g['halo'] is not None and g['halo'][1] > 0          # rows do arrive from other ranks
-        assert g['sparse'] == 1 and g['dense'] == 1, (g['sparse'], g['dense'])
+        # (a step that is followed by an exchange is two launches: the rows other ranks wait for, then the rest)
+        assert g['sparse'] == 2 and g['dense'] == 1, (g['sparse'], g['dense'])
         np.testing.assert_array_equal(g['nam'], one['nam'])
         assert g['k'] == one['k'] and g['p'] == pytest.approx(one['p'], rel=1e-12)
         np.testing.assert_allclose(g['ncorrs'], one['ncorrs'], rtol=1e-9, atol=1e-13)
