@@ -987,6 +987,47 @@ def test_nam_cache_on_device(eng):
         e.close()
 
 
+def test_nam_cache_after_a_walk_that_left_the_selection_instead_of_the_nam(monkeypatch):
+    """The schedule of large inputs: the walk's last step does the selection pass and does not write the raw NAM
+    (cna_nam_select_hint).  A second phenotype on the same dataset finds the NAM 'resident' all the same: the library
+    runs that last step once more, for the NAM (c_api.hip:need_nam), and everything after it is what a from-scratch
+    run gives; so is res.nam of the first call, read before the second one starts."""
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.engine import Engine
+    from cna_amd.tools import _association as A
+    monkeypatch.setattr(A, '_DEFER_LAST_CELLS', 0)
+    data, meta = synth.make_dataset(20000, 100, k=15, seed=3)          # (96 samples or more: the second step is the compressed one)
+    y2 = pd.Series(np.random.RandomState(9).randn(100), index=meta['y'].index)
+    kw = dict(nsteps=3, Nnull=200, seed=4, return_full=True)
+    e = Engine(device=0)
+    try:
+        assert e.reuse_nam
+        e.prof_reset(); e.prof_enable(True)
+        r1 = cna.tl.association(data, meta['y'], 'id', engine=e, **kw)
+        e.sync()
+        assert 'select' not in e.prof() and e.prof()['nam_step'][1] == 1          # by-product; NAM not materialised yet
+        nam1 = r1.nam.values.copy()                                                # ... now it is (one more dense launch)
+        e.sync()
+        assert e.prof()['nam_step'][1] == 2
+        e.prof_reset()
+        r2 = cna.tl.association(data, y2, 'id', engine=e, **kw)
+        e.sync(); e.prof_enable(False)
+        assert not any(k.startswith('nam_') for k in e.prof()), e.prof().keys()    # resident NAM, its own selection pass
+        assert e.prof()['select'][1] == 1
+        nam2 = r2.nam.values.copy()
+        e.reuse_nam = False
+        monkeypatch.setenv('CNA_WALK_SELECT', '0')
+        r3 = cna.tl.association(data, y2, 'id', engine=e, **kw)
+        assert r2.p == r3.p and r2.k == r3.k
+        np.testing.assert_array_equal(r2.ncorrs.values, r3.ncorrs.values)
+        np.testing.assert_array_equal(r2.fdrs.values, r3.fdrs.values)
+        np.testing.assert_array_equal(nam2, r3.nam.values)
+        np.testing.assert_array_equal(nam1, nam2)
+    finally:
+        e.close()
+
+
 def test_properties_at_baseline_config2_size(eng):
     """BASELINE.json configs[1] (200k cells x 50 samples, k=30, nsteps=3, Nnull=1000) through
     size-independent properties: oracle-free identities on the fetched matrices, the per-cell columns
