@@ -223,7 +223,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   prof_flush(c);
   comm_destroy(c);
-  void* bufs[] = {c->i8_buf, c->xq, c->xq_scale, c->coef_dev, c->proj, c->sp_pair, c->sp_cnt, c->null_part, c->halo_send_idx, c->halo_recv_idx, c->halo_rows_b, c->halo_rows_i, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+  void* bufs[] = {c->i8_buf, c->xq, c->xq_scale, c->coef_dev, c->proj, c->sp_pair, c->sp_cnt, c->null_part, c->rp16_buf, c->halo_send_idx, c->halo_recv_idx, c->halo_rows_b, c->halo_rows_i, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
                   c->nam, c->X, c->X2, c->resid_f, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -1226,7 +1226,7 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
     CNA_TRY(launch_selgram(c, c->gram_buf, nz, yd, mb, with_q ? (unsigned char*)c->xq : nullptr,
                            with_q ? c->xq_scale : nullptr, 32 * KSq));
   } else {
-    CNA_TRY(launch_select_std(c, colmap ? cm : nullptr, nz, y ? yd : nullptr, y ? mb : nullptr, c->resid_f,
+    CNA_TRY(launch_select_std(c, (colmap && !in_place) ? cm : nullptr, nz, y ? yd : nullptr, y ? mb : nullptr, c->resid_f,
                               c->resid_f ? c->resid_f + (size_t)rk * Nx : nullptr, rk,
                               with_q ? (unsigned char*)c->xq : nullptr, with_q ? c->xq_scale : nullptr, 32 * KSq));
   }

@@ -220,6 +220,8 @@ struct cna_ctx {
   unsigned long long* i8_qcount = nullptr;   // device: [0] outputs sent to the f64 recheck by the last pass, [1] low word = status
   void* null_part = nullptr;      // per-block counter slabs of the local-null kernel
   int64_t null_part_cap = 0;
+  void* rp16_buf = nullptr;       // operands of rows16.hip:k_rowpass16 (k_rowpass16_prep)
+  int64_t rp16_cap = 0;
   void* scratch2 = nullptr;
   int64_t scratch2_cap = 0;
   int gram_tiles_nt = -1;        // upper-triangular tile table of the Gram kernel (depends on nt only)
@@ -304,6 +306,10 @@ int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, 
 int launch_tail_sums(cna_ctx* c, const int64_t* tails, int P, int T, int64_t* sums);
 int launch_store_host(cna_ctx* c, const double* src, int64_t n, double* dst_host);
 int launch_fdr_table(cna_ctx* c, const int64_t* sums, const int64_t* ranks, int T, int P, double* fdr, double* runmin);
+// rows16.hip: sixteen rows per wave, projector on the matrix cores; 1 = queued, 0 = not eligible
+int launch_rowpass16(cna_ctx* c, const double* src, int lds, double* dst, int ldd, int64_t nrows, int N, const double* W_dev,
+                     const double* Ct_dev, int r, int center, int standardize, int write_out, const double* y_dev,
+                     unsigned long long* maxword, const int32_t* bk_order, const int32_t* bk_boff, int nb, double* bk_out);
 int launch_percell_bins(cna_ctx* c, hipStream_t st, const double* coef_local, const double* thr_dev, int T, double thr0,
                         double inv_step, unsigned short* bins);
 extern "C" int cna_host_expand_u16(double* dst, const uint16_t* bins, int64_t n, const double* runmin, int T, int nthreads);

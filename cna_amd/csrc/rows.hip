@@ -1221,6 +1221,12 @@ int launch_batch_kurtosis(cna_ctx* c, const double* mat, int64_t rows, int ncols
   if (rows == 0) return 0;
   if (n_batches > 256) CNA_FAIL(CNA_EINVAL, "more than 256 batches are not supported");
   ProfScope ps(c, CNA_K_BATCH_KURT);
+  {
+    const int rc = launch_rowpass16(c, mat, ld, nullptr, 0, rows, ncols, nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr,
+                                    order_dev, boff_dev, n_batches, out);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
+  }
   if (n_batches <= BK_FAST && ncols <= 64 * MAXQ && !getenv("CNA_BK_SERIAL")) {
 #define BKF(Q) hipLaunchKernelGGL(k_batch_kurtosis_fast<Q>, dim3(wave_grid(rows)), dim3(256), 0, c->stream, mat, rows, ncols, ld, order_dev, boff_dev, n_batches, out)
     switch ((ncols + 63) / 64) {
@@ -1283,6 +1289,9 @@ int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long*
   const unsigned grid = wave_grid((c->nx + 3) / 4);
   const size_t smem = sizeof(double) * 2 * (size_t)rk * c->Nx;
   if (smem > 128 * 1024) CNA_FAIL(CNA_EINVAL, "projector factors too large for LDS");
+  // (rows16.hip's sixteen-rows-per-wave pass with the projector on the matrix cores, extended by this pass's extras --
+  // row selection, zero-variance count, digit planes -- measured slower here: 1217 against 785 us at 1M x 100 with three
+  // covariates, 731 against 405 at 500k x 128; it serves the in-place ridge pass and the batch kurtosis only)
   // sixteen lanes per cell up to 256 samples; with a projector the wave-per-cell kernel keeps the lead (its four
   // cells share every LDS read of the factors: 2.42 vs 2.71 ms at 2M x 200 with 5 covariates)
   if (c->Nx <= 256 && rk == 0 && !getenv("CNA_SELECT_WAVE")) {
@@ -1391,6 +1400,12 @@ int launch_resid_lowrank(cna_ctx* c, const double* W_dev, const double* Ct_dev, 
   const size_t smem = sizeof(double) * (2 * (size_t)r * c->Nx + (bk_out ? 4 * (size_t)c->ldx : 0));
   if (smem > 128 * 1024) CNA_FAIL(CNA_EINVAL, "cna_resid_lowrank: r x N too large for LDS");
   ProfScope ps(c, CNA_K_RESID);
+  {
+    const int rc = launch_rowpass16(c, c->X, c->ldx, c->X, c->ldx, c->nx, c->Nx, W_dev, Ct_dev, r, center, standardize, 1,
+                                    y_dev, maxbits_dev, bk_order, bk_boff, nb, bk_out);
+    if (rc < 0) return rc;
+    if (rc == 1) return 0;
+  }
   const int64_t want = (c->nx + 15) / 16;
   const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
 #define LR_CASE(Q) { static bool once = false; if (!once) { HIP_TRY(hipFuncSetAttribute((const void*)k_resid_lowrank<Q>, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)); once = true; } \
