@@ -205,6 +205,14 @@ class FakeEngine(_order.CellOrder):
         for i in range(nsteps):
             self.nam_step(False, i + 1 < nsteps, i + 1 == nsteps)
 
+    def nam_select_hint(self, y_std):
+        # (the device engine lets the walk's last step do the selection pass; this double only records the hint -- the
+        # host-side schedule that produces it is what the CPU tests exercise)
+        self.calls.append(('nam_select_hint', None if y_std is None else np.array(y_std, dtype=np.float64)))
+
+    def clear_resid_factors(self):
+        self.calls.append(('clear_resid_factors',))
+
     def stat_median(self):
         with np.errstate(all='ignore'):
             return float(np.median(self.stat))

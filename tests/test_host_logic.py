@@ -62,6 +62,39 @@ def test_progress_text(name):
     np.testing.assert_allclose(a, b, rtol=1e-5, equal_nan=True)
 
 
+@pytest.mark.parametrize('ncov', [0, 2])
+def test_schedule_of_large_inputs_holds_the_last_walk_step_back(monkeypatch, ncov):
+    """Large inputs, three or more steps, more than 64 samples: the walk's last step is queued after validation and
+    planning, with the call's own standardised phenotype as a hint for the selection pass when nothing is filtered or
+    regressed out (tools/_nam.py:_nam_device, _association.py:compute_nam_and_reindex).  Through the test double: same
+    calls in the same order with and without the schedule except for the hint, same results, and the oracle's."""
+    from cna_amd import synth
+    from cna_amd.tools import _association as A
+    from oracle import cna_oracle as orc
+    data, meta = synth.make_dataset(1500, 70, k=10, seed=5, n_covs=ncov)
+    kw = dict(covs=meta['covs'] if ncov else None, nsteps=3, Nnull=100, seed=3)
+    out = {}
+    for defer in (True, False):
+        monkeypatch.setattr(A, '_DEFER_LAST_CELLS', 0 if defer else 10 ** 9)
+        eng = FakeEngine()
+        res = cna.tl.association(data, meta['y'], 'id', return_full=True, engine=eng, **kw)
+        out[defer] = (res, [c[0] for c in eng.calls], [c for c in eng.calls if c[0] == 'nam_select_hint'])
+    hints = out[True][2]
+    assert not out[False][2] and len(hints) == (0 if ncov else 1)
+    if not ncov:
+        yv = meta['y'].values
+        np.testing.assert_array_equal(hints[0][1], (yv - yv.mean()) / yv.std())
+    steps = [c for c in out[True][1] if c in ('nam_step', 'nam_select_hint')]
+    assert steps == (['nam_step'] * 3 if ncov else ['nam_step', 'nam_step', 'nam_select_hint', 'nam_step'])
+    a, b = out[True][0], out[False][0]
+    assert a.p == b.p and a.k == b.k
+    np.testing.assert_array_equal(a.ncorrs.values, b.ncorrs.values)
+    np.testing.assert_array_equal(a.fdrs.values, b.fdrs.values)
+    ref = orc.association(data, meta['y'], 'id', mode='f64', **kw)
+    assert int(a.k) == int(ref['k']) and a.p == pytest.approx(ref['p'], rel=1e-9)
+    np.testing.assert_allclose(a.ncorrs.values, ref['ncorrs'], rtol=1e-9, atol=1e-13)
+
+
 def test_ridge_loop_runs_the_whole_schedule():
     case = load_case('c16_ridge_loop')
     buf = io.StringIO()
