@@ -318,6 +318,15 @@ def summary(m, world, steps):
     roofline = dict(kernel=dom, bound=kd['bound'], achieved=kd['achieved'], peak=kd['peak'], unit=kd['unit'],
                     frac=kd['frac'], traffic=traffic, traffic_source=src, avg_us=kd['avg_us'],
                     launches_per_step=kd['launches'] // steps)
+    if dom == 'nam_step':
+        # what the row-gather actually moves, beside the algorithmic bytes the fraction is priced on: every edge fetches
+        # its neighbour's 8N-byte state row through the vector L1 (the chip delivers 17-19 TB/s on this
+        # pattern), and `traffic` of it comes from behind the L2 (4.8-5.8 TB/s of 128-byte lines at these sizes)
+        gathered = float(m['nnz_loc']) * 8.0 * m['N']
+        roofline['gathered_bytes_per_launch'] = gathered
+        roofline['gathered_TBps'] = round(gathered / (kd['avg_us'] * 1e-6) / 1e12, 2)
+        if traffic:
+            roofline['behind_l2_TBps'] = round(traffic / (kd['avg_us'] * 1e-6) / 1e12, 2)
     gpu_ms = sum(v['total_ms'] for v in kernels.values()) / steps
     ms_per_step = m['dt'] / steps * 1e3
     return dict(value=round(m['n'] * m['Nnull'] * steps / m['dt'], 1), ms_per_step=round(ms_per_step, 3), roofline=roofline,
