@@ -218,6 +218,7 @@ int cna_ctx_create(int device, cna_ctx** out) {
 int cna_ctx_destroy(cna_ctx* c) {
   if (c && c->auto_state) { (void)hipFree(c->auto_state); c->auto_state = nullptr; }
   if (c && c->byp_buf) { (void)hipFree(c->byp_buf); c->byp_buf = nullptr; }
+  if (c && c->pair_buf) { (void)hipFree(c->pair_buf); c->pair_buf = nullptr; }
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
@@ -1231,8 +1232,19 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
                               with_q ? (unsigned char*)c->xq : nullptr, with_q ? c->xq_scale : nullptr, 32 * KSq));
   }
   c->resid_rk = 0;
-  CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)nz, 1));
-  if (y) CNA_TRY(comm_allreduce_f64_max(c, (double*)mb, 1));
+  if (y && comm_active(c) && c->nranks > 1 && c->nranks <= 64) {
+    // the two counters of this pass in ONE collective: every rank's {zero-variance rows, bits of max |coefficient|}
+    // gathered (16 bytes per rank), summed / maximised by a one-wave kernel -- the same numbers as an integer sum and
+    // a floating-point maximum over the ranks (non-negative doubles and the NaN pattern order like their bit patterns)
+    if (!c->pair_buf) HIP_TRY(hipMalloc(&c->pair_buf, 16 * 65));
+    unsigned long long* pb = (unsigned long long*)c->pair_buf;
+    CNA_TRY(launch_pair_pack(c, nz, mb, pb + 2 * (size_t)c->rank));
+    CNA_TRY(comm_allgather_bytes(c, pb + 2 * (size_t)c->rank, pb, 16));
+    CNA_TRY(launch_pair_fold(c, pb, c->nranks, nz, mb));
+  } else {
+    CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)nz, 1));
+    if (y) CNA_TRY(comm_allreduce_f64_max(c, (double*)mb, 1));
+  }
   unsigned long long h = 0;
   double m = 0.0;
   HIP_TRY(hipMemcpyAsync(&h, nz, 8, hipMemcpyDeviceToHost, c->stream));

@@ -142,6 +142,7 @@ struct cna_ctx {
   bool nam_lazy = false;           // the NAM is one more run of the last step away (c_api.hip:need_nam)
   int lazy_steps_before = 0;       // steps_done when that step was launched
   bool byp_arm = false;            // the launch being issued is that last step (launch_nam_step reads it)
+  void* pair_buf = nullptr;        // {count, max bits} of every rank: the selection pass's two counters in one collective
   void* byp_buf = nullptr;         // device: [0] zero-variance rows, [1] max |coef| bits, then y (1024 doubles)
 
   // ---- per-cell vectors
@@ -284,6 +285,8 @@ int launch_gather_rows(cna_ctx* c, const double* src, int ld, const int64_t* row
 int launch_digit_hist(cna_ctx* c, const double* v, int64_t n, unsigned long long prefix, int shift,
                       unsigned long long* hist_dev);
 int launch_max_fold(cna_ctx* c, const unsigned long long* blockmax, int nblocks, unsigned long long* out);
+int launch_pair_pack(cna_ctx* c, const unsigned long long* cnt, const unsigned long long* maxbits, unsigned long long* slot);
+int launch_pair_fold(cna_ctx* c, const unsigned long long* slots, int nranks, unsigned long long* cnt, unsigned long long* maxbits);
 // exact median of v[0..n) (np.median semantics) on the device, then the walk's stop rule for step `step` (0-based):
 // nothing returns to the host; `state` is the AutoState block of the walk, `hist` 2 x 257 words of scratch
 int launch_auto_median(cna_ctx* c, const double* v, int64_t n, void* state, unsigned long long* hist, int step, int min_steps,

@@ -1355,6 +1355,31 @@ int launch_qc_count(cna_ctx* c, const double* v, int64_t n, void* state) {
   return 0;
 }
 
+namespace {
+__global__ void k_pair_pack(const unsigned long long* cnt, const unsigned long long* maxbits, unsigned long long* slot) {
+  slot[0] = cnt[0];
+  slot[1] = maxbits[0];
+}
+__global__ void k_pair_fold(const unsigned long long* slots, int nranks, unsigned long long* cnt, unsigned long long* maxbits) {
+  unsigned long long s = 0, m = 0;
+  for (int r = 0; r < nranks; ++r) {              // fixed rank order: identical on every rank
+    s += slots[2 * r];
+    m = slots[2 * r + 1] > m ? slots[2 * r + 1] : m;
+  }
+  cnt[0] = s;
+  maxbits[0] = m;
+}
+}  // namespace
+int launch_pair_pack(cna_ctx* c, const unsigned long long* cnt, const unsigned long long* maxbits, unsigned long long* slot) {
+  hipLaunchKernelGGL(k_pair_pack, dim3(1), dim3(1), 0, c->stream, cnt, maxbits, slot);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+int launch_pair_fold(cna_ctx* c, const unsigned long long* slots, int nranks, unsigned long long* cnt, unsigned long long* maxbits) {
+  hipLaunchKernelGGL(k_pair_fold, dim3(1), dim3(1), 0, c->stream, slots, nranks, cnt, maxbits);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 int launch_max_fold(cna_ctx* c, const unsigned long long* blockmax, int nblocks, unsigned long long* out) {
   hipLaunchKernelGGL(k_max_fold, dim3(1), dim3(256), 0, c->stream, blockmax, nblocks, out);
   HIP_TRY(hipGetLastError());
