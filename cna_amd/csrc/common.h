@@ -53,7 +53,8 @@ struct cna_ctx {
   hipEvent_t null_done = nullptr;      // results of the last local-null launch are in h_res
   void* h_res = nullptr;               // pinned host staging for asynchronously fetched results
   int64_t h_res_cap = 0;
-  int null_P = 0, null_T = 0, null_has_tails = 0, null_pending = 0;
+  int null_P = 0, null_T = 0, null_has_tails = 0;
+  std::atomic<int> null_pending{0};   // (read by the helper thread's cna_percell_fdr_copy_early, like the four flags below)
   int64_t gram_cap = 0;
   int gram_n = 0;
   int64_t dev_bytes = 0;
@@ -185,11 +186,11 @@ struct cna_ctx {
   double* coef_dev = nullptr;     // early copy of the per-cell coefficients (cna_percell_coef_launch): 2 x n_pad
   int64_t coef_dev_cap = 0;
   hipEvent_t coef_ready = nullptr, coef_copied = nullptr;
-  bool coef_early = false;        // h_cell[0, n_out) already holds the coefficients of the current ncorrs
-  bool fdr_inline = false;        // ... and h_cell[n_out, 2 n_out) the per-cell FDRs of the last local-null pass
+  std::atomic<bool> coef_early{false};        // h_cell[0, n_out) already holds the coefficients of the current ncorrs
+  std::atomic<bool> fdr_inline{false};        // ... and h_cell[n_out, 2 n_out) the per-cell FDRs of the last local-null pass
   double null_thr0 = 0, null_thr_step = 0;   // linear guess over the thresholds of the prepared pass
-  bool fdr_early_copied = false;  // cna_percell_fdr_copy_early took the FDR column of the pending pass ...
-  bool fdr_early_served = false;  // ... and cna_percell_fdr_pinned then returned that same column
+  std::atomic<bool> fdr_early_copied{false};  // cna_percell_fdr_copy_early took the FDR column of the pending pass ...
+  std::atomic<bool> fdr_early_served{false};  // ... and cna_percell_fdr_pinned then returned that same column
   // the FDR column behind a local-null pass that was launched with the coefficient column already out (fdr_inline):
   // the per-cell threshold counts (16 bits, caller's order) cross PCIe while the null runs, the FDR table follows it,
   // and the host puts the two together (cna_percell_fdr_copy_early / cna_percell_fdr_pinned)

@@ -196,6 +196,55 @@ def test_dense_row_kernels_vs_numpy(eng, orc, n, N):
     assert relerr(nc, ref) < 1e-12 and m == pytest.approx(np.abs(ref).max(), rel=1e-12)
 
 
+@pytest.mark.parametrize('n,N,r,nb', [(1000, 5, 1, 2), (777, 17, 3, 3), (4097, 64, 16, 16), (3000, 100, 7, 5), (2000, 128, 8, 9),
+                                      (1500, 130, 0, 4), (999, 255, 0, 16), (15, 33, 2, 1), (16 * 257 + 3, 48, 5, 7),
+                                      (640, 100, 20, 6), (500, 160, 4, 3)])
+def test_sixteen_rows_per_wave_passes_vs_numpy(eng, orc, monkeypatch, n, N, r, nb):
+    """rows16.hip: batch kurtosis (_nam.py:78-82) and the in-place ridge pass -- centre, M = I - C.W in factored form,
+    batch kurtosis of the result, / std, coefficients (_nam.py:122,143-150,159, _association.py:77) -- with sixteen
+    rows per wave and the projector on the matrix cores, against numpy and against the wave-per-row kernels
+    (CNA_ROWPASS16=0).  Shapes: sample counts off the multiples of 4 and 16, row counts off the multiples of 16, ranks 1
+    ... 16, one batch, sixteen batches; 130 / 255 / 160 samples and rank 20 are beyond the pass with a projector and
+    must fall through to the wave-per-row kernels with the same results."""
+    from cna_amd import _ffi
+    import scipy.sparse as sp
+    eng.ensure_graph(sp.identity(n, format='csr', dtype=np.float32))      # (the per-cell buffers are sized by the graph)
+    rs = np.random.RandomState(n + 3 * N + r)
+    X = _random_x(rs, n, N)
+    bc = rs.randint(0, nb, size=N)
+    bc[:nb] = np.arange(nb)                                   # every batch has a sample
+    y = rs.randn(N)
+    Xc = X - X.mean(axis=1, keepdims=True)
+    out = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('CNA_ROWPASS16', mode)
+        eng.upload_x(X)
+        eng.batch_kurtosis(_ffi.MAT_X, bc, nb)
+        bk0 = eng.x_stat().copy()
+        if r > 0:
+            Cm = rs.randn(N, r) if mode == '1' else out['C']
+            Cm = Cm - Cm.mean(axis=0)
+            W = np.linalg.solve(Cm.T.dot(Cm) + 0.3 * N * np.eye(r), Cm.T)
+            out['C'] = Cm
+            maxabs, med = eng.resid_lowrank_bk(Cm, W, y, bc, nb)
+            want = Xc - Xc.dot(W.T).dot(Cm.T)
+            bk1 = eng.x_stat().copy()
+            ref_bk1 = orc.batch_kurtosis(want, bc, nb)
+            want = want / want.std(axis=1, ddof=1)[:, None]
+            got = eng.fetch_matrix(_ffi.MAT_X)
+            assert relerr(got, want) < 1e-11
+            np.testing.assert_allclose(bk1, ref_bk1, rtol=1e-8)
+            np.testing.assert_allclose(med, np.median(ref_bk1), rtol=1e-8)         # (one batch: NaN on both sides)
+            ref_nc = (want * y[None, :]).sum(axis=1) / N
+            assert maxabs == pytest.approx(np.abs(ref_nc).max(), rel=1e-10)
+            out[mode] = (bk0, got, bk1, maxabs)
+        else:
+            out[mode] = (bk0,)
+        np.testing.assert_allclose(bk0, orc.batch_kurtosis(X, bc, nb), rtol=1e-9)
+    for a, b in zip(out['1'], out['0']):
+        np.testing.assert_allclose(a, b, rtol=1e-8, atol=1e-13)
+
+
 @pytest.mark.parametrize('n,N,P', [(3000, 20, 100), (2049, 50, 200), (1000, 100, 70), (600, 200, 130),
                                    (100, 256, 64), (16, 12, 5), (700, 160, 90), (333, 224, 33),
                                    (500, 192, 40), (250, 157, 70), (260, 221, 65),
