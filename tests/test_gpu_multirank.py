@@ -187,8 +187,10 @@ def _sparse_worker(rank, world, seg, q):
         res = cna.tl.association(data, meta['y'], 'id', nsteps=3, Nnull=100, seed=2, return_full=True, engine=eng)
         eng.sync()
         prof = eng.prof()
-        out = dict(p=res.p, k=int(res.k), nam=res.nam.values, ncorrs=res.ncorrs.values, halo=getattr(eng, 'halo', None),
-                   sparse=prof.get('nam_step_sparse', (0, 0))[1], dense=prof.get('nam_step', (0, 0))[1])
+        out = dict(p=res.p, k=int(res.k), ncorrs=res.ncorrs.values, halo=getattr(eng, 'halo', None),
+                   sparse=prof.get('nam_step_sparse', (0, 0))[1], dense=prof.get('nam_step', (0, 0))[1],
+                   select=prof.get('select', (0, 0))[1], fdr=res.fdrs.fdr.values, num=res.fdrs.num_detected.values)
+        out['nam'] = res.nam.values           # (last: with the selection by-product the raw NAM is one more dense launch)
         eng.close()
         q.put((rank, out))
     except BaseException as e:
@@ -197,8 +199,8 @@ def _sparse_worker(rank, world, seg, q):
         os._exit(1)
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_compressed_second_step_across_ranks(world):
+@pytest.mark.parametrize('world,defer', [(2, False), (3, False), (2, True)])
+def test_compressed_second_step_across_ranks(world, defer, monkeypatch):
     """120 samples: the second walk step gathers (sample, value) pairs instead of dense rows (k_nam_step_sparse).
     Sharded, a rank has the pairs of its own rows only; the rows the halo exchange brings arrive dense and are
     marked so -- the step then runs on every rank (one sparse and one dense step, as on one GPU) and the NAM is
@@ -207,6 +209,9 @@ def test_compressed_second_step_across_ranks(world):
     import multiprocessing as mp
     ctx = mp.get_context('spawn')
     results = {}
+    # defer: the schedule of large inputs on every rank (the workers read the variable when they import the package) --
+    # the last walk step also does the selection pass, the two counters of that pass cross the ranks in one collective
+    monkeypatch.setenv('CNA_DEFER_LAST_CELLS', '0' if defer else '1000000000')
     for w in (1, world):
         q = ctx.Queue()
         seg = 'cna_sp_%d_%d' % (os.getpid(), w)
@@ -232,7 +237,10 @@ def test_compressed_second_step_across_ranks(world):
         assert g['halo'] is not None and g['halo'][1] > 0          # rows do arrive from other ranks
         # (a step that is followed by an exchange is two launches: the rows other ranks wait for, then the rest)
         assert g['sparse'] == 2 and g['dense'] == 1, (g['sparse'], g['dense'])
+        assert g['select'] == (0 if defer else 1) and one['select'] == (0 if defer else 1)
         np.testing.assert_array_equal(g['nam'], one['nam'])
+        np.testing.assert_array_equal(g['num'], one['num'])
+        np.testing.assert_allclose(g['fdr'], one['fdr'], rtol=1e-9, atol=1e-13, equal_nan=True)
         assert g['k'] == one['k'] and g['p'] == pytest.approx(one['p'], rel=1e-12)
         np.testing.assert_allclose(g['ncorrs'], one['ncorrs'], rtol=1e-9, atol=1e-13)
 
