@@ -25,26 +25,6 @@
 __device__ __forceinline__ double mul_rn(double a, double b) { return a * b; }
 __device__ __forceinline__ double add_rn(double a, double b) { return a + b; }
 
-// Stores of the write-out, by cache policy (StepArgs::store_mode; experiments): 0 plain, 1 sc1 (written through, the
-// line is not kept in this XCD's L2 -- nothing in the launch reads it again), 2 nt
-typedef double d2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void st_f64(double* p, double v, int mode) {
-  if (mode == 1) asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-  else if (mode == 2) __builtin_nontemporal_store(v, p);
-  else *p = v;
-}
-__device__ __forceinline__ void st_f64x2(double* p, double a, double b, int mode) {
-  d2v v = {a, b};
-  if (mode == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-  else if (mode == 2) __builtin_nontemporal_store(v, (d2v*)p);
-  else *(d2v*)p = v;
-}
-__device__ __forceinline__ void st_u32(unsigned* p, unsigned v, int mode) {
-  if (mode == 1) asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-  else if (mode == 2) __builtin_nontemporal_store(v, p);
-  else *p = v;
-}
-
 namespace {
 
 struct CellInfo {      // one gather per edge in the first step
@@ -88,7 +68,7 @@ struct StepArgs {
   double2* sel_xscale;
   unsigned long long* sel_nz;   // [0] rows of zero variance, [1] bits of max |coefficient| (NaN pattern if any is NaN)
   int sel_ldx, sel_Kp;
-  int store_mode;           // cache policy of the write-out stores (st_f64); bit 2: the NAM itself is not stored
+  int skip_nam;             // with the by-product: the raw NAM is not stored (c_api.hip:need_nam materialises it on demand)
 };
 #define STEP_STOPPED(a) ((a).stop != nullptr && __builtin_nontemporal_load((a).stop) != 0)
 // One 16-byte record per non-zero: the second step then fetches an edge's whole neighbour row with ONE
@@ -173,7 +153,7 @@ __device__ __forceinline__ void select_tail(const StepArgs& a, int64_t row, int 
     if (c0 < a.width) dot += a.sel_y[c0] * x0;
     if (c0 + 1 < a.width) dot += a.sel_y[c0 + 1] * x1;
     amax = fmax(amax, fmax(fabs(x0), fabs(x1)));          // NaN rows (zero variance): fmax drops them, q = 0 below
-    if (c0 + 1 < a.sel_ldx) st_f64x2(dst + c0, x0, x1, a.store_mode & 3);
+    if (c0 + 1 < a.sel_ldx) *(double2*)(dst + c0) = make_double2(x0, x1);
   }
   if (a.sel_xq) {
     const double rmax = wave_max_d(amax);
@@ -197,9 +177,9 @@ __device__ __forceinline__ void select_tail(const StepArgs& a, int64_t row, int 
       const unsigned o2 = (unsigned)__builtin_amdgcn_ds_bpermute(4 * (lane + 1), (int)h2);
       const int c0 = ColPair::col(lane, k);
       if ((lane & 1) == 0 && c0 < a.sel_Kp) {
-        st_u32((unsigned*)(rq + c0), (p01 & 0xffffu) | (o01 << 16), a.store_mode & 3);
-        st_u32((unsigned*)(rq + a.sel_Kp + c0), (p01 >> 16) | (o01 & 0xffff0000u), a.store_mode & 3);
-        st_u32((unsigned*)(rq + 2 * a.sel_Kp + c0), (h2 & 0xffffu) | (o2 << 16), a.store_mode & 3);
+        *(unsigned*)(rq + c0) = (p01 & 0xffffu) | (o01 << 16);
+        *(unsigned*)(rq + a.sel_Kp + c0) = (p01 >> 16) | (o01 & 0xffff0000u);
+        *(unsigned*)(rq + 2 * a.sel_Kp + c0) = (h2 & 0xffffu) | (o2 << 16);
       }
     }
     const double l1 = rmax > 0.0 ? n * (I8_QMAX / rmax) + n : 0.0;
@@ -214,16 +194,21 @@ __device__ __forceinline__ void select_tail(const StepArgs& a, int64_t row, int 
   }
 }
 
-template <int NV, typename CM>
+// FL: what a launch's instantiation compiles in -- bit 0: the selection by-product (select_tail; the last step of a
+// walk with a hint), bit 1: a row list (halo overlap).  Kept out of the plain instantiations on purpose: the fields
+// they need are kernel arguments that stay live in scalar registers across the gather loop, and the compressed second
+// step lost 9 % (4.09 -> 4.45 ms at 2M x 200) when it carried them.
+template <int NV, typename CM, int FL = 0>
 __device__ __forceinline__ void finish_row(const StepArgs& a, int64_t row, int64_t grow, int lane,
                                            const double (&s)[NV]) {
+  constexpr bool BYP = (FL & 1) != 0;
   const double cs = a.colsum[grow];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int col = CM::col(lane, k);
     if (col < a.ld) {
       const bool in = col < a.width;
-      if (a.write_t) st_f64(&a.Tout[grow * a.ld + col], in ? __ddiv_rn(s[k], cs) : 0.0, a.store_mode & 3);
+      if (a.write_t) a.Tout[grow * a.ld + col] = in ? __ddiv_rn(s[k], cs) : 0.0;
       if (a.dense_out) a.dense_out[row * a.ld + col] = in ? s[k] : 0.0;
     }
   }
@@ -235,7 +220,7 @@ __device__ __forceinline__ void finish_row(const StepArgs& a, int64_t row, int64
       const int col = CM::col(lane, k);
       const bool in = col < a.width;
       x[k] = in ? __ddiv_rn(s[k], a.counts[col]) : 0.0;     // s / C   (_nam.py:59,73)
-      if (a.write_nam && col < a.ld && !(a.store_mode & 4)) st_f64(&a.nam[row * a.ld + col], x[k], a.store_mode & 3);
+      if (a.write_nam && col < a.ld && !(BYP && a.skip_nam)) a.nam[row * a.ld + col] = x[k];
       sum += x[k];
     }
     if (a.want_kurt) {
@@ -258,7 +243,7 @@ __device__ __forceinline__ void finish_row(const StepArgs& a, int64_t row, int64
       const double k4 = (m2 <= em * em) ? __builtin_nan("") : m4 / (m2 * m2);
       if (lane == 0) a.stat[grow] = k4 - 3.0;
     }
-    if constexpr (std::is_same<CM, ColPair>::value) {
+    if constexpr (BYP && std::is_same<CM, ColPair>::value) {
       if (a.sel_X) select_tail<NV>(a, row, lane, x);
     }
   }
@@ -325,7 +310,7 @@ __device__ __forceinline__ void first_tail(const StepArgs& a, const double* accl
 // makes that a single gather per edge; every lane takes one edge and adds its term into the
 // wave's LDS accumulator row with ds_add_f64 (edges of one row rarely share a sample, and
 // same-address adds of one instruction retire in lane order, i.e. CSR order).
-template <typename VT, int NQ>
+template <typename VT, int NQ, int FL = 0>
 __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* __restrict__ info) {
   extern __shared__ double sm[];
   if (STEP_STOPPED(a)) return;
@@ -336,7 +321,7 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
   for (int q = 0; q < NQ; ++q) accl[lane + 64 * q] = 0.0;
   int64_t row = my_row(wv, a.xcd_chunk);
   if (row >= a.n_local) return;
-  if (a.rows) row = uniform64(a.rows[row]);
+  if ((FL & 2) != 0) row = uniform64(a.rows[row]);
   const int64_t grow = a.row0 + row;
   const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
   for (int64_t base = start; base < end; base += 64) {
@@ -356,7 +341,7 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
 // per row, and with one row per wave at full occupancy (8 waves per SIMD) part of the step is the latency of
 // that chain.  Both rows' loads of a phase are in flight together: 1002 -> 917-928 us at 2M x 200, 462 -> 399 at
 // 1M x 100, 77 -> 61 at 200k x 50; four rows per wave: 1120 / 418 / 62 (profiles/r02_kbench_first_rows.txt).
-template <typename VT, int NQ, int R>
+template <typename VT, int NQ, int R, int FL = 0>
 __global__ __launch_bounds__(256) void k_nam_first2(StepArgs a, const CellInfo* __restrict__ info) {
   extern __shared__ double sm[];
   if (STEP_STOPPED(a)) return;
@@ -374,7 +359,7 @@ __global__ __launch_bounds__(256) void k_nam_first2(StepArgs a, const CellInfo* 
     const int64_t blk = (b / a.xcd_chunk) * (8 * (int64_t)a.xcd_chunk) + x * a.xcd_chunk + (b % a.xcd_chunk);
     row[r] = uniform64(blk * 4 + wv);
     live[r] = row[r] < a.n_local;
-    if (live[r] && a.rows) row[r] = uniform64(a.rows[row[r]]);
+    if ((FL & 2) != 0 && live[r]) row[r] = uniform64(a.rows[row[r]]);
     start[r] = end[r] = 0;
   }
 #pragma unroll
@@ -422,14 +407,14 @@ __global__ __launch_bounds__(256) void k_nam_first2(StepArgs a, const CellInfo* 
 // lanes cost half the load instructions of 8-byte ones, -18 % time at N=100).  Neighbour index
 // and weight travel lane -> SGPR by v_readlane, the row base T + j*ld is scalar arithmetic, and
 // products / sums are unfused and in CSR order (scipy's csr_matvecs rounding sequence).
-template <typename VT, int NQ2, int U = 8>       // U: neighbour rows in flight per wave (8 beats 16 and 32; 4 beyond 512 columns: registers)
+template <typename VT, int NQ2, int U = 8, int FL = 0>       // U: neighbour rows in flight per wave (8 beats 16 and 32; 4 beyond 512 columns: registers)
 __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
   if (STEP_STOPPED(a)) return;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int64_t row = my_row(wv, a.xcd_chunk);
   if (row >= a.n_local) return;
-  if (a.rows) row = uniform64(a.rows[row]);
+  if ((FL & 2) != 0) row = uniform64(a.rows[row]);
   const int64_t grow = a.row0 + row;
   const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
   const double2* __restrict__ Tin = (const double2*)a.Tin;
@@ -488,7 +473,7 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
     s[2 * q] = add_rn(acc[q].x, mul_rn(a.w, own.x));          // + w*s/colsums  (exact for w=1)
     s[2 * q + 1] = add_rn(acc[q].y, mul_rn(a.w, own.y));
   }
-  finish_row<2 * NQ2, ColPair>(a, row, grow, lane, s);
+  finish_row<2 * NQ2, ColPair, FL>(a, row, grow, lane, s);
 }
 
 // Narrow states (ld <= 64 columns, i.e. at most 32 column pairs): TWO destination rows per wave, one
@@ -517,7 +502,7 @@ __device__ __forceinline__ double half_sum(double v, int h) {
   return h ? (r2 + r3) : (r0 + r1);           // what wave_sum gives when the other half holds zeros
 }
 
-template <typename VT>
+template <typename VT, int FL = 0>
 __global__ __launch_bounds__(256) void k_nam_step_pair(StepArgs a) {
   if (STEP_STOPPED(a)) return;
   constexpr int U = 4;                          // neighbour rows in flight per half-wave (8: +2 % time, 16: +16 %)
@@ -527,7 +512,7 @@ __global__ __launch_bounds__(256) void k_nam_step_pair(StepArgs a) {
   const int64_t row_a = my_row(wv, a.xcd_chunk) * 2;          // this wave: rows row_a, row_a + 1
   if (row_a >= a.n_local) return;
   const bool have = row_a + h < a.n_local;                    // odd n_local: the last wave's upper half idles
-  const int64_t row = a.rows ? (int64_t)a.rows[have ? row_a + h : row_a] : (have ? row_a + h : row_a);
+  const int64_t row = (FL & 2) != 0 ? (int64_t)a.rows[have ? row_a + h : row_a] : (have ? row_a + h : row_a);
   const int64_t grow = a.row0 + row;
   const int64_t start = a.indptr[row];
   const int deg = have ? (int)(a.indptr[row + 1] - start) : 0;
@@ -645,7 +630,7 @@ __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p
 // (tools/micro/lds_scatter_pattern.hip: 14.3 -> 11.7 clk per ds_add_f64, floor 7.4) is therefore not worth its
 // bookkeeping.  Counters (profiles/r03_pmc_summary_C4.txt): VALU 42 % and LDS 49 % of the cycles, 61 % of the wave
 // cycles waiting, 12.5 vector instructions per edge: no single unit is the limit.
-template <typename VT, int NQ2, int U = 6>
+template <typename VT, int NQ2, int U = 6, int FL = 0>
 __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
   if (STEP_STOPPED(a)) return;
   extern __shared__ double sm[];
@@ -656,7 +641,7 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
   for (int q = 0; q < 2 * NQ2; ++q) acc[lane + 64 * q] = 0.0;
   int64_t row = my_row(wv, a.xcd_chunk);
   if (row >= a.n_local) return;
-  if (a.rows) row = uniform64(a.rows[row]);
+  if ((FL & 2) != 0) row = uniform64(a.rows[row]);
   const int64_t grow = a.row0 + row;
   const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
   const double2* __restrict__ Tin = (const double2*)a.Tin;
@@ -735,7 +720,7 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
       s[2 * q + 1] = act ? acc[2 * c2 + 1] : 0.0;
     }
   }
-  finish_row<2 * NQ2, ColPair>(a, row, grow, lane, s);
+  finish_row<2 * NQ2, ColPair, FL>(a, row, grow, lane, s);
 }
 
 __global__ void k_cellinfo(const double* __restrict__ colsum, const int32_t* __restrict__ sid, int64_t n,
@@ -921,24 +906,33 @@ __global__ void k_scale_rows(const double* __restrict__ s, const double* __restr
 template <typename VT, int NQ>
 int launch_first_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
   static const bool one = getenv("CNA_FIRST_ONE_ROW") != nullptr;      // A/B switch
-  if (!one && (grid.x & 15) == 0) {       // an even number of workgroups per XCD: one workgroup takes two of them
-    hipLaunchKernelGGL((k_nam_first2<VT, NQ, 2>), dim3(grid.x / 2), dim3(256), sizeof(double) * 8 * 64 * NQ, c->stream, a,
-                       (const CellInfo*)c->cellinfo);
-    return 0;
+  const bool two = !one && (grid.x & 15) == 0;     // an even number of workgroups per XCD: one workgroup takes two of them
+  const size_t lds = sizeof(double) * (two ? 8 : 4) * 64 * NQ;
+  const CellInfo* info = (const CellInfo*)c->cellinfo;
+  if (a.rows) {
+    if (two) hipLaunchKernelGGL((k_nam_first2<VT, NQ, 2, 2>), dim3(grid.x / 2), dim3(256), lds, c->stream, a, info);
+    else hipLaunchKernelGGL((k_nam_first<VT, NQ, 2>), grid, dim3(256), lds, c->stream, a, info);
+  } else {
+    if (two) hipLaunchKernelGGL((k_nam_first2<VT, NQ, 2, 0>), dim3(grid.x / 2), dim3(256), lds, c->stream, a, info);
+    else hipLaunchKernelGGL((k_nam_first<VT, NQ, 0>), grid, dim3(256), lds, c->stream, a, info);
   }
-  hipLaunchKernelGGL((k_nam_first<VT, NQ>), grid, dim3(256), sizeof(double) * 4 * 64 * NQ, c->stream, a,
-                     (const CellInfo*)c->cellinfo);
   return 0;
 }
+// the instantiation of a step kernel by what the launch needs (finish_row): row list, selection by-product, or neither
 template <typename VT, int NQ2, int U = 8>
 int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
-  hipLaunchKernelGGL((k_nam_step<VT, NQ2, U>), grid, dim3(256), 0, c->stream, a);
+  if (a.rows) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 2>), grid, dim3(256), 0, c->stream, a);
+  else if (a.sel_X) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 1>), grid, dim3(256), 0, c->stream, a);
+  else hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 0>), grid, dim3(256), 0, c->stream, a);
   return 0;
 }
 
 template <typename VT, int NQ2>
 int launch_step_sparse_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
-  hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2>), grid, dim3(256), sizeof(double) * 4 * 128 * NQ2, c->stream, a);
+  const size_t lds = sizeof(double) * 4 * 128 * NQ2;
+  if (a.rows) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 6, 2>), grid, dim3(256), lds, c->stream, a);
+  else if (a.sel_X) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 6, 1>), grid, dim3(256), lds, c->stream, a);
+  else hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 6, 0>), grid, dim3(256), lds, c->stream, a);
   return 0;
 }
 
@@ -983,7 +977,8 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
       default: launch_step_sparse_t<VT, 8>(c, a, grid); break;
     }
   } else if (pair) {
-    hipLaunchKernelGGL((k_nam_step_pair<VT>), grid, dim3(256), 0, c->stream, a);
+    if (a.rows) hipLaunchKernelGGL((k_nam_step_pair<VT, 2>), grid, dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_nam_step_pair<VT, 0>), grid, dim3(256), 0, c->stream, a);
   } else {
     switch ((a.ld / 2 + 63) / 64) {
       case 1: launch_step_t<VT, 1>(c, a, grid); break;
@@ -1099,9 +1094,7 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
   a.sel_xscale = nullptr;
   a.sel_nz = nullptr;
   a.sel_ldx = a.sel_Kp = 0;
-  a.store_mode = 0;
-  if (const char* e = getenv("CNA_STEP_STORE")) a.store_mode = atoi(e) & 3;      // experiments
-  if (c->byp_arm && c->byp_skip_nam) a.store_mode |= 4;
+  a.skip_nam = (c->byp_arm && c->byp_skip_nam) ? 1 : 0;
   if (c->byp_arm) {            // c_api.hip:arm_select_byproduct has sized X / planes / coefficients for this launch
     a.sel_X = c->X;
     a.sel_ldx = c->ldx;
