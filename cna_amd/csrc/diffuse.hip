@@ -341,8 +341,12 @@ __global__ __launch_bounds__(256) void k_nam_first(StepArgs a, const CellInfo* _
 // per row, and with one row per wave at full occupancy (8 waves per SIMD) part of the step is the latency of
 // that chain.  Both rows' loads of a phase are in flight together: 1002 -> 917-928 us at 2M x 200, 462 -> 399 at
 // 1M x 100, 77 -> 61 at 200k x 50; four rows per wave: 1120 / 418 / 62 (profiles/r02_kbench_first_rows.txt).
+// (amdgpu_num_sgpr(80): with more than 80 scalar registers a CU admits 7 or 6 of these workgroups instead of 8 --
+// MI355X_MICROARCH.md, residency -- and the latency-bound steps feel it: this kernel 0.94 -> 0.84 ms at 2M x 200 with its
+// 98 registers capped, the spills are a handful of lane moves outside the loops; the same cap on the compressed step, the selection and the
+// batch-kurtosis kernels changed nothing or cost 2-4 %)
 template <typename VT, int NQ, int R, int FL = 0>
-__global__ __launch_bounds__(256) void k_nam_first2(StepArgs a, const CellInfo* __restrict__ info) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80))) void k_nam_first2(StepArgs a, const CellInfo* __restrict__ info) {
   extern __shared__ double sm[];
   if (STEP_STOPPED(a)) return;
   const int lane = threadIdx.x & 63;
