@@ -64,6 +64,7 @@ SIGNATURES = {
     'cna_gram_launch': (C.c_int, [c_ctx]),
     'cna_gram_fetch': (C.c_int, [c_ctx, C.c_void_p]),
     'cna_project': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p]),
+    'cna_x_identity': (C.c_int, [c_ctx, C.POINTER(C.c_int)]),
     'cna_ncorrs': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, c_f64p]),
     'cna_null_local': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'cna_condition_phenotypes': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),

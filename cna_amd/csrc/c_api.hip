@@ -312,9 +312,9 @@ int cna_graph_upload(cna_ctx* c, int64_t n_global, int64_t row0, int64_t n_local
   c->t_valid = false;
   c->nam_valid = false; c->nam_lazy = false;
   c->x_valid = false;
-  c->xq_valid = false; c->byp_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
   c->ncorrs_valid = false;
-  c->xq_valid = false; c->byp_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
   c->coef_early = false;
   c->fdr_inline = false;
   c->steps_done = 0;
@@ -461,7 +461,7 @@ int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const doubl
   c->t_valid = false;
   c->nam_valid = false; c->nam_lazy = false;
   c->x_valid = false;
-  c->xq_valid = false; c->byp_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
   CNA_TRY(ensure_sparse_state(c));
   return 0;
 }
@@ -479,7 +479,7 @@ int cna_restart_nam(cna_ctx* c) {
   c->t_valid = false;
   c->nam_valid = false; c->nam_lazy = false;
   c->x_valid = false;
-  c->xq_valid = false; c->byp_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
   return 0;
 }
 
@@ -642,6 +642,7 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
   const bool first = c->steps_done == 0;
   if (!first && !c->t_valid) CNA_FAIL(CNA_ESTATE, "previous step did not keep its state (may_continue=0)");
   c->byp_valid = false;
+  c->x_ident = false;
   c->nam_lazy = false;
   const bool arm = !first && !may_continue && may_stop && !c->auto_stop && arm_select_byproduct(c) == 1;
   // ... and then the NAM itself is not written: the analysis reads X, and whoever does ask for the NAM (res.nam, a later
@@ -1075,7 +1076,7 @@ int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_
   c->x_valid = true;
   c->x_from_nam = true;
   c->ncorrs_valid = false;
-  c->xq_valid = false; c->byp_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1144,7 +1145,7 @@ int cna_select_checked(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, cons
   c->x_valid = true;
   c->x_from_nam = true;
   c->ncorrs_valid = false;
-  c->xq_valid = false; c->byp_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1203,7 +1204,7 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
   }
   const int rk = (c->resid_rk > 0 && c->resid_n == Nx) ? c->resid_rk : 0;     // one-shot: cna_set_resid_factors
   // the rows leave this pass final: their fixed-point digit planes for the integer local null go out with them
-  c->xq_valid = false; c->byp_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
   const bool with_q = y != nullptr && Nx <= 256 && nx > 0 && null_i8_enabled();
   const int KSq = (Nx + 31) / 32;
   if (with_q) CNA_TRY(ensure_xq(c, KSq));
@@ -1256,6 +1257,10 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
   c->x_from_nam = true;
   c->ncorrs_valid = y != nullptr;     // meaningful only when no cell had zero variance (the caller checks)
   c->xq_valid = with_q;
+  // X is now the standardised NAM of every cell with the samples in place and nothing regressed out: a function of
+  // the NAM alone, so a further analysis of the resident dataset that asks for the same selection can keep it
+  // (cna_x_identity) and take only its coefficients (cna_ncorrs)
+  c->x_ident = !keep_idx && in_place && rk == 0 && h == 0 && Nx == c->N && nx == c->n_local;
   c->coef_early = false;
   c->fdr_inline = false;
   if (fused) {                                   // what cna_gram_launch does after its kernels
@@ -1348,7 +1353,7 @@ int cna_upload_x(cna_ctx* c, const double* x_local, int64_t n_rows, int n_cols) 
   c->x_valid = true;
   c->x_from_nam = false;
   c->ncorrs_valid = false;
-  c->xq_valid = false; c->byp_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1368,7 +1373,7 @@ int cna_resid_apply(cna_ctx* c, const double* M, int center) {
   CNA_TRY(launch_xb(c, (const double*)c->scratch, ldb, Nx, center != 0, c->X, ldx));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->ncorrs_valid = false;
-  c->xq_valid = false; c->byp_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1411,7 +1416,7 @@ int cna_resid_lowrank(cna_ctx* c, const double* C, const double* W, int r, int c
   HIP_TRY(hipStreamSynchronize(c->stream));        // Ct is a local
   if (max_abs_out) *max_abs_out = m;
   c->ncorrs_valid = y != nullptr;
-  c->xq_valid = false; c->byp_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1478,7 +1483,7 @@ int cna_resid_lowrank_bk(cna_ctx* c, const double* C, const double* W, int r, co
   if (max_abs_out) *max_abs_out = m;
   *median_out = med;
   c->ncorrs_valid = true;
-  c->xq_valid = false; c->byp_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1489,7 +1494,7 @@ int cna_standardize(cna_ctx* c, int center) {
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
   CNA_TRY(launch_standardize(c, center));
   c->ncorrs_valid = false;
-  c->xq_valid = false; c->byp_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1570,6 +1575,13 @@ int cna_project_keep(cna_ctx* c, const double* W, int n_w) {
 }
 
 // ------------------------------------------------------------------------- association
+int cna_x_identity(cna_ctx* c, int* yes) {
+  CHECK_CTX(c);
+  if (!yes) CNA_FAIL(CNA_EINVAL, "cna_x_identity: yes is required");
+  *yes = (c->x_valid && c->x_ident && !c->auto_pending) ? 1 : 0;
+  return 0;
+}
+
 int cna_ncorrs(cna_ctx* c, const double* y, double* out_local, double* max_abs) {
   CHECK_CTX(c);
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");

@@ -130,6 +130,7 @@ struct cna_ctx {
   int64_t* keep_store = nullptr;  // allocation behind keep_idx
   int64_t keep_cap = 0;
   bool x_valid = false, x_from_nam = false;
+  bool x_ident = false;            // X = standardised NAM, every cell, samples in place, nothing regressed out (cna_x_identity)
   // The selection pass as a by-product of the walk's last step (cna_nam_select_hint): when the caller says which
   // standardised phenotype the analysis will use and nothing will be filtered or regressed out, the last step's
   // write-out also leaves X = centred / standardised NAM, its digit planes, the coefficients X.y/N and the

@@ -60,6 +60,9 @@ class Engine(_order.CellOrder):
         # keep the NAM across analyses of one dataset (tools._nam._nam_device); CNA_NAM_CACHE=0 or
         # engine.reuse_nam = False recomputes it every call (what bench.py measures)
         self.reuse_nam = os.environ.get('CNA_NAM_CACHE', '1') not in ('0', 'off', 'no')
+        # ... and, opt-in, the standardised NAM of an analysis without covariates and batches: a further phenotype then
+        # only takes new coefficients (tools._association.compute_nam_and_reindex); CNA_X_CACHE=1 or engine.reuse_x = True
+        self.reuse_x = os.environ.get('CNA_X_CACHE', '0') in ('1', 'on', 'yes')
 
     # ---------------------------------------------------------------- lifetime
     def close(self):
@@ -517,6 +520,13 @@ class Engine(_order.CellOrder):
         return out
 
     # ---------------------------------------------------------------- association
+    def x_identity_resident(self):
+        """True when X on the device is the standardised NAM of the resident walk for "every cell, samples in place,
+        nothing regressed out": a further analysis of the dataset with that selection keeps it (ncorrs(y) next)."""
+        yes = C.c_int(0)
+        check(self.lib.cna_x_identity(self.h, C.byref(yes)), 'cna_x_identity')
+        return bool(yes.value)
+
     def ncorrs(self, y, fetch=False):
         y = _f64(y)
         rows, cols = self.matrix_shape(MAT_X)

@@ -438,7 +438,21 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     kept = _qc_device(engine, labels, batches_qc, show_progress=show_progress)
 
     nzero = -1
-    if plan is not None and (plan.kind == 'identity' or single):
+    if (plan is not None and plan.kind == 'identity' and finish_walk is None and y_std is not None
+            and len(y_std) == len(colmap) == len(labels) and np.array_equal(colmap, np.arange(len(colmap))) and kept.all()
+            and getattr(engine, 'reuse_nam', False) and getattr(engine, 'reuse_x', False)
+            and hasattr(engine, 'x_identity_resident') and engine.x_identity_resident()):
+        # A further phenotype on the resident dataset (the walk was skipped: NAM cache): the standardised NAM of this
+        # very selection is still on the device from the previous analysis -- it does not depend on the phenotype -- so
+        # only the coefficients are new.  Opt-in (engine.reuse_x): the coefficients then come from
+        # another kernel than in a from-scratch call (same X, another order of the row sums: last-bit differences), and
+        # what a call returns should not depend on which calls came before it unless the caller says so.
+        engine._fused = None
+        _, maxabs = engine.ncorrs(y_std)
+        nzero = 0
+        plan.maxabs = maxabs
+        plan.standardized = True
+    elif plan is not None and (plan.kind == 'identity' or single):
         # nothing to regress out, or a projector that the selection pass applies in factored form
         # (covariates without batches): select + centre [+ M] + /std in one pass over the NAM
         if single:

@@ -241,6 +241,11 @@ int  cna_project(cna_ctx* ctx, const double* W, int n_w, double* out_local);
 int  cna_project_keep(cna_ctx* ctx, const double* W, int n_w);
 
 /* ---- association (_association.py:77-120, _stats.py:34-83) ----------------------------- */
+/* *yes = 1 when the working matrix X on the device is the standardised NAM of the resident walk with every cell and
+ * every sample kept and nothing regressed out (what cna_select_standardized leaves for a call without covariates and
+ * batches, _nam.py:122,159): it depends on the NAM only, not on the phenotype, so a further analysis of the same dataset
+ * keeps it and takes its coefficients with cna_ncorrs (_association.py:77) instead of repeating the selection pass. */
+int  cna_x_identity(cna_ctx* ctx, int* yes);
 /* ncorrs = (y[:,None]*NAMresid).mean(axis=0) (_association.py:77); kept on the device and
  * optionally copied out (local rows); max_abs = max|ncorrs| over all ranks (_association.py:101). */
 int  cna_ncorrs(cna_ctx* ctx, const double* y, double* out_local, double* max_abs);
