@@ -1794,10 +1794,7 @@ static int null_local_go(cna_ctx* c, int col0) {
     int64_t* otails = cv.take<int64_t>(2 * (int64_t)T);    // [ranks | num_detected]
     const int64_t n_out = c->local_view ? c->n_local : c->n_global;
     double* coef_local = c->coef_dev;
-    double* fdr_local = c->coef_dev + 2 * c->n_pad;
-    double* fdr_u = c->coef_dev + 3 * c->n_pad;
     double* tab = c->coef_dev + 4 * c->n_pad;
-    (void)fdr_local; (void)fdr_u;
     // Behind the null only the FDR table is formed and sent (2.4 KB).  The per-cell half of the lookup -- how many
     // thresholds lie at or below |coef_i| -- needs nothing from the null: it runs on the coefficient stream now and its
     // 2 bytes per cell cross PCIe under the null kernel; the host puts table and counts together.  (Round 2 stored

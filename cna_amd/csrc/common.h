@@ -309,7 +309,6 @@ int launch_obs_counts(cna_ctx* c, const double* edges_dev, const double* thr_dev
                       double inv_step, unsigned long long* hist_dev /* 2*T */);
 int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, int64_t* tails);
 int launch_tail_sums(cna_ctx* c, const int64_t* tails, int P, int T, int64_t* sums);
-int launch_store_host(cna_ctx* c, const double* src, int64_t n, double* dst_host);
 int launch_fdr_table(cna_ctx* c, const int64_t* sums, const int64_t* ranks, int T, int P, double* fdr, double* runmin);
 // rows16.hip: sixteen rows per wave, projector on the matrix cores; 1 = queued, 0 = not eligible
 int launch_rowpass16(cna_ctx* c, const double* src, int lds, double* dst, int ldd, int64_t nrows, int N, const double* W_dev,
@@ -318,8 +317,6 @@ int launch_rowpass16(cna_ctx* c, const double* src, int lds, double* dst, int ld
 int launch_percell_bins(cna_ctx* c, hipStream_t st, const double* coef_local, const double* thr_dev, int T, double thr0,
                         double inv_step, unsigned short* bins);
 extern "C" int cna_host_expand_u16(double* dst, const uint16_t* bins, int64_t n, const double* runmin, int T, int nthreads);
-int launch_percell_lookup(cna_ctx* c, const double* coef_local, const double* thr_dev, const double* runmin_dev, int T,
-                          double thr0, double inv_step, double* fdr_local);
 int launch_unpermute2(cna_ctx* c, const double* a, const double* b, const int64_t* idx, int64_t n, double* oa,
                       double* ob);
 int launch_percell_fdr(cna_ctx* c, const double* thr_dev, const double* runmin_dev, int T, double thr0,

@@ -1541,21 +1541,6 @@ __global__ __launch_bounds__(512) void k_fdr_table(const int64_t* __restrict__ s
   if (t < T) runmin[t] = sh[cur][t];
 }
 
-// device -> pinned host by store instructions (a hipMemcpyAsync queued behind a long kernel holds up
-// the copy engine's queue for every other stream's copies until that kernel is done)
-__global__ void k_store_host(const double* __restrict__ src, int64_t n, double* __restrict__ dst_host) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    __builtin_nontemporal_store(src[i], &dst_host[i]);
-}
-
-int launch_store_host(cna_ctx* c, const double* src, int64_t n, double* dst_host) {
-  if (n == 0) return 0;
-  const int64_t want = (n + 255) / 256;
-  hipLaunchKernelGGL(k_store_host, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(256), 0, c->stream, src, n, dst_host);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
 int launch_fdr_table(cna_ctx* c, const int64_t* sums, const int64_t* ranks, int T, int P, double* fdr, double* runmin) {
   hipLaunchKernelGGL(k_fdr_table, dim3(1), dim3(512), 0, c->stream, sums, ranks, T, P, fdr, runmin);
   HIP_TRY(hipGetLastError());
@@ -1568,17 +1553,6 @@ int launch_percell_bins(cna_ctx* c, hipStream_t st, const double* coef_local, co
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_percell_bins, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, coef_local, n, thr_dev, T, thr0,
                      inv_step, c->orig_idx, bins);
-  HIP_TRY(hipGetLastError());
-  return 0;
-}
-
-int launch_percell_lookup(cna_ctx* c, const double* coef_local, const double* thr_dev, const double* runmin_dev, int T,
-                          double thr0, double inv_step, double* fdr_local) {
-  const int64_t n = c->n_local;
-  if (n == 0) return 0;
-  ProfScope ps(c, CNA_K_PERCELL_FDR);
-  hipLaunchKernelGGL(k_percell_fdr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, coef_local, n, thr_dev,
-                     runmin_dev, T, thr0, inv_step, fdr_local);
   HIP_TRY(hipGetLastError());
   return 0;
 }
