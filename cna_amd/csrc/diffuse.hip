@@ -986,7 +986,9 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
   } else {
     switch ((a.ld / 2 + 63) / 64) {
       case 1: launch_step_t<VT, 1>(c, a, grid); break;
-      case 2: launch_step_t<VT, 2, 10>(c, a, grid); break;      // 129 ... 256 columns: ten rows in flight (7.82 -> 7.69 ms at 2M x 200; 9: the same, 11 / 12: as 8)
+      // 129 ... 256 columns: ten rows in flight (7.82 -> 7.69 ms at 2M x 200; 9: the same, 11 / 12: as 8); with the
+      // selection by-product in the write-out, eight (8.45 against 8.55 ms, three runs each on one box; 6: 8.61, 12: 8.95)
+      case 2: if (a.sel_X) launch_step_t<VT, 2, 8>(c, a, grid); else launch_step_t<VT, 2, 10>(c, a, grid); break;
       case 3: launch_step_t<VT, 3>(c, a, grid); break;
       case 4: launch_step_t<VT, 4>(c, a, grid); break;
       case 5: case 6: launch_step_t<VT, 6, 4>(c, a, grid); break;
