@@ -282,6 +282,10 @@ def kernel_table(m, world):
             # the last step also did the selection pass (diffuse.hip:select_tail): it writes X instead of the NAM (same
             # bytes) plus what that pass adds -- three digit planes of 32 ceil(N/32) bytes, coefficient, row scale
             work += m['n_loc'] * (3 * 32 * ((m['N'] + 31) // 32) + 24)
+        if name == 'gram' and cnt > m['steps']:
+            # the product ran range by range under the walk's last step (c_api.hip:ranged_last_step): a launch covers
+            # 1 / ranges of the cells
+            work /= cnt / m['steps']
         avg_s = ms / cnt * 1e-3
         ach = work / avg_s / (1e9 if bound == 'hbm' else 1e12)
         peak = HBM_PEAK_GBS if bound == 'hbm' else F64_MFMA_PEAK_TF

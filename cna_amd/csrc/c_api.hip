@@ -83,6 +83,8 @@ static void prof_flush(cna_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   (void)hipStreamSynchronize(c->copy_stream);
   if (c->coef_stream) (void)hipStreamSynchronize(c->coef_stream);
+  if (c->gram_stream) (void)hipStreamSynchronize(c->gram_stream);
+  if (c->walk_stream) (void)hipStreamSynchronize(c->walk_stream);
   std::lock_guard<std::mutex> lock(c->prof_mu);
   if (c->prof_pending.empty()) return;
   for (auto& s : c->prof_pending) {
@@ -216,16 +218,18 @@ int cna_ctx_create(int device, cna_ctx** out) {
 }
 
 int cna_ctx_destroy(cna_ctx* c) {
-  if (c && c->auto_state) { (void)hipFree(c->auto_state); c->auto_state = nullptr; }
-  if (c && c->byp_buf) { (void)hipFree(c->byp_buf); c->byp_buf = nullptr; }
-  if (c && c->pair_buf) { (void)hipFree(c->pair_buf); c->pair_buf = nullptr; }
   if (!c) return 0;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  if (c->gram_stream) (void)hipStreamSynchronize(c->gram_stream);
+  if (c->walk_stream) (void)hipStreamSynchronize(c->walk_stream);
+  if (c->auto_state) { (void)hipFree(c->auto_state); c->auto_state = nullptr; }
+  if (c->byp_buf) { (void)hipFree(c->byp_buf); c->byp_buf = nullptr; }
+  if (c->pair_buf) { (void)hipFree(c->pair_buf); c->pair_buf = nullptr; }
   prof_flush(c);
   comm_destroy(c);
   void* bufs[] = {c->i8_buf, c->xq, c->xq_scale, c->coef_dev, c->proj, c->sp_pair, c->sp_cnt, c->null_part, c->rp16_buf, c->halo_send_idx, c->halo_recv_idx, c->halo_rows_b, c->halo_rows_i, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
-                  c->nam, c->X, c->X2, c->resid_f, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf};
+                  c->nam, c->X, c->X2, c->resid_f, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf, c->gram_part, c->bins_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto e : c->ev_pool) (void)hipEventDestroy(e);
@@ -240,6 +244,10 @@ int cna_ctx_destroy(cna_ctx* c) {
   if (c->coef_copied) (void)hipEventDestroy(c->coef_copied);
   if (c->null_done) (void)hipEventDestroy(c->null_done);
   if (c->bins_copied) (void)hipEventDestroy(c->bins_copied);
+  if (c->gram_stream) (void)hipStreamDestroy(c->gram_stream);
+  if (c->walk_stream) (void)hipStreamDestroy(c->walk_stream);
+  for (hipEvent_t e : {c->gram_pre_done, c->range_done, c->walk_fork, c->walk_join})
+    if (e) (void)hipEventDestroy(e);
   if (c->halo_stream) (void)hipStreamDestroy(c->halo_stream);
   if (c->halo_e1) (void)hipEventDestroy(c->halo_e1);
   if (c->halo_e2) (void)hipEventDestroy(c->halo_e2);
@@ -255,6 +263,7 @@ int cna_ctx_sync(cna_ctx* c) {
   CHECK_CTX(c);
   AUTO_FINISH(c);
   HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->gram_stream && c->gram_pre_pending) HIP_TRY(hipStreamSynchronize(c->gram_stream));
   return 0;
 }
 
@@ -312,9 +321,9 @@ int cna_graph_upload(cna_ctx* c, int64_t n_global, int64_t row0, int64_t n_local
   c->t_valid = false;
   c->nam_valid = false; c->nam_lazy = false;
   c->x_valid = false;
-  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false; c->gram_pre = false;
   c->ncorrs_valid = false;
-  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false; c->gram_pre = false;
   c->coef_early = false;
   c->fdr_inline = false;
   c->steps_done = 0;
@@ -461,7 +470,7 @@ int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const doubl
   c->t_valid = false;
   c->nam_valid = false; c->nam_lazy = false;
   c->x_valid = false;
-  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false; c->gram_pre = false;
   CNA_TRY(ensure_sparse_state(c));
   return 0;
 }
@@ -479,7 +488,7 @@ int cna_restart_nam(cna_ctx* c) {
   c->t_valid = false;
   c->nam_valid = false; c->nam_lazy = false;
   c->x_valid = false;
-  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false; c->gram_pre = false;
   return 0;
 }
 
@@ -635,6 +644,105 @@ static int arm_select_byproduct(cna_ctx* c) {
   return 1;
 }
 
+// ---- the Gram matrix under the walk's last step (see common.h: gram_pre) -------------------------------------
+// CNA_GRAM_OVERLAP = K: the step that leaves the selection by-product runs in K row ranges (0 / 1: one launch, the
+// Gram kernel afterwards as before).  CNA_GRAM_CUS = m (experiments): the Gram kernels confined to m CUs of every XCD
+// and the ranged step to the others (hipExtStreamCreateWithCUMask; bit i of the mask = CU i / 8 of XCD i % 8).
+static int gram_overlap_ranges() {
+  const char* e = getenv("CNA_GRAM_OVERLAP");
+  const int k = e ? atoi(e) : 4;
+  return k < 0 ? 0 : (k > 64 ? 64 : k);
+}
+static int ensure_gram_stream(cna_ctx* c) {
+  if (c->gram_stream_state) return c->gram_stream_state;
+  c->gram_stream_state = -1;
+  const char* e = getenv("CNA_GRAM_CUS");
+  const int cus = e ? atoi(e) : 0;
+  hipError_t err;
+  if (cus > 0 && cus < 32) {
+    uint32_t gm[8] = {0}, wm[8] = {0};
+    for (int i = 0; i < 256; ++i) ((i / 8 < cus) ? gm : wm)[i / 32] |= 1u << (i % 32);
+    err = hipExtStreamCreateWithCUMask(&c->gram_stream, 8, gm);
+    if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&c->walk_stream, 8, wm);
+  } else {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    const char* pe = getenv("CNA_GRAM_PRIO");
+    const int pr = pe ? atoi(pe) : 0;                      // > 0: above the walk's stream, < 0: below
+    err = hipStreamCreateWithPriority(&c->gram_stream, hipStreamNonBlocking, pr > 0 ? hi : (pr < 0 ? lo : (lo + hi) / 2));
+  }
+  if (err == hipSuccess) err = hipEventCreateWithFlags(&c->gram_pre_done, hipEventDisableTiming);
+  if (err == hipSuccess) err = hipEventCreateWithFlags(&c->range_done, hipEventDisableTiming);
+  if (err == hipSuccess) err = hipEventCreateWithFlags(&c->walk_fork, hipEventDisableTiming);
+  if (err == hipSuccess) err = hipEventCreateWithFlags(&c->walk_join, hipEventDisableTiming);
+  if (err != hipSuccess) { (void)hipGetLastError(); return -1; }
+  c->gram_stream_state = 1;
+  return 1;
+}
+// whoever is about to write c->gram_buf / c->gram_part on another stream, or to start the next ranged product
+static int gram_pre_settle(cna_ctx* c) {
+  if (c->gram_pre_pending) {
+    HIP_TRY(hipStreamWaitEvent(c->stream, c->gram_pre_done, 0));
+    c->gram_pre_pending = false;
+  }
+  return 0;
+}
+static int64_t lcm64(int64_t a, int64_t b) {
+  int64_t x = a, y = b;
+  while (y) { const int64_t t = x % y; x = y; y = t; }
+  return a / x * b;
+}
+// The last step of a walk that leaves the selection by-product, in K row ranges with the Gram kernel of every range
+// behind it on gram_stream.  1: queued that way (c->gram_pre set), 0: not eligible (the caller launches the step as
+// one kernel), < 0 never; errors are returned as positive codes through *rc.
+static int ranged_last_step(cna_ctx* c, bool first, bool want_kurt, bool may_stop, int* rc) {
+  *rc = 0;
+  const int K = gram_overlap_ranges();
+  if (K < 2 || c->nx != c->n_local || c->Nx < 2 || c->Nx > 1024) return 0;
+  if (ensure_gram_stream(c) != 1) return 0;
+  const int64_t turn = nam_step_turn_rows(c, c->n_local);
+  if (turn <= 0) return 0;
+  if ((*rc = gram_pre_settle(c)) != 0) return 1;
+  int64_t unit_g = 0;
+  if ((*rc = gram_pre_begin(c, &unit_g)) != 0) return 1;
+  const int64_t unit = lcm64(turn, unit_g);
+  const int64_t nunits = c->n_local / unit;
+  if (nunits < 2 * K || nam_step_turn_rows(c, unit) != turn) return 0;
+  void* g = c->gram_buf;
+  if ((*rc = dev_reserve(c, &g, &c->gram_cap, (int64_t)sizeof(double) * c->Nx * c->Nx)) != 0) return 1;
+  c->gram_buf = (double*)g;
+  hipStream_t W = c->walk_stream ? c->walk_stream : c->stream;
+#define RL_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cna_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); *rc = (int)e_; return 1; } } while (0)
+  if (W != c->stream) {
+    RL_TRY(hipEventRecord(c->walk_fork, c->stream));
+    RL_TRY(hipStreamWaitEvent(W, c->walk_fork, 0));
+  }
+  const bool sparse_step = c->sp_cnt && c->steps_done == 1;
+  const int kid = sparse_step ? CNA_K_NAM_STEP_SPARSE : CNA_K_NAM_STEP;
+  if (c->prof) prof_begin(c, kid, W);                     // one span over all ranges: the step as the other launches report it
+  int64_t b0 = 0;
+  for (int r = 0; r < K; ++r) {
+    const int64_t b1 = r + 1 == K ? c->n_local : (nunits * (r + 1) / K) * unit;
+    if ((*rc = launch_nam_step(c, first, want_kurt, false, may_stop, false, nullptr, 0, b0, b1 - b0, W, false)) != 0) break;
+    if (r + 1 == K && c->prof) prof_end(c, kid, W);
+    RL_TRY(hipEventRecord(c->range_done, W));
+    RL_TRY(hipStreamWaitEvent(c->gram_stream, c->range_done, 0));
+    if ((*rc = gram_pre_range(c, b0, b1, c->gram_stream)) != 0) break;
+    b0 = b1;
+  }
+  if (*rc) return 1;
+  if ((*rc = gram_pre_finish(c, c->gram_buf, c->gram_stream)) != 0) return 1;
+  RL_TRY(hipEventRecord(c->gram_pre_done, c->gram_stream));
+  if (W != c->stream) {
+    RL_TRY(hipEventRecord(c->walk_join, W));
+    RL_TRY(hipStreamWaitEvent(c->stream, c->walk_join, 0));
+  }
+#undef RL_TRY
+  c->gram_pre = true;
+  c->gram_pre_pending = true;
+  return 1;
+}
+
 int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
   CHECK_CTX(c);
   if (!c->sid || !c->have_colsum) CNA_FAIL(CNA_ESTATE, "cna_nam_step needs cna_colsums and cna_set_samples");
@@ -644,6 +752,7 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
   c->byp_valid = false;
   c->x_ident = false;
   c->nam_lazy = false;
+  c->gram_pre = false;
   const bool arm = !first && !may_continue && may_stop && !c->auto_stop && arm_select_byproduct(c) == 1;
   // ... and then the NAM itself is not written: the analysis reads X, and whoever does ask for the NAM (res.nam, a later
   // call with other covariates) gets it from a second run of this step (need_nam), whose input state stays where it is
@@ -673,7 +782,9 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
     c->t_cur ^= 1;
     c->lazy_steps_before = c->steps_done;
   } else {
-    const int rc_step = launch_nam_step(c, first, want_kurt != 0, may_continue != 0, may_stop != 0, false);
+    int rc_step = 0;
+    if (!(arm && ranged_last_step(c, first, want_kurt != 0, may_stop != 0, &rc_step) == 1))
+      rc_step = launch_nam_step(c, first, want_kurt != 0, may_continue != 0, may_stop != 0, false);
     c->byp_arm = false;
     c->byp_skip_nam = false;
     CNA_TRY(rc_step);
@@ -1076,7 +1187,7 @@ int cna_select(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_
   c->x_valid = true;
   c->x_from_nam = true;
   c->ncorrs_valid = false;
-  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false; c->gram_pre = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1145,7 +1256,7 @@ int cna_select_checked(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, cons
   c->x_valid = true;
   c->x_from_nam = true;
   c->ncorrs_valid = false;
-  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false; c->gram_pre = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1170,7 +1281,9 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
   if (gram_too) *gram_too = false;
   if (!c->nam_valid && !c->nam_lazy) CNA_FAIL(CNA_ESTATE, "NAM not available");
   const bool byp_was = c->byp_valid;
+  const bool gram_pre_was = c->gram_pre;
   c->byp_valid = false;
+  c->gram_pre = false;
   const int64_t nx = keep_idx ? n_keep : c->n_local;
   const int Nx = colmap ? n_sel : c->N;
   if (nx < 0 || nx > c->n_local || Nx < 2) CNA_FAIL(CNA_EINVAL, "cna_select_standardized: bad sizes");
@@ -1219,6 +1332,7 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
     mb = nz + 1;
   }
   if (!byp) CNA_TRY(need_nam(c));           // (a last step that left X instead of the NAM is run again for the NAM)
+  if (!byp) CNA_TRY(gram_pre_settle(c));    // (... and a Gram matrix taken under it is dropped; its kernels read the X this pass rewrites)
   const bool fused = !byp && gram_too && y && !keep_idx && in_place && rk == 0 && gram_fused_ok(c, Nx, c->ldx, 32 * KSq);
   if (byp) {
   } else if (fused) {
@@ -1268,6 +1382,12 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
     HIP_TRY(hipEventRecord(c->gram_done, c->stream));
     c->gram_n = Nx;
     *gram_too = true;
+  } else if (byp && gram_pre_was) {
+    c->gram_pre = true;                          // X^T X of this X was taken under the walk: cna_gram_launch finds it
+    if (gram_too) {
+      CNA_TRY(cna_gram_launch(c));
+      *gram_too = true;
+    }
   }
   return 0;
 }
@@ -1353,7 +1473,7 @@ int cna_upload_x(cna_ctx* c, const double* x_local, int64_t n_rows, int n_cols) 
   c->x_valid = true;
   c->x_from_nam = false;
   c->ncorrs_valid = false;
-  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false; c->gram_pre = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1373,7 +1493,7 @@ int cna_resid_apply(cna_ctx* c, const double* M, int center) {
   CNA_TRY(launch_xb(c, (const double*)c->scratch, ldb, Nx, center != 0, c->X, ldx));
   HIP_TRY(hipStreamSynchronize(c->stream));
   c->ncorrs_valid = false;
-  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false; c->gram_pre = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1416,7 +1536,7 @@ int cna_resid_lowrank(cna_ctx* c, const double* C, const double* W, int r, int c
   HIP_TRY(hipStreamSynchronize(c->stream));        // Ct is a local
   if (max_abs_out) *max_abs_out = m;
   c->ncorrs_valid = y != nullptr;
-  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false; c->gram_pre = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1483,7 +1603,7 @@ int cna_resid_lowrank_bk(cna_ctx* c, const double* C, const double* W, int r, co
   if (max_abs_out) *max_abs_out = m;
   *median_out = med;
   c->ncorrs_valid = true;
-  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false; c->gram_pre = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1494,7 +1614,7 @@ int cna_standardize(cna_ctx* c, int center) {
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
   CNA_TRY(launch_standardize(c, center));
   c->ncorrs_valid = false;
-  c->xq_valid = false; c->byp_valid = false; c->x_ident = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false; c->gram_pre = false;
   c->coef_early = false;
   c->fdr_inline = false;
   return 0;
@@ -1504,10 +1624,15 @@ int cna_gram_launch(cna_ctx* c) {
   CHECK_CTX(c);
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
   const int Nx = c->Nx;
-  void* g = c->gram_buf;
-  CNA_TRY(dev_reserve(c, &g, &c->gram_cap, (int64_t)sizeof(double) * Nx * Nx));
-  c->gram_buf = (double*)g;
-  CNA_TRY(launch_gram(c, c->gram_buf));
+  const bool pre = c->gram_pre && c->gram_pre_pending;     // taken under the walk's last step (ranged_last_step), X untouched since
+  c->gram_pre = false;
+  CNA_TRY(gram_pre_settle(c));
+  if (!pre) {
+    void* g = c->gram_buf;
+    CNA_TRY(dev_reserve(c, &g, &c->gram_cap, (int64_t)sizeof(double) * Nx * Nx));
+    c->gram_buf = (double*)g;
+    CNA_TRY(launch_gram(c, c->gram_buf));
+  }
   CNA_TRY(comm_allreduce_f64_sum(c, c->gram_buf, (size_t)Nx * Nx));
   HIP_TRY(hipEventRecord(c->gram_done, c->stream));
   c->gram_n = Nx;

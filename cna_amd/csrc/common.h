@@ -43,6 +43,16 @@ struct ProfSpan {
   hipEvent_t a, b;
 };
 
+// X^T X in parts (mfma.hip: gram_plan / launch_gram_range / launch_gram_finish)
+struct GramPlan {
+  int Nx = 0, nt = 0, ntri = 0, ldp = 0, slab_rows = 32, nblocks = 1;
+  bool use_blk = false;
+  int64_t nslab = 0;
+  int32_t* tiles_dev = nullptr;
+  double* partial = nullptr;
+  size_t smem = 0;
+};
+
 struct cna_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -227,6 +237,20 @@ struct cna_ctx {
   int64_t rp16_cap = 0;
   void* scratch2 = nullptr;
   int64_t scratch2_cap = 0;
+  // The Gram matrix of the selection by-product taken UNDER the walk's last step (cna_nam_step): that step runs in
+  // row ranges on the main stream, and behind each range's event the Gram kernel of the same rows runs on gram_stream
+  // (the gather leaves the matrix pipe idle); partial tiles carry over from range to range in gram_part, so the sum
+  // is the one launch_gram would form.  gram_pre: c->gram_buf holds (will hold, after gram_pre_done) X^T X of the
+  // by-product X, not yet summed over the ranks.
+  hipStream_t gram_stream = nullptr;
+  hipStream_t walk_stream = nullptr;     // experiments: the ranged step on a CU-masked stream of its own (CNA_GRAM_CUS)
+  int gram_stream_state = 0;             // 0: not created yet, 1: ready, -1: unavailable
+  hipEvent_t gram_pre_done = nullptr, range_done = nullptr, walk_fork = nullptr, walk_join = nullptr;
+  bool gram_pre = false;
+  bool gram_pre_pending = false;         // kernels of a ranged product may still run on gram_stream (nobody has waited for gram_pre_done yet)
+  void* gram_part = nullptr;
+  int64_t gram_part_cap = 0;
+  GramPlan gram_pre_plan;
   int gram_tiles_nt = -1;        // upper-triangular tile table of the Gram kernel (depends on nt only)
   void* gram_tiles_ptr = nullptr;
   int64_t gram_tiles_cap = 0;
@@ -273,7 +297,10 @@ int comm_allgather_bytes(cna_ctx* c, const void* send, void* recv, size_t bytes_
 int launch_colsum(cna_ctx* c);
 int launch_add_scalar(cna_ctx* c, double* v, int64_t n, double s);
 int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool write_nam, bool dense,
-                    const int32_t* rows = nullptr, int64_t n_rows = 0);      // rows: this launch's rows of the block (null: all)
+                    const int32_t* rows = nullptr, int64_t n_rows = 0,       // rows: this launch's rows of the block (null: all)
+                    int64_t base = 0, int64_t count = -1,                    // ... or the contiguous rows [base, base + count) (count < 0: all)
+                    hipStream_t st = nullptr, bool timed = true);
+int64_t nam_step_turn_rows(const cna_ctx* c, int64_t n_rows);               // rows one turn of all eight XCDs covers in the wide step kernels (0: not that kernel)
 int launch_scale_rows(cna_ctx* c, const double* s_local, double* t_global, int m, int ld);
 // rows.hip
 int launch_batch_kurtosis(cna_ctx* c, const double* mat, int64_t rows, int ncols, int ld,
@@ -325,6 +352,11 @@ int launch_transpose(cna_ctx* c, const double* in, int64_t rows, int cols, int l
 // mfma.hip
 int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, double* out, int ld_out);
 int launch_gram(cna_ctx* c, double* G_dev);
+// the same product range by range (rows [row0, row1), boundaries multiples of *unit_rows) on stream st, partial tiles
+// carried in c->gram_part; bit-identical to launch_gram
+int gram_pre_begin(cna_ctx* c, int64_t* unit_rows);
+int gram_pre_range(cna_ctx* c, int64_t row0, int64_t row1, hipStream_t st);
+int gram_pre_finish(cna_ctx* c, double* G_dev, hipStream_t st);
 // selection (all cells, samples in place, no projector) + standardisation + coefficients + digit planes + Gram in one
 // kernel (k_selgram_blk); gram_fused_ok: the shapes it covers (c->nx, c->ld set)
 bool gram_fused_ok(const cna_ctx* c, int Nx, int ldx, int Kp);

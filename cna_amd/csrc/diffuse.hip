@@ -908,91 +908,100 @@ __global__ void k_scale_rows(const double* __restrict__ s, const double* __restr
 }
 
 template <typename VT, int NQ>
-int launch_first_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
-  static const bool one = getenv("CNA_FIRST_ONE_ROW") != nullptr;      // A/B switch
-  const bool two = !one && (grid.x & 15) == 0;     // an even number of workgroups per XCD: one workgroup takes two of them
+int launch_first_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
+  const bool two = (grid.x & 15) == 0;     // an even number of workgroups per XCD: one workgroup takes two of them
   const size_t lds = sizeof(double) * (two ? 8 : 4) * 64 * NQ;
   const CellInfo* info = (const CellInfo*)c->cellinfo;
   if (a.rows) {
-    if (two) hipLaunchKernelGGL((k_nam_first2<VT, NQ, 2, 2>), dim3(grid.x / 2), dim3(256), lds, c->stream, a, info);
-    else hipLaunchKernelGGL((k_nam_first<VT, NQ, 2>), grid, dim3(256), lds, c->stream, a, info);
+    if (two) hipLaunchKernelGGL((k_nam_first2<VT, NQ, 2, 2>), dim3(grid.x / 2), dim3(256), lds, st, a, info);
+    else hipLaunchKernelGGL((k_nam_first<VT, NQ, 2>), grid, dim3(256), lds, st, a, info);
   } else {
-    if (two) hipLaunchKernelGGL((k_nam_first2<VT, NQ, 2, 0>), dim3(grid.x / 2), dim3(256), lds, c->stream, a, info);
-    else hipLaunchKernelGGL((k_nam_first<VT, NQ, 0>), grid, dim3(256), lds, c->stream, a, info);
+    if (two) hipLaunchKernelGGL((k_nam_first2<VT, NQ, 2, 0>), dim3(grid.x / 2), dim3(256), lds, st, a, info);
+    else hipLaunchKernelGGL((k_nam_first<VT, NQ, 0>), grid, dim3(256), lds, st, a, info);
   }
   return 0;
 }
 // the instantiation of a step kernel by what the launch needs (finish_row): row list, selection by-product, or neither
 template <typename VT, int NQ2, int U = 8>
-int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
-  if (a.rows) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 2>), grid, dim3(256), 0, c->stream, a);
-  else if (a.sel_X) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 1>), grid, dim3(256), 0, c->stream, a);
-  else hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 0>), grid, dim3(256), 0, c->stream, a);
+int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
+  if (a.rows) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 2>), grid, dim3(256), 0, st, a);
+  else if (a.sel_X) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 1>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 0>), grid, dim3(256), 0, st, a);
   return 0;
 }
 
 template <typename VT, int NQ2>
-int launch_step_sparse_t(cna_ctx* c, const StepArgs& a, dim3 grid) {
+int launch_step_sparse_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(double) * 4 * 128 * NQ2;
-  if (a.rows) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 6, 2>), grid, dim3(256), lds, c->stream, a);
-  else if (a.sel_X) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 6, 1>), grid, dim3(256), lds, c->stream, a);
-  else hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 6, 0>), grid, dim3(256), lds, c->stream, a);
+  if (a.rows) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 6, 2>), grid, dim3(256), lds, st, a);
+  else if (a.sel_X) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 6, 1>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 6, 0>), grid, dim3(256), lds, st, a);
   return 0;
 }
 
-template <typename VT>
-int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in) {
-  StepArgs a = a_in;
-  // two rows per wave when a row fits a half-wave and byte offsets into the state fit 32 bits
-  const bool pair = !first && !a.sp_cnt && a.ld <= 64 && c->n_pad * (int64_t)a.ld * 8 < (int64_t)4 << 30 &&
-                    !getenv("CNA_STEP_WIDE");
-  const int64_t nblk = pair ? (a.n_local + 7) / 8 : (a.n_local + 3) / 4;
-  int64_t cpx = (nblk + 7) / 8;
+// two rows per wave when a row fits a half-wave and byte offsets into the state fit 32 bits
+static bool step_takes_pairs(const cna_ctx* c, bool first, bool sparse, int ld) {
+  return !first && !sparse && ld <= 64 && c->n_pad * (int64_t)ld * 8 < (int64_t)4 << 30 &&
+         !getenv("CNA_STEP_WIDE");            // (test_two_rows_per_wave_step_matches_wave_per_row compares the two kernels)
+}
+// consecutive workgroups (4 rows each, 8 for the two-rows-per-wave kernel) one XCD takes per turn
+static int64_t step_xcd_chunk(bool pair, int ld, int64_t nblk) {
+  const int64_t cpx = (nblk + 7) / 8;
   // measured (tools/kbench.py): one contiguous eighth per XCD is best at 200k x 50 (+4 % over
   // round-robin) and within 2 % of every chunk size at 1M x 100
   int64_t chunk = cpx;
   // wide states (wave-per-row kernels): 128 workgroups = 512 consecutive rows = one cluster of the device
   // order (cna_amd/_order.py) per XCD at a time -- the cluster's neighbour rows then stay in that XCD's L2
   // (2M x 200, dense step: 10.9 ms with one contiguous eighth per XCD under RCM, 7.8 ms this way)
-  if (!pair && a.ld > 64 && cpx > 128) chunk = 128;
-  if (const char* e = getenv("CNA_XCD_CHUNK")) { const int64_t v = atoll(e); if (v > 0 && v < cpx) chunk = v; }   // experiments
+  if (!pair && ld > 64 && cpx > 128) chunk = 128;
+  if (const char* e = getenv("CNA_XCD_CHUNK")) { const int64_t v = atoll(e); if (v > 0 && v < cpx) chunk = v; }   // experiments (tools/kbench_order.py)
+  return chunk;
+}
+
+template <typename VT>
+int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in, hipStream_t st) {
+  StepArgs a = a_in;
+  const bool pair = step_takes_pairs(c, first, a.sp_cnt != nullptr, a.ld);
+  const int64_t nblk = pair ? (a.n_local + 7) / 8 : (a.n_local + 3) / 4;
+  int64_t cpx = (nblk + 7) / 8;
+  const int64_t chunk = step_xcd_chunk(pair, a.ld, nblk);
   cpx = (cpx + chunk - 1) / chunk * chunk;      // whole chunks per XCD
   a.xcd_chunk = (int)chunk;
   dim3 grid((unsigned)(cpx * 8));
   if (a.ld > 1024) CNA_FAIL(CNA_EINVAL, "more than 1024 samples / state columns are not supported");
   if (first) {
     switch ((a.ld + 63) / 64) {
-      case 1: launch_first_t<VT, 1>(c, a, grid); break;
-      case 2: launch_first_t<VT, 2>(c, a, grid); break;
-      case 3: launch_first_t<VT, 3>(c, a, grid); break;
-      case 4: launch_first_t<VT, 4>(c, a, grid); break;
-      case 5: case 6: launch_first_t<VT, 6>(c, a, grid); break;
-      case 7: case 8: launch_first_t<VT, 8>(c, a, grid); break;
-      case 9: case 10: case 11: case 12: launch_first_t<VT, 12>(c, a, grid); break;
-      default: launch_first_t<VT, 16>(c, a, grid); break;
+      case 1: launch_first_t<VT, 1>(c, a, grid, st); break;
+      case 2: launch_first_t<VT, 2>(c, a, grid, st); break;
+      case 3: launch_first_t<VT, 3>(c, a, grid, st); break;
+      case 4: launch_first_t<VT, 4>(c, a, grid, st); break;
+      case 5: case 6: launch_first_t<VT, 6>(c, a, grid, st); break;
+      case 7: case 8: launch_first_t<VT, 8>(c, a, grid, st); break;
+      case 9: case 10: case 11: case 12: launch_first_t<VT, 12>(c, a, grid, st); break;
+      default: launch_first_t<VT, 16>(c, a, grid, st); break;
     }
   } else if (a.sp_cnt) {
     switch ((a.ld / 2 + 63) / 64) {
-      case 1: launch_step_sparse_t<VT, 1>(c, a, grid); break;
-      case 2: launch_step_sparse_t<VT, 2>(c, a, grid); break;
-      case 3: launch_step_sparse_t<VT, 3>(c, a, grid); break;
-      case 4: launch_step_sparse_t<VT, 4>(c, a, grid); break;
-      case 5: case 6: launch_step_sparse_t<VT, 6>(c, a, grid); break;
-      default: launch_step_sparse_t<VT, 8>(c, a, grid); break;
+      case 1: launch_step_sparse_t<VT, 1>(c, a, grid, st); break;
+      case 2: launch_step_sparse_t<VT, 2>(c, a, grid, st); break;
+      case 3: launch_step_sparse_t<VT, 3>(c, a, grid, st); break;
+      case 4: launch_step_sparse_t<VT, 4>(c, a, grid, st); break;
+      case 5: case 6: launch_step_sparse_t<VT, 6>(c, a, grid, st); break;
+      default: launch_step_sparse_t<VT, 8>(c, a, grid, st); break;
     }
   } else if (pair) {
-    if (a.rows) hipLaunchKernelGGL((k_nam_step_pair<VT, 2>), grid, dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL((k_nam_step_pair<VT, 0>), grid, dim3(256), 0, c->stream, a);
+    if (a.rows) hipLaunchKernelGGL((k_nam_step_pair<VT, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_nam_step_pair<VT, 0>), grid, dim3(256), 0, st, a);
   } else {
     switch ((a.ld / 2 + 63) / 64) {
-      case 1: launch_step_t<VT, 1>(c, a, grid); break;
+      case 1: launch_step_t<VT, 1>(c, a, grid, st); break;
       // 129 ... 256 columns: ten rows in flight (7.82 -> 7.69 ms at 2M x 200; 9: the same, 11 / 12: as 8); with the
       // selection by-product in the write-out, eight (8.45 against 8.55 ms, three runs each on one box; 6: 8.61, 12: 8.95)
-      case 2: if (a.sel_X) launch_step_t<VT, 2, 8>(c, a, grid); else launch_step_t<VT, 2, 10>(c, a, grid); break;
-      case 3: launch_step_t<VT, 3>(c, a, grid); break;
-      case 4: launch_step_t<VT, 4>(c, a, grid); break;
-      case 5: case 6: launch_step_t<VT, 6, 4>(c, a, grid); break;
-      default: launch_step_t<VT, 8, 4>(c, a, grid); break;
+      case 2: if (a.sel_X) launch_step_t<VT, 2, 8>(c, a, grid, st); else launch_step_t<VT, 2, 10>(c, a, grid, st); break;
+      case 3: launch_step_t<VT, 3>(c, a, grid, st); break;
+      case 4: launch_step_t<VT, 4>(c, a, grid, st); break;
+      case 5: case 6: launch_step_t<VT, 6, 4>(c, a, grid, st); break;
+      default: launch_step_t<VT, 8, 4>(c, a, grid, st); break;
     }
   }
   HIP_TRY(hipGetLastError());
@@ -1052,20 +1061,26 @@ int launch_add_scalar(cna_ctx* c, double* v, int64_t n, double s) {
   return 0;
 }
 
+int64_t nam_step_turn_rows(const cna_ctx* c, int64_t n_rows) {
+  if (c->t_ld <= 64) return 0;                               // (the two-rows-per-wave kernel and narrow states are not split)
+  return 8 * step_xcd_chunk(false, c->t_ld, (n_rows + 3) / 4) * 4;
+}
+
 int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool write_nam, bool dense, const int32_t* rows,
-                    int64_t n_rows) {
-  if (c->n_local == 0 || (rows && n_rows == 0)) return 0;
+                    int64_t n_rows, int64_t base, int64_t count, hipStream_t st_in, bool timed) {
+  if (c->n_local == 0 || (rows && n_rows == 0) || count == 0) return 0;
+  hipStream_t st = st_in ? st_in : c->stream;
   if (first && !c->cellinfo_valid) {
     void* p = c->cellinfo;
     CNA_TRY(dev_reserve(c, &p, &c->cellinfo_cap, (int64_t)sizeof(CellInfo) * c->n_global));
     c->cellinfo = p;
-    hipLaunchKernelGGL(k_cellinfo, dim3((unsigned)((c->n_global + 255) / 256)), dim3(256), 0, c->stream, c->colsum,
+    hipLaunchKernelGGL(k_cellinfo, dim3((unsigned)((c->n_global + 255) / 256)), dim3(256), 0, st, c->colsum,
                        c->sid, c->n_global, (CellInfo*)c->cellinfo);
     HIP_TRY(hipGetLastError());
     c->cellinfo_valid = true;
   }
   const bool sparse_step = !first && !dense && c->sp_cnt && c->steps_done == 1;       // launch_step_q takes k_nam_step_sparse then
-  ProfScope ps(c, first ? CNA_K_NAM_FIRST : (sparse_step ? CNA_K_NAM_STEP_SPARSE : CNA_K_NAM_STEP));
+  ProfScope ps(c, !timed ? -1 : (first ? CNA_K_NAM_FIRST : (sparse_step ? CNA_K_NAM_STEP_SPARSE : CNA_K_NAM_STEP)), st);
   StepArgs a;
   a.indptr = c->indptr;
   a.idx = c->indices;
@@ -1113,7 +1128,22 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
       a.sel_Kp = 32 * ((c->N + 31) / 32);
     }
   }
-  return c->data_f64 ? launch_step_q<double>(c, first, a) : launch_step_q<float>(c, first, a);
+  if (count > 0) {
+    // the rows [base, base + count) only: every per-row array moves up by `base` rows, the kernels number from zero
+    // (arrays indexed by the global row -- state, column sums, pairs, cell records -- follow row0)
+    if (rows) CNA_FAIL(CNA_EINVAL, "launch_nam_step: a row list and a row range exclude each other");
+    a.indptr += base;
+    a.row0 += base;
+    a.n_local = count;
+    if (a.nam) a.nam += base * (int64_t)a.ld;
+    if (a.dense_out) a.dense_out += base * (int64_t)a.ld;
+    if (a.sel_X) {
+      a.sel_X += base * (int64_t)a.sel_ldx;
+      a.sel_nc += base;
+      if (a.sel_xq) { a.sel_xq += (size_t)base * 3 * a.sel_Kp; a.sel_xscale += base; }
+    }
+  }
+  return c->data_f64 ? launch_step_q<double>(c, first, a, st) : launch_step_q<float>(c, first, a, st);
 }
 
 int launch_scale_rows(cna_ctx* c, const double* s_local, double* t_global, int m, int ld) {

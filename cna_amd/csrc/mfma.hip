@@ -204,7 +204,7 @@ __global__ __launch_bounds__(1024) void k_xb_res(const double* __restrict__ X, i
 template <int TPW, int NW = 8, int SLAB = 32>
 __global__ __launch_bounds__(64 * NW) void k_gram(const double* __restrict__ X, int64_t nx, int ldx, int nt,
                                               int ldp, int ntri, const int32_t* __restrict__ tiles,
-                                              double* __restrict__ partial) {
+                                              double* __restrict__ partial, int64_t slab0, int64_t slab1, int accumulate) {
   extern __shared__ double sm[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -221,10 +221,15 @@ __global__ __launch_bounds__(64 * NW) void k_gram(const double* __restrict__ X, 
     const int packed = live[t] ? __builtin_amdgcn_readfirstlane(tiles[tix]) : 0;
     off_i[t] = (packed >> 16) * 16;
     off_j[t] = (packed & 0xffff) * 16;
+    if (accumulate && live[t]) {                          // a later row range of the same product (launch_gram_range)
+      const double* p = partial + ((size_t)blockIdx.x * ntri + tix) * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = p[r * 64 + lane];
+    }
   }
   for (int i = tid; i < SLAB * ldp; i += 64 * NW) sm[i] = 0.0;
-  const int64_t nslab = (nx + SLAB - 1) / SLAB;
-  for (int64_t slab = blockIdx.x; slab < nslab; slab += gridDim.x) {
+  const int64_t nslab = slab1;
+  for (int64_t slab = slab0 + blockIdx.x; slab < nslab; slab += gridDim.x) {
     __syncthreads();
     const int64_t r0 = slab * SLAB;
     for (int r = wv; r < SLAB; r += NW) {
@@ -266,7 +271,8 @@ __global__ __launch_bounds__(64 * NW) void k_gram(const double* __restrict__ X, 
 template <int NW, int SLAB>
 __global__ __launch_bounds__(64 * NW) void k_gram_blk(const double* __restrict__ X, int64_t nx, int ldx, int nt,
                                                   int ldp, int ntri, const int32_t* __restrict__ blocks,
-                                                  const int32_t* __restrict__ tixmap, double* __restrict__ partial) {
+                                                  const int32_t* __restrict__ tixmap, double* __restrict__ partial,
+                                                  int64_t slab0, int64_t slab1, int accumulate) {
   extern __shared__ double sm[];
   constexpr int NT = 64 * NW, PF = 5;
   const int tid = threadIdx.x;
@@ -285,9 +291,14 @@ __global__ __launch_bounds__(64 * NW) void k_gram_blk(const double* __restrict__
   for (int t = 0; t < 9; ++t) {
     acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
     live[t] = ri[t / 3] >= 0 && cj[t % 3] >= ri[t / 3];
+    if (accumulate && live[t]) {                          // a later row range of the same product (launch_gram_range)
+      const double* p = partial + ((size_t)blockIdx.x * ntri + tixmap[ri[t / 3] * nt + cj[t % 3]]) * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = p[r * 64 + lane];
+    }
   }
   for (int i = tid; i < 2 * SLAB * ldp; i += NT) sm[i] = 0.0;
-  const int64_t nslab = (nx + SLAB - 1) / SLAB;
+  const int64_t nslab = slab1;
   const int slab2 = SLAB * ldx / 2;
   int lrow[PF], lcol[PF];
 #pragma unroll
@@ -313,7 +324,7 @@ __global__ __launch_bounds__(64 * NW) void k_gram_blk(const double* __restrict__
     for (int u = 0; u < PF; ++u)
       if (tid + u * NT < slab2) *(double2*)(buf + lrow[u] * ldp + lcol[u]) = v[u];
   };
-  int64_t slab = blockIdx.x;
+  int64_t slab = slab0 + blockIdx.x;
   __syncthreads();
   if (slab < nslab) { gload(slab); lstore(sm); }
   __syncthreads();
@@ -642,7 +653,7 @@ __global__ __launch_bounds__(512) void k_selgram_blk(const double* __restrict__ 
 template <int TPW, int NW, int SLAB>
 __global__ __launch_bounds__(64 * NW) void k_gram_db(const double* __restrict__ X, int64_t nx, int ldx, int nt,
                                                  int ldp, int ntri, const int32_t* __restrict__ tiles,
-                                                 double* __restrict__ partial) {
+                                                 double* __restrict__ partial, int64_t slab0, int64_t slab1, int accumulate) {
   extern __shared__ double sm[];
   constexpr int NT = 64 * NW, PF = 5;                  // PF double2 per thread cover SLAB x ldx doubles up to ldx = 320
   const int tid = threadIdx.x;
@@ -660,9 +671,14 @@ __global__ __launch_bounds__(64 * NW) void k_gram_db(const double* __restrict__ 
     const int packed = live[t] ? __builtin_amdgcn_readfirstlane(tiles[tix]) : 0;
     off_i[t] = (packed >> 16) * 16;
     off_j[t] = (packed & 0xffff) * 16;
+    if (accumulate && live[t]) {
+      const double* p = partial + ((size_t)blockIdx.x * ntri + tix) * 256;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = p[r * 64 + lane];
+    }
   }
   for (int i = tid; i < 2 * SLAB * ldp; i += NT) sm[i] = 0.0;
-  const int64_t nslab = (nx + SLAB - 1) / SLAB;
+  const int64_t nslab = slab1;
   const int slab2 = SLAB * ldx / 2;                     // double2 elements of a slab (contiguous in X)
   int lrow[PF], lcol[PF];
 #pragma unroll
@@ -688,7 +704,7 @@ __global__ __launch_bounds__(64 * NW) void k_gram_db(const double* __restrict__ 
     for (int u = 0; u < PF; ++u)
       if (tid + u * NT < slab2) *(double2*)(buf + lrow[u] * ldp + lcol[u]) = v[u];
   };
-  int64_t slab = blockIdx.x;
+  int64_t slab = slab0 + blockIdx.x;
   __syncthreads();                                      // zero fill done
   if (slab < nslab) { gload(slab); lstore(sm); }
   __syncthreads();
@@ -1128,7 +1144,7 @@ __global__ void k_hist_reduce(const unsigned int* __restrict__ partial, int nchu
 
 template <int TPW, int NW = 8, int SLAB = 32>
 int launch_gram_t(cna_ctx* c, int nt, int ldp, int ntri, const int32_t* tiles_dev, double* partial, int nblocks,
-                  size_t smem) {
+                  size_t smem, int64_t slab0, int64_t slab1, int accumulate, hipStream_t st) {
   const int npass = (ntri + NW * TPW - 1) / (NW * TPW);
   static bool attr_set = false;
   if (!attr_set) {
@@ -1136,20 +1152,19 @@ int launch_gram_t(cna_ctx* c, int nt, int ldp, int ntri, const int32_t* tiles_de
     attr_set = true;
   }
   // two slabs in LDS when they fit (up to ~256 samples): loads of the next slab overlap the MFMAs
-  static const bool use_db = !getenv("CNA_GRAM_SINGLE");
-  if (use_db && SLAB == 32 && 2 * smem <= 150 * 1024 && c->ldx <= 320) {
+  if (SLAB == 32 && 2 * smem <= 150 * 1024 && c->ldx <= 320) {
     static bool attr_db = false;
     if (!attr_db) {
       HIP_TRY(hipFuncSetAttribute((const void*)k_gram_db<TPW, NW, SLAB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_db = true;
     }
-    hipLaunchKernelGGL((k_gram_db<TPW, NW, SLAB>), dim3(nblocks, npass), dim3(64 * NW), 2 * smem, c->stream, c->X, c->nx, c->ldx,
-                       nt, ldp, ntri, tiles_dev, partial);
+    hipLaunchKernelGGL((k_gram_db<TPW, NW, SLAB>), dim3(nblocks, npass), dim3(64 * NW), 2 * smem, st, c->X, c->nx, c->ldx,
+                       nt, ldp, ntri, tiles_dev, partial, slab0, slab1, accumulate);
     HIP_TRY(hipGetLastError());
     return 0;
   }
-  hipLaunchKernelGGL((k_gram<TPW, NW, SLAB>), dim3(nblocks, npass), dim3(64 * NW), smem, c->stream, c->X, c->nx, c->ldx, nt, ldp,
-                     ntri, tiles_dev, partial);
+  hipLaunchKernelGGL((k_gram<TPW, NW, SLAB>), dim3(nblocks, npass), dim3(64 * NW), smem, st, c->X, c->nx, c->ldx, nt, ldp,
+                     ntri, tiles_dev, partial, slab0, slab1, accumulate);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -1314,6 +1329,12 @@ bool gram_fused_ok(const cna_ctx* c, int Nx, int ldx, int Kp) {
   return on && nt >= 11 && ng * (ng + 1) / 2 <= 16 && ldx <= 320 && (c->ld & 1) == 0 && cols <= 256 &&
          lds <= 158 * 1024 && c->nx >= 32;
 }
+// The product in three parts, so that it can also be taken range by range behind the pass that writes X
+// (c_api.hip:cna_nam_step, the walk's last step in row ranges): gram_plan fixes shapes, tile tables and the buffer of
+// per-workgroup partial tiles; launch_gram_range queues the kernel for the slabs [slab0, slab1) of X -- workgroup b
+// takes slabs slab0 + b, slab0 + b + nblocks, ...; a range that starts at a multiple of nblocks and continues from the
+// partial tiles of the ranges before it (accumulate) therefore adds the same products in the same order as ONE launch
+// over all slabs, and the result is bit-identical to it; launch_gram_finish sums the partial tiles in a fixed order.
 static int launch_gram_impl(cna_ctx* c, double* G_dev, const SelGramArgs* selgram);
 int launch_gram(cna_ctx* c, double* G_dev) { return launch_gram_impl(c, G_dev, nullptr); }
 int launch_selgram(cna_ctx* c, double* G_dev, unsigned long long* nzero, const double* y, unsigned long long* maxbits,
@@ -1322,73 +1343,154 @@ int launch_selgram(cna_ctx* c, double* G_dev, unsigned long long* nzero, const d
   return launch_gram_impl(c, G_dev, &a);
 }
 
-static int launch_gram_impl(cna_ctx* c, double* G_dev, const SelGramArgs* selgram) {
+// own_partial: the partial tiles live in c->gram_part (kept apart from c->scratch2, which other entry points reuse
+// while a ranged product is still under way)
+static int gram_plan(cna_ctx* c, GramPlan& g, bool own_partial) {
   const int Nx = c->Nx;
-  const int nt = (Nx + 15) / 16;
-  const int ntri = nt * (nt + 1) / 2;
-  const int ldp = 16 * nt + ((nt & 1) ? 0 : 16);
-  HIP_TRY(hipMemsetAsync(G_dev, 0, sizeof(double) * Nx * Nx, c->stream));
-  if (c->nx == 0) return 0;
+  g.Nx = Nx;
+  const int nt = g.nt = (Nx + 15) / 16;
+  const int ntri = g.ntri = nt * (nt + 1) / 2;
+  const int ldp = g.ldp = 16 * nt + ((nt & 1) ? 0 : 16);
   // tile table (ti<<16 | tj), upper triangle, row-major
   std::vector<int32_t> tiles;
   for (int i = 0; i < nt; ++i)
     for (int j = i; j < nt; ++j) tiles.push_back((i << 16) | j);
   // 32-cell slabs of X in LDS (32 x ldp doubles) up to 512 samples, 16-cell slabs up to 1024; beyond 256
   // samples the upper-triangular tiles exceed one pass of 16 waves x 9 tiles and grid.y walks the passes
-  const int slab_rows = (size_t)32 * ldp * sizeof(double) <= 150 * 1024 ? 32 : 16;
+  const int slab_rows = g.slab_rows = (size_t)32 * ldp * sizeof(double) <= 150 * 1024 ? 32 : 16;
   if ((size_t)slab_rows * ldp * sizeof(double) > 160 * 1024) CNA_FAIL(CNA_EINVAL, "more than 1024 samples are not supported");
-  const int64_t nslab = (c->nx + slab_rows - 1) / slab_rows;
+  const int64_t nslab = g.nslab = (c->nx + slab_rows - 1) / slab_rows;
   int nblocks = (int)(nslab < 512 ? nslab : 512);
   const int64_t blocks_1g = ((int64_t)1 << 30) / ((int64_t)ntri * 2048);      // per-block partial tiles: keep the slab under 1 GiB
   if (nblocks > blocks_1g) nblocks = (int)(blocks_1g > 1 ? blocks_1g : 1);
-  CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, (int64_t)sizeof(double) * nblocks * ntri * 256));
-  double* partial = (double*)c->scratch2;
   // 3 x 3 blocks of tiles, one per wave (k_gram_blk), when the triangle has at most 16 of them and enough to
   // keep 16 waves busy: 11 ... 15 tiles per side (161 ... 240 samples)
   static const bool blk_on = !getenv("CNA_GRAM_NOBLK");
   const int ng = (nt + 2) / 3;
-  const bool use_blk = blk_on && nt >= 11 && ng * (ng + 1) / 2 <= 16 && slab_rows == 32 &&
-                       2 * (size_t)32 * ldp * sizeof(double) <= 150 * 1024 && c->ldx <= 320;
+  const bool use_blk = g.use_blk = blk_on && nt >= 11 && ng * (ng + 1) / 2 <= 16 && slab_rows == 32 &&
+                                   2 * (size_t)32 * ldp * sizeof(double) <= 150 * 1024 && c->ldx <= 320;
   if (use_blk && nblocks > 256) nblocks = 256;             // one workgroup per CU, every slab after the first prefetched
-  std::vector<int32_t> extra(128 + (size_t)nt * nt, -1);   // [16 waves x 8] block table | tixmap
-  if (use_blk) {
-    struct Blk { int rg, cg, work; };
-    std::vector<Blk> bl;
-    for (int rg = 0; rg < ng; ++rg)
-      for (int cg = rg; cg < ng; ++cg) {
-        int w = 0;
-        for (int r = 0; r < 3; ++r)
-          for (int q = 0; q < 3; ++q) {
-            const int i = 3 * rg + r, j = 3 * cg + q;
-            w += i < nt && j < nt && j >= i;
-          }
-        bl.push_back({rg, cg, w});
-      }
-    std::stable_sort(bl.begin(), bl.end(), [](const Blk& a, const Blk& b) { return a.work > b.work; });
-    for (size_t p = 0; p < bl.size(); ++p) {               // snake over the four SIMDs (waves w, w+4, w+8, w+12 share one)
-      const int round = (int)p / 4, pos = (int)p % 4;
-      const int wave = 4 * round + ((round & 1) ? 3 - pos : pos);
-      for (int r = 0; r < 3; ++r) {
-        const int i = 3 * bl[p].rg + r, j = 3 * bl[p].cg + r;
-        extra[wave * 8 + r] = i < nt ? i : -1;
-        extra[wave * 8 + 3 + r] = j < nt ? j : -1;
-      }
-    }
-    for (int t = 0; t < ntri; ++t) extra[128 + (tiles[t] >> 16) * nt + (tiles[t] & 0xffff)] = t;
+  if (nblocks < 1) nblocks = 1;
+  g.nblocks = nblocks;
+  const int64_t part_bytes = (int64_t)sizeof(double) * nblocks * ntri * 256;
+  if (own_partial) {
+    void* pp = c->gram_part;
+    CNA_TRY(dev_reserve(c, &pp, &c->gram_part_cap, part_bytes));
+    c->gram_part = pp;
+    g.partial = (double*)pp;
+  } else {
+    CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, part_bytes));
+    g.partial = (double*)c->scratch2;
   }
   if (c->gram_tiles_nt != nt) {                          // the tables depend on nt only: upload once
+    std::vector<int32_t> extra(128 + (size_t)nt * nt, -1);   // [16 waves x 8] block table | tixmap
+    if (use_blk) {
+      struct Blk { int rg, cg, work; };
+      std::vector<Blk> bl;
+      for (int rg = 0; rg < ng; ++rg)
+        for (int cg = rg; cg < ng; ++cg) {
+          int w = 0;
+          for (int r = 0; r < 3; ++r)
+            for (int q = 0; q < 3; ++q) {
+              const int i = 3 * rg + r, j = 3 * cg + q;
+              w += i < nt && j < nt && j >= i;
+            }
+          bl.push_back({rg, cg, w});
+        }
+      std::stable_sort(bl.begin(), bl.end(), [](const Blk& a, const Blk& b) { return a.work > b.work; });
+      for (size_t p = 0; p < bl.size(); ++p) {               // snake over the four SIMDs (waves w, w+4, w+8, w+12 share one)
+        const int round = (int)p / 4, pos = (int)p % 4;
+        const int wave = 4 * round + ((round & 1) ? 3 - pos : pos);
+        for (int r = 0; r < 3; ++r) {
+          const int i = 3 * bl[p].rg + r, j = 3 * bl[p].cg + r;
+          extra[wave * 8 + r] = i < nt ? i : -1;
+          extra[wave * 8 + 3 + r] = j < nt ? j : -1;
+        }
+      }
+      for (int t = 0; t < ntri; ++t) extra[128 + (tiles[t] >> 16) * nt + (tiles[t] & 0xffff)] = t;
+    }
     void* tp = c->gram_tiles_ptr;
     CNA_TRY(dev_reserve(c, &tp, &c->gram_tiles_cap, (int64_t)sizeof(int32_t) * (ntri + extra.size())));
     c->gram_tiles_ptr = tp;
-    HIP_TRY(hipMemcpyAsync(tp, tiles.data(), sizeof(int32_t) * ntri, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync((int32_t*)tp + ntri, extra.data(), sizeof(int32_t) * extra.size(), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));            // the vectors go out of scope
+    HIP_TRY(hipMemcpyAsync(tp, tiles.data(), sizeof(int32_t) * ntri, hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(hipMemcpyAsync((int32_t*)tp + ntri, extra.data(), sizeof(int32_t) * extra.size(), hipMemcpyHostToDevice, c->copy_stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));       // the vectors go out of scope (the copy stream: the main one may be busy with a walk)
     c->gram_tiles_nt = nt;
   }
-  int32_t* tiles_dev = (int32_t*)c->gram_tiles_ptr;
-  const size_t smem = sizeof(double) * slab_rows * ldp;
+  g.tiles_dev = (int32_t*)c->gram_tiles_ptr;
+  g.smem = sizeof(double) * slab_rows * ldp;
+  return 0;
+}
+
+static int launch_gram_range(cna_ctx* c, const GramPlan& g, int64_t slab0, int64_t slab1, int accumulate, hipStream_t st) {
+  if (slab1 <= slab0) return 0;
+  const int nt = g.nt, ldp = g.ldp, ntri = g.ntri, nblocks = g.nblocks;
+  ProfScope ps(c, CNA_K_GRAM, st);
+  if (g.use_blk) {
+    static bool attr_blk = false;
+    if (!attr_blk) {
+      HIP_TRY(hipFuncSetAttribute((const void*)k_gram_blk<16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_blk = true;
+    }
+    hipLaunchKernelGGL((k_gram_blk<16, 32>), dim3(nblocks), dim3(1024), 2 * g.smem, st, c->X, c->nx, c->ldx, nt, ldp, ntri,
+                       g.tiles_dev + ntri, g.tiles_dev + ntri + 128, g.partial, slab0, slab1, accumulate);
+    HIP_TRY(hipGetLastError());
+    return 0;
+  }
+  int r;
+  // 16 waves per workgroup, the tiles dealt ceil(ntri/16) to a wave: against 8 waves with up to 12
+  // tiles each (154 VGPRs, one workgroup of two waves per SIMD per CU) 2025 -> 1489 us at 1M x 200,
+  // 3958 -> 2034 us at 1M x 256, 57 -> 45 us at 200k x 50; faster at every N tried (20 ... 256)
+#define GRAM_T(...) launch_gram_t<__VA_ARGS__>(c, nt, ldp, ntri, g.tiles_dev, g.partial, nblocks, g.smem, slab0, slab1, accumulate, st)
+  switch ((ntri + 15) / 16) {
+    case 1: r = GRAM_T(1, 16); break;
+    case 2: r = GRAM_T(2, 16); break;
+    case 3: r = GRAM_T(3, 16); break;
+    case 4: r = GRAM_T(4, 16); break;
+    case 5: r = GRAM_T(5, 16); break;
+    case 6: r = GRAM_T(6, 16); break;
+    case 7: r = GRAM_T(7, 16); break;
+    case 8: r = GRAM_T(8, 16); break;
+    default: r = g.slab_rows == 32 ? GRAM_T(9, 16)   // 144 tiles per pass
+                                   : GRAM_T(9, 16, 16);
+             break;
+  }
+#undef GRAM_T
+  return r;
+}
+
+static int launch_gram_finish(cna_ctx* c, const GramPlan& g, double* G_dev, hipStream_t st) {
+  ProfScope ps(c, CNA_K_GRAM_REDUCE, st);
+  hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)g.ntri * 4), dim3(64, 16), 0, st, g.partial, g.nblocks, g.ntri,
+                     g.tiles_dev, g.Nx, G_dev);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// ---- the product behind a pass that writes X range by range (c_api.hip:cna_nam_step): opaque handle for c_api.hip
+int gram_pre_begin(cna_ctx* c, int64_t* unit_rows) {
+  CNA_TRY(gram_plan(c, c->gram_pre_plan, true));
+  *unit_rows = (int64_t)c->gram_pre_plan.nblocks * c->gram_pre_plan.slab_rows;
+  return 0;
+}
+int gram_pre_range(cna_ctx* c, int64_t row0, int64_t row1, hipStream_t st) {
+  const GramPlan& g = c->gram_pre_plan;
+  const int64_t s0 = row0 / g.slab_rows, s1 = (row1 + g.slab_rows - 1) / g.slab_rows;
+  return launch_gram_range(c, g, s0, s1 < g.nslab ? s1 : g.nslab, row0 > 0 ? 1 : 0, st);
+}
+int gram_pre_finish(cna_ctx* c, double* G_dev, hipStream_t st) { return launch_gram_finish(c, c->gram_pre_plan, G_dev, st); }
+
+static int launch_gram_impl(cna_ctx* c, double* G_dev, const SelGramArgs* selgram) {
+  const int Nx = c->Nx;
+  HIP_TRY(hipMemsetAsync(G_dev, 0, sizeof(double) * Nx * Nx, c->stream));
+  if (c->nx == 0) return 0;
+  GramPlan g;
+  CNA_TRY(gram_plan(c, g, false));
   if (selgram) {
-    if (!use_blk) CNA_FAIL(CNA_ESTATE, "launch_selgram: shape outside the fused kernel's range");
+    const int nt = g.nt, ldp = g.ldp, ntri = g.ntri, nblocks = g.nblocks;
+    int32_t* tiles_dev = g.tiles_dev;
+    double* partial = g.partial;
+    if (!g.use_blk) CNA_FAIL(CNA_ESTATE, "launch_selgram: shape outside the fused kernel's range");
     HIP_TRY(hipMemsetAsync(selgram->nzero, 0, sizeof(unsigned long long), c->stream));
     if (selgram->maxbits) HIP_TRY(hipMemsetAsync(selgram->maxbits, 0, sizeof(unsigned long long), c->stream));
     const int cols = c->ldx > selgram->Kp ? c->ldx : selgram->Kp;
@@ -1406,58 +1508,10 @@ static int launch_gram_impl(cna_ctx* c, double* G_dev, const SelGramArgs* selgra
       HIP_TRY(hipGetLastError());
     }
     if (selgram->y) launch_max_fold(c, selgram->maxbits + 1, nblocks, selgram->maxbits);
-    ProfScope ps(c, CNA_K_GRAM_REDUCE);
-    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ntri * 4), dim3(64, 16), 0, c->stream, partial, nblocks, ntri,
-                       tiles_dev, Nx, G_dev);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return launch_gram_finish(c, g, G_dev, c->stream);
   }
-  if (use_blk) {
-    {
-      ProfScope ps(c, CNA_K_GRAM);
-      static bool attr_blk = false;
-      if (!attr_blk) {
-        HIP_TRY(hipFuncSetAttribute((const void*)k_gram_blk<16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_blk = true;
-      }
-      hipLaunchKernelGGL((k_gram_blk<16, 32>), dim3(nblocks), dim3(1024), 2 * smem, c->stream, c->X, c->nx, c->ldx, nt, ldp, ntri,
-                         tiles_dev + ntri, tiles_dev + ntri + 128, partial);
-      HIP_TRY(hipGetLastError());
-    }
-    ProfScope ps(c, CNA_K_GRAM_REDUCE);
-    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ntri * 4), dim3(64, 16), 0, c->stream, partial, nblocks, ntri,
-                       tiles_dev, Nx, G_dev);
-    HIP_TRY(hipGetLastError());
-    return 0;
-  }
-  {
-    ProfScope ps(c, CNA_K_GRAM);
-    int r;
-    // 16 waves per workgroup, the tiles dealt ceil(ntri/16) to a wave: against 8 waves with up to 12
-    // tiles each (154 VGPRs, one workgroup of two waves per SIMD per CU) 2025 -> 1489 us at 1M x 200,
-    // 3958 -> 2034 us at 1M x 256, 57 -> 45 us at 200k x 50; faster at every N tried (20 ... 256)
-    switch ((ntri + 15) / 16) {
-      case 1: r = launch_gram_t<1, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
-      case 2: r = launch_gram_t<2, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
-      case 3: r = launch_gram_t<3, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
-      case 4: r = launch_gram_t<4, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
-      case 5: r = launch_gram_t<5, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
-      case 6: r = launch_gram_t<6, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
-      case 7: r = launch_gram_t<7, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
-      case 8: r = launch_gram_t<8, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem); break;
-      default: r = slab_rows == 32 ? launch_gram_t<9, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem)   // 144 tiles per pass
-                                   : launch_gram_t<9, 16, 16>(c, nt, ldp, ntri, tiles_dev, partial, nblocks, smem);
-               break;
-    }
-    CNA_TRY(r);
-  }
-  {
-    ProfScope ps(c, CNA_K_GRAM_REDUCE);
-    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)ntri * 4), dim3(64, 16), 0, c->stream, partial, nblocks, ntri,
-                       tiles_dev, Nx, G_dev);
-    HIP_TRY(hipGetLastError());
-  }
-  return 0;
+  CNA_TRY(launch_gram_range(c, g, 0, g.nslab, 0, c->stream));
+  return launch_gram_finish(c, g, G_dev, c->stream);
 }
 
 int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* cuts_dev, int T,

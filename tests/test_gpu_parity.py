@@ -892,6 +892,41 @@ def test_selection_as_a_by_product_of_the_last_walk_step(eng, monkeypatch, n, N,
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize('n,N,K,nsteps', [(70001, 200, 4, 3), (66001, 100, 2, 3), (41000, 180, 2, 2), (30000, 200, 4, 3)])
+def test_gram_under_the_walks_last_step(eng, monkeypatch, n, N, K, nsteps):
+    """NAM.dot(NAM.T) (_nam.py:105) is a sum over cells, and the walk's last step writes the standardised rows one by one
+    (select_tail): that step runs in K row ranges and the Gram kernel of each range follows it on a second stream, carrying
+    its partial tiles from range to range (c_api.hip:ranged_last_step, mfma.hip:launch_gram_range).  Every workgroup adds
+    the same slabs in the same order as the one-launch kernel, so the matrix -- and with it every result -- is the same
+    bit for bit.  The 3 x 3-block kernel (200 / 180 samples) and the strided one (100), a dense and a compressed last
+    step, a ragged last range; 30 000 cells are too few for four ranges (one launch, Gram afterwards)."""
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.tools import _association as A
+    monkeypatch.setattr(A, '_DEFER_LAST_CELLS', 0)
+    data, meta = synth.make_dataset(n, N, k=15, seed=33)
+    out = {}
+    for ranged in (True, False):
+        monkeypatch.setenv('CNA_GRAM_OVERLAP', str(K) if ranged else '0')
+        eng.prof_reset(); eng.prof_enable(True)
+        res = cna.tl.association(data, meta['y'], 'id', Nnull=200, seed=5, nsteps=nsteps, return_full=True, engine=eng)
+        eng.sync(); eng.prof_enable(False)
+        prof = eng.prof()
+        out[ranged] = (res.p, int(res.k), eng.gram_fetch().copy(), res.ncorrs.values.copy(), res.namresid.values.copy(),
+                       res.fdrs.values.copy(), res.nullminps.copy(), res.namresid_sampleXpc.values.copy(),
+                       data.obs['coef_fdr'].values.copy(), res.nam.values.copy())
+        out[ranged, 'gram launches'] = prof.get('gram', (0, 0))[1]
+        assert prof.get('select', (0, 0))[1] == 0           # the by-product in both runs
+    assert out[False, 'gram launches'] == 1
+    assert out[True, 'gram launches'] == (K if n > 40000 else 1)
+    assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
+    for a, b in zip(out[True][2:], out[False][2:]):
+        np.testing.assert_array_equal(a, b)
+    G = out[True][2]
+    X = out[True][4]                                      # samples x cells
+    np.testing.assert_allclose(G, X @ X.T, rtol=1e-10, atol=1e-7)
+
+
 @pytest.mark.parametrize('n,N', [(20011, 200), (5000, 170), (9999, 233), (40, 180)])
 def test_selection_and_gram_in_one_kernel(eng, monkeypatch, n, N):
     """161 ... 240 samples, all cells kept, samples in place, nothing regressed out: the selection pass
