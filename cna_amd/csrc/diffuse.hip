@@ -924,9 +924,10 @@ int launch_first_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
 // the instantiation of a step kernel by what the launch needs (finish_row): row list, selection by-product, or neither
 template <typename VT, int NQ2, int U = 8>
 int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
-  if (a.rows) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 2>), grid, dim3(256), 0, st, a);
-  else if (a.sel_X) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 1>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 0>), grid, dim3(256), 0, st, a);
+  static const size_t pad = getenv("CNA_WALK_LDS_PAD") ? (size_t)atoll(getenv("CNA_WALK_LDS_PAD")) : 0;   // experiment: fewer workgroups per CU
+  if (a.rows) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 2>), grid, dim3(256), pad, st, a);
+  else if (a.sel_X) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 1>), grid, dim3(256), pad, st, a);
+  else hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 0>), grid, dim3(256), pad, st, a);
   return 0;
 }
 
