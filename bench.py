@@ -270,7 +270,8 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
         i8 = (False, 0, False)
     return dict(name=name, n=n, N=N, k=k, nsteps=nsteps, Nnull=Nnull, n_covs=n_covs, n_batches=n_batches, nnz=nnz, wA=wA, dt=dt, t_cold=t_cold, i8=i8,
                 t_gen=t_gen, prof=prof, p=p_last, n_loc=n_loc, nnz_loc=nnz_loc, halo=getattr(eng, 'halo', None),
-                sharded_inputs=sharded_inputs, data=data, meta=meta, kw=kw, steps=steps, warmup=warmup, comm=eng.comm_info())
+                sharded_inputs=sharded_inputs, data=data, meta=meta, kw=kw, steps=steps, warmup=warmup, comm=eng.comm_info(),
+                halo_comm=getattr(eng, 'halo_comm', False))
 
 
 def kernel_table(m, world):
@@ -495,7 +496,8 @@ def main():
                        '' if m['halo'] is None else ', halo exchange %d/%d rows out/in on rank 0' % m['halo'],
                        ' [--comm shm: ranks share one GPU, plumbing check only]' if args.comm == 'shm' and world > 1 else ''),
                    'communicator': {'backend': m['comm'][0], 'nranks_reported_by_communicator': m['comm'][1],
-                                    'halo_rows_out_in_rank0': m['halo']},
+                                    'halo_rows_out_in_rank0': m['halo'],
+                                    'halo_exchange_overlaps_the_walk_step': bool(m.get('halo_comm')) or (m['comm'][0] == 'shm' and world > 1)},
                    'arithmetic': 'f64 throughout (diffusion, QC, residualisation, Gram, F-tests); the local-null products '
                                  'as exact 24-bit fixed-point digits on the i8 matrix cores with an f64 recheck of every '
                                  'output within the error bound of a threshold (same integer counts as the f64 kernel)'

@@ -30,6 +30,7 @@ SIGNATURES = {
     'cna_graph_upload': (C.c_int, [c_ctx, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int]),
     'cna_comm_info': (C.c_int, [c_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'cna_comm_selftest': (C.c_int, [c_ctx, C.c_double, C.POINTER(C.c_int)]),
     'cna_comm_init_shm': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_char_p, C.c_int64]),
     'cna_set_halo': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cna_set_cell_order': (C.c_int, [c_ctx, C.c_void_p]),

@@ -650,7 +650,7 @@ static int arm_select_byproduct(cna_ctx* c) {
 // and the ranged step to the others (hipExtStreamCreateWithCUMask; bit i of the mask = CU i / 8 of XCD i % 8).
 static int gram_overlap_ranges() {
   const char* e = getenv("CNA_GRAM_OVERLAP");
-  const int k = e ? atoi(e) : 4;
+  const int k = e ? atoi(e) : 0;               // off by default: measured, no gain (profiles/r04_ab_gram_overlap.txt)
   return k < 0 ? 0 : (k > 64 ? 64 : k);
 }
 static int ensure_gram_stream(cna_ctx* c) {
@@ -764,7 +764,10 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
   // stream while the rest of the block is walked; the next step waits for both.  (The buffers are sized before anything
   // is queued: a reallocation would wait for the device.)
   const char* ov = getenv("CNA_HALO_OVERLAP");
-  const bool overlap = may_continue && c->halo_on && c->halo_stream && c->halo_nb > 0 && c->halo_ni > 0 && !(ov && atoi(ov) == 0);
+  // (RCCL: only with a communicator of the halo stream's own, cna_comm_init; the shared-memory test backend stages
+  // through the host and has no such constraint)
+  const bool overlap = may_continue && c->halo_on && c->halo_stream && c->halo_nb > 0 && c->halo_ni > 0 && !(ov && atoi(ov) == 0) &&
+                       (c->shm || c->comm_halo);
   if (overlap) {
     c->byp_arm = false;
     c->byp_skip_nam = false;
@@ -2340,7 +2343,7 @@ int cna_percell_fdr(cna_ctx* c, const double* thr, const double* runmin_fdr, int
 
 // -------------------------------------------------------------------------------- D2H
 int cna_matrix_shape(cna_ctx* c, int which, int64_t* n_rows_local, int* n_cols) {
-  if (!c) CNA_FAIL(CNA_EINVAL, "null context");
+  CHECK_CTX(c);                                  // (the NAM may be materialised here: kernels on this context's device)
   if (which == CNA_MAT_NAM) AUTO_FINISH(c);
   if (which == CNA_MAT_NAM) {
     CNA_TRY(need_nam(c));

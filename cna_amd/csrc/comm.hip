@@ -12,6 +12,7 @@
 #include <sched.h>
 #include <sys/mman.h>
 #include <unistd.h>
+#include <time.h>
 
 namespace {
 
@@ -20,6 +21,8 @@ struct Rccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, ncclConfig_t*) = nullptr;      // optional (RCCL >= 2.18)
   ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -52,6 +55,8 @@ int rccl_load() {
   SYM(GroupEnd);
   SYM(GetErrorString);
 #undef SYM
+  g_rccl.CommAbort = (decltype(g_rccl.CommAbort))dlsym(h, "ncclCommAbort");
+  g_rccl.CommSplit = (decltype(g_rccl.CommSplit))dlsym(h, "ncclCommSplit");
   g_rccl.h = h;
   return 0;
 }
@@ -239,6 +244,79 @@ extern "C" int cna_comm_init(cna_ctx* c, int rank, int nranks, const void* id128
   ncclComm_t comm;
   NCCL_TRY(g_rccl.CommInitRank(&comm, nranks, id, rank));
   c->comm = (void*)comm;
+  // The halo exchange of a walk step runs on its own stream under the interior rows of that step (cna_nam_step); it
+  // gets a communicator of its own -- a duplicate of this one, same ranks -- so that no communicator is ever driven
+  // from two streams.  Without ncclCommSplit (or when it fails) the exchange stays on the main stream, after the step.
+  c->comm_halo = nullptr;
+  if (nranks > 1 && g_rccl.CommSplit && !getenv("CNA_NO_HALO_COMM")) {
+    ncclComm_t dup = nullptr;
+    if (g_rccl.CommSplit(comm, 0, rank, &dup, nullptr) == ncclSuccess && dup) c->comm_halo = (void*)dup;
+  }
+  return 0;
+}
+
+// Start-up check of the communicators with a time limit (a rank that cannot reach a peer would otherwise hang in the
+// first collective of the benchmark): one all-reduce on the main stream, then -- when the halo communicator exists --
+// a ring send / receive on the halo stream while the main stream carries a second all-reduce, i.e. the two
+// communicators active at the same time as in cna_nam_step.  *halo_ok = 0: the halo communicator did not answer in
+// time on some rank and was aborted on all of them; the exchange then runs on the main stream (no overlap).
+// An error return: the main communicator itself does not work.
+static int poll_stream(hipStream_t st, double timeout_s) {
+  const double t0 = (double)clock() / CLOCKS_PER_SEC;
+  struct timespec a; clock_gettime(CLOCK_MONOTONIC, &a);
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) return -1;
+    struct timespec b; clock_gettime(CLOCK_MONOTONIC, &b);
+    if ((b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec) > timeout_s) return 1;
+    usleep(200);
+  }
+  (void)t0;
+}
+
+extern "C" int cna_comm_selftest(cna_ctx* c, double timeout_s, int* halo_ok) {
+  if (!c) CNA_FAIL(CNA_EINVAL, "null context");
+  if (halo_ok) *halo_ok = c->comm_halo ? 1 : 0;
+  if (!c->comm || c->nranks < 2) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  double* buf = nullptr;
+  HIP_TRY(hipMalloc(&buf, 64));
+  const double host[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+  HIP_TRY(hipMemcpy(buf, host, 64, hipMemcpyHostToDevice));
+  ncclComm_t comm = (ncclComm_t)c->comm;
+  NCCL_TRY(g_rccl.AllReduce(buf, buf, 1, ncclFloat64, ncclSum, comm, c->stream));
+  if (poll_stream(c->stream, timeout_s) != 0) {
+    if (g_rccl.CommAbort) g_rccl.CommAbort(comm);
+    c->comm = nullptr;
+    CNA_FAIL(CNA_ERCCL, "cna_comm_selftest: the first all-reduce did not finish in time");
+  }
+  int ok = 1;
+  if (c->comm_halo) {
+    if (!c->halo_stream) HIP_TRY(hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
+    ncclComm_t hc = (ncclComm_t)c->comm_halo;
+    const int next = (c->rank + 1) % c->nranks, prev = (c->rank + c->nranks - 1) % c->nranks;
+    ncclResult_t r = g_rccl.GroupStart();
+    if (r == ncclSuccess) r = g_rccl.Send(buf + 2, 1, ncclFloat64, next, hc, c->halo_stream);
+    if (r == ncclSuccess) r = g_rccl.Recv(buf + 3, 1, ncclFloat64, prev, hc, c->halo_stream);
+    const ncclResult_t e = g_rccl.GroupEnd();
+    if (r != ncclSuccess || e != ncclSuccess || poll_stream(c->halo_stream, timeout_s) != 0) ok = 0;
+  }
+  // every rank learns whether every rank's halo communicator answered (minimum = -max(-ok))
+  double flag = ok ? 0.0 : 1.0;
+  HIP_TRY(hipMemcpy(buf + 4, &flag, 8, hipMemcpyHostToDevice));
+  NCCL_TRY(g_rccl.AllReduce(buf + 4, buf + 4, 1, ncclFloat64, ncclMax, comm, c->stream));
+  if (poll_stream(c->stream, timeout_s) != 0) CNA_FAIL(CNA_ERCCL, "cna_comm_selftest: the second all-reduce did not finish in time");
+  HIP_TRY(hipMemcpy(&flag, buf + 4, 8, hipMemcpyDeviceToHost));
+  double sum = 0;
+  HIP_TRY(hipMemcpy(&sum, buf, 8, hipMemcpyDeviceToHost));
+  (void)hipFree(buf);
+  if (sum != (double)c->nranks) CNA_FAIL(CNA_ERCCL, "cna_comm_selftest: the all-reduce over the ranks returned a wrong sum");
+  if (flag != 0.0 && c->comm_halo) {
+    if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t)c->comm_halo);
+    c->comm_halo = nullptr;
+  }
+  if (halo_ok) *halo_ok = c->comm_halo ? 1 : 0;
   return 0;
 }
 
@@ -257,6 +335,10 @@ extern "C" int cna_comm_info(cna_ctx* c, int* backend, int* nranks) {
 
 int comm_destroy(cna_ctx* c) {
   shm_destroy(c);
+  if (c->comm_halo) {
+    g_rccl.CommDestroy((ncclComm_t)c->comm_halo);
+    c->comm_halo = nullptr;
+  }
   if (c->comm) {
     g_rccl.CommDestroy((ncclComm_t)c->comm);
     c->comm = nullptr;
@@ -300,6 +382,10 @@ int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64
   if (!st) st = c->stream;
   if (c->shm) return shm_halo(c, sendbuf, recvbuf, doubles_per_row, st);
   if (!c->comm) CNA_FAIL(CNA_ESTATE, "halo exchange without cna_comm_init");
+  // a stream of its own only ever sees the communicator of its own (cna_comm_init); cna_nam_step does not ask for
+  // the overlap without one
+  ncclComm_t comm = (st != c->stream && c->comm_halo) ? (ncclComm_t)c->comm_halo : (ncclComm_t)c->comm;
+  if (st != c->stream && !c->comm_halo) CNA_FAIL(CNA_ESTATE, "halo exchange on a second stream without a halo communicator");
   ProfScope ps(c, CNA_K_ALLGATHER, st);
   NCCL_TRY(g_rccl.GroupStart());
   int64_t so = 0, ro = 0;
@@ -307,11 +393,9 @@ int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64
   for (int p = 0; p < c->nranks; ++p) {
     const int64_t ns = c->halo_send_cnt[p], nr = c->halo_recv_cnt[p];
     if (ns > 0 && bad == ncclSuccess)
-      bad = g_rccl.Send(sendbuf + so * doubles_per_row, (size_t)(ns * doubles_per_row), ncclFloat64, p,
-                        (ncclComm_t)c->comm, st);
+      bad = g_rccl.Send(sendbuf + so * doubles_per_row, (size_t)(ns * doubles_per_row), ncclFloat64, p, comm, st);
     if (nr > 0 && bad == ncclSuccess)
-      bad = g_rccl.Recv(recvbuf + ro * doubles_per_row, (size_t)(nr * doubles_per_row), ncclFloat64, p,
-                        (ncclComm_t)c->comm, st);
+      bad = g_rccl.Recv(recvbuf + ro * doubles_per_row, (size_t)(nr * doubles_per_row), ncclFloat64, p, comm, st);
     so += ns;
     ro += nr;
   }

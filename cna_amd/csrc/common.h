@@ -73,6 +73,7 @@ struct cna_ctx {
   // ---- communicator
   int rank = 0, nranks = 1;
   void* comm = nullptr;  // ncclComm_t
+  void* comm_halo = nullptr;   // ncclComm_t: a duplicate of `comm` (ncclCommSplit) for the halo stream; null: exchanges stay on the main stream
   void* shm = nullptr;   // host-staged communicator of cna_comm_init_shm (several ranks on one GPU: tests)
   // neighbour ("halo") exchange of the diffusion state, replacing the all-gather (cna_set_halo)
   bool halo_on = false;

@@ -8,6 +8,7 @@
  *   cna_host_cluster_order   (below) the cell order of the device copy of the graph
  */
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -298,6 +299,7 @@ struct co_shared {
   int32_t* state; unsigned char* queued;
   int64_t* out_full; int64_t* n_full; int64_t* out_short; int64_t* n_short;   /* per region, written at rstart[p] */
   volatile int failed; volatile int64_t next_region;
+  int gate;                                      /* start gate of the workers (co_worker) */
 };
 struct co_job { struct co_shared* sh; int tid; };
 
@@ -389,6 +391,14 @@ static void* co_worker(void* arg) {
   struct co_job* jb = (struct co_job*)arg;
   struct co_shared* sh = jb->sh;
   const int t = jb->tid, T = sh->nthreads;
+  /* start gate: the barrier below counts nthreads participants, so nobody enters it before every thread exists
+     (1: go; -1: a thread could not be created, leave) */
+  for (;;) {
+    const int g = __atomic_load_n(&sh->gate, __ATOMIC_ACQUIRE);
+    if (g > 0) break;
+    if (g < 0) return NULL;
+    sched_yield();
+  }
   /* ---- 1. regions: level-synchronous multi-source BFS */
   for (;;) {
     const int64_t nf = sh->nfront;
@@ -485,7 +495,7 @@ int64_t cna_host_cluster_order_mt(int64_t n, const int64_t* indptr, const int32_
   int64_t rc = -1;
   pthread_t th[64];
   struct co_job jobs[64];
-  int started = 0, bar_ok = 0;
+  int started = 0, bar_ok = 0, seq_fallback = 0;
   if (!sh.region || !sh.cand || !sh.frontier || !sh.next || !sh.nnext || !sh.capnext || !sh.rstart || !sh.members ||
       !sh.state || !sh.queued || !sh.out_full || !sh.out_short || !sh.n_full || !sh.n_short) goto done;
   for (int64_t i = 0; i < n; ++i) { sh.region[i] = -1; sh.cand[i] = 0x7fffffff; }
@@ -500,15 +510,17 @@ int64_t cna_host_cluster_order_mt(int64_t n, const int64_t* indptr, const int32_
   for (int t = 0; t < nthreads; ++t) { jobs[t].sh = &sh; jobs[t].tid = t; }
   for (int t = 1; t < nthreads; ++t) {
     if (pthread_create(&th[t], NULL, co_worker, &jobs[t]) != 0) {
-      /* cannot run with fewer participants than the barrier counts: give up on threads */
-      sh.failed = 1;
-      for (int k = 1; k < t; ++k) pthread_cancel(th[k]);
+      /* cannot run with fewer participants than the barrier counts: the threads that exist are still at the start
+         gate -- send them home and take the sequential path */
+      __atomic_store_n(&sh.gate, -1, __ATOMIC_RELEASE);
       for (int k = 1; k < t; ++k) pthread_join(th[k], NULL);
       started = 0;
+      seq_fallback = 1;
       goto done;
     }
     started = t;
   }
+  __atomic_store_n(&sh.gate, 1, __ATOMIC_RELEASE);
   co_worker(&jobs[0]);
   for (int t = 1; t <= started; ++t) pthread_join(th[t], NULL);
   started = 0;
@@ -525,6 +537,7 @@ done:
   if (sh.next) for (int t = 0; t < nthreads; ++t) free(sh.next[t]);
   free(sh.next); free(sh.nnext); free(sh.capnext); free(sh.region); free(sh.cand); free(sh.frontier); free(sh.rstart);
   free(sh.members); free(sh.state); free(sh.queued); free(sh.out_full); free(sh.out_short); free(sh.n_full); free(sh.n_short);
+  (void)seq_fallback;                            /* (sh.failed stays 0 on that path: the sequential order below) */
   if (rc < 0 && !sh.failed) return cna_host_cluster_order(n, indptr, indices, B, order_out);
   return rc;
 }

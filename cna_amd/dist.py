@@ -57,6 +57,7 @@ def _exchange_id(rank, nranks, key, make, timeout=600.0):
     behind and a stale name cannot exist -- the kernel drops it with the last descriptor) and hands the id to the
     nranks - 1 processes that connect."""
     import socket
+    import struct
     import time
     name = b'\0cna_amd_rdzv_' + str(key).encode()
     if rank == 0:
@@ -64,12 +65,24 @@ def _exchange_id(rank, nranks, key, make, timeout=600.0):
         srv = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
         srv.bind(name)
         srv.listen(max(nranks, 1))
-        srv.settimeout(timeout)
+        deadline = time.time() + timeout
+        served = 0
         try:
-            for _ in range(nranks - 1):
+            # only processes of this user are served (SO_PEERCRED), and a stranger's connection does not use up one
+            # of the nranks - 1 hand-overs
+            while served < nranks - 1:
+                srv.settimeout(max(0.1, deadline - time.time()))
                 conn, _ = srv.accept()
                 with conn:
+                    try:
+                        cred = conn.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize('3i'))
+                        uid_peer = struct.unpack('3i', cred)[1]
+                    except OSError:
+                        uid_peer = -1
+                    if uid_peer != os.getuid():
+                        continue
                     conn.sendall(uid)
+                    served += 1
         finally:
             srv.close()
         return uid
@@ -107,6 +120,13 @@ def init_from_env(always_comm=False, shm=None):
         return rank, nranks
     uid = None
     if nranks > 1 or always_comm:
+        # the id travels over a Unix-domain socket: the ranks of ONE node (a multi-node launcher must hand the id over
+        # itself: init(rank, nranks, unique_id))
+        local = os.environ.get('LOCAL_WORLD_SIZE')
+        nnodes = os.environ.get('GROUP_WORLD_SIZE') or os.environ.get('NNODES')
+        if (local is not None and int(local) != nranks) or (nnodes is not None and nnodes.isdigit() and int(nnodes) > 1):
+            raise RuntimeError('cna_amd.dist.init_from_env serves the ranks of one node (WORLD_SIZE=%d, LOCAL_WORLD_SIZE=%s); '
+                               'pass the RCCL id yourself with init(rank, nranks, unique_id)' % (nranks, local))
         key = os.environ.get('MASTER_PORT', '29533') + '_' + os.environ.get('TORCHELASTIC_RUN_ID', 'none')
         uid = _exchange_id(rank, nranks, key, new_unique_id) if nranks > 1 else new_unique_id()
     init(rank, nranks, uid, device)

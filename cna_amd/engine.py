@@ -34,12 +34,18 @@ class Engine(_order.CellOrder):
         if nranks > 1 and unique_id is None and shm is None:
             raise ValueError('nranks > 1 needs the RCCL unique id created by rank 0')
         self._has_comm = unique_id is not None or shm is not None
+        self.halo_comm = False
         if shm is not None:
             check(self.lib.cna_comm_init_shm(self.h, self.rank, self.nranks, str(shm[0]).encode(), int(shm[1])),
                   'cna_comm_init_shm')
         elif unique_id is not None:   # also with one rank: every collective then really goes through RCCL
             buf = (C.c_char * 128).from_buffer_copy(bytes(unique_id))
             check(self.lib.cna_comm_init(self.h, self.rank, self.nranks, C.cast(buf, C.c_void_p)), 'cna_comm_init')
+            # a rank that cannot reach a peer should say so now, not hang in the first collective of an analysis
+            ok = C.c_int(0)
+            check(self.lib.cna_comm_selftest(self.h, float(os.environ.get('CNA_COMM_TIMEOUT', '120')), C.byref(ok)),
+                  'cna_comm_selftest')
+            self.halo_comm = bool(ok.value)     # the halo exchange has a communicator of its own (overlaps the walk step)
         self._graph_key = None
         self._graph_hash = None
         self._pending_check = None
@@ -302,6 +308,10 @@ class Engine(_order.CellOrder):
         cells, samples in place, nothing regressed out): its last step then does that pass on its way out."""
         yv = None if y_std is None else _f64(y_std)
         check(self.lib.cna_nam_select_hint(self.h, ptr(yv), 0 if yv is None else len(yv)), 'cna_nam_select_hint')
+        if yv is not None:
+            # the step that follows overwrites the working matrix: results of earlier calls that still read it lazily
+            # (res.namresid, res.namresid_nbhdXpc) must see that now, not only once select_standardized() has run
+            self.x_epoch += 1
 
     def nam_auto(self, maxnsteps=15):
         """The walk with the reference's stop rule (nsteps=None, _nam.py:64-68) in one call, medians and rule on

@@ -74,6 +74,13 @@ int  cna_comm_init_shm(cna_ctx* ctx, int rank, int nranks, const char* name, int
 /* which communicator the context holds (0 none, 1 RCCL, 2 the shared-memory test communicator) and the
  * number of ranks as the communicator itself reports it (ncclCommCount) -- bench.py prints both */
 int  cna_comm_info(cna_ctx* ctx, int* backend, int* nranks);
+/* Start-up check of an RCCL communicator with a time limit per collective: an all-reduce on the main stream, then a
+ * ring send / receive on the halo stream's own communicator (cna_comm_init duplicates the communicator for it:
+ * the exchange of the diffusion state between steps -- SURVEY.md 8e, the rows of _nam.py:33's s the other ranks
+ * need -- runs under the step that produces it) while the main one carries a second all-reduce.  *halo_ok = 0: the
+ * halo communicator is absent or did not answer on some rank and was aborted everywhere; exchanges then stay on
+ * the main stream.  An error: the main communicator does not work.  No-op without RCCL or with one rank. */
+int  cna_comm_selftest(cna_ctx* ctx, double timeout_s, int* halo_ok);
 
 /* Neighbour ("halo") exchange of the diffusion state between steps instead of the all-gather.
  * After cna_graph_upload on every rank: send_rows = LOCAL row indices other ranks need, grouped by

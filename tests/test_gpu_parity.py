@@ -906,6 +906,7 @@ def test_gram_under_the_walks_last_step(eng, monkeypatch, n, N, K, nsteps):
     monkeypatch.setattr(A, '_DEFER_LAST_CELLS', 0)
     data, meta = synth.make_dataset(n, N, k=15, seed=33)
     out = {}
+    monkeypatch.setattr(eng, 'reuse_nam', False)          # both runs walk
     for ranged in (True, False):
         monkeypatch.setenv('CNA_GRAM_OVERLAP', str(K) if ranged else '0')
         eng.prof_reset(); eng.prof_enable(True)
