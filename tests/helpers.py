@@ -61,6 +61,35 @@ def relerr(a, b):
     return float(np.nanmax(np.abs(a - b)) / scale) if a.size else 0.0
 
 
+def assert_elementwise(a, b, rtol=1e-5, floor=1e-12, what=''):
+    """|a - b| <= rtol |b| + floor max|b| for EVERY entry (NaNs must coincide): BASELINE.json's "float within 1e-5
+    rel" taken entry by entry, with an absolute floor for entries that are differences of much larger numbers."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if not a.size:
+        return
+    assert np.array_equal(np.isnan(a), np.isnan(b)), what
+    scale = np.nanmax(np.abs(b)) if np.isfinite(b).any() else 0.0
+    bad = np.abs(a - b) > rtol * np.abs(b) + floor * scale
+    assert not bad.any(), '%s: %d entries off, worst |a-b|/|b| = %.3g, worst |a-b|/max|b| = %.3g' % (
+        what, int(bad.sum()), float(np.nanmax(np.abs(a - b)[bad] / np.maximum(np.abs(b)[bad], 1e-300))),
+        float(np.nanmax(np.abs(a - b)[bad]) / max(scale, 1e-300)))
+
+
+def golden_floors(z, name=''):
+    """Absolute floors (fractions of max |reference|) of the entry-wise comparison with a golden fixture.  The NAM is a
+    sum of non-negative products: purely relative.  Coefficients and the residualised NAM are differences of such sums;
+    on a float32 graph the reference takes column sums and the first walk step in float32 (_nam.py:28,33 on scipy's
+    float32 CSR) and this implementation in float64 -- a 3e-7 relative difference of the NAM that cancellation turns
+    into up to 6e-8 / 8e-8 of the largest entry (measured over the fixtures with the float64 oracle, which the GPU
+    matches to 1e-10; 1.5e-6 where the ridge loop of c16 amplifies it).  On a float64 graph: 1e-12."""
+    f64_graph = z['in_data'].dtype == np.float64
+    if f64_graph:
+        return dict(nam=1e-12, ncorrs=1e-12, namresid=1e-12)
+    return dict(nam=1e-12, ncorrs=2e-7, namresid=5e-6 if 'ridge_loop' in str(name) else 2e-7)
+
+
 # --------------------------------------------------------------------------------------
 # running the product API on a fixture and comparing with the reference's outputs
 def run_product(case, engine, **overrides):
@@ -82,7 +111,7 @@ def run_product(case, engine, **overrides):
     return res, err, msgs
 
 
-def assert_matches_golden(res, data, z, tol=1e-5, check_lazy=True):
+def assert_matches_golden(res, data, z, tol=1e-5, check_lazy=True, name=''):
     """Every result field of SURVEY.md §8a a20 against the reference's values.
     ints / masks exact; floats within `tol` relative (BASELINE.json: 1e-5) -- observed maxima over the 19
     fixtures are 2e-8 ... 7e-7 (the reference's float32 first walk step on float32 graphs).  One exception, the
@@ -95,7 +124,8 @@ def assert_matches_golden(res, data, z, tol=1e-5, check_lazy=True):
     assert int(res.r) == int(z['r'])
     assert np.array_equal(res.kept, z['kept'])
     assert float(res.p) == pytest.approx(float(z['p']), rel=1e-12)
-    assert relerr(res.ncorrs.values, z['ncorrs']) < tol
+    fl = golden_floors(z, name)
+    assert_elementwise(res.ncorrs.values, z['ncorrs'], tol, fl['ncorrs'], 'ncorrs')
     assert relerr(res.M.values, z['M']) < tol
     assert relerr(res.nullminps, z['nullminps']) < tol
     assert relerr(res.namresid_svs.values, z['svs']) < tol
@@ -129,8 +159,8 @@ def assert_matches_golden(res, data, z, tol=1e-5, check_lazy=True):
         np.testing.assert_allclose(data.obs['coef_fdr'].values, z['obs_coef_fdr'], rtol=tol * 10, atol=1e-12)
     if check_lazy:
         assert list(res.nam.index) == z['nam_index'].tolist()
-        assert relerr(res.nam.values, z['nam']) < tol
-        assert relerr(res.namresid.values, z['namresid']) < tol
+        assert_elementwise(res.nam.values, z['nam'], tol, fl['nam'], 'nam')
+        assert_elementwise(res.namresid.values, z['namresid'], tol, fl['namresid'], 'namresid')
         V, Vref = sign_align(res.namresid_nbhdXpc.values, z['V'], kk)
         assert relerr(V, Vref) < tol
         assert res.nam.shape == z['nam'].shape and list(res.nam.columns) == list(data.obs.index[z['kept']])

@@ -77,8 +77,18 @@ def _check_full_result(res, data, y, N, Nnull, covs=None):
     assert nam.shape == (N, n)
     np.testing.assert_allclose(nam.sum(axis=1), 1.0, rtol=1e-9)        # column-stochastic walk, _nam.py:28,33,73
     assert nam.min() >= 0.0
-    del nam
     X = res.namresid.values
+    if covs is None:
+        # Under the default schedule X is the by-product of the walk's last step (diffuse.hip:select_tail) and the raw
+        # NAM comes from a SECOND run of that step (c_api.hip:need_nam): the two must be the same matrix -- X is the
+        # NAM centred and divided by its std per cell (_nam.py:122,159), entry by entry, at full size
+        for c0 in range(0, n, 250_000):
+            blk = nam[:, c0:c0 + 250_000]
+            want = blk - blk.mean(axis=0)
+            want /= want.std(axis=0, ddof=1)
+            np.testing.assert_allclose(X[:, c0:c0 + 250_000], want, rtol=1e-9, atol=1e-11)
+        del blk, want
+    del nam
     assert np.abs(X.mean(axis=0)).max() < 1e-10                        # _nam.py:122
     np.testing.assert_allclose(X.std(axis=0, ddof=1), 1.0, rtol=1e-10)  # _nam.py:159
     if covs is not None:

@@ -417,7 +417,7 @@ def test_association_matches_reference(eng, name):
                                    atol=1e-5 * np.nanmax(np.abs(z['obs_coef'])), equal_nan=True)
         return
     assert err is None, repr(err)
-    assert_matches_golden(res, case['data'], z, tol=1e-5)
+    assert_matches_golden(res, case['data'], z, tol=1e-5, name=name)
 
 
 @pytest.mark.parametrize('name', ['c01_plain_f32', 'c03_covs_batches', 'c09_y_nan_extra_reordered', 'c15_ridges_custom'])
@@ -538,7 +538,7 @@ def test_rccl_path_with_one_rank(orc, monkeypatch, selftest):
         res, err, _ = run_product(case, e)
         assert err is None, repr(err)
         assert (e.halo is not None and e.halo[0] == e.halo[1] >= selftest) if selftest else e.halo is None
-        assert_matches_golden(res, case['data'], case['z'], tol=1e-5)
+        assert_matches_golden(res, case['data'], case['z'], tol=1e-5, name='c12_batchy_qc')
         import cna_amd as cna
         A = sp.csr_matrix(case['data'].obsp['connectivities'])
         s0 = np.random.RandomState(1).rand(A.shape[0], 5)

@@ -36,7 +36,7 @@ def test_association_host_logic(name, order):
                                    atol=1e-5 * np.nanmax(np.abs(z['obs_coef'])), equal_nan=True)
         return
     assert err is None, repr(err)
-    assert_matches_golden(res, case['data'], z)
+    assert_matches_golden(res, case['data'], z, name=name)
     import json
     ref_msgs = [m for m in json.loads(z['warnings'].item()) if 'already exists' not in m]
     assert [m for m in msgs if 'already exists' not in m] == ref_msgs
