@@ -279,6 +279,14 @@ def kernel_table(m, world):
     kernels = {}
     for name, (ms, cnt) in m['prof'].items():
         bound, work = algorithmic_work(name, m['n_loc'], m['nnz_loc'], m['N'], min(1000, m['Nnull']), T, m['wA'])
+        step_work = work if name == 'nam_step' else None           # SURVEY 8(d)'s bytes of a diffusion step, whatever the launch also does
+        if name == 'nam_first' and m['N'] >= 96 and world == 1 and m['n_loc']:
+            # from 96 samples on (one GPU) the first step leaves a row as its non-zeros -- 16-byte {value, sample} records,
+            # at most 64, and a count byte -- instead of the dense 8N-byte row 8(d) prices (diffuse.hip:first_tail): priced
+            # on the EXPECTED number of distinct samples among a cell and its neighbours, N (1 - (1 - 1/N)^(deg + 1))
+            deg = m['nnz_loc'] / m['n_loc']
+            pairs = min(64.0, m['N'] * (1.0 - (1.0 - 1.0 / m['N']) ** (deg + 1.0)))
+            work = work - 8 * m['n_loc'] * m['N'] + m['n_loc'] * (16.0 * pairs + 1.0)
         if name == 'nam_step' and 'select' not in m['prof'] and m['N'] > 64:
             # the last step also did the selection pass (diffuse.hip:select_tail): it writes X instead of the NAM (same
             # bytes) plus what that pass adds -- three digit planes of 32 ceil(N/32) bytes, coefficient, row scale
@@ -293,6 +301,8 @@ def kernel_table(m, world):
         kernels[name] = dict(total_ms=round(ms, 4), launches=cnt, avg_us=round(ms / cnt * 1e3, 2), bound=bound,
                              achieved=round(ach, 3), peak=peak, unit='GB/s' if bound == 'hbm' else 'TFLOP/s',
                              frac=round(ach / peak, 4))
+        if step_work is not None:
+            kernels[name]['frac_step_bytes'] = round(step_work / avg_s / 1e9 / peak, 4)
         if name == 'null_local' and m.get('i8', (False,))[0]:
             # the pass ran on the integer matrix cores (csrc/null_i8.hip): six exact i8 digit products stand in for
             # one f64 product, so the algorithmic work is 6 x 2nNP' integer operations against the i8 peak; the time
@@ -323,6 +333,10 @@ def summary(m, world, steps):
     roofline = dict(kernel=dom, bound=kd['bound'], achieved=kd['achieved'], peak=kd['peak'], unit=kd['unit'],
                     frac=kd['frac'], traffic=traffic, traffic_source=src, avg_us=kd['avg_us'],
                     launches_per_step=kd['launches'] // steps)
+    if 'frac_step_bytes' in kd:
+        # the same launch priced on SURVEY 8(d)'s step bytes alone (`frac` also counts what the fused selection pass
+        # writes: X instead of the NAM, digit planes, coefficients)
+        roofline['frac_step_bytes'] = kd['frac_step_bytes']
     if dom == 'nam_step':
         # what the row-gather actually moves, beside the algorithmic bytes the fraction is priced on: every edge fetches
         # its neighbour's 8N-byte state row through the vector L1 (the chip delivers 17-19 TB/s on this
