@@ -94,6 +94,9 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cna_host_set_threads': (None, [C.c_int]),
     'cna_host_argsort_gather': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'cna_host_draw_start': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    'cna_host_draw_wait': (C.c_int, []),
     'cna_global_test_launch': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     'cna_global_test_fetch': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cna_select_standardized_fused': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -194,47 +194,85 @@ struct sort_job {
 };
 
 #define SORT_CB 64                                        /* columns handled together: row segments of 512 bytes */
+
+/* rank of every entry of one column (m <= RANK_MAX): rank[i] = #{j : v[j] < v[i]}, m*m comparisons that the
+ * compiler turns into vector compares -- for the short columns of a cohort (50 ... 128 samples) several times
+ * faster than any comparison sort.  Returns 0 when the ranks are a permutation (no ties), else -1. */
+#define RANK_MAX 128
+CLONES static int rank_column(const double* restrict v, int m, int32_t* restrict rank) {
+  uint64_t seen[RANK_MAX / 64] = {0};
+  double acc[RANK_MAX];
+  for (int i = 0; i < m; ++i) acc[i] = 0.0;
+  for (int j = 0; j < m; ++j) {                            /* vector over i: no horizontal sums */
+    const double vj = v[j];
+    for (int i = 0; i < m; ++i) acc[i] += vj < v[i] ? 1.0 : 0.0;
+  }
+  for (int i = 0; i < m; ++i) {
+    const int r = (int)acc[i];
+    const uint64_t bit = 1ull << (r & 63);
+    if (seen[r >> 6] & bit) return -1;
+    seen[r >> 6] |= bit;
+    rank[i] = r;
+  }
+  return 0;
+}
+
+/* longer columns: stable merge sort of (value, row) pairs; idx[r] = row of the r-th smallest */
+static void sort_column(const double* v, int m, struct sort_pair* a, struct sort_pair* b, int32_t* idx) {
+  for (int i = 0; i < m; ++i) { a[i].v = v[i]; a[i].i = i; }
+  for (int lo = 0; lo < m; lo += 8) {                /* runs of 8 by insertion */
+    const int hi = lo + 8 < m ? lo + 8 : m;
+    for (int i = lo + 1; i < hi; ++i) {
+      const struct sort_pair x = a[i];
+      int k = i - 1;
+      while (k >= lo && a[k].v > x.v) { a[k + 1] = a[k]; --k; }
+      a[k + 1] = x;
+    }
+  }
+  struct sort_pair *src = a, *dst = b;
+  for (int wd = 8; wd < m; wd *= 2) {                /* bottom-up merges (stable) */
+    for (int lo = 0; lo < m; lo += 2 * wd) {
+      const int mid = lo + wd < m ? lo + wd : m, hi = lo + 2 * wd < m ? lo + 2 * wd : m;
+      int i = lo, k = mid, o = lo;
+      while (i < mid && k < hi) dst[o++] = src[k].v < src[i].v ? src[k++] : src[i++];
+      while (i < mid) dst[o++] = src[i++];
+      while (k < hi) dst[o++] = src[k++];
+    }
+    struct sort_pair* t = src; src = dst; dst = t;
+  }
+  for (int i = 0; i < m; ++i) idx[i] = src[i].i;
+}
+
 static void* sort_worker(void* arg) {
   struct sort_job* j = (struct sort_job*)arg;
   const int m = j->m;
   struct sort_pair* a = (struct sort_pair*)malloc(sizeof(struct sort_pair) * (size_t)m * 2);
-  double* blk = (double*)malloc(sizeof(double) * (size_t)m * SORT_CB * 2);     /* draws | results, m x SORT_CB each */
-  if (!a || !blk) { free(a); free(blk); return (void*)1; }
+  double* blk = (double*)malloc(sizeof(double) * (size_t)m * (SORT_CB * 2 + 1));     /* draws (column-major) | results, m x SORT_CB each | one column */
+  int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)m);
+  if (!a || !blk || !idx) { free(a); free(blk); free(idx); return (void*)1; }
   struct sort_pair* b = a + m;
   double* res = blk + (size_t)m * SORT_CB;
   for (int cb = j->c0; cb < j->c1; cb += SORT_CB) {
     const int w = j->c1 - cb < SORT_CB ? j->c1 - cb : SORT_CB;
-    for (int i = 0; i < m; ++i) memcpy(blk + (size_t)i * SORT_CB, j->R + (size_t)i * j->num + cb, sizeof(double) * (size_t)w);
+    for (int i = 0; i < m; ++i) {                          /* the block transposed: every column contiguous */
+      const double* src = j->R + (size_t)i * j->num + cb;
+      for (int cc = 0; cc < w; ++cc) blk[(size_t)cc * m + i] = src[cc];
+    }
     for (int cc = 0; cc < w; ++cc) {
-      for (int i = 0; i < m; ++i) { a[i].v = blk[(size_t)i * SORT_CB + cc]; a[i].i = i; }
-      for (int lo = 0; lo < m; lo += 8) {                /* runs of 8 by insertion */
-        const int hi = lo + 8 < m ? lo + 8 : m;
-        for (int i = lo + 1; i < hi; ++i) {
-          const struct sort_pair v = a[i];
-          int k = i - 1;
-          while (k >= lo && a[k].v > v.v) { a[k + 1] = a[k]; --k; }
-          a[k + 1] = v;
-        }
+      const double* col = blk + (size_t)cc * m;
+      if (m <= RANK_MAX && rank_column(col, m, idx) == 0) {
+        for (int i = 0; i < m; ++i) res[(size_t)idx[i] * SORT_CB + cc] = j->y[i];        /* idx = rank here */
+      } else {
+        sort_column(col, m, a, b, idx);
+        for (int i = 0; i < m; ++i) res[(size_t)i * SORT_CB + cc] = j->y[idx[i]];
       }
-      struct sort_pair *src = a, *dst = b;
-      for (int wd = 8; wd < m; wd *= 2) {                /* bottom-up merges (stable) */
-        for (int lo = 0; lo < m; lo += 2 * wd) {
-          const int mid = lo + wd < m ? lo + wd : m, hi = lo + 2 * wd < m ? lo + 2 * wd : m;
-          int i = lo, k = mid, o = lo;
-          while (i < mid && k < hi) dst[o++] = src[k].v < src[i].v ? src[k++] : src[i++];
-          while (i < mid) dst[o++] = src[i++];
-          while (k < hi) dst[o++] = src[k++];
-        }
-        struct sort_pair* t = src; src = dst; dst = t;
-      }
-      for (int i = 0; i < m; ++i) res[(size_t)i * SORT_CB + cc] = j->y[src[i].i];
     }
     for (int i = 0; i < m; ++i) {
       const int64_t row = j->rows ? j->rows[i] : i;
       memcpy(j->out + (size_t)row * j->ld_out + cb, res + (size_t)i * SORT_CB, sizeof(double) * (size_t)w);
     }
   }
-  free(a); free(blk);
+  free(a); free(blk); free(idx);
   return NULL;
 }
 
@@ -247,7 +285,8 @@ int cna_host_argsort_gather(const double* R, int m, int num, const double* y, do
   int started[64];
   int nt = g_host_threads;
   if (nt > 64) nt = 64;
-  if (nt > num / 64) nt = num / 64;
+  if (nt > num / 128) nt = num / 128;                    /* at least two blocks of 64 columns per thread */
+  if ((int64_t)m * num < 32768) nt = 1;                  /* (a thread costs ~30 us to start) */
   if (nt < 1) nt = 1;
   for (int t = 0; t < nt; ++t) {
     jobs[t].R = R; jobs[t].y = y; jobs[t].out = out; jobs[t].rows = rows; jobs[t].ld_out = ld_out;
@@ -265,4 +304,100 @@ int cna_host_argsort_gather(const double* R, int m, int num, const double* y, do
     bad |= rv != NULL;
   }
   return bad ? -1 : 0;
+}
+
+
+/* ---- the permutation draw of conditional_permutation (_stats.py:4-18) off the interpreter ---------------------
+ * One persistent worker thread takes a request -- the generator state (numpy's own memory, freshly seeded: no
+ * cached normal pending), the standardised phenotype y[m], the levels of the batch vector as member lists
+ * (np.unique order), an even number `num` of permutations -- and fills out[r * ld_out + p] = permuted y: per level
+ * one randn(len(level), num) block of the legacy stream, then y[members][argsort(block, axis=0)] written to the
+ * members' rows: exactly the reference's RNG consumption and values.  The caller goes on with its own work and
+ * collects the result with cna_host_draw_wait().  Nothing here needs the interpreter lock: on a small cohort the
+ * draw is the longest host item of an analysis, and a Python helper thread got to it 0.35 ms late and took
+ * 0.54 ms for 0.39 ms of work (tools/host_trace.py at 200k cells x 50 samples). */
+struct draw_req {
+  uint32_t* key; int* pos; const double* y; int m, num, nlev; const int64_t* lev_off; const int64_t* members;
+  double* out; int64_t ld_out; int threads;
+};
+static pthread_mutex_t g_draw_mu = PTHREAD_MUTEX_INITIALIZER;
+static pthread_cond_t g_draw_cv = PTHREAD_COND_INITIALIZER;
+static pthread_t g_draw_th;
+static int g_draw_alive = 0, g_draw_state = 0, g_draw_rc = 0;        /* state 0 idle, 1 posted, 2 running, 3 done */
+static struct draw_req g_draw_req;
+
+static int draw_run(const struct draw_req* q) {
+  int64_t mmax = 0;
+  for (int l = 0; l < q->nlev; ++l) { const int64_t ml = q->lev_off[l + 1] - q->lev_off[l]; if (ml > mmax) mmax = ml; }
+  double* R = (double*)malloc(sizeof(double) * (size_t)(mmax > 0 ? mmax : 1) * (size_t)q->num);
+  double* ysub = (double*)malloc(sizeof(double) * (size_t)(mmax > 0 ? mmax : 1));
+  if (!R || !ysub) { free(R); free(ysub); return -1; }
+  int rc = 0;
+  const int saved = g_host_threads;
+  g_host_threads = q->threads > 0 ? q->threads : 1;
+  for (int l = 0; l < q->nlev && rc == 0; ++l) {
+    const int64_t* mem = q->members + q->lev_off[l];
+    const int ml = (int)(q->lev_off[l + 1] - q->lev_off[l]);
+    if (ml == 0) continue;
+    int hg = 0;
+    double g = 0.0;
+    if (cna_host_legacy_randn(q->key, q->pos, &hg, &g, (int64_t)ml * q->num, R) != 0 || hg != 0) { rc = -1; break; }
+    for (int i = 0; i < ml; ++i) ysub[i] = q->y[mem[i]];
+    if (cna_host_argsort_gather(R, ml, q->num, ysub, q->out, q->ld_out, mem) != 0) rc = -1;
+  }
+  g_host_threads = saved;
+  free(R); free(ysub);
+  return rc;
+}
+
+static void* draw_thread(void* arg) {
+  (void)arg;
+  pthread_mutex_lock(&g_draw_mu);
+  for (;;) {
+    while (g_draw_state != 1) pthread_cond_wait(&g_draw_cv, &g_draw_mu);
+    g_draw_state = 2;
+    const struct draw_req q = g_draw_req;
+    pthread_mutex_unlock(&g_draw_mu);
+    const int rc = draw_run(&q);
+    pthread_mutex_lock(&g_draw_mu);
+    g_draw_rc = rc;
+    g_draw_state = 3;
+    pthread_cond_broadcast(&g_draw_cv);
+  }
+  return NULL;
+}
+
+/* 0: the request is with the worker (every pointer must stay valid until cna_host_draw_wait returns);
+ * -1: bad arguments / an earlier request not collected / no thread: the caller draws the usual way, the generator
+ * state has not been touched */
+int cna_host_draw_start(uint32_t* key, int* pos, const double* y, int m, int num, int nlev, const int64_t* lev_off,
+                        const int64_t* members, double* out, int64_t ld_out, int threads) {
+  if (!key || !pos || !y || !lev_off || !members || !out || m < 1 || num < 2 || (num & 1) || nlev < 1 || ld_out < num) return -1;
+  if (*pos < 0 || *pos > MT_N) return -1;
+  for (int l = 0; l < nlev; ++l) if (lev_off[l + 1] < lev_off[l] || lev_off[l + 1] > m) return -1;
+  for (int64_t i = 0; i < lev_off[nlev]; ++i) if (members[i] < 0 || members[i] >= m) return -1;
+  pthread_mutex_lock(&g_draw_mu);
+  if (g_draw_state != 0) { pthread_mutex_unlock(&g_draw_mu); return -1; }
+  if (!g_draw_alive) {
+    if (pthread_create(&g_draw_th, NULL, draw_thread, NULL) != 0) { pthread_mutex_unlock(&g_draw_mu); return -1; }
+    pthread_detach(g_draw_th);
+    g_draw_alive = 1;
+  }
+  g_draw_req = (struct draw_req){key, pos, y, m, num, nlev, lev_off, members, out, ld_out, threads};
+  g_draw_state = 1;
+  pthread_cond_broadcast(&g_draw_cv);
+  pthread_mutex_unlock(&g_draw_mu);
+  return 0;
+}
+
+/* blocks until the request of cna_host_draw_start is done; 0, or -1 when it failed (allocation) -- the generator
+ * state is then undefined and the caller must raise; -2: nothing was started */
+int cna_host_draw_wait(void) {
+  pthread_mutex_lock(&g_draw_mu);
+  if (g_draw_state == 0) { pthread_mutex_unlock(&g_draw_mu); return -2; }
+  while (g_draw_state != 3) pthread_cond_wait(&g_draw_cv, &g_draw_mu);
+  const int rc = g_draw_rc;
+  g_draw_state = 0;
+  pthread_mutex_unlock(&g_draw_mu);
+  return rc;
 }

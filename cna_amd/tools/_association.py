@@ -24,7 +24,7 @@ from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_plan, _resid_r
                    shard_of, global_samples,
                    _small_svd, _defer_pcs, host_blas_threads, _top_pcs, GramPCs)
 from ._out import select_output
-from ._stats import conditional_permutation, grouplevel_permutation, default_ks, minp_stats
+from ._stats import conditional_permutation, grouplevel_permutation, default_ks, minp_stats, native_draw_start
 
 
 _pool = None
@@ -48,6 +48,7 @@ _EARLY_WALK = os.environ.get('CNA_EARLY_WALK', '1') not in ('0', 'off', 'no')
 _EARLY_COEF = os.environ.get('CNA_EARLY_COEF', '1') not in ('0', 'off', 'no')     # ablation switches
 _EARLY_FDR = os.environ.get('CNA_EARLY_FDR', '1') not in ('0', 'off', 'no')
 _DRAW_THREAD = os.environ.get('CNA_DRAW_THREAD', '1') not in ('0', 'off', 'no')
+_NATIVE_DRAW = os.environ.get('CNA_NATIVE_DRAW', '1') not in ('0', 'off', 'no')   # the draw on the library's host thread (tests compare both)
 _SWITCH_INTERVAL = float(os.environ.get('CNA_SWITCH_INTERVAL', '5e-5'))   # GIL hand-over between the helper thread and this one: 2.08 -> 1.86 ms per call at 200k cells (default interval: 5 ms)
 
 
@@ -606,7 +607,34 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     # few cells: the draw is on the critical path and starts at once (holding it back: 2.46 -> 3.0 ms at 200k)
     hold_draw = _DRAW_THREAD and len(data.obs) >= _COEF_FIRST_CELLS
 
+    # The draw itself -- numpy's legacy normal stream, an argsort per permutation (_stats.py:4-18) -- runs on the
+    # library's own host thread from here on when the call has the common shape (a seed, no donor groups, an even
+    # number of permutations): it needs no interpreter, so it neither waits for this thread's Python nor slows it
+    # (a Python helper thread got to it 0.35 ms late and took 0.54 ms for 0.39 ms of work at 200k cells x 50 samples)
+    native = None
+    if _NATIVE_DRAW and dv is None and len(yv) and kwargs.get('seed') is not None:
+        try:
+            native = native_draw_start(np.ones(len(yv)) if kwargs.get('force_permute_all', False) else bv, y_std, Nnull,
+                                       kwargs.get('seed'))
+        except Exception:                     # noqa: BLE001 - the usual draw below reports whatever is wrong
+            native = None
+        if native is not None:
+            _mark('native draw started')
+
     def null_job():
+        if native is not None:
+            table = native.wait()
+            _mark('draw done')
+            out_ = (table[:, 0], table[:, 1:])
+            M_ = early.get('M')
+            if M_ is not None and len(table) == len(M_):
+                try:
+                    engine.condition(M_, table)
+                    early['conditioned'] = True
+                    _mark('conditioned (helper)')
+                except Exception as exc:      # the main thread conditions again and reports what it finds
+                    early['condition_error'] = exc
+            return out_
         if hold_draw:
             walk_queued.wait(0.004)
         _mark('draw starts')
@@ -658,6 +686,11 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     except BaseException:
         walk_queued.set()
         null_future.cancel() or null_future.exception()     # do not leave the helper thread running
+        if native is not None:
+            try:
+                native.wait()                               # ... nor the library's draw uncollected
+            except Exception:                               # noqa: BLE001
+                pass
         raise
     finally:
         engine._on_walk_queued = None
@@ -674,6 +707,11 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         res = _resid_run(engine, plan, cell_index, show_progress=show_progress)
     except BaseException:
         null_future.cancel() or null_future.exception()     # do not leave the helper thread running
+        if native is not None:
+            try:
+                native.wait()                               # ... nor the library's draw uncollected
+            except Exception:                               # noqa: BLE001
+                pass
         raise
 
     _mark('resid queued')

@@ -121,6 +121,78 @@ def conditional_permutation(B, Y, num, clean=False):
     return out
 
 
+class NativeDraw:
+    """conditional_permutation(B, Y, num) of a freshly seeded generator, started on the library's own host thread
+    (csrc/host_rng.c:cna_host_draw_start): no interpreter involved, so the draw runs while this thread validates,
+    plans and launches kernels.  ``wait()`` returns the samples x (1 + num) matrix [Y | permutations] -- the matrix
+    the phenotypes are conditioned from -- whose columns 1.. equal the reference's draw bit for bit, numpy's global
+    generator left where the reference leaves it."""
+
+    def __init__(self, lib, keep, table):
+        self._lib, self._keep, self.table, self._done = lib, keep, table, False
+
+    def wait(self):
+        if not self._done:
+            rc = self._lib.cna_host_draw_wait()
+            self._done = True
+            self._keep = None
+            if rc != 0:
+                raise MemoryError('cna_host_draw_wait: the permutation draw failed (%d)' % rc)
+        return self.table
+
+    def __del__(self):                         # the worker writes into buffers this object keeps alive
+        try:
+            self.wait()
+        except Exception:                      # noqa: BLE001
+            pass
+
+
+def native_draw_start(B, Y, num, seed, threads=1):
+    """Seed numpy's global generator (np.random.seed(seed), _association.py:15-16) and start
+    conditional_permutation(B, Y, num) on the library's host thread; None when the shape is not covered (the caller
+    then draws as before, from the generator as this function found it: nothing is consumed before the decision)."""
+    import ctypes as C
+    if seed is None or num < 2 or num % 2 or len(Y) < 1 or len(B) != len(Y):
+        return None
+    Y = np.asarray(Y)
+    if Y.dtype != np.float64:
+        return None
+    rs = getattr(np.random.mtrand, '_rand', None)
+    bg = getattr(rs, '_bit_generator', None)
+    if bg is None or type(bg).__name__ != 'MT19937':
+        return None
+    try:
+        from .. import _ffi
+        lib = _ffi.load()
+        lib.cna_host_draw_start
+    except Exception:
+        return None
+    levels = np.unique(B)
+    if len(levels) == 1 and bool((np.asarray(B) == levels[0]).all()):
+        members = np.arange(len(Y), dtype=np.int64)
+        off = np.array([0, len(Y)], dtype=np.int64)
+    else:
+        parts = [np.flatnonzero(B == b).astype(np.int64) for b in levels]
+        members = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+        off = np.zeros(len(parts) + 1, dtype=np.int64)
+        off[1:] = np.cumsum([len(q) for q in parts])
+    if len(members) == 0:
+        return None
+    Yc = np.ascontiguousarray(Y)
+    table = np.empty((len(Y), num + 1))
+    table[:, 0] = Yc
+    if len(members) < len(Y):
+        table[:, 1:] = Yc[0]                  # rows of no level (NaN batch labels): upstream's src stays 0 there
+    np.random.seed(seed)
+    addr = bg.ctypes.state_address             # struct mt19937_state { uint32_t key[624]; int pos; }
+    rc = lib.cna_host_draw_start(addr, C.cast(addr + 624 * 4, C.POINTER(C.c_int)), Yc.ctypes.data, len(Y), int(num),
+                                 len(off) - 1, off.ctypes.data, members.ctypes.data, table.ctypes.data + 8, num + 1,
+                                 int(threads))
+    if rc != 0:
+        return None                            # (seeded, nothing drawn: the caller's own draw seeds again)
+    return NativeDraw(lib, (Yc, off, members, bg), table)
+
+
 def grouplevel_permutation(G, Y, num, clean=False):
     """Permute whole groups (donors): samples sharing a value of G keep a common Y
     (reference _stats.py:20-32)."""

@@ -361,6 +361,16 @@ void cna_host_set_threads(int n);
  * threads (host only; rows NULL = identity) */
 int  cna_host_argsort_gather(const double* R, int m, int num, const double* y, double* out, int64_t ld_out,
                              const int64_t* rows);
+/* The whole draw of conditional_permutation (reference _stats.py:4-18: per level of the batch vector, in np.unique
+ * order, Y[members][argsort(randn(len(members), num), axis=0)]) on the library's own host thread, so that it runs
+ * beside the caller's interpreter instead of inside it.  key / pos: numpy's MT19937 state memory, freshly seeded (no
+ * cached normal), num even; members[lev_off[l] .. lev_off[l+1]) = rows of level l; out[r * ld_out + p] receives the
+ * permuted phenotypes.  All pointers stay valid until cna_host_draw_wait() has returned (0; -1: the draw failed and the
+ * generator state is undefined; -2: nothing started).  cna_host_draw_start: 0 = accepted, -1 = not accepted, nothing
+ * touched.  One request at a time per process. */
+int  cna_host_draw_start(uint32_t* key, int* pos, const double* y, int m, int num, int nlev, const int64_t* lev_off,
+                         const int64_t* members, double* out, int64_t ld_out, int threads);
+int  cna_host_draw_wait(void);
 
 /* ---- host-side helpers: graph identity and the device cell order (csrc/host_graph.c) ------- */
 /* 64-bit content hash of a buffer, computed on up to nthreads threads (the value does not depend on the

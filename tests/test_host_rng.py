@@ -95,3 +95,71 @@ def test_large_draws_take_the_threaded_helpers_and_stay_bit_identical(n, num, nb
         assert np.array_equal(got, want)
         assert st[2] == st_want[2] and np.array_equal(st[1], st_want[1]) and st[3] == st_want[3] and st[4] == st_want[4]
     _stats._threads_set = False
+
+
+def _reference_conditional_permutation(B, Y, num):
+    """reference _stats.py:4-18, verbatim semantics, numpy's own generator"""
+    B = np.asarray(B)
+    batchind = np.array([np.where(B == b)[0] for b in np.unique(B)], dtype=object)
+    ix = np.concatenate([bi[np.argsort(np.random.randn(len(bi), num), axis=0)] for bi in batchind])
+    bix = np.zeros((len(Y), num)).astype(int)
+    bix[np.concatenate(list(batchind)).astype(int)] = ix
+    return Y[bix]
+
+
+@pytest.mark.parametrize('m,num,levels', [(50, 1000, 1), (50, 1000, 5), (24, 100, 3), (130, 200, 1), (200, 400, 4),
+                                          (7, 2, 7), (300, 64, 2)])
+def test_native_draw_equals_the_reference_draw(m, num, levels):
+    """The whole conditional_permutation on the library's host thread (csrc/host_rng.c:cna_host_draw_start, what
+    association() uses for its null): the same permuted phenotypes and the same generator state as the reference's
+    np.random.seed + randn + argsort sequence (_association.py:15-16, _stats.py:4-18) -- short columns through the
+    rank counts (<= 128 rows per level), long ones through the merge sort."""
+    from cna_amd.tools import _stats
+    rs = np.random.RandomState(m * 1000 + num + levels)
+    Y = rs.randn(m)
+    B = rs.randint(0, levels, m).astype(float) if levels > 1 else np.ones(m)
+    seed = 17 + m
+    h = _stats.native_draw_start(B, Y, num, seed)
+    assert h is not None
+    table = h.wait()
+    after = np.random.get_state()
+    nxt = np.random.randn(3)
+    np.random.seed(seed)
+    want = _reference_conditional_permutation(B, Y, num)
+    ref_after = np.random.get_state()
+    assert np.array_equal(table[:, 0], Y) and np.array_equal(table[:, 1:], want)
+    assert after[2] == ref_after[2] and np.array_equal(after[1], ref_after[1]) and after[3] == ref_after[3] == 0
+    assert np.array_equal(nxt, np.random.randn(3))
+    # what is not covered falls back (None) without touching the generator
+    np.random.seed(5)
+    before = np.random.get_state()
+    assert _stats.native_draw_start(B, Y, 101, seed) is None and _stats.native_draw_start(B, Y, num, None) is None
+    assert np.array_equal(np.random.get_state()[1], before[1])
+
+
+def test_native_draw_rows_of_no_level_and_ties():
+    """NaN batch labels belong to no level: the reference's index matrix stays 0 there (every permutation shows Y[0]);
+    exact ties between draws cannot come out of randn, so the rank counts' fall-back is driven directly."""
+    from cna_amd.tools import _stats
+    Y = np.arange(10, dtype=float)
+    B = np.array([0, 0, 1, np.nan, 1, 0, np.nan, 1, 0, 1])
+    h = _stats.native_draw_start(B, Y, 50, 3)
+    if h is not None:                                     # np.unique keeps NaN as a level of its own: rows with B == NaN are in none
+        t = h.wait()
+        np.random.seed(3)
+        want = np.empty((10, 50))
+        want[:] = Y[0]
+        for b in np.unique(B):
+            mm = np.flatnonzero(B == b)
+            if len(mm):
+                want[mm] = Y[mm][np.argsort(np.random.randn(len(mm), 50), axis=0)]
+            else:
+                np.random.randn(0, 50)
+        assert np.array_equal(t[:, 1:], want)
+    from cna_amd import _ffi
+    lib = _ffi.load()
+    R = np.array([[1.0, 2.0], [1.0, 0.5], [0.0, 2.0], [1.0, 2.0]])
+    y = np.array([10.0, 11.0, 12.0, 13.0])
+    out = np.empty((4, 2))
+    assert lib.cna_host_argsort_gather(_ffi.ptr(R), 4, 2, _ffi.ptr(y), _ffi.ptr(out), 2, None) == 0
+    assert np.array_equal(out, y[np.argsort(R, axis=0, kind='stable')])
