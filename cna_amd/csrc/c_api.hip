@@ -1400,6 +1400,7 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
 // ceil((stop - start) / step) and its values start + i*delta with delta = (start + step) - start;
 // the edge expression rounds after every operation, left to right.  Returns T (0: out of range).
 static int null_local_prepare(cna_ctx* c, int P, const double* edges, int T, int want_tails, const double* thr);
+static int null_local_go(cna_ctx* c, int col0);
 
 int cna_reference_thresholds(double maxabs, int cap, double* thr, double* edges) {
 #pragma clang fp contract(off)
@@ -1429,10 +1430,11 @@ int cna_reference_thresholds(double maxabs, int cap, double* thr, double* edges)
 // that none of it waits for the interpreter.  *T_out = 0: nothing beyond the selection was issued.
 int cna_select_standardized_fused(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
                                   int64_t* n_zero_out, const double* y, double* max_abs_out, int null_P, int* T_out,
-                                  double* thr_out, int* gram_queued, int* coef_queued) {
+                                  double* thr_out, int* gram_queued, int* coef_queued, int null_col0, int* null_launched) {
   if (T_out) *T_out = 0;
   if (gram_queued) *gram_queued = 0;
   if (coef_queued) *coef_queued = 0;
+  if (null_launched) *null_launched = 0;
   int64_t nz = 0;
   double m = 0.0;
   bool gram_done = false;
@@ -1455,6 +1457,13 @@ int cna_select_standardized_fused(cna_ctx* c, const int64_t* keep_idx, int64_t n
   if (T < 1) return 0;
   CNA_TRY(null_local_prepare(c, null_P, edges, T, 0, thr_out));
   *T_out = T;
+  // ... and, when the caller says that the conditioned phenotypes of THIS analysis are already resident (columns
+  // null_col0 .. null_col0 + null_P of Zc: the draw and cna_condition_phenotypes ran beside the walk), the local-null
+  // pass itself: it then starts right behind the Gram kernel instead of after the interpreter's next few statements
+  if (null_col0 >= 0 && null_launched && c->zc && null_col0 + null_P <= c->zc_cols && c->zc_rows == c->Nx) {
+    CNA_TRY(null_local_go(c, null_col0));
+    *null_launched = 1;
+  }
   return 0;
 }
 

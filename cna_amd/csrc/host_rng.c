@@ -195,26 +195,49 @@ struct sort_job {
 
 #define SORT_CB 64                                        /* columns handled together: row segments of 512 bytes */
 
-/* rank of every entry of one column (m <= RANK_MAX): rank[i] = #{j : v[j] < v[i]}, m*m comparisons that the
- * compiler turns into vector compares -- for the short columns of a cohort (50 ... 128 samples) several times
- * faster than any comparison sort.  Returns 0 when the ranks are a permutation (no ties), else -1. */
-#define RANK_MAX 128
-CLONES static int rank_column(const double* restrict v, int m, int32_t* restrict rank) {
-  uint64_t seen[RANK_MAX / 64] = {0};
-  double acc[RANK_MAX];
-  for (int i = 0; i < m; ++i) acc[i] = 0.0;
-  for (int j = 0; j < m; ++j) {                            /* vector over i: no horizontal sums */
-    const double vj = v[j];
-    for (int i = 0; i < m; ++i) acc[i] += vj < v[i] ? 1.0 : 0.0;
+/* Short columns (m <= NET_MAX rows, the sample axis of a cohort): a sorting network over SORT_CB columns at once.
+ * Every entry carries its row in the low NET_BITS bits of its mantissa, so that min / max on the doubles themselves move
+ * (value, row) pairs -- two vector instructions per comparator and four columns, no branches, against ~40 ns per
+ * element of a comparison sort.  Entries whose remaining bits coincide would be ordered by row instead of by their
+ * true low bits: such a column (probability ~1e-9) is reported and redone exactly by the caller. */
+#define NET_MAX 128
+#define NET_BITS 7
+static int g_net_n[5] = {8, 16, 32, 64, 128};
+static int* g_net_pairs[5];                              /* comparators (i, j), i < j, of Batcher's odd-even merge sort */
+static int g_net_count[5];
+static pthread_once_t g_net_once = PTHREAD_ONCE_INIT;
+
+static void net_build(void) {
+  for (int k = 0; k < 5; ++k) {
+    const int n = g_net_n[k];
+    int cap = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+      int cnt = 0;
+      for (int p = 1; p < n; p *= 2)
+        for (int q = p; q >= 1; q /= 2)
+          for (int j = q % p; j <= n - 1 - q; j += 2 * q)
+            for (int i = 0; i < (q < n - j - q ? q : n - j - q); ++i)
+              if ((i + j) / (2 * p) == (i + j + q) / (2 * p)) {
+                if (pass) { g_net_pairs[k][2 * cnt] = i + j; g_net_pairs[k][2 * cnt + 1] = i + j + q; }
+                ++cnt;
+              }
+      if (!pass) { cap = cnt; g_net_pairs[k] = (int*)malloc(sizeof(int) * 2 * (size_t)(cap > 0 ? cap : 1)); if (!g_net_pairs[k]) { g_net_count[k] = -1; break; } }
+      else g_net_count[k] = cnt;
+    }
   }
-  for (int i = 0; i < m; ++i) {
-    const int r = (int)acc[i];
-    const uint64_t bit = 1ull << (r & 63);
-    if (seen[r >> 6] & bit) return -1;
-    seen[r >> 6] |= bit;
-    rank[i] = r;
+}
+
+/* A: n x SORT_CB doubles, row-major (row r of every column side by side); sorted along r, column by column */
+CLONES static void net_sort(double* restrict A, const int* restrict pairs, int count) {
+  for (int c = 0; c < count; ++c) {
+    double* restrict lo = A + (size_t)pairs[2 * c] * SORT_CB;
+    double* restrict hi = A + (size_t)pairs[2 * c + 1] * SORT_CB;
+    for (int k = 0; k < SORT_CB; ++k) {
+      const double a = lo[k], b = hi[k];
+      lo[k] = a < b ? a : b;
+      hi[k] = a < b ? b : a;
+    }
   }
-  return 0;
 }
 
 /* longer columns: stable merge sort of (value, row) pairs; idx[r] = row of the r-th smallest */
@@ -243,29 +266,61 @@ static void sort_column(const double* v, int m, struct sort_pair* a, struct sort
   for (int i = 0; i < m; ++i) idx[i] = src[i].i;
 }
 
+typedef uint64_t __attribute__((may_alias)) u64a;
 static void* sort_worker(void* arg) {
   struct sort_job* j = (struct sort_job*)arg;
   const int m = j->m;
+  int net = -1;
+  if (m <= NET_MAX && m >= 2) {
+    pthread_once(&g_net_once, net_build);
+    for (int k = 0; k < 5 && net < 0; ++k) if (g_net_n[k] >= m && g_net_count[k] > 0) net = k;
+  }
+  const int n = net >= 0 ? g_net_n[net] : 0;
   struct sort_pair* a = (struct sort_pair*)malloc(sizeof(struct sort_pair) * (size_t)m * 2);
-  double* blk = (double*)malloc(sizeof(double) * (size_t)m * (SORT_CB * 2 + 1));     /* draws (column-major) | results, m x SORT_CB each | one column */
+  double* blk = (double*)malloc(sizeof(double) * ((size_t)m * SORT_CB * 2 + (size_t)n * SORT_CB + m));  /* draws | results | network | one column */
   int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)m);
   if (!a || !blk || !idx) { free(a); free(blk); free(idx); return (void*)1; }
   struct sort_pair* b = a + m;
   double* res = blk + (size_t)m * SORT_CB;
+  double* A = res + (size_t)m * SORT_CB;
+  double* col = A + (size_t)n * SORT_CB;
+  const uint64_t lowmask = ((uint64_t)1 << NET_BITS) - 1;
   for (int cb = j->c0; cb < j->c1; cb += SORT_CB) {
     const int w = j->c1 - cb < SORT_CB ? j->c1 - cb : SORT_CB;
-    for (int i = 0; i < m; ++i) {                          /* the block transposed: every column contiguous */
-      const double* src = j->R + (size_t)i * j->num + cb;
-      for (int cc = 0; cc < w; ++cc) blk[(size_t)cc * m + i] = src[cc];
+    unsigned char redo[SORT_CB];
+    memset(redo, net < 0, sizeof(redo));
+    if (net >= 0) {
+      u64a* Au = (u64a*)A;
+      for (int i = 0; i < n; ++i) {
+        u64a* dst = Au + (size_t)i * SORT_CB;
+        if (i < m) {
+          const u64a* src = (const u64a*)(j->R + (size_t)i * j->num + cb);
+          for (int cc = 0; cc < w; ++cc) dst[cc] = (src[cc] & ~lowmask) | (uint64_t)i;
+          for (int cc = w; cc < SORT_CB; ++cc) dst[cc] = (uint64_t)i;
+        } else {
+          for (int cc = 0; cc < SORT_CB; ++cc) A[(size_t)i * SORT_CB + cc] = 1e300;      /* padding rows sort to the end */
+        }
+      }
+      net_sort(A, g_net_pairs[net], g_net_count[net]);
+      uint64_t same[SORT_CB];
+      for (int cc = 0; cc < SORT_CB; ++cc) same[cc] = 0;
+      for (int i = 1; i < m; ++i) {                          /* neighbours the compared bits do not separate */
+        const u64a* r1 = Au + (size_t)i * SORT_CB;
+        const u64a* r0 = r1 - SORT_CB;
+        for (int cc = 0; cc < SORT_CB; ++cc) same[cc] |= (((r1[cc] ^ r0[cc]) & ~lowmask) == 0);
+      }
+      for (int cc = 0; cc < w; ++cc) redo[cc] = same[cc] != 0 || !(A[(size_t)(m - 1) * SORT_CB + cc] < 1e299);
+      for (int i = 0; i < m; ++i) {
+        const u64a* srow = Au + (size_t)i * SORT_CB;
+        double* rrow = res + (size_t)i * SORT_CB;
+        for (int cc = 0; cc < w; ++cc) rrow[cc] = j->y[srow[cc] & lowmask];
+      }
     }
     for (int cc = 0; cc < w; ++cc) {
-      const double* col = blk + (size_t)cc * m;
-      if (m <= RANK_MAX && rank_column(col, m, idx) == 0) {
-        for (int i = 0; i < m; ++i) res[(size_t)idx[i] * SORT_CB + cc] = j->y[i];        /* idx = rank here */
-      } else {
-        sort_column(col, m, a, b, idx);
-        for (int i = 0; i < m; ++i) res[(size_t)i * SORT_CB + cc] = j->y[idx[i]];
-      }
+      if (!redo[cc]) continue;
+      for (int i = 0; i < m; ++i) col[i] = j->R[(size_t)i * j->num + cb + cc];
+      sort_column(col, m, a, b, idx);
+      for (int i = 0; i < m; ++i) res[(size_t)i * SORT_CB + cc] = j->y[idx[i]];
     }
     for (int i = 0; i < m; ++i) {
       const int64_t row = j->rows ? j->rows[i] : i;

@@ -422,7 +422,7 @@ class Engine(_order.CellOrder):
         self.x_epoch += 1
         return nz.value
 
-    def select_standardized(self, keep_global, colmap, y=None, fuse_null=0):
+    def select_standardized(self, keep_global, colmap, y=None, fuse_null=0, null_ready=None):
         """select() + centre + divide by std in one pass (M = I); returns the number of selected
         cells with zero variance (non-zero: redo with zero_variance()/select()).  With ``y`` (the
         standardised phenotype in the selected samples' order) the neighbourhood coefficients are
@@ -430,7 +430,9 @@ class Engine(_order.CellOrder):
         ``fuse_null`` = P > 0 (with y): when no cell has zero variance the same call also queues what
         would follow from values it returns -- gram_launch(), the thresholds of the local null from
         max|ncorrs|, null_local_prepare(P, ...) and percell_coef_launch(); those methods then find
-        their work done (they compare arguments) and return at once."""
+        their work done (they compare arguments) and return at once.  ``null_ready``: a callable asked right before
+        the call whether the conditioned phenotypes of this analysis are on the device already (condition() has
+        returned); the prepared local-null pass is then launched in the same call (columns 1 .. P)."""
         cm = None if colmap is None else np.ascontiguousarray(colmap, dtype=np.int32)
         idx, nk = self._selection(keep_global)
         nz = C.c_int64(0)
@@ -438,15 +440,16 @@ class Engine(_order.CellOrder):
         yv = None if y is None else _f64(y)
         self._fused = None
         if yv is not None and fuse_null > 0:
-            T, gq, cq = C.c_int(0), C.c_int(0), C.c_int(0)
+            T, gq, cq, nl = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
             thr = np.empty(512)
+            col0 = 1 if (null_ready is not None and null_ready()) else -1
             check(self.lib.cna_select_standardized_fused(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm),
                                                          C.byref(nz), ptr(yv), C.byref(m), int(fuse_null), C.byref(T),
-                                                         ptr(thr), C.byref(gq), C.byref(cq)),
+                                                         ptr(thr), C.byref(gq), C.byref(cq), col0, C.byref(nl)),
                   'cna_select_standardized_fused')
             self.x_epoch += 1
             self._fused = dict(epoch=self.x_epoch, P=int(fuse_null), thr=thr[:T.value], gram=bool(gq.value),
-                               coef=bool(cq.value), prepared=T.value > 0)
+                               coef=bool(cq.value), prepared=T.value > 0 and not nl.value, null=bool(nl.value))
             if gq.value:
                 self._gram_cols = self.N if cm is None else len(cm)
             if T.value:
@@ -593,6 +596,14 @@ class Engine(_order.CellOrder):
                 and np.array_equal(f['thr'], thr)):
             f['prepared'] = False             # the fused selection call prepared exactly this pass
             return
+        if f is not None and f['epoch'] == self.x_epoch and f.get('null'):
+            if thr is not None and f['P'] == int(P) and np.array_equal(f['thr'], thr):
+                return                        # ... and launched it as well (null_local_launch finds that out)
+            # the fused call's own thresholds are not the caller's (never seen; numpy's arange and its C restatement
+            # are compared in the tests): collect that pass and start over
+            f['null'] = False
+            self._null_T, self._null_obs = len(f['thr']), True
+            self.null_local_fetch()
         if f is not None:
             f['coef'] = False                 # a fresh prepare: whatever rode along with the fused one is void
         check(self.lib.cna_null_local_prepare(self.h, int(P), ptr(edges), len(edges), 0, ptr(thr)),
@@ -604,6 +615,8 @@ class Engine(_order.CellOrder):
         """Queue a local-null pass on resident columns; collect with null_local_fetch().  With `thr`
         the threshold counts of the observed coefficients (obs_counts) are queued in front of it."""
         if edges is None:                       # prepared pass
+            if int(col0) == 1 and self._fused_done('null'):
+                return                          # the fused selection call launched it already
             check(self.lib.cna_null_local_launch(self.h, int(col0), int(P), None, self._null_T, 0, None),
                   'cna_null_local_launch')
             return

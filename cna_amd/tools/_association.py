@@ -383,7 +383,7 @@ def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_si
 
 def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
                             show_progress, codes_labels=None, overlap=None, nam_queued=None, y_std=None,
-                            fuse_null=0, **kwargs):
+                            fuse_null=0, null_ready=None, **kwargs):
     """Reference compute_nam_and_reindex (_association.py:175-191) on the device: build the NAM,
     QC it, put the sample axis in ``y.index`` order restricted to ``filter_samples``, drop the
     cells whose remaining entries have zero variance.  Leaves the selected NAM in the engine's
@@ -460,7 +460,7 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
             engine.set_resid_factors(np.asarray(plan.C.values, dtype=np.float64), plan.W)
         if y_std is not None and len(y_std) == len(colmap):
             nzero, maxabs = engine.select_standardized(None if kept.all() else kept, colmap, y=y_std,
-                                                       fuse_null=fuse_null)
+                                                       fuse_null=fuse_null, **({'null_ready': null_ready} if null_ready is not None else {}))
             plan.maxabs = maxabs if nzero == 0 else None
         else:
             nzero = engine.select_standardized(None if kept.all() else kept, colmap)
@@ -682,7 +682,11 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
             compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
                                     show_progress, codes_labels=(codes, labels, counts, token), overlap=host_side,
                                     nam_queued=nam_queued, y_std=y_std,
-                                    fuse_null=min(1000, Nnull) if kwargs.get('local_test', True) and _FUSE else 0)
+                                    fuse_null=min(1000, Nnull) if kwargs.get('local_test', True) and _FUSE else 0,
+                                    # (the conditioned phenotypes of THIS call on the device before the selection is
+                                    # asked for: that call then launches the local null itself)
+                                    null_ready=(lambda: bool(early.get('conditioned'))) if (hasattr(engine, 'h') and getattr(engine, 'nranks', 1) == 1
+                                                                                           and not getattr(engine, '_has_comm', False)) else None)
     except BaseException:
         walk_queued.set()
         null_future.cancel() or null_future.exception()     # do not leave the helper thread running

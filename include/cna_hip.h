@@ -206,10 +206,14 @@ int  cna_select_standardized(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_ke
  * values it has to wait for here anyway: the Gram kernels (cna_gram_launch), the local null's
  * thresholds np.arange(m/4, m, m/400) from m = max|ncorrs| (returned in thr_out[<= 512], *T_out of
  * them; _association.py:101), cna_null_local_prepare(null_P, edges(thr), thr) and
- * cna_percell_coef_launch.  *T_out = 0: only the selection (and possibly the Gram) was issued. */
+ * cna_percell_coef_launch.  *T_out = 0: only the selection (and possibly the Gram) was issued.
+ * null_col0 >= 0: the caller vouches that the conditioned phenotypes of this analysis are resident already
+ * (cna_condition_phenotypes has returned); the prepared pass is then launched on columns null_col0 ... as
+ * cna_null_local_launch(ctx, null_col0, null_P, NULL, T, 0, NULL) would, *null_launched = 1. */
 int  cna_select_standardized_fused(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap,
                                    int n_sel, int64_t* n_zero_out, const double* y, double* max_abs_out,
-                                   int null_P, int* T_out, double* thr_out, int* gram_queued, int* coef_queued);
+                                   int null_P, int* T_out, double* thr_out, int* gram_queued, int* coef_queued,
+                                   int null_col0, int* null_launched);
 /* numpy's thresholds / bin edges of the local null for a given max|ncorrs| (host arithmetic only) */
 int  cna_reference_thresholds(double maxabs, int cap, double* thr, double* edges);
 /* upload a cells x samples matrix as X (cna.tl.svd_nam on a user NAM, _nam.py:102) */
