@@ -97,9 +97,10 @@ SIGNATURES = {
     'cna_host_draw_start': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     'cna_host_draw_wait': (C.c_int, []),
+    'cna_host_draw_then_condition': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'cna_global_test_launch': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     'cna_global_test_fetch': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'cna_select_standardized_fused': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
+    'cna_select_standardized_fused': (C.c_int, [c_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_void_p, C.POINTER(C.c_int)]),
     'cna_reference_thresholds': (C.c_int, [C.c_double, C.c_int, C.c_void_p, C.c_void_p]),
     'cna_percell_coef_launch': (C.c_int, [c_ctx]),
     'cna_percell_coef_wait': (C.c_int, [c_ctx, C.POINTER(C.c_void_p)]),

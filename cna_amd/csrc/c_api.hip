@@ -1430,7 +1430,8 @@ int cna_reference_thresholds(double maxabs, int cap, double* thr, double* edges)
 // that none of it waits for the interpreter.  *T_out = 0: nothing beyond the selection was issued.
 int cna_select_standardized_fused(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
                                   int64_t* n_zero_out, const double* y, double* max_abs_out, int null_P, int* T_out,
-                                  double* thr_out, int* gram_queued, int* coef_queued, int null_col0, int* null_launched) {
+                                  double* thr_out, int* gram_queued, int* coef_queued, int null_col0, const int* null_flag,
+                                  int* null_launched) {
   if (T_out) *T_out = 0;
   if (gram_queued) *gram_queued = 0;
   if (coef_queued) *coef_queued = 0;
@@ -1457,10 +1458,12 @@ int cna_select_standardized_fused(cna_ctx* c, const int64_t* keep_idx, int64_t n
   if (T < 1) return 0;
   CNA_TRY(null_local_prepare(c, null_P, edges, T, 0, thr_out));
   *T_out = T;
-  // ... and, when the caller says that the conditioned phenotypes of THIS analysis are already resident (columns
-  // null_col0 .. null_col0 + null_P of Zc: the draw and cna_condition_phenotypes ran beside the walk), the local-null
+  // ... and, when the conditioned phenotypes of THIS analysis are already resident (columns null_col0 .. null_col0 +
+  // null_P of Zc: the draw and cna_condition_phenotypes ran beside the walk -- the caller vouches for it, or *null_flag,
+  // set by the library's draw thread when its conditioning has returned, says so at this very moment), the local-null
   // pass itself: it then starts right behind the Gram kernel instead of after the interpreter's next few statements
-  if (null_col0 >= 0 && null_launched && c->zc && null_col0 + null_P <= c->zc_cols && c->zc_rows == c->Nx) {
+  if (null_col0 >= 0 && null_launched && (!null_flag || __atomic_load_n(null_flag, __ATOMIC_ACQUIRE) == 1) && c->zc &&
+      null_col0 + null_P <= c->zc_cols && c->zc_rows == c->Nx) {
     CNA_TRY(null_local_go(c, null_col0));
     *null_launched = 1;
   }

@@ -199,16 +199,17 @@ struct sort_job {
  * Every entry carries its row in the low NET_BITS bits of its mantissa, so that min / max on the doubles themselves move
  * (value, row) pairs -- two vector instructions per comparator and four columns, no branches, against ~40 ns per
  * element of a comparison sort.  Entries whose remaining bits coincide would be ordered by row instead of by their
- * true low bits: such a column (probability ~1e-9) is reported and redone exactly by the caller. */
-#define NET_MAX 128
-#define NET_BITS 7
-static int g_net_n[5] = {8, 16, 32, 64, 128};
-static int* g_net_pairs[5];                              /* comparators (i, j), i < j, of Batcher's odd-even merge sort */
-static int g_net_count[5];
+ * true low bits: such a column (probability ~1e-8) is reported and redone exactly by the caller. */
+#define NET_MAX 512
+#define NET_BITS 9
+#define NET_SIZES 7
+static int g_net_n[NET_SIZES] = {8, 16, 32, 64, 128, 256, 512};
+static int* g_net_pairs[NET_SIZES];                      /* comparators (i, j), i < j, of Batcher's odd-even merge sort */
+static int g_net_count[NET_SIZES];
 static pthread_once_t g_net_once = PTHREAD_ONCE_INIT;
 
 static void net_build(void) {
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < NET_SIZES; ++k) {
     const int n = g_net_n[k];
     int cap = 0;
     for (int pass = 0; pass < 2; ++pass) {
@@ -273,7 +274,7 @@ static void* sort_worker(void* arg) {
   int net = -1;
   if (m <= NET_MAX && m >= 2) {
     pthread_once(&g_net_once, net_build);
-    for (int k = 0; k < 5 && net < 0; ++k) if (g_net_n[k] >= m && g_net_count[k] > 0) net = k;
+    for (int k = 0; k < NET_SIZES && net < 0; ++k) if (g_net_n[k] >= m && g_net_count[k] > 0) net = k;
   }
   const int n = net >= 0 ? g_net_n[net] : 0;
   struct sort_pair* a = (struct sort_pair*)malloc(sizeof(struct sort_pair) * (size_t)m * 2);
@@ -375,11 +376,16 @@ struct draw_req {
   uint32_t* key; int* pos; const double* y; int m, num, nlev; const int64_t* lev_off; const int64_t* members;
   double* out; int64_t ld_out; int threads;
 };
+struct cna_ctx;
+extern int cna_condition_phenotypes(struct cna_ctx* c, const double* M, const double* Y, int N, int P);
+struct draw_then { struct cna_ctx* ctx; const double* M; const double* table; int N, cols; int* flag; };
 static pthread_mutex_t g_draw_mu = PTHREAD_MUTEX_INITIALIZER;
 static pthread_cond_t g_draw_cv = PTHREAD_COND_INITIALIZER;
 static pthread_t g_draw_th;
 static int g_draw_alive = 0, g_draw_state = 0, g_draw_rc = 0;        /* state 0 idle, 1 posted, 2 running, 3 done */
+static int g_then_state = 0;                                           /* follow-up: 0 none, 1 posted, 2 running, 3 done */
 static struct draw_req g_draw_req;
+static struct draw_then g_draw_then;
 
 static int draw_run(const struct draw_req* q) {
   int64_t mmax = 0;
@@ -409,14 +415,25 @@ static void* draw_thread(void* arg) {
   (void)arg;
   pthread_mutex_lock(&g_draw_mu);
   for (;;) {
-    while (g_draw_state != 1) pthread_cond_wait(&g_draw_cv, &g_draw_mu);
-    g_draw_state = 2;
-    const struct draw_req q = g_draw_req;
-    pthread_mutex_unlock(&g_draw_mu);
-    const int rc = draw_run(&q);
-    pthread_mutex_lock(&g_draw_mu);
-    g_draw_rc = rc;
-    g_draw_state = 3;
+    while (!(g_draw_state == 1 || (g_draw_state == 3 && g_then_state == 1))) pthread_cond_wait(&g_draw_cv, &g_draw_mu);
+    if (g_draw_state == 1) {
+      g_draw_state = 2;
+      const struct draw_req q = g_draw_req;
+      pthread_mutex_unlock(&g_draw_mu);
+      const int rc = draw_run(&q);
+      pthread_mutex_lock(&g_draw_mu);
+      g_draw_rc = rc;
+      g_draw_state = 3;
+    } else {
+      g_then_state = 2;
+      const struct draw_then t = g_draw_then;
+      const int ok = g_draw_rc == 0;
+      pthread_mutex_unlock(&g_draw_mu);
+      const int rc = ok ? cna_condition_phenotypes(t.ctx, t.M, t.table, t.N, t.cols) : -1;
+      __atomic_store_n(t.flag, rc == 0 ? 1 : -1, __ATOMIC_RELEASE);
+      pthread_mutex_lock(&g_draw_mu);
+      g_then_state = 3;
+    }
     pthread_cond_broadcast(&g_draw_cv);
   }
   return NULL;
@@ -440,19 +457,36 @@ int cna_host_draw_start(uint32_t* key, int* pos, const double* y, int m, int num
   }
   g_draw_req = (struct draw_req){key, pos, y, m, num, nlev, lev_off, members, out, ld_out, threads};
   g_draw_state = 1;
+  g_then_state = 0;
   pthread_cond_broadcast(&g_draw_cv);
   pthread_mutex_unlock(&g_draw_mu);
   return 0;
 }
 
-/* blocks until the request of cna_host_draw_start is done; 0, or -1 when it failed (allocation) -- the generator
- * state is then undefined and the caller must raise; -2: nothing was started */
+/* A follow-up for the request under way (or finished and not yet collected): once the draw is there the worker
+ * conditions the phenotypes itself -- cna_condition_phenotypes(ctx, M, table, N, cols), table = the N x cols matrix
+ * [y | permutations] the draw fills -- and stores 1 (done) or -1 (failed) in *flag, which the caller and
+ * cna_select_standardized_fused read.  0: accepted; -1: nothing to follow (no request, or one follow-up already). */
+int cna_host_draw_then_condition(struct cna_ctx* ctx, const double* M, const double* table, int N, int cols, int* flag) {
+  if (!ctx || !M || !table || !flag || N < 2 || cols < 1) return -1;
+  pthread_mutex_lock(&g_draw_mu);
+  if (g_draw_state == 0 || g_then_state != 0) { pthread_mutex_unlock(&g_draw_mu); return -1; }
+  g_draw_then = (struct draw_then){ctx, M, table, N, cols, flag};
+  g_then_state = 1;
+  pthread_cond_broadcast(&g_draw_cv);
+  pthread_mutex_unlock(&g_draw_mu);
+  return 0;
+}
+
+/* blocks until the request of cna_host_draw_start (and its follow-up, if one was posted) is done; 0, or -1 when the
+ * draw failed (allocation) -- the generator state is then undefined and the caller must raise; -2: nothing was started */
 int cna_host_draw_wait(void) {
   pthread_mutex_lock(&g_draw_mu);
   if (g_draw_state == 0) { pthread_mutex_unlock(&g_draw_mu); return -2; }
-  while (g_draw_state != 3) pthread_cond_wait(&g_draw_cv, &g_draw_mu);
+  while (!(g_draw_state == 3 && (g_then_state == 0 || g_then_state == 3))) pthread_cond_wait(&g_draw_cv, &g_draw_mu);
   const int rc = g_draw_rc;
   g_draw_state = 0;
+  g_then_state = 0;
   pthread_mutex_unlock(&g_draw_mu);
   return rc;
 }

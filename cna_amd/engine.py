@@ -442,10 +442,13 @@ class Engine(_order.CellOrder):
         if yv is not None and fuse_null > 0:
             T, gq, cq, nl = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
             thr = np.empty(512)
-            col0 = 1 if (null_ready is not None and null_ready()) else -1
+            # null_ready: a callable (the caller's own word, now) or an int32 array of one element that the library's
+            # draw thread sets once its conditioning has returned (read by the C call at the moment it matters)
+            flag = null_ready if isinstance(null_ready, np.ndarray) else None
+            col0 = 1 if (flag is not None or (null_ready is not None and null_ready())) else -1
             check(self.lib.cna_select_standardized_fused(self.h, ptr(idx), nk, ptr(cm), 0 if cm is None else len(cm),
                                                          C.byref(nz), ptr(yv), C.byref(m), int(fuse_null), C.byref(T),
-                                                         ptr(thr), C.byref(gq), C.byref(cq), col0, C.byref(nl)),
+                                                         ptr(thr), C.byref(gq), C.byref(cq), col0, ptr(flag), C.byref(nl)),
                   'cna_select_standardized_fused')
             self.x_epoch += 1
             self._fused = dict(epoch=self.x_epoch, P=int(fuse_null), thr=thr[:T.value], gram=bool(gq.value),

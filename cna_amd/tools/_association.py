@@ -627,7 +627,11 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
             _mark('draw done')
             out_ = (table[:, 0], table[:, 1:])
             M_ = early.get('M')
-            if M_ is not None and len(table) == len(M_):
+            if native.conditioned:
+                engine._zc_cols = table.shape[1]          # (what engine.condition notes)
+                early['conditioned'] = True
+                _mark('conditioned (library thread)')
+            elif M_ is not None and len(table) == len(M_):
                 try:
                     engine.condition(M_, table)
                     early['conditioned'] = True
@@ -672,6 +676,12 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
             plan.coef_first = _EARLY_COEF and len(data.obs) >= _COEF_FIRST_CELLS and kwargs.get('local_test', True)
         if plan.M is not None:
             early['M'] = np.asarray(plan.M, dtype=np.float64)     # the draw conditions with it
+            if native is not None and hasattr(engine, 'h') and len(early['M']) == len(native.table):
+                # ... on the library's own thread, the moment it has the permutations
+                try:
+                    early['native_cond'] = native.then_condition(engine, early['M'])
+                except Exception:             # noqa: BLE001 - the helper below conditions instead
+                    early['native_cond'] = False
         if not _DRAW_THREAD:
             null_future.run()
         return plan
@@ -685,8 +695,9 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                                     fuse_null=min(1000, Nnull) if kwargs.get('local_test', True) and _FUSE else 0,
                                     # (the conditioned phenotypes of THIS call on the device before the selection is
                                     # asked for: that call then launches the local null itself)
-                                    null_ready=(lambda: bool(early.get('conditioned'))) if (hasattr(engine, 'h') and getattr(engine, 'nranks', 1) == 1
-                                                                                           and not getattr(engine, '_has_comm', False)) else None)
+                                    null_ready=((native.flag if native is not None else (lambda: bool(early.get('conditioned'))))
+                                                if (hasattr(engine, 'h') and getattr(engine, 'nranks', 1) == 1
+                                                    and not getattr(engine, '_has_comm', False)) else None))
     except BaseException:
         walk_queued.set()
         null_future.cancel() or null_future.exception()     # do not leave the helper thread running

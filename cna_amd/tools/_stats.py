@@ -130,6 +130,26 @@ class NativeDraw:
 
     def __init__(self, lib, keep, table):
         self._lib, self._keep, self.table, self._done = lib, keep, table, False
+        self.flag = np.zeros(1, dtype=np.int32)      # 1: the worker has conditioned the phenotypes itself (then_condition)
+        self._m = None
+
+    def then_condition(self, engine, M):
+        """Ask the worker to condition the phenotypes on the device as soon as the draw is there (no interpreter in
+        between): engine.condition(M, table).  False when it is too late for that (already collected)."""
+        if self._done or self._m is not None:
+            return False
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        if M.shape != (len(self.table), len(self.table)):
+            return False
+        if self._lib.cna_host_draw_then_condition(engine.h, M.ctypes.data, self.table.ctypes.data, len(self.table),
+                                                  self.table.shape[1], self.flag.ctypes.data) != 0:
+            return False
+        self._m = M
+        return True
+
+    @property
+    def conditioned(self):
+        return int(self.flag[0]) == 1
 
     def wait(self):
         if not self._done:

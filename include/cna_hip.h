@@ -207,13 +207,14 @@ int  cna_select_standardized(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_ke
  * thresholds np.arange(m/4, m, m/400) from m = max|ncorrs| (returned in thr_out[<= 512], *T_out of
  * them; _association.py:101), cna_null_local_prepare(null_P, edges(thr), thr) and
  * cna_percell_coef_launch.  *T_out = 0: only the selection (and possibly the Gram) was issued.
- * null_col0 >= 0: the caller vouches that the conditioned phenotypes of this analysis are resident already
- * (cna_condition_phenotypes has returned); the prepared pass is then launched on columns null_col0 ... as
+ * null_col0 >= 0: the conditioned phenotypes of this analysis are resident already -- the caller vouches for it
+ * (null_flag NULL: cna_condition_phenotypes has returned), or *null_flag == 1 at the moment the pass could start
+ * (cna_host_draw_then_condition sets it); the prepared pass is then launched on columns null_col0 ... as
  * cna_null_local_launch(ctx, null_col0, null_P, NULL, T, 0, NULL) would, *null_launched = 1. */
 int  cna_select_standardized_fused(cna_ctx* ctx, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap,
                                    int n_sel, int64_t* n_zero_out, const double* y, double* max_abs_out,
                                    int null_P, int* T_out, double* thr_out, int* gram_queued, int* coef_queued,
-                                   int null_col0, int* null_launched);
+                                   int null_col0, const int* null_flag, int* null_launched);
 /* numpy's thresholds / bin edges of the local null for a given max|ncorrs| (host arithmetic only) */
 int  cna_reference_thresholds(double maxabs, int cap, double* thr, double* edges);
 /* upload a cells x samples matrix as X (cna.tl.svd_nam on a user NAM, _nam.py:102) */
@@ -374,6 +375,10 @@ int  cna_host_argsort_gather(const double* R, int m, int num, const double* y, d
  * touched.  One request at a time per process. */
 int  cna_host_draw_start(uint32_t* key, int* pos, const double* y, int m, int num, int nlev, const int64_t* lev_off,
                          const int64_t* members, double* out, int64_t ld_out, int threads);
+/* follow-up of the request under way: the worker conditions the phenotypes itself when the draw is there --
+ * cna_condition_phenotypes(ctx, M, table, N, cols) with table = the N x cols matrix [y | permutations] being filled --
+ * and stores 1 / -1 (failed) in *flag.  0 accepted, -1 nothing to follow.  cna_host_draw_wait covers it. */
+int  cna_host_draw_then_condition(cna_ctx* ctx, const double* M, const double* table, int N, int cols, int* flag);
 int  cna_host_draw_wait(void);
 
 /* ---- host-side helpers: graph identity and the device cell order (csrc/host_graph.c) ------- */
