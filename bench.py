@@ -227,8 +227,20 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
     p_first = cna.tl.association(data, y, 'id', **kw)
     sync()
     t_cold = time.perf_counter() - t0
+    # A large graph is analysed in the caller's cell order first while the device order is computed on a host thread
+    # (engine.ensure_graph); the first later call that finds it done re-uploads the graph in that order.  Here: wait
+    # for it, time that adopting call on its own, then warm up -- the timed steps run in the steady state.
+    t_adopt = None
+    if getattr(eng, 'reorder_pending', lambda: False)():
+        eng.wait_reorder()
+        sync()
+        t0 = time.perf_counter()
+        cna.tl.association(data, y, 'id', **kw)
+        sync()
+        t_adopt = time.perf_counter() - t0
     for _ in range(max(warmup - 1, 0)):
         cna.tl.association(data, y, 'id', **kw)
+    assert not getattr(eng, 'reorder_pending', lambda: False)()
 
     eng.prof_reset()
     eng.prof_enable(True)
@@ -269,7 +281,7 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
     except Exception:
         i8 = (False, 0, False)
     return dict(name=name, n=n, N=N, k=k, nsteps=nsteps, Nnull=Nnull, n_covs=n_covs, n_batches=n_batches, nnz=nnz, wA=wA, dt=dt, t_cold=t_cold, i8=i8,
-                t_gen=t_gen, prof=prof, p=p_last, n_loc=n_loc, nnz_loc=nnz_loc, halo=getattr(eng, 'halo', None),
+                t_gen=t_gen, prof=prof, p=p_last, t_adopt=t_adopt, n_loc=n_loc, nnz_loc=nnz_loc, halo=getattr(eng, 'halo', None),
                 sharded_inputs=sharded_inputs, data=data, meta=meta, kw=kw, steps=steps, warmup=warmup, comm=eng.comm_info(),
                 halo_comm=getattr(eng, 'halo_comm', False))
 
@@ -352,8 +364,10 @@ def summary(m, world, steps):
                 kernels=kernels, gpu_kernel_ms_per_step=round(gpu_ms, 3),
                 host_ms_per_step=round(ms_per_step - gpu_ms, 3),
                 cold_first_call=dict(ms=round(m['t_cold'] * 1e3, 1), value=round(m['n'] * m['Nnull'] / m['t_cold'], 1),
-                                     note='first call: device cell order + block lists on the host, graph H2D over PCIe, '
-                                          'column sums, then one analysis'),
+                                     call_that_adopts_the_device_order_ms=None if m.get('t_adopt') is None else round(m['t_adopt'] * 1e3, 1),
+                                     note='first call: graph H2D over PCIe (in the caller\'s cell order when the graph is large: '
+                                          'the device order is computed on a host thread beside it and adopted by a later call, '
+                                          'whose time -- a second upload -- is listed too), column sums, first-use allocations, one analysis'),
                 dataset_gen_s=round(m['t_gen'], 1), p_value=m['p'])
 
 

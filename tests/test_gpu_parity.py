@@ -892,7 +892,7 @@ def test_selection_as_a_by_product_of_the_last_walk_step(eng, monkeypatch, n, N,
         np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize('n,N,K,nsteps', [(70001, 200, 4, 3), (66001, 100, 2, 3), (41000, 180, 2, 2), (30000, 200, 4, 3)])
+@pytest.mark.parametrize('n,N,K,nsteps', [(70001, 200, 4, 3), (66001, 100, 2, 3), (41000, 180, 2, 3), (30000, 200, 4, 3)])
 def test_gram_under_the_walks_last_step(eng, monkeypatch, n, N, K, nsteps):
     """NAM.dot(NAM.T) (_nam.py:105) is a sum over cells, and the walk's last step writes the standardised rows one by one
     (select_tail): that step runs in K row ranges and the Gram kernel of each range follows it on a second stream, carrying

@@ -21,8 +21,10 @@ def wrap(obj, name, label):
     setattr(obj, name, w)
 for name in dir(Engine):
     if name.startswith('__') or name in ('block', 'prof', 'close', 'h'): continue
+    import inspect
+    raw = inspect.getattr_static(Engine, name)
     fn = getattr(Engine, name)
-    if callable(fn) and not isinstance(fn, (staticmethod, property)):
+    if callable(fn) and not isinstance(raw, (staticmethod, classmethod, property)):
         def mk(fn, name):
             def w(self, *a, **k):
                 t0 = time.perf_counter(); r = fn(self, *a, **k); ev.append((t0, time.perf_counter(), name, threading.current_thread().name[:4])); return r
