@@ -70,8 +70,8 @@ def cluster_order(A, B):
     indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
     indices = np.ascontiguousarray(A.indices, dtype=np.int32)
     # on several threads from 131072 cells up (regions by a multi-source BFS, ordered independently): the result
-    # depends on the graph only, not on the thread count (CNA_ORDER_THREADS=0: the sequential pass)
-    threads = int(os.environ.get('CNA_ORDER_THREADS', usable_cpus(16)))
+    # depends on the graph only, not on the thread count
+    threads = usable_cpus(16)
     if threads >= 1:
         got = _ffi.load().cna_host_cluster_order_mt(n, _ffi.ptr(indptr), _ffi.ptr(indices), int(B), threads, _ffi.ptr(order))
     else:

@@ -84,7 +84,6 @@ static void prof_flush(cna_ctx* c) {
   (void)hipStreamSynchronize(c->copy_stream);
   if (c->coef_stream) (void)hipStreamSynchronize(c->coef_stream);
   if (c->gram_stream) (void)hipStreamSynchronize(c->gram_stream);
-  if (c->walk_stream) (void)hipStreamSynchronize(c->walk_stream);
   std::lock_guard<std::mutex> lock(c->prof_mu);
   if (c->prof_pending.empty()) return;
   for (auto& s : c->prof_pending) {
@@ -222,7 +221,6 @@ int cna_ctx_destroy(cna_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   if (c->gram_stream) (void)hipStreamSynchronize(c->gram_stream);
-  if (c->walk_stream) (void)hipStreamSynchronize(c->walk_stream);
   if (c->auto_state) { (void)hipFree(c->auto_state); c->auto_state = nullptr; }
   if (c->byp_buf) { (void)hipFree(c->byp_buf); c->byp_buf = nullptr; }
   if (c->pair_buf) { (void)hipFree(c->pair_buf); c->pair_buf = nullptr; }
@@ -245,8 +243,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   if (c->null_done) (void)hipEventDestroy(c->null_done);
   if (c->bins_copied) (void)hipEventDestroy(c->bins_copied);
   if (c->gram_stream) (void)hipStreamDestroy(c->gram_stream);
-  if (c->walk_stream) (void)hipStreamDestroy(c->walk_stream);
-  for (hipEvent_t e : {c->gram_pre_done, c->range_done, c->walk_fork, c->walk_join})
+  for (hipEvent_t e : {c->gram_pre_done, c->range_done})
     if (e) (void)hipEventDestroy(e);
   if (c->halo_stream) (void)hipStreamDestroy(c->halo_stream);
   if (c->halo_e1) (void)hipEventDestroy(c->halo_e1);
@@ -410,7 +407,7 @@ static int ensure_sparse_state(cna_ctx* c) {
   int min_n = 96;
   if (const char* e = getenv("CNA_SPARSE_MIN_N")) min_n = atoi(e);
   const bool multi = c->nranks > 1 || comm_active(c);
-  const bool want = min_n > 0 && c->N >= min_n && (!multi || (c->halo_on && !getenv("CNA_SPARSE_ONE_GPU_ONLY")));
+  const bool want = min_n > 0 && c->N >= min_n && (!multi || c->halo_on);
   if (!want) {
     if (c->sp_cnt) {
       HIP_TRY(hipStreamSynchronize(c->stream));
@@ -453,7 +450,6 @@ int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const doubl
   }
   c->N = n_samples;
   int ld_align = 4;
-  if (const char* e = getenv("CNA_LD_ALIGN")) ld_align = std::max(4, atoi(e));   // experiments
   c->ld = round_up(n_samples, ld_align);
   HIP_TRY(hipMemcpyAsync(c->sid, codes, sizeof(int32_t) * c->n_global, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipMemcpyAsync(c->counts, counts, sizeof(double) * n_samples, hipMemcpyHostToDevice, c->stream));
@@ -646,35 +642,22 @@ static int arm_select_byproduct(cna_ctx* c) {
 
 // ---- the Gram matrix under the walk's last step (see common.h: gram_pre) -------------------------------------
 // CNA_GRAM_OVERLAP = K: the step that leaves the selection by-product runs in K row ranges (0 / 1: one launch, the
-// Gram kernel afterwards as before).  CNA_GRAM_CUS = m (experiments): the Gram kernels confined to m CUs of every XCD
-// and the ranged step to the others (hipExtStreamCreateWithCUMask; bit i of the mask = CU i / 8 of XCD i % 8).
+// Gram kernel afterwards as before).  Measured on C4 (profiles/r04_ab_gram_overlap.txt): without stream priorities the
+// Gram ranges take the chip whenever they become ready and the step grows by what they take; with priorities, or with
+// the two sides confined to disjoint CUs (hipExtStreamCreateWithCUMask), nothing is gained either -- the gather is bound
+// per CU and a Gram workgroup displaces the walk waves of the CU it lands on.  Off by default; the switch stays for the
+// bit-identity test of the ranged product.
 static int gram_overlap_ranges() {
   const char* e = getenv("CNA_GRAM_OVERLAP");
-  const int k = e ? atoi(e) : 0;               // off by default: measured, no gain (profiles/r04_ab_gram_overlap.txt)
+  const int k = e ? atoi(e) : 0;
   return k < 0 ? 0 : (k > 64 ? 64 : k);
 }
 static int ensure_gram_stream(cna_ctx* c) {
   if (c->gram_stream_state) return c->gram_stream_state;
   c->gram_stream_state = -1;
-  const char* e = getenv("CNA_GRAM_CUS");
-  const int cus = e ? atoi(e) : 0;
-  hipError_t err;
-  if (cus > 0 && cus < 32) {
-    uint32_t gm[8] = {0}, wm[8] = {0};
-    for (int i = 0; i < 256; ++i) ((i / 8 < cus) ? gm : wm)[i / 32] |= 1u << (i % 32);
-    err = hipExtStreamCreateWithCUMask(&c->gram_stream, 8, gm);
-    if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&c->walk_stream, 8, wm);
-  } else {
-    int lo = 0, hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    const char* pe = getenv("CNA_GRAM_PRIO");
-    const int pr = pe ? atoi(pe) : 0;                      // > 0: above the walk's stream, < 0: below
-    err = hipStreamCreateWithPriority(&c->gram_stream, hipStreamNonBlocking, pr > 0 ? hi : (pr < 0 ? lo : (lo + hi) / 2));
-  }
+  hipError_t err = hipStreamCreateWithFlags(&c->gram_stream, hipStreamNonBlocking);
   if (err == hipSuccess) err = hipEventCreateWithFlags(&c->gram_pre_done, hipEventDisableTiming);
   if (err == hipSuccess) err = hipEventCreateWithFlags(&c->range_done, hipEventDisableTiming);
-  if (err == hipSuccess) err = hipEventCreateWithFlags(&c->walk_fork, hipEventDisableTiming);
-  if (err == hipSuccess) err = hipEventCreateWithFlags(&c->walk_join, hipEventDisableTiming);
   if (err != hipSuccess) { (void)hipGetLastError(); return -1; }
   c->gram_stream_state = 1;
   return 1;
@@ -711,12 +694,8 @@ static int ranged_last_step(cna_ctx* c, bool first, bool want_kurt, bool may_sto
   void* g = c->gram_buf;
   if ((*rc = dev_reserve(c, &g, &c->gram_cap, (int64_t)sizeof(double) * c->Nx * c->Nx)) != 0) return 1;
   c->gram_buf = (double*)g;
-  hipStream_t W = c->walk_stream ? c->walk_stream : c->stream;
+  hipStream_t W = c->stream;
 #define RL_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cna_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); *rc = (int)e_; return 1; } } while (0)
-  if (W != c->stream) {
-    RL_TRY(hipEventRecord(c->walk_fork, c->stream));
-    RL_TRY(hipStreamWaitEvent(W, c->walk_fork, 0));
-  }
   const bool sparse_step = c->sp_cnt && c->steps_done == 1;
   const int kid = sparse_step ? CNA_K_NAM_STEP_SPARSE : CNA_K_NAM_STEP;
   if (c->prof) prof_begin(c, kid, W);                     // one span over all ranges: the step as the other launches report it
@@ -733,10 +712,6 @@ static int ranged_last_step(cna_ctx* c, bool first, bool want_kurt, bool may_sto
   if (*rc) return 1;
   if ((*rc = gram_pre_finish(c, c->gram_buf, c->gram_stream)) != 0) return 1;
   RL_TRY(hipEventRecord(c->gram_pre_done, c->gram_stream));
-  if (W != c->stream) {
-    RL_TRY(hipEventRecord(c->walk_join, W));
-    RL_TRY(hipStreamWaitEvent(c->stream, c->walk_join, 0));
-  }
 #undef RL_TRY
   c->gram_pre = true;
   c->gram_pre_pending = true;
@@ -1155,7 +1130,7 @@ int cna_zero_variance(cna_ctx* c, const int32_t* colmap, int n_sel, uint8_t* fla
 // as it is: the MFMA kernels' instantiations end at 64 quads.
 static int x_ld(int Nx) {
   int ld = round_up(Nx, 4);
-  if (ld > 128 && (ld * 8) % 256 == 0 && ld + 4 <= 256 && !getenv("CNA_X_LD_PLAIN")) ld += 4;
+  if (ld > 128 && (ld * 8) % 256 == 0 && ld + 4 <= 256) ld += 4;
   return ld;
 }
 

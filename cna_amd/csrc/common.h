@@ -244,9 +244,8 @@ struct cna_ctx {
   // is the one launch_gram would form.  gram_pre: c->gram_buf holds (will hold, after gram_pre_done) X^T X of the
   // by-product X, not yet summed over the ranks.
   hipStream_t gram_stream = nullptr;
-  hipStream_t walk_stream = nullptr;     // experiments: the ranged step on a CU-masked stream of its own (CNA_GRAM_CUS)
   int gram_stream_state = 0;             // 0: not created yet, 1: ready, -1: unavailable
-  hipEvent_t gram_pre_done = nullptr, range_done = nullptr, walk_fork = nullptr, walk_join = nullptr;
+  hipEvent_t gram_pre_done = nullptr, range_done = nullptr;
   bool gram_pre = false;
   bool gram_pre_pending = false;         // kernels of a ranged product may still run on gram_stream (nobody has waited for gram_pre_done yet)
   void* gram_part = nullptr;

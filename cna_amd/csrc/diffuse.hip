@@ -924,7 +924,9 @@ int launch_first_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
 // the instantiation of a step kernel by what the launch needs (finish_row): row list, selection by-product, or neither
 template <typename VT, int NQ2, int U = 8>
 int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
-  static const size_t pad = getenv("CNA_WALK_LDS_PAD") ? (size_t)atoll(getenv("CNA_WALK_LDS_PAD")) : 0;   // experiment: fewer workgroups per CU
+  // (resident workgroups per CU, limited by a dynamic LDS allocation: 6 -> 5 changes nothing, 4 costs 4.5 %, 2 costs 47 %:
+  // profiles/r04_ab_gram_overlap.txt)
+  const size_t pad = 0;
   if (a.rows) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 2>), grid, dim3(256), pad, st, a);
   else if (a.sel_X) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 1>), grid, dim3(256), pad, st, a);
   else hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 0>), grid, dim3(256), pad, st, a);

@@ -1298,7 +1298,7 @@ int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, 
   {
     const int nct = ((ldb + 63) / 64) * 4;
     const size_t whole = sizeof(double) * (size_t)c->ldx * (16 * nct + 16);
-    if (kq <= 32 && whole <= 160 * 1024 && ntile >= 64 && !getenv("CNA_XB_STRIPS")) {   // all of B resident in LDS
+    if (kq <= 32 && whole <= 160 * 1024 && ntile >= 64) {   // all of B resident in LDS
       const int64_t want = (ntile + 15) / 16;
       return kXbRes[kq - 1](c, (unsigned)(want < 512 ? want : 512), whole, B_dev, ldb, center ? 1 : 0, out, ld_out, ntile);
     }
@@ -1323,7 +1323,7 @@ bool gram_fused_ok(const cna_ctx* c, int Nx, int ldx, int Kp) {
   // pass (about a millisecond of whole-chip issue) ADDS to the 1.75 ms of matrix work instead of hiding under it, and
   // with 18 accumulator tiles per wave the standardisation runs out of spilled registers.  Kept for the parity test and
   // as the measured answer to "fuse selection and Gram" (DESIGN 8); CNA_SELGRAM=1 selects it (read per call).
-  const bool on = getenv("CNA_SELGRAM") && !getenv("CNA_GRAM_NOBLK");
+  const bool on = getenv("CNA_SELGRAM") != nullptr;
   const int cols = ldx > Kp ? ldx : Kp;
   const size_t lds = sizeof(double) * ((size_t)32 * ldp + (size_t)32 * c->ld + 64 * ((cols + 63) / 64) + 8);
   return on && nt >= 11 && ng * (ng + 1) / 2 <= 16 && ldx <= 320 && (c->ld & 1) == 0 && cols <= 256 &&
@@ -1365,9 +1365,8 @@ static int gram_plan(cna_ctx* c, GramPlan& g, bool own_partial) {
   if (nblocks > blocks_1g) nblocks = (int)(blocks_1g > 1 ? blocks_1g : 1);
   // 3 x 3 blocks of tiles, one per wave (k_gram_blk), when the triangle has at most 16 of them and enough to
   // keep 16 waves busy: 11 ... 15 tiles per side (161 ... 240 samples)
-  static const bool blk_on = !getenv("CNA_GRAM_NOBLK");
   const int ng = (nt + 2) / 3;
-  const bool use_blk = g.use_blk = blk_on && nt >= 11 && ng * (ng + 1) / 2 <= 16 && slab_rows == 32 &&
+  const bool use_blk = g.use_blk = nt >= 11 && ng * (ng + 1) / 2 <= 16 && slab_rows == 32 &&
                                    2 * (size_t)32 * ldp * sizeof(double) <= 150 * 1024 && c->ldx <= 320;
   if (use_blk && nblocks > 256) nblocks = 256;             // one workgroup per CU, every slab after the first prefetched
   if (nblocks < 1) nblocks = 1;
@@ -1575,22 +1574,6 @@ int launch_null_local(cna_ctx* c, const double* Yc_dev, int ldy, int P, const do
   c->null_part = part;
   dim3 grid((unsigned)nchunks, (unsigned)nptile);
   ProfScope ps(c, guard ? -1 : CNA_K_NULL_LOCAL);     // stand-by behind the integer path: that one is timed
-  if (const char* dbg = getenv("CNA_NULL_DEBUG")) {                    // experiments, N=50 only
-    if (kq == 13 && NS == 4 && atoi(dbg) >= 1 && atoi(dbg) <= 2) {
-      auto kfn = atoi(dbg) == 1 ? k_null<13, 4, 0, 16, 1> : k_null<13, 4, 0, 16, 2>;
-      HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      hipLaunchKernelGGL(kfn, grid, dim3(1024), lds(NS), c->stream, c->X, c->nx, chunk_rows, Yc_dev, ldy, P, cuts_dev, T,
-                         cut0, inv_step, eps, (unsigned int*)c->null_part, 0, guard);
-      return 0;
-    }
-    if (kq == 50 && NS == 2 && atoi(dbg) >= 1 && atoi(dbg) <= 2) {     // N = 200
-      auto kfn = atoi(dbg) == 1 ? k_null<50, 2, 0, 8, 1> : k_null<50, 2, 0, 8, 2>;
-      HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      hipLaunchKernelGGL(kfn, grid, dim3(512), lds(NS), c->stream, c->X, c->nx, chunk_rows, Yc_dev, ldy, P, cuts_dev, T,
-                         cut0, inv_step, eps, (unsigned int*)c->null_part, 0, guard);
-      return 0;
-    }
-  }
   null_launch_fn fn = NS == 4 ? kNullNS4[kq - 1] : (NS == 2 ? kNullNS2[kq - 1] : kNullNS1[kq - 1]);
   CNA_TRY(fn(c, grid, lds(NS), chunk_rows, Yc_dev, ldy, P, cuts_dev, T, cut0, inv_step, eps, (unsigned int*)c->null_part, guard));
   const int64_t tot = (int64_t)P * T;

@@ -469,20 +469,7 @@ static int launch_i8_t(cna_ctx* c, unsigned grid, size_t smem, const unsigned ch
     HIP_TRY(hipFuncSetAttribute((const void*)k_null_i8<KS, G>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  static const int rotate = getenv("CNA_I8_ROT") ? atoi(getenv("CNA_I8_ROT")) : 0;   // measured: 2.53 -> 2.76 ms at 2M x 200, no change at N = 100 / 50 (tools/i8_rot.sh)
-  if (const char* dbg = getenv("CNA_I8_MODE")) {                          // experiments
-    const int m = atoi(dbg);
-    if ((KS == 7 || KS == 2) && m >= 1 && m <= 3) {
-      constexpr int K2 = (KS == 7 || KS == 2) ? KS : 7;
-      constexpr int G2 = i8_stage_strips(K2);
-      auto kfn = m == 1 ? k_null_i8<K2, G2, 1> : (m == 2 ? k_null_i8<K2, G2, 2> : k_null_i8<K2, G2, 3>);
-      HIP_TRY(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), smem, c->stream, Xq, rowinfo, ntiles, Yq, nstages, nsplit, spp, T, bconst, partial,
-                         queue, qcount, qcap, status, rotate);
-      HIP_TRY(hipGetLastError());
-      return 0;
-    }
-  }
+  const int rotate = 0;       // (the second wave of a SIMD half a period behind the first: measured 2.53 -> 2.76 ms at 2M x 200)
   hipLaunchKernelGGL((k_null_i8<KS, G>), dim3(grid), dim3(512), smem, c->stream, Xq, rowinfo, ntiles, Yq, nstages, nsplit, spp, T,
                      bconst, partial, queue, qcount, qcap, status, rotate);
   HIP_TRY(hipGetLastError());

@@ -1227,7 +1227,7 @@ int launch_batch_kurtosis(cna_ctx* c, const double* mat, int64_t rows, int ncols
     if (rc < 0) return rc;
     if (rc == 1) return 0;
   }
-  if (n_batches <= BK_FAST && ncols <= 64 * MAXQ && !getenv("CNA_BK_SERIAL")) {
+  if (n_batches <= BK_FAST && ncols <= 64 * MAXQ) {
 #define BKF(Q) hipLaunchKernelGGL(k_batch_kurtosis_fast<Q>, dim3(wave_grid(rows)), dim3(256), 0, c->stream, mat, rows, ncols, ld, order_dev, boff_dev, n_batches, out)
     switch ((ncols + 63) / 64) {
       case 1: BKF(1); break;
@@ -1294,7 +1294,7 @@ int launch_select_std(cna_ctx* c, const int32_t* colmap_dev, unsigned long long*
   // covariates, 731 against 405 at 500k x 128; it serves the in-place ridge pass and the batch kurtosis only)
   // sixteen lanes per cell up to 256 samples; with a projector the wave-per-cell kernel keeps the lead (its four
   // cells share every LDS read of the factors: 2.42 vs 2.71 ms at 2M x 200 with 5 covariates)
-  if (c->Nx <= 256 && rk == 0 && !getenv("CNA_SELECT_WAVE")) {
+  if (c->Nx <= 256 && rk == 0) {
     const int cols = c->ldx > Kp ? c->ldx : Kp;
     const int G = (cols + 63) / 64;
     const unsigned grid16 = wave_grid((c->nx + 3) / 4);      // 16 rows per workgroup and turn

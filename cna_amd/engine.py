@@ -921,7 +921,7 @@ _check_pool = None
 
 
 _REORDER_ASYNC = os.environ.get('CNA_REORDER_ASYNC', '1') not in ('0', 'off', 'no')
-_REORDER_ASYNC_CELLS = int(os.environ.get('CNA_REORDER_ASYNC_CELLS', '100000'))
+_REORDER_ASYNC_CELLS = 100000
 _reorder_workers = None
 
 

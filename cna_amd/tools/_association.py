@@ -44,12 +44,12 @@ def _background():
     return _pool
 
 
-_EARLY_WALK = os.environ.get('CNA_EARLY_WALK', '1') not in ('0', 'off', 'no')
-_EARLY_COEF = os.environ.get('CNA_EARLY_COEF', '1') not in ('0', 'off', 'no')     # ablation switches
-_EARLY_FDR = os.environ.get('CNA_EARLY_FDR', '1') not in ('0', 'off', 'no')
-_DRAW_THREAD = os.environ.get('CNA_DRAW_THREAD', '1') not in ('0', 'off', 'no')
-_NATIVE_DRAW = os.environ.get('CNA_NATIVE_DRAW', '1') not in ('0', 'off', 'no')   # the draw on the library's host thread (tests compare both)
-_SWITCH_INTERVAL = float(os.environ.get('CNA_SWITCH_INTERVAL', '5e-5'))   # GIL hand-over between the helper thread and this one: 2.08 -> 1.86 ms per call at 200k cells (default interval: 5 ms)
+_EARLY_WALK = True       # the walk queued before the (pandas) validation of the sample-level inputs
+_EARLY_COEF = True       # (module constants, not environment switches: each was measured against its alternative --
+_EARLY_FDR = True        #  DESIGN.md 6 -- and tests that need the other side patch the attribute)
+_DRAW_THREAD = True
+_NATIVE_DRAW = os.environ.get('CNA_NATIVE_DRAW', '1') != '0'      # the draw on the library's host thread (0: the interpreter's helper thread, for A/B runs)
+_SWITCH_INTERVAL = 5e-5   # GIL hand-over between the helper thread and this one: 2.08 -> 1.86 ms per call at 200k cells (default interval: 5 ms)
 
 
 import threading as _threading
@@ -105,12 +105,12 @@ class _InlineJob:
 
     def exception(self):
         return None
-_FUSE = os.environ.get('CNA_FUSE_SELECT', '1') not in ('0', 'off', 'no')
+_FUSE = True
 
 _TRACE = None      # list of (label, perf_counter) when tools/host_trace.py switches tracing on
 
 
-_COEF_FIRST_CELLS = int(os.environ.get('CNA_COEF_FIRST_CELLS', '500000'))
+_COEF_FIRST_CELLS = 500000
 # From this many cells on (and three or more steps) the walk's last step is queued after validation and planning, which
 # run under the first steps; it then knows what the selection pass will be asked for and does it on its way out
 # (compute_nam_and_reindex).  Below, the first steps are too short to hide the host work.
@@ -422,7 +422,7 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     plan = extra if hasattr(extra, 'kind') else None
     from ._nam import _lowrank_ok
     single = (plan is not None and plan.kind == 'single' and hasattr(engine, 'set_resid_factors') and _lowrank_ok(engine, plan)
-              and os.environ.get('CNA_RESID_IN_SELECT', '1') not in ('0', 'off', 'no'))
+              )
     if finish_walk is not None:
         # The walk's last step is queued here, with the selection pass's arguments when they are "every cell, the
         # samples in place, nothing to regress out" -- what the call below then asks for: that step leaves X, its

@@ -580,10 +580,8 @@ def _ridge_factors(C, n_batch_cols, ridge, N):
 
 def _lowrank_ok(engine, plan):
     """Apply M = I - C.W in factored form (engine.resid_lowrank)?  When the engine has it and both factors
-    fit the kernel's LDS budget (2 r N doubles <= 128 KB); CNA_RESID_GEMM=1 forces the N x N product."""
-    import os
-    return (hasattr(engine, 'resid_lowrank') and 0 < plan.r and 2 * plan.r * plan.N * 8 <= 128 * 1024
-            and os.environ.get('CNA_RESID_GEMM', '0') in ('0', '', 'off', 'no'))
+    fit the kernel's LDS budget (2 r N doubles <= 128 KB)."""
+    return hasattr(engine, 'resid_lowrank') and 0 < plan.r and 2 * plan.r * plan.N * 8 <= 128 * 1024
 
 
 def _resid_run(engine, plan, cell_index, show_progress=False):
