@@ -195,7 +195,10 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
     sharded_inputs = (world > 1 or args.force_dist) and args.inputs == 'sharded'
     if sharded_inputs:
         from cna_amd import dist
-        data = dist.shard(data, rank, world)     # from here on this rank knows its own cells only
+        # from here on this rank knows its own cells only; which cells those are: whole populations of the graph packed
+        # into the blocks (cna_amd._order.partition_order, what a loader that cares about the exchange volume does), or
+        # --partition caller: contiguous runs of the generator's order
+        data = dist.shard(data, rank, world, partition=(args.partition == 'populations'))
         del A
     y = meta['y']
     with stdout_to_stderr():
@@ -403,6 +406,8 @@ def main():
                     help='N>1 only.  sharded (default): every rank is handed its own block of cells '
                          '(cna_amd.dist.shard) and gets per-cell results for that block; replicated: every rank '
                          'holds the whole dataset and the whole result, like a replicated AnnData')
+    ap.add_argument('--partition', default='populations', choices=['populations', 'caller'],
+                    help='N>1, sharded inputs: how the cells are dealt to the ranks (see cna_amd.dist.shard)')
     ap.add_argument('--force-dist', action='store_true',
                     help='take the communicator (RCCL) code path even with one rank (plumbing check)')
     args = ap.parse_args()
@@ -519,7 +524,8 @@ def main():
         'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': workload_text(m, world, args),
                    'parallelism': 'cells sharded in %d row block(s)%s%s%s' % (
-                       world, '' if world == 1 else (', every rank holds its block of cells only' if m['sharded_inputs']
+                       world, '' if world == 1 else ((', every rank holds its block of cells only (blocks: %s)' % (
+                           'whole populations of the graph packed per block' if args.partition == 'populations' else "contiguous runs of the caller's order")) if m['sharded_inputs']
                                                      else ', dataset and per-cell results replicated on every rank'),
                        '' if m['halo'] is None else ', halo exchange %d/%d rows out/in on rank 0' % m['halo'],
                        ' [--comm shm: ranks share one GPU, plumbing check only]' if args.comm == 'shm' and world > 1 else ''),

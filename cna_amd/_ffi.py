@@ -86,6 +86,7 @@ SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     'cna_host_cluster_order': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'cna_host_cluster_order_mt': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'cna_host_cluster_graph': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cna_host_block_sources': (C.c_int64, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
     'cna_host_walk_blocks': (C.c_int64, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -58,6 +58,114 @@ def locality_order(A):
     return np.ascontiguousarray(perm, dtype=np.int64)
 
 
+def cluster_graph(A, order, B):
+    """Symmetric weight matrix (scipy CSR, nc x nc) of the clusters of a cell order: entry (c, d) = number of graph
+    edges between the cells order[c*B:(c+1)*B] and order[d*B:(d+1)*B] (csrc/host_graph.c:cna_host_cluster_graph)."""
+    from . import _ffi
+    lib = _ffi.load()
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    nc = -(-n // B)
+    indptr = np.ascontiguousarray(A.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(A.indices, dtype=np.int32)
+    order = np.ascontiguousarray(order, dtype=np.int64)
+    ptr = np.zeros(nc + 1, dtype=np.int64)
+    tot = lib.cna_host_cluster_graph(n, _ffi.ptr(indptr), _ffi.ptr(indices), _ffi.ptr(order), int(B), _ffi.ptr(ptr), None, None)
+    if tot < 0:
+        raise MemoryError('cna_host_cluster_graph')
+    col = np.zeros(max(tot, 1), dtype=np.int32)
+    cnt = np.zeros(max(tot, 1), dtype=np.int64)
+    if lib.cna_host_cluster_graph(n, _ffi.ptr(indptr), _ffi.ptr(indices), _ffi.ptr(order), int(B), _ffi.ptr(ptr), _ffi.ptr(col),
+                                  _ffi.ptr(cnt)) != tot:
+        raise RuntimeError('cna_host_cluster_graph')
+    W = sp.csr_matrix((cnt[:tot].astype(np.float64), col[:tot], ptr), shape=(nc, nc))
+    return ((W + W.T) * 0.5).tocsr()                  # (a directed input graph: both directions count)
+
+
+def partition_order(A, nparts, B=None):
+    """A cell order whose `nparts` contiguous blocks of ceil(n / nparts) cells make good row blocks for a sharded run
+    (the state rows of foreign neighbours are what the ranks exchange between diffusion steps):
+    order[i] = caller's index of the i-th cell.
+
+    The clusters of the library's cluster order (512 cells that share neighbours) are merged into communities of at most
+    one block -- heaviest normalised link first, Kruskal with a size cap, so that what is tightly linked ends up
+    together and populations are not cut while anything lighter can be -- and the communities are packed whole into the
+    blocks, best fit, largest first; what fits nowhere is poured into the room that is left, in cluster order.  On the
+    benchmark's generator (2M cells, 20 populations, eight blocks) the rows a block must send drop from 12-77 % of the
+    block (the caller's order; 28-71 % for the plain cluster order) to 3-22 %, the edges cut from 20 % to 3.3 %.
+    Host work, once per dataset, before `dist.shard`; deterministic (every rank computes the same order)."""
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    if nparts < 2 or n < 2 * nparts:
+        return cluster_order(A, B or DEFAULT_CLUSTER)
+    cap = -(-n // nparts)
+    if B is None:                                     # at least ~16 clusters per block to pack with
+        B = DEFAULT_CLUSTER
+        while B > 16 and cap < 16 * B:
+            B //= 2
+    base = cluster_order(A, B)
+    nc = -(-n // B)
+    csize = np.full(nc, B, dtype=np.int64)
+    csize[-1] = n - B * (nc - 1)
+    W = sp.triu(cluster_graph(A, base, B), k=1).tocoo()
+    score = W.data / np.sqrt(csize[W.row].astype(np.float64) * csize[W.col])
+    parent = np.arange(nc, dtype=np.int64)
+    size = csize.copy()
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    rows, cols = W.row.tolist(), W.col.tolist()
+    for e in np.argsort(-score, kind='stable').tolist():
+        a, b = find(rows[e]), find(cols[e])
+        if a != b and size[a] + size[b] <= cap:
+            if size[a] < size[b]:
+                a, b = b, a
+            parent[b] = a
+            size[a] += size[b]
+    lab_c = np.unique(np.array([find(x) for x in range(nc)]), return_inverse=True)[1]
+    ncomp = int(lab_c.max()) + 1
+    sizes = np.bincount(lab_c, weights=csize, minlength=ncomp).astype(np.int64)
+    room = np.full(nparts, cap, dtype=np.int64)
+    room[-1] = n - cap * (nparts - 1)
+    home = np.full(ncomp, -1, dtype=np.int64)
+    for c in np.argsort(-sizes, kind='stable'):
+        fits = np.flatnonzero(room >= sizes[c])
+        if len(fits):
+            g = fits[np.argmin(room[fits])]          # best fit: the fullest block that still takes it
+            home[c] = g
+            room[g] -= sizes[c]
+    # the sequence of clusters: block by block its whole communities (each in cluster order), the others poured into
+    # what room is left, in cluster order
+    cl_home = home[lab_c]
+    seq_key = np.where(cl_home >= 0, cl_home, nparts)
+    cl_seq = np.lexsort((np.arange(nc), lab_c, seq_key))
+    whole = cl_seq[seq_key[cl_seq] < nparts]
+    split = cl_seq[seq_key[cl_seq] == nparts]
+    # cells: clusters may straddle the fill line of a block, so the pouring is done cell by cell
+    def cells_of(clusters):
+        if len(clusters) == 0:
+            return np.zeros(0, dtype=np.int64)
+        return np.concatenate([base[c * B:(c + 1) * B] for c in clusters.tolist()])
+    out = np.empty(n, dtype=np.int64)
+    pour = cells_of(split)
+    o = take = 0
+    wh_home = cl_home[whole]
+    for g in range(nparts):
+        mine = cells_of(whole[wh_home == g])
+        size_g = min(cap, n - g * cap)
+        out[o:o + len(mine)] = mine
+        o += len(mine)
+        need = size_g - len(mine)
+        out[o:o + need] = pour[take:take + need]
+        o += need
+        take += need
+    assert o == n and take == len(pour)
+    return out
+
+
 def cluster_order(A, B):
     """Order in which clusters of B cells that share neighbours are consecutive (csrc/host_graph.c:
     cna_host_cluster_order): order[i] = caller's index of device row i.  Integer work on the host, a

@@ -924,3 +924,45 @@ int64_t cna_host_walk_tiles(int64_t n_local, const int64_t* indptr, const int32_
   free(blk_src);
   return ntiles;
 }
+
+/* Graph of the clusters of a cell order: order[c * B .. (c + 1) * B) are the cells of cluster c (the last one may be
+ * short).  For every cluster the other clusters its cells have edges into, with the number of such edges:
+ * ptr[nc + 1], then (col, cnt) lists.  Two calls: col == NULL counts (returns the number of entries and fills ptr),
+ * the second fills.  Used by cna_amd._order.partition_order (blocks of cells for a sharded run).
+ * -1: out of memory / bad arguments. */
+int64_t cna_host_cluster_graph(int64_t n, const int64_t* indptr, const int32_t* indices, const int64_t* order, int B,
+                               int64_t* ptr, int32_t* col, int64_t* cnt) {
+  if (n < 0 || B < 1 || !indptr || !indices || !order || !ptr) return -1;
+  const int64_t nc = (n + B - 1) / B;
+  int32_t* cl = (int32_t*)malloc(4 * (size_t)(n > 0 ? n : 1));
+  int64_t* acc = (int64_t*)calloc((size_t)(nc > 0 ? nc : 1), 8);
+  int32_t* touched = (int32_t*)malloc(4 * (size_t)(nc > 0 ? nc : 1));
+  if (!cl || !acc || !touched) { free(cl); free(acc); free(touched); return -1; }
+  for (int64_t p = 0; p < n; ++p) cl[order[p]] = (int32_t)(p / B);
+  int64_t total = 0;
+  for (int64_t c = 0; c < nc; ++c) {
+    int64_t nt = 0;
+    const int64_t p1 = (c + 1) * B < n ? (c + 1) * B : n;
+    for (int64_t p = c * B; p < p1; ++p) {
+      const int64_t i = order[p];
+      for (int64_t e = indptr[i]; e < indptr[i + 1]; ++e) {
+        const int32_t j = indices[e];
+        if (j < 0 || j >= n) continue;
+        const int32_t d = cl[j];
+        if (d == c) continue;
+        if (acc[d]++ == 0) touched[nt++] = d;
+      }
+    }
+    if (col) {
+      if (ptr[c] != total) { free(cl); free(acc); free(touched); return -1; }
+      for (int64_t k = 0; k < nt; ++k) { col[total + k] = touched[k]; cnt[total + k] = acc[touched[k]]; }
+    } else {
+      ptr[c] = total;
+    }
+    for (int64_t k = 0; k < nt; ++k) acc[touched[k]] = 0;
+    total += nt;
+  }
+  if (!col) ptr[nc] = total;
+  free(cl); free(acc); free(touched);
+  return total;
+}

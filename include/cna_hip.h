@@ -405,6 +405,11 @@ int64_t cna_host_cluster_order(int64_t n, const int64_t* indptr, const int32_t* 
  * The result depends on n and the graph only, not on nthreads.  Below 131072 cells: the sequential order. */
 int64_t cna_host_cluster_order_mt(int64_t n, const int64_t* indptr, const int32_t* indices, int B, int nthreads,
                                   int64_t* order_out);
+/* graph of the clusters of a cell order (cluster c = order[c * B .. (c + 1) * B)): per cluster the clusters its cells
+ * have edges into and how many; first call with col == NULL fills ptr[nc + 1] and returns the entry count, the second
+ * fills col / cnt.  Host only; the blocks of a sharded run are packed from it (cna_amd._order.partition_order). */
+int64_t cna_host_cluster_graph(int64_t n, const int64_t* indptr, const int32_t* indices, const int64_t* order, int B,
+                               int64_t* ptr, int32_t* col, int64_t* cnt);
 /* Per block of B consecutive rows: the distinct columns referenced (<= cap per block, in order of first
  * appearance) and, per edge, its column's position in the block's list (0xFFFF: not listed).  src_ptr
  * int64[nblocks+1], src int32[>= nnz], slot uint16[nnz].  Returns the total length of the lists or -1. */

@@ -170,3 +170,110 @@ def test_sharded_inputs_local_view(name, world, order):
     if 'tlnam' in z.files if hasattr(z, 'files') else 'tlnam' in z:
         assert relerr(cat('tlnam', 1), z['tlnam']) < 1e-5
     assert cat('tlkeep').shape == (n,)
+
+
+def _partition_worker(rank, world, port, name, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import warnings
+    warnings.simplefilter('ignore')
+    import torch.distributed as td
+    td.init_process_group('gloo', init_method='tcp://127.0.0.1:%d' % port, rank=rank, world_size=world)
+    import cna_amd as cna
+    from cna_amd import dist
+    from fake_engine import FakeEngine, GlooColl
+    from helpers import load_case
+    case = load_case(name)
+    part = dist.shard(case['data'], rank, world, partition=True)     # whole populations of the graph per block
+    eng = FakeEngine(GlooColl(), order='rcm')
+    res = cna.tl.association(part, case['y'], case['sid_name'], batches=case['batches'], covs=case['covs'],
+                             donorids=case['donorids'], return_full=True, engine=eng, **case['call'])
+    out = dict(p=res.p, k=int(res.k), kept=res.kept, num=res.fdrs.num_detected.values, fdr=res.fdrs.fdr.values,
+               cells=list(part.obs.index), coef=part.obs['coef'].values, coef_fdr=part.obs['coef_fdr'].values,
+               nam=res.nam.values, nam_cells=list(res.nam.columns), order=part.uns['cna_shard']['order'],
+               halo=None if eng.halo is None else int(eng.halo[3].sum()))
+    q.put((rank, out))
+    td.barrier()
+    td.destroy_process_group()
+
+
+@pytest.mark.parametrize('name,world', [('c01_plain_f32', 2), ('c12_batchy_qc', 4)])
+def test_sharded_inputs_partitioned_by_population(name, world):
+    """dist.shard(..., partition=True): the blocks are made of whole populations of the graph
+    (_order.partition_order) instead of contiguous runs of the caller's cells.  The analysis is the reference's on the
+    renumbered dataset: per-cell results matched by cell name, sample-level results equal on every rank and equal to
+    the golden values (integers exact, floats to 1e-5; the column sums add their rows in another order: rounding)."""
+    import torch.multiprocessing as mp
+    from helpers import load_case, relerr
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_partition_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    case = load_case(name)
+    z = case['z']
+    names = list(case['data'].obs.index)
+    where = {c: i for i, c in enumerate(names)}
+    n = len(names)
+    a = got[0]
+    order = a['order']
+    assert sorted(order.tolist()) == list(range(n))
+    rpr = -(-n // world)
+    coef = np.full(n, np.nan)
+    cfdr = np.full(n, np.nan)
+    kept = np.zeros(n, dtype=bool)
+    nam = np.full((z['nam'].shape[0], n), np.nan)
+    for r in range(world):
+        g = got[r]
+        assert g['cells'] == [names[i] for i in order[r * rpr:(r + 1) * rpr]]
+        assert g['p'] == a['p'] and g['k'] == a['k']
+        np.testing.assert_array_equal(g['num'], a['num'])
+        idx = np.array([where[c] for c in g['cells']])
+        coef[idx], cfdr[idx], kept[idx] = g['coef'], g['coef_fdr'], g['kept']
+        nam[:, [where[c] for c in g['nam_cells']]] = g['nam']
+    assert a['k'] == int(z['k']) and a['p'] == pytest.approx(float(z['p']), rel=1e-12)
+    assert np.array_equal(kept, z['kept'])
+    T = min(len(a['num']), len(z['fdr_num_detected']))
+    assert np.array_equal(a['num'][:T], z['fdr_num_detected'][:T])
+    assert relerr(a['fdr'][:T], z['fdr_fdr'][:T]) < 1e-4
+    assert np.array_equal(np.isnan(coef), np.isnan(z['obs_coef']))
+    assert relerr(coef[~np.isnan(coef)], z['obs_coef'][~np.isnan(coef)]) < 1e-5
+    np.testing.assert_allclose(cfdr, z['obs_coef_fdr'], rtol=1e-4, atol=1e-12)
+    assert relerr(nam[:, z['kept']], z['nam']) < 1e-5
+
+
+def test_partition_order_packs_populations():
+    """_order.partition_order on a graph of separated populations whose cells come in random order: a permutation;
+    its blocks send far fewer rows than blocks of the caller's order or of the plain cluster order (what a rank
+    ships between diffusion steps), and about as few as the generator's own population-sorted order."""
+    sys.path.insert(0, ROOT)
+    import scipy.sparse as sp
+    from cna_amd import synth, _order
+    X, _ = synth.mixture_points(24000)
+    A0 = synth.fuzzy_knn_graph(X, k=15).tocsr()
+    n = A0.shape[0]
+    shuffle = np.random.RandomState(0).permutation(n)
+    A = A0[shuffle][:, shuffle].tocsr()
+    deg = np.diff(A.indptr)
+
+    def boundary(order, G):
+        inv = np.empty(n, np.int64)
+        inv[order] = np.arange(n)
+        rpr = -(-n // G)
+        cut = np.repeat(inv // rpr, deg) != inv[A.indices] // rpr
+        b = np.zeros(n, bool)
+        b[np.repeat(inv, deg)[cut]] = True
+        return b.mean()
+    for G in (2, 4, 8):
+        o = _order.partition_order(A, G)
+        assert sorted(o.tolist()) == list(range(n))
+        sorted_by_population = boundary(np.argsort(shuffle), G)        # the generator's order, undone
+        assert boundary(np.arange(n), G) > 0.9                           # a random order: every row is wanted elsewhere
+        assert boundary(o, G) < 0.6 * boundary(_order.cluster_order(A, 512), G)
+        assert boundary(o, G) < max(0.35, 1.3 * sorted_by_population), (G, boundary(o, G), sorted_by_population)
+    assert np.array_equal(_order.partition_order(A, 1), _order.cluster_order(A, 512))
