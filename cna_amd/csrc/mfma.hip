@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * NW) void k_gram(const double* __restrict__ X, 
 // <= 15 (161 ... 240 samples); `blocks` holds per wave {i0, i1, i2, j0, j1, j2} (tile indices, -1: unused) in
 // an order that spreads the work over the four SIMDs; tixmap[i * nt + j] = index of tile (i, j) in the
 // upper-triangular table k_gram_reduce walks.
-template <int NW, int SLAB>
+template <int NW, int SLAB, bool ACC = false>
 __global__ __launch_bounds__(64 * NW) void k_gram_blk(const double* __restrict__ X, int64_t nx, int ldx, int nt,
                                                   int ldp, int ntri, const int32_t* __restrict__ blocks,
                                                   const int32_t* __restrict__ tixmap, double* __restrict__ partial,
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(64 * NW) void k_gram_blk(const double* __restrict__
   for (int t = 0; t < 9; ++t) {
     acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
     live[t] = ri[t / 3] >= 0 && cj[t % 3] >= ri[t / 3];
-    if (accumulate && live[t]) {                          // a later row range of the same product (launch_gram_range)
+    if (ACC && live[t]) {                                 // a later row range of the same product (launch_gram_range)
       const double* p = partial + ((size_t)blockIdx.x * ntri + tixmap[ri[t / 3] * nt + cj[t % 3]]) * 256;
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[t][r] = p[r * 64 + lane];
@@ -1428,11 +1428,16 @@ static int launch_gram_range(cna_ctx* c, const GramPlan& g, int64_t slab0, int64
   if (g.use_blk) {
     static bool attr_blk = false;
     if (!attr_blk) {
-      HIP_TRY(hipFuncSetAttribute((const void*)k_gram_blk<16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_gram_blk<16, 32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIP_TRY(hipFuncSetAttribute((const void*)k_gram_blk<16, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_blk = true;
     }
-    hipLaunchKernelGGL((k_gram_blk<16, 32>), dim3(nblocks), dim3(1024), 2 * g.smem, st, c->X, c->nx, c->ldx, nt, ldp, ntri,
-                       g.tiles_dev + ntri, g.tiles_dev + ntri + 128, g.partial, slab0, slab1, accumulate);
+    if (accumulate)
+      hipLaunchKernelGGL((k_gram_blk<16, 32, true>), dim3(nblocks), dim3(1024), 2 * g.smem, st, c->X, c->nx, c->ldx, nt, ldp, ntri,
+                         g.tiles_dev + ntri, g.tiles_dev + ntri + 128, g.partial, slab0, slab1, 1);
+    else
+      hipLaunchKernelGGL((k_gram_blk<16, 32, false>), dim3(nblocks), dim3(1024), 2 * g.smem, st, c->X, c->nx, c->ldx, nt, ldp, ntri,
+                         g.tiles_dev + ntri, g.tiles_dev + ntri + 128, g.partial, slab0, slab1, 0);
     HIP_TRY(hipGetLastError());
     return 0;
   }

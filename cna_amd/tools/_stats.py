@@ -167,7 +167,7 @@ class NativeDraw:
             pass
 
 
-def native_draw_start(B, Y, num, seed, threads=1):
+def native_draw_start(B, Y, num, seed, threads=None):
     """Seed numpy's global generator (np.random.seed(seed), _association.py:15-16) and start
     conditional_permutation(B, Y, num) on the library's host thread; None when the shape is not covered (the caller
     then draws as before, from the generator as this function found it: nothing is consumed before the decision)."""
@@ -203,6 +203,12 @@ def native_draw_start(B, Y, num, seed, threads=1):
     table[:, 0] = Yc
     if len(members) < len(Y):
         table[:, 1:] = Yc[0]                  # rows of no level (NaN batch labels): upstream's src stays 0 there
+    if threads is None:                        # large draws (10 000 permutations of 200 samples): normals and sorts on several threads
+        if len(Y) * num >= _BIG_DRAW:
+            from .._order import usable_cpus
+            threads = usable_cpus(16)
+        else:
+            threads = 1
     np.random.seed(seed)
     addr = bg.ctypes.state_address             # struct mt19937_state { uint32_t key[624]; int pos; }
     rc = lib.cna_host_draw_start(addr, C.cast(addr + 624 * 4, C.POINTER(C.c_int)), Yc.ctypes.data, len(Y), int(num),
