@@ -612,7 +612,10 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     # number of permutations): it needs no interpreter, so it neither waits for this thread's Python nor slows it
     # (a Python helper thread got to it 0.35 ms late and took 0.54 ms for 0.39 ms of work at 200k cells x 50 samples)
     native = None
-    if _NATIVE_DRAW and dv is None and len(yv) and kwargs.get('seed') is not None:
+    # (few cells only: from 500k cells on the walk hides the draw wherever it runs, and a draw that starts while this
+    # thread is still queueing the walk costs it CPU time -- measured 6.62 -> 6.73 ms at 1M x 100, 20.1 -> 20.7 at
+    # 2M x 200 with 10 000 permutations, against 1.94 -> 1.51 ms at 200k x 50)
+    if _NATIVE_DRAW and dv is None and len(yv) and kwargs.get('seed') is not None and len(data.obs) < _COEF_FIRST_CELLS:
         try:
             native = native_draw_start(np.ones(len(yv)) if kwargs.get('force_permute_all', False) else bv, y_std, Nnull,
                                        kwargs.get('seed'))
