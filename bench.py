@@ -44,7 +44,7 @@ I8_MFMA_PEAK_TOPS = 5033.0   # dense i8 matrix: 2x the bf16 rate (guide: >= 4404
 # profiles/*_pmc_traffic.json: bytes = 2 * FETCH_SIZE KB + WRITE_SIZE KB; the factor 2 on FETCH_SIZE is the
 # guide's gfx950 correction, re-calibrated on k_ncorrs, which streams the matrix once).  Counted at the L2's
 # fabric side, i.e. Infinity-Cache hits included.  Only valid for the profiled workload on one GPU.
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
 
 WORKLOADS = {
     # name: (cells, samples, kNN k, nsteps, Nnull, covariates[, batches])

@@ -12,6 +12,7 @@ import sys
 import pandas as pd
 
 d = sys.argv[1]
+STEPS = int(os.environ.get('PMC_STEPS', '6'))      # --steps of the profiled bench command (tools/profile_round4.sh)
 # device kernel -> bench kernel name (cna_prof_*), and how many bench launches one step makes
 NAMES = [('k_nam_first', 'nam_first'), ('k_nam_step_sparse', 'nam_step_sparse'), ('k_nam_step', 'nam_step'), ('k_null', 'null_local'), ('k_hist_reduce', 'null_local'), ('k_quant_', 'null_local'), ('k_y_', 'null_local'),
          ('k_i8_', 'null_local'),
@@ -33,6 +34,11 @@ for W in ('C4', 'C3', 'C2', 'C5'):
     frames = []
     for f in sorted(glob.glob('%s/*_%s_counter_collection.csv' % (d, W)) + glob.glob('%s/*/*_%s_counter_collection.csv' % (d, W))):
         df = pd.read_csv(f)
+        # the timed region only: the last STEPS analyses (the first call of a large graph runs in the caller's cell
+        # order, the next one re-uploads the graph -- engine.ensure_graph -- and the warm-up follows)
+        firsts = df.loc[df['Kernel_Name'].str.contains('k_nam_first'), 'Dispatch_Id'].drop_duplicates().sort_values()
+        if len(firsts) > STEPS:
+            df = df[df['Dispatch_Id'] >= firsts.iloc[-STEPS]]
         df['k'] = (df['Kernel_Name'].str.replace(r'\(anonymous namespace\)::', '', regex=True)
                    .str.replace('void ', '').str.replace(r'\(.*', '', regex=True))
         frames.append(df)
@@ -63,6 +69,6 @@ for W in ('C4', 'C3', 'C2', 'C5'):
         w = sums.loc[k, 'WRITE_SIZE'] / steps_w if steps_w else 0.0
         traffic[name] = traffic.get(name, 0.0) + (2.0 * f + w) * 1e3
     out[W] = {name: round(v / PER_STEP.get(name, 1), 0) for name, v in traffic.items()}
-with open(os.path.join(d, 'r03_pmc_traffic.json'), 'w') as fh:
+with open(os.path.join(d, os.environ.get('PMC_TRAFFIC_NAME', 'r04_pmc_traffic.json')), 'w') as fh:
     json.dump(out, fh, indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))
