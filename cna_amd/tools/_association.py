@@ -666,7 +666,7 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     # Where the draw runs.  Default: the helper thread, from now on, overlapping this thread's own host work
     # (it shares the GIL, so the 0.4 ms draw takes ~0.9 ms in context -- still the better schedule at 200k
     # cells: 1.96-1.99 ms per call against 2.2-2.4 ms with the draw on this thread after the walk is queued,
-    # CNA_DRAW_THREAD=0; no difference at 1M / 2M cells, where the walk hides either).
+    # _DRAW_THREAD = False; no difference at 1M / 2M cells, where the walk hides either).
     null_future = _background().submit(null_job) if _DRAW_THREAD else _InlineJob(null_job)
     _mark('submitted')
 
