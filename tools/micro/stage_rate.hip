@@ -46,7 +46,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned lds_base) {
 
 struct Args {
   const long* blk_tile; const int* tsrc;      // tsrc: S ids per tile (fixed stride)
-  const char* T; long nblocks; int ldb, S, nchunk, xcd_chunk, G, buf_bytes;
+  const char* T; long nblocks; int ldb, S, nchunk, xcd_chunk, G, buf_bytes, nbuf;
   unsigned long long* sink;
 };
 
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(NW * 64) void k_stage(Args a) {
   for (int c = c0; c < c1; ++c) {
     const char* Tc = a.T + (long)c * PB + within;
     for (int t = 0; t < nt; ++t, ++it) {
-      const int p = it & 1;
+      const int p = it % a.nbuf;
       cint_p ids = (cint_p)a.tsrc + (T0 + t) * a.S;
       for (int u = 0; u < ni; ++u) {
         int p0 = (u * NW + wv) * PPI;                    // first piece of this instruction
@@ -96,12 +96,16 @@ __global__ __launch_bounds__(NW * 64) void k_stage(Args a) {
         }
         dma16(Tc + (long)id * a.ldb, lds0 + (unsigned)(p * a.buf_bytes + p0 * PB));
       }
-      // the copies of the previous tile have landed once at most this tile's are outstanding
-      if (ni == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      else if (ni == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else if (ni == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else if (ni == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      // the copies of tile it - (nbuf - 1) have landed once at most (nbuf - 1) tiles' copies are outstanding
+      const int keep = ni * (a.nbuf - 1);
+      if (keep <= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (keep <= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (keep <= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (keep <= 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if (keep <= 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (keep <= 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      else if (keep <= 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
       __syncthreads();
     }
   }
@@ -128,7 +132,7 @@ __global__ void k_fill(double* p, long n) {
 
 template <int NW, int LPP>
 static void sweep(Args a, double staged, int rep) {
-  const size_t smem = 2 * (size_t)a.buf_bytes;
+  const size_t smem = (size_t)a.nbuf * a.buf_bytes;
   (void)hipFuncSetAttribute((const void*)k_stage<NW, LPP, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   (void)hipFuncSetAttribute((const void*)k_stage<NW, LPP, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   for (int xc : {1, 4, 16, 64}) {
@@ -167,6 +171,8 @@ int main(int argc, char** argv) {
   a.blk_tile = up(blktile); a.tsrc = up(tsrc);
   a.nblocks = (long)blktile.size() - 1; a.ldb = ldb; a.S = S; a.nchunk = nchunk; a.xcd_chunk = 4; a.G = 32;
   a.buf_bytes = (S * PB + 1023) / 1024 * 1024;
+  a.nbuf = getenv("NBUF") ? atoi(getenv("NBUF")) : 2;
+  if ((size_t)a.nbuf * a.buf_bytes > 160 * 1024) { printf("ring of %d x %d B exceeds the LDS\n", a.nbuf, a.buf_bytes); return 1; }
   double* T; (void)hipMalloc(&T, (size_t)(n + 64) * ldb);
   hipLaunchKernelGGL(k_fill, dim3((unsigned)(((n + 64) * (long)ldb / 8 + 255) / 256)), dim3(256), 0, 0, T, (n + 64) * (long)ldb / 8);
   a.T = (const char*)T;
@@ -174,10 +180,10 @@ int main(int argc, char** argv) {
   const double staged = (double)tilesrc.size() * PB * nchunk;
   const double edges = (double)indptr[n];
   printf("n = %ld, N = %d: %d chunks of %d B (row stride %d B), %ld blocks, %.1f tiles of %d pieces per block and chunk, "
-         "edges/sources %.2f; staged %.2f GB per pass (gather: %.2f GB), LDS 2 x %d B\n", n, N, nchunk, PB, ldb, a.nblocks,
-         (double)ntiles / a.nblocks, S, edges / tilesrc.size(), staged / 1e9, edges * N * 8 / 1e9, a.buf_bytes);
+         "edges/sources %.2f; staged %.2f GB per pass (gather: %.2f GB), LDS %d x %d B\n", n, N, nchunk, PB, ldb, a.nblocks,
+         (double)ntiles / a.nblocks, S, edges / tilesrc.size(), staged / 1e9, edges * N * 8 / 1e9, a.nbuf, a.buf_bytes);
   if (only >= 0) {
-    const size_t smem = 2 * (size_t)a.buf_bytes;
+    const size_t smem = (size_t)a.nbuf * a.buf_bytes;
     if (NW != 8 || PB != 256) { printf("counter mode wants NW=8 PB=256\n"); return 1; }
     if (only == 0) {
       (void)hipFuncSetAttribute((const void*)k_stage<8, 16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
