@@ -656,6 +656,61 @@ def test_results_do_not_depend_on_device_cell_order(monkeypatch):
         np.testing.assert_allclose(a[key][:, :15], b[key][:, :15], rtol=1e-6, atol=1e-9)
 
 
+def test_large_graph_is_analysed_first_and_reordered_beside_it(monkeypatch):
+    """A graph of 100 000 cells or more goes to the device in the caller's order; the cluster order is computed on a
+    host thread meanwhile and adopted -- a second upload -- by the first later call that finds it done
+    (engine.ensure_graph).  The first result, the adopting call's and a later one's are the same analysis: NAM bit for
+    bit, the rest to rounding (the Gram sum runs over the cells in another order); an in-place edit of the matrix
+    between the calls is still seen (the order computed from the old content is dropped)."""
+    import cna_amd as cna
+    from cna_amd import synth, engine as eng_mod
+    from cna_amd.engine import Engine
+    monkeypatch.setattr(eng_mod, '_REORDER_ASYNC_CELLS', 20000)
+    data, meta = synth.make_dataset(30000, 30, k=15, seed=5, cluster_sorted=False)
+    e = Engine(device=0)
+    e.reuse_nam = False
+    try:
+        outs = []
+        for call in range(3):
+            res = cna.tl.association(data, meta['y'], 'id', Nnull=200, seed=3, return_full=True, engine=e)
+            outs.append(dict(p=res.p, k=res.k, nam=res.nam.values.copy(), ncorrs=res.ncorrs.values.copy(),
+                             fdr=res.fdrs.values.copy(), coef_fdr=data.obs['coef_fdr'].values.copy(),
+                             perm=None if e.perm is None else e.perm.copy()))
+            if call == 0:
+                assert e.perm is None and e.reorder_pending()
+                e.wait_reorder()
+            else:
+                assert e.perm is not None and not e.reorder_pending()
+                assert not np.array_equal(e.perm, np.arange(len(e.perm)))
+        for o in outs[1:]:
+            assert o['p'] == outs[0]['p'] and o['k'] == outs[0]['k']
+            np.testing.assert_array_equal(o['nam'], outs[0]['nam'])
+            for key in ('ncorrs', 'fdr', 'coef_fdr'):
+                np.testing.assert_allclose(o[key], outs[0][key], rtol=1e-9, atol=1e-12, equal_nan=True)
+        for key in ('ncorrs', 'fdr', 'coef_fdr', 'nam'):
+            np.testing.assert_array_equal(outs[2][key], outs[1][key])          # steady state: the same call twice
+        # a new graph, edited in place while its order is being computed: the stale order must not be adopted
+        data2, meta2 = synth.make_dataset(30000, 30, k=15, seed=6, cluster_sorted=False)
+        A = data2.obsp['connectivities']
+        r1 = cna.tl.association(data2, meta2['y'], 'id', Nnull=100, seed=3, return_full=True, engine=e)
+        nam1 = r1.nam.values.copy()
+        assert e.reorder_pending()
+        e.wait_reorder()
+        A.data[:1000] *= 0.5
+        r2 = cna.tl.association(data2, meta2['y'], 'id', Nnull=100, seed=3, return_full=True, engine=e)
+        fresh = Engine(device=0)
+        try:
+            monkeypatch.setattr(eng_mod, '_REORDER_ASYNC', False)
+            nam2 = r2.nam.values.copy()
+            r3 = cna.tl.association(data2, meta2['y'], 'id', Nnull=100, seed=3, return_full=True, engine=fresh)
+            np.testing.assert_array_equal(nam2, r3.nam.values)
+            assert not np.array_equal(nam1, r3.nam.values)
+        finally:
+            fresh.close()
+    finally:
+        e.close()
+
+
 def test_ordered_fetch_on_device_equals_host_reorder(monkeypatch):
     """nam / namresid / V leave the device already restricted to the kept cells and samples, in the
     caller's order and layout (cna_fetch_rows); the sharded path reorders on the host instead.  Both
