@@ -113,3 +113,28 @@ def test_host_copy_is_a_memcpy_whatever_the_thread_count(n, threads):
     dst = np.full(n + 2, -7.0)
     assert lib.cna_host_copy(dst[1:1 + n].ctypes.data if n else None, src.ctypes.data if n else None, 8 * n, threads) == 0
     assert np.array_equal(dst[1:1 + n], src) and dst[0] == -7.0 and dst[-1] == -7.0
+
+
+def test_cluster_graph_counts_edges_between_clusters():
+    """cna_host_cluster_graph (what _order.partition_order packs the blocks of a sharded run from): entry (c, d) = number
+    of edges between the cells of cluster c and of cluster d of a cell order, against scipy's sparse product P^T A P."""
+    import scipy.sparse as sp
+    from cna_amd import _order
+    rs = np.random.RandomState(4)
+    n, B = 1000, 64
+    A = sp.random(n, n, density=0.01, random_state=rs, format='csr')
+    A = (A + A.T).tocsr()
+    A.setdiag(0)
+    A.eliminate_zeros()
+    order = rs.permutation(n)
+    W = _order.cluster_graph(A, order, B)
+    nc = -(-n // B)
+    cl = np.empty(n, dtype=np.int64)
+    cl[order] = np.arange(n) // B
+    P = sp.csr_matrix((np.ones(n), (np.arange(n), cl)), shape=(n, nc))
+    pattern = A.copy()
+    pattern.data[:] = 1.0
+    want = (P.T @ pattern @ P).toarray()
+    np.fill_diagonal(want, 0.0)
+    np.testing.assert_array_equal(W.toarray(), want)
+    assert W.shape == (nc, nc) and (W != W.T).nnz == 0
