@@ -1,3 +1,4 @@
+# round 4: ring depth and tile size of the staging-rate probe (tools/micro/stage_rate.hip); run on the GPU box
 cd /root/repo
 for cfg in "8 16 192" "8 16 96" "8 16 64"; do
   set -- $cfg
