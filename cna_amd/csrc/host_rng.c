@@ -439,6 +439,17 @@ static void* draw_thread(void* arg) {
   return NULL;
 }
 
+/* a forked child has no worker thread (threads do not survive fork): it starts its own on first use */
+static void draw_atfork_child(void) {
+  pthread_mutex_init(&g_draw_mu, NULL);
+  pthread_cond_init(&g_draw_cv, NULL);
+  g_draw_alive = 0;
+  g_draw_state = 0;
+  g_then_state = 0;
+}
+static pthread_once_t g_draw_fork_once = PTHREAD_ONCE_INIT;
+static void draw_register_atfork(void) { pthread_atfork(NULL, NULL, draw_atfork_child); }
+
 /* 0: the request is with the worker (every pointer must stay valid until cna_host_draw_wait returns);
  * -1: bad arguments / an earlier request not collected / no thread: the caller draws the usual way, the generator
  * state has not been touched */
@@ -448,6 +459,7 @@ int cna_host_draw_start(uint32_t* key, int* pos, const double* y, int m, int num
   if (*pos < 0 || *pos > MT_N) return -1;
   for (int l = 0; l < nlev; ++l) if (lev_off[l + 1] < lev_off[l] || lev_off[l + 1] > m) return -1;
   for (int64_t i = 0; i < lev_off[nlev]; ++i) if (members[i] < 0 || members[i] >= m) return -1;
+  pthread_once(&g_draw_fork_once, draw_register_atfork);
   pthread_mutex_lock(&g_draw_mu);
   if (g_draw_state != 0) { pthread_mutex_unlock(&g_draw_mu); return -1; }
   if (!g_draw_alive) {

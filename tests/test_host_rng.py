@@ -163,3 +163,30 @@ def test_native_draw_rows_of_no_level_and_ties():
     out = np.empty((4, 2))
     assert lib.cna_host_argsort_gather(_ffi.ptr(R), 4, 2, _ffi.ptr(y), _ffi.ptr(out), 2, None) == 0
     assert np.array_equal(out, y[np.argsort(R, axis=0, kind='stable')])
+
+
+def test_native_draw_in_a_forked_child():
+    """The draw's worker thread does not survive fork(): a child that inherits 'a worker exists' must start its own
+    (pthread_atfork handler in csrc/host_rng.c) instead of waiting for one that is not there."""
+    import os
+    from cna_amd.tools import _stats
+    Y = np.arange(20, dtype=float)
+    h = _stats.native_draw_start(np.ones(20), Y, 10, 1)
+    assert h is not None
+    want = h.wait().copy()
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        ok = b'0'
+        try:
+            import signal
+            signal.alarm(20)
+            h2 = _stats.native_draw_start(np.ones(20), Y, 10, 1)
+            ok = b'1' if h2 is not None and np.array_equal(h2.wait(), want) else b'0'
+        finally:
+            os.write(w, ok)
+            os._exit(0)
+    os.close(w)
+    got = os.read(r, 1)
+    os.waitpid(pid, 0)
+    assert got == b'1'
