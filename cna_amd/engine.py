@@ -180,6 +180,9 @@ class Engine(_order.CellOrder):
             return None
         if out is None or out[4] != self._graph_hash:
             return None                        # edited in place since: the next content check uploads it afresh
+        pinned = self._pinned is not None and self._pinned[0]() is A and self._pinned[1] == self._buffers(A)
+        if not pinned and self._full_hash(A) != out[4]:
+            return None                        # ... or edited after the order was made (an unpinned matrix is hashed in full, as always)
         return out
 
     def reorder_pending(self):
