@@ -262,7 +262,6 @@ extern "C" int cna_comm_init(cna_ctx* c, int rank, int nranks, const void* id128
 // time on some rank and was aborted on all of them; the exchange then runs on the main stream (no overlap).
 // An error return: the main communicator itself does not work.
 static int poll_stream(hipStream_t st, double timeout_s) {
-  const double t0 = (double)clock() / CLOCKS_PER_SEC;
   struct timespec a; clock_gettime(CLOCK_MONOTONIC, &a);
   for (;;) {
     const hipError_t q = hipStreamQuery(st);
@@ -272,7 +271,6 @@ static int poll_stream(hipStream_t st, double timeout_s) {
     if ((b.tv_sec - a.tv_sec) + 1e-9 * (b.tv_nsec - a.tv_nsec) > timeout_s) return 1;
     usleep(200);
   }
-  (void)t0;
 }
 
 extern "C" int cna_comm_selftest(cna_ctx* c, double timeout_s, int* halo_ok) {
@@ -282,6 +280,7 @@ extern "C" int cna_comm_selftest(cna_ctx* c, double timeout_s, int* halo_ok) {
   HIP_TRY(hipSetDevice(c->device));
   double* buf = nullptr;
   HIP_TRY(hipMalloc(&buf, 64));
+  struct Free { double* p; ~Free() { (void)hipFree(p); } } free_buf{buf};      // (also on the error returns)
   const double host[8] = {1, 1, 1, 1, 1, 1, 1, 1};
   HIP_TRY(hipMemcpy(buf, host, 64, hipMemcpyHostToDevice));
   ncclComm_t comm = (ncclComm_t)c->comm;
@@ -310,7 +309,6 @@ extern "C" int cna_comm_selftest(cna_ctx* c, double timeout_s, int* halo_ok) {
   HIP_TRY(hipMemcpy(&flag, buf + 4, 8, hipMemcpyDeviceToHost));
   double sum = 0;
   HIP_TRY(hipMemcpy(&sum, buf, 8, hipMemcpyDeviceToHost));
-  (void)hipFree(buf);
   if (sum != (double)c->nranks) CNA_FAIL(CNA_ERCCL, "cna_comm_selftest: the all-reduce over the ranks returned a wrong sum");
   if (flag != 0.0 && c->comm_halo) {
     if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t)c->comm_halo);
