@@ -945,28 +945,54 @@ __global__ __launch_bounds__(256) void k_digit_hist2(const double* __restrict__ 
 }
 // one thread per order statistic: pick the digit, descend; zero the histograms for the next pass; after the last
 // pass (decide >= 0) the median and the stop rule
-__global__ void k_auto_pick(unsigned long long* __restrict__ hist, AutoState* __restrict__ st, int pass, int step,
-                            int min_steps) {
+__global__ __launch_bounds__(256) void k_auto_pick(unsigned long long* __restrict__ hist, AutoState* __restrict__ st, int pass, int step,
+                                                   int min_steps) {
   if (st->stopped_at) return;
   __shared__ unsigned long long val[2];
-  const int w = threadIdx.x;
-  if (w < 2) {
-    const unsigned long long* h = hist + (pass == 0 ? 0 : 257 * w);
+  __shared__ long long incl[2][256];
+  __shared__ int digit[2];
+  const int t = threadIdx.x;                          // 256 threads: one per bin, both order statistics side by side
+  // inclusive prefix sums of the two histograms (the first pass has one, shared by both): the serial scan of 256 bins
+  // by one thread took 17 us per pass, 0.4 ms per walk with the default stop rule at 1M cells
+  for (int w = 0; w < 2; ++w) incl[w][t] = (long long)hist[(pass == 0 ? 0 : 257 * w) + t];
+  if (t < 2) digit[t] = 255;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    long long a0 = 0, a1 = 0;
+    if (t >= off) { a0 = incl[0][t - off]; a1 = incl[1][t - off]; }
+    __syncthreads();
+    incl[0][t] += a0;
+    incl[1][t] += a1;
+    __syncthreads();
+  }
+  if (t < 2) {
+    const int w = t;
     long long k;
     if (pass == 0) {
-      long long tot = 0;
-      for (int d = 0; d < 256; ++d) tot += (long long)h[d];
-      if (w == 0) { st->n_tot = tot + (long long)h[256]; st->n_nan = (long long)h[256]; }
+      const long long tot = incl[w][255];
+      const long long nan = (long long)hist[256];
+      if (w == 0) { st->n_tot = tot + nan; st->n_nan = nan; }
       k = w == 0 ? (tot - 1) / 2 : tot / 2;
       if (k >= tot) k = tot - 1;
       if (k < 0) k = 0;
     } else {
       k = st->k[w];
     }
-    int d = 0;
-    long long before = 0;
-    while (d < 255 && before + (long long)h[d] <= k) before += (long long)h[d++];
-    st->k[w] = k - before;
+    val[w] = (unsigned long long)k;                   // (handed to the search below)
+  }
+  __syncthreads();
+  // the digit: the first bin whose inclusive sum exceeds k (the last one if none does)
+  for (int w = 0; w < 2; ++w) {
+    const long long k = (long long)val[w];
+    const long long before = t ? incl[w][t - 1] : 0;
+    if (t < 255 && before <= k && incl[w][t] > k) digit[w] = t;
+  }
+  __syncthreads();
+  if (t < 2) {
+    const int w = t;
+    const int d = digit[w];
+    const long long before = d ? incl[w][d - 1] : 0;
+    st->k[w] = (long long)val[w] - before;
     const unsigned long long prefix = ((pass == 0 ? 0ull : st->prefix[w]) << 8) | (unsigned long long)d;
     st->prefix[w] = prefix;
     val[w] = (prefix >> 63) ? (prefix & 0x7fffffffffffffffull) : ~prefix;
