@@ -46,6 +46,8 @@ def _worker(rank, world, seg, name, halo, q):
     except BaseException as e:     # report instead of leaving the other ranks in a barrier forever
         import traceback
         q.put((rank, 'ERROR %r\n%s' % (e, traceback.format_exc())))
+        q.close()
+        q.join_thread()                                    # the report must be out before the process is
         os._exit(1)
 
 
@@ -131,6 +133,8 @@ def _fuzz_worker(rank, world, seg, seed, q):
     except BaseException as e:
         import traceback
         q.put((rank, 'ERROR %r\n%s' % (e, traceback.format_exc())))
+        q.close()
+        q.join_thread()                                    # the report must be out before the process is
         os._exit(1)
 
 
@@ -196,6 +200,8 @@ def _sparse_worker(rank, world, seg, q):
     except BaseException as e:
         import traceback
         q.put((rank, 'ERROR %r\n%s' % (e, traceback.format_exc())))
+        q.close()
+        q.join_thread()                                    # the report must be out before the process is
         os._exit(1)
 
 
@@ -280,6 +286,38 @@ def _shard_worker(rank, world, seg, name, q):
     except BaseException as e:
         import traceback
         q.put((rank, 'ERROR %r\n%s' % (e, traceback.format_exc())))
+        q.close()
+        q.join_thread()                                    # the report must be out before the process is
+        os._exit(1)
+
+
+def _partition_shard_worker(rank, world, seg, name, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import warnings
+    warnings.simplefilter('ignore')
+    try:
+        import cna_amd as cna
+        from cna_amd import dist
+        from cna_amd.engine import Engine
+        from helpers import load_case
+        case = load_case(name)
+        part = dist.shard(case['data'], rank, world, partition=True)   # whole populations of the graph per block
+        eng = Engine(device=0, rank=rank, nranks=world, shm=(seg, 8 << 20))
+        res = cna.tl.association(part, case['y'], case['sid_name'], batches=case['batches'], covs=case['covs'],
+                                 donorids=case['donorids'], return_full=True, engine=eng, **case['call'])
+        out = dict(p=res.p, k=int(res.k), kept=res.kept, num=res.fdrs.num_detected.values, fdr=res.fdrs.fdr.values,
+                   cells=list(part.obs.index), coef=part.obs['coef'].values, coef_fdr=part.obs['coef_fdr'].values,
+                   ncorrs=res.ncorrs.values, nam=res.nam.values, nam_cells=list(res.nam.columns),
+                   namresid=res.namresid.values, order=part.uns['cna_shard']['order'], view=eng.view_local,
+                   halo=eng.halo)
+        eng.close()
+        q.put((rank, out))
+    except BaseException as e:
+        import traceback
+        q.put((rank, 'ERROR %r\n%s' % (e, traceback.format_exc())))
+        q.close()
+        q.join_thread()                                    # the report must be out before the process is
         os._exit(1)
 
 
@@ -365,3 +403,70 @@ def test_sharded_inputs_on_one_gpu(name, world):
     # second phenotype: equal to what one GPU holding everything computes
     assert a['p2'] == pytest.approx(one['p2'], rel=1e-12)
     np.testing.assert_allclose(cat('ncorrs2'), one['ncorrs2'], rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize('name,world', [('c01_plain_f32', 2), ('c12_batchy_qc', 4), ('c03_covs_batches', 3)])
+def test_sharded_inputs_partitioned_by_population_on_one_gpu(name, world):
+    """dist.shard(..., partition=True) through the HIP path: each rank's block is made of whole populations of the
+    graph (_order.partition_order), the cells renumbered accordingly.  Per-cell results, matched by cell name, and the
+    sample-level results are the reference's (integers exact, floats to 1e-5: the column sums add their rows in
+    another order); every rank reports the same sample-level results.  The gloo twin of this test is
+    tests/test_sharded_gloo.py::test_sharded_inputs_partitioned_by_population."""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import load_case, relerr
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    seg = 'cna_pp_%d_%s' % (os.getpid(), name[:3])
+    procs = [ctx.Process(target=_partition_shard_worker, args=(r, world, seg, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            r, out = q.get(timeout=240)
+            assert not isinstance(out, str), out
+            got[r] = out
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    case = load_case(name)
+    z = case['z']
+    names = list(case['data'].obs.index)
+    where = {c: i for i, c in enumerate(names)}
+    n = len(names)
+    a = got[0]
+    order = a['order']
+    assert sorted(order.tolist()) == list(range(n))
+    rpr = -(-n // world)
+    coef = np.full(n, np.nan)
+    cfdr = np.full(n, np.nan)
+    kept = np.zeros(n, dtype=bool)
+    nam = np.full((z['nam'].shape[0], n), np.nan)
+    namresid = np.full((z['namresid'].shape[0], n), np.nan)
+    ncorrs = np.full(n, np.nan)
+    for r in range(world):
+        g = got[r]
+        assert g['view'] and g['cells'] == [names[i] for i in order[r * rpr:(r + 1) * rpr]]
+        assert g['p'] == a['p'] and g['k'] == a['k']
+        np.testing.assert_array_equal(g['num'], a['num'])
+        np.testing.assert_array_equal(g['fdr'], a['fdr'])
+        idx = np.array([where[c] for c in g['cells']], dtype=np.int64)
+        coef[idx], cfdr[idx], kept[idx] = g['coef'], g['coef_fdr'], g['kept']
+        cols = [where[c] for c in g['nam_cells']]
+        nam[:, cols] = g['nam']
+        namresid[:, cols] = g['namresid']
+        ncorrs[cols] = g['ncorrs']
+    assert a['k'] == int(z['k']) and a['p'] == pytest.approx(float(z['p']), rel=1e-12)
+    assert np.array_equal(kept, z['kept'])
+    T = min(len(a['num']), len(z['fdr_num_detected']))
+    assert np.array_equal(a['num'][:T], z['fdr_num_detected'][:T])
+    assert relerr(a['fdr'][:T], z['fdr_fdr'][:T]) < 1e-4
+    assert np.array_equal(np.isnan(coef), np.isnan(z['obs_coef']))
+    assert relerr(coef[~np.isnan(coef)], z['obs_coef'][~np.isnan(coef)]) < 1e-5
+    np.testing.assert_allclose(cfdr, z['obs_coef_fdr'], rtol=1e-4, atol=1e-12)
+    assert relerr(nam[:, z['kept']], z['nam']) < 1e-5
+    assert relerr(namresid[:, z['kept']], z['namresid']) < 1e-5
+    assert relerr(ncorrs[z['kept']], z['ncorrs']) < 1e-5
