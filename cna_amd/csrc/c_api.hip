@@ -541,11 +541,10 @@ int cna_set_halo(cna_ctx* c, const int64_t* send_rows, const int64_t* send_count
     CNA_TRY(dev_alloc(c, (void**)&c->halo_rows_i, sizeof(int32_t) * std::max<int64_t>(c->halo_ni, 1)));
     if (c->halo_nb) HIP_TRY(hipMemcpy(c->halo_rows_b, rb.data(), sizeof(int32_t) * c->halo_nb, hipMemcpyHostToDevice));
     if (c->halo_ni) HIP_TRY(hipMemcpy(c->halo_rows_i, ri.data(), sizeof(int32_t) * c->halo_ni, hipMemcpyHostToDevice));
-    if (!c->halo_stream) {
-      HIP_TRY(hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
-      HIP_TRY(hipEventCreateWithFlags(&c->halo_e1, hipEventDisableTiming));
-      HIP_TRY(hipEventCreateWithFlags(&c->halo_e2, hipEventDisableTiming));
-    }
+    // (the stream may exist already: cna_comm_selftest makes it for its own exchange)
+    if (!c->halo_stream) HIP_TRY(hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
+    if (!c->halo_e1) HIP_TRY(hipEventCreateWithFlags(&c->halo_e1, hipEventDisableTiming));
+    if (!c->halo_e2) HIP_TRY(hipEventCreateWithFlags(&c->halo_e2, hipEventDisableTiming));
   }
   return 0;
 }
