@@ -1,6 +1,6 @@
 """Multi-rank HIP path on ONE GPU (-m gpu): G processes, each with its own context on device 0,
 cells sharded by row blocks, the library's host-staged shared-memory communicator in place of RCCL
-(which refuses two ranks per GPU).  Everything else is the production path: the C ABI's block
+(which refuses two ranks per GPU unless told they are on different hosts: tests/test_gpu_rccl_ranks.py does that).  Everything else is the production path: the C ABI's block
 offsets, ragged gathers, halo pack / exchange / unpack, the unpermuting all-reduce, and the Python
 host code on every rank.  Results must equal the golden vectors of the reference and be identical
 on all ranks."""
