@@ -236,3 +236,94 @@ def test_rccl_selftest_reports_a_silent_peer():
                     pass
                 p.kill()
             p.join(timeout=10)
+
+
+def _replicated_worker(rank, world, port, name, halo, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import warnings
+    warnings.simplefilter('ignore')
+    _rank_env(rank, world, port)
+    os.environ['CNA_HALO'] = '1' if halo else '0'
+    try:
+        import cna_amd as cna
+        from cna_amd import dist
+        from cna_amd.engine import get_engine
+        from helpers import load_case
+        case = load_case(name)
+        dist.init_from_env()
+        eng = get_engine()
+        res = cna.tl.association(case['data'], case['y'], case['sid_name'], batches=case['batches'],
+                                 covs=case['covs'], donorids=case['donorids'], return_full=True, **case['call'])
+        out = dict(p=res.p, k=int(res.k), ncorrs=res.ncorrs.values, kept=res.kept, fdr=res.fdrs.fdr.values,
+                   num=res.fdrs.num_detected.values, coef=case['data'].obs['coef'].values,
+                   coef_fdr=case['data'].obs['coef_fdr'].values, nam=res.nam.values, namresid=res.namresid.values,
+                   V=res.namresid_nbhdXpc.values, rows=(eng.row0, eng.n_local), halo=eng.halo, comm=eng.comm_info())
+        s0 = np.random.RandomState(1).rand(case['data'].obsp['connectivities'].shape[0], 3)
+        out['diffuse'] = cna.tl.diffuse(case['data'], s0, 2)
+        NAM, keep = cna.tl.nam(case['data'], case['sid_name'], batches=case['batches'])
+        out['tlnam'], out['tlkeep'] = NAM.values, keep
+        dist.barrier()
+        eng.close()
+        q.put((rank, out))
+    except BaseException as e:
+        import traceback
+        q.put((rank, 'ERROR %r\n%s' % (e, traceback.format_exc())))
+        q.close()
+        q.join_thread()
+        os._exit(1)
+
+
+@pytest.mark.parametrize('name,world,halo', [('c12_batchy_qc', 2, True), ('c03_covs_batches', 3, False)])
+def test_rccl_ranks_replicated_inputs(name, world, halo):
+    """The drop-in convention under real RCCL: every rank passes the whole dataset, owns a block of rows on the device
+    and returns results for all cells (all-gathers of the per-cell results, the unpermuting all-reduce); with the halo
+    exchange and with the all-gather of the state (CNA_HALO=0).  Reference results, the same on every rank."""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from helpers import load_case, relerr
+    from oracle import cna_oracle as orc
+    import scipy.sparse as sp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replicated_worker, args=(r, world, port, name, halo, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(world):
+            r, out = q.get(timeout=300)
+            assert not isinstance(out, str), out
+            got[r] = out
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    z = load_case(name)['z']
+    a = got[0]
+    n = len(z['kept'])
+    rpr = -(-n // world)
+    for r in range(world):
+        g = got[r]
+        assert tuple(g['comm']) == ('rccl', world)
+        assert g['rows'] == (min(r * rpr, n), max(0, min(rpr, n - r * rpr)))
+        assert (g['halo'] is not None) == halo
+        assert g['p'] == a['p'] and g['k'] == a['k']
+        for key in ('ncorrs', 'kept', 'fdr', 'num', 'coef', 'coef_fdr', 'nam', 'namresid', 'V', 'diffuse', 'tlnam', 'tlkeep'):
+            np.testing.assert_array_equal(g[key], a[key], err_msg=key)
+    assert a['k'] == int(z['k']) and a['p'] == pytest.approx(float(z['p']), rel=1e-12)
+    assert np.array_equal(a['kept'], z['kept'])
+    assert relerr(a['ncorrs'], z['ncorrs']) < 1e-5
+    assert relerr(a['nam'], z['nam']) < 1e-5 and relerr(a['namresid'], z['namresid']) < 1e-5
+    T = min(len(a['fdr']), len(z['fdr_fdr']))
+    assert np.array_equal(a['num'][:T], z['fdr_num_detected'][:T])
+    assert relerr(a['fdr'][:T], z['fdr_fdr'][:T]) < 1e-4
+    assert np.array_equal(np.isnan(a['coef']), np.isnan(z['obs_coef']))
+    assert relerr(a['coef'][~np.isnan(a['coef'])], z['obs_coef'][~np.isnan(a['coef'])]) < 1e-5
+    case = load_case(name)
+    A = sp.csr_matrix(case['data'].obsp['connectivities'])
+    s0 = np.random.RandomState(1).rand(A.shape[0], 3)
+    assert relerr(a['diffuse'], orc.diffuse(A, s0, 2, mode='f64')) < 1e-12
+    assert np.array_equal(a['tlkeep'], z['kept'])
