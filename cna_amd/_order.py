@@ -82,7 +82,66 @@ def cluster_graph(A, order, B):
     return ((W + W.T) * 0.5).tocsr()                  # (a directed input graph: both directions count)
 
 
-def partition_order(A, nparts, B=None):
+def block_traffic(A, order, nparts):
+    """Rows every block of a cell order sends between diffusion steps, peers counted: out[g] = number of distinct
+    (row of block g, other block that has a neighbour of it) pairs -- what `cna_graph_upload`'s halo plan comes to for the
+    contiguous blocks of ceil(n / nparts) cells of `order` (None: the caller's order)."""
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    cap = -(-n // nparts)
+    if order is None:
+        blk = (np.arange(n, dtype=np.int64) // cap).astype(np.int32)
+    else:
+        blk = np.empty(n, dtype=np.int32)
+        blk[np.asarray(order, dtype=np.int64)] = (np.arange(n, dtype=np.int64) // cap).astype(np.int32)
+    wants = np.repeat(blk, np.diff(A.indptr))                       # block of the row that reads column j
+    cut = np.flatnonzero(wants != blk[A.indices])
+    pairs = np.unique(A.indices[cut].astype(np.int64) * nparts + wants[cut])
+    return np.bincount(blk[pairs // nparts], minlength=nparts)
+
+
+def _swap_refine(W, blk, movable, nparts, max_swaps=100000):
+    """Kernighan-Lin hill climbing on the cluster graph: while a pair of equal-sized clusters in two blocks exists whose
+    exchange lowers the weight between the blocks, exchange the best such pair (block pairs in turn, until a whole round
+    finds none).  blk: block of every cluster (>= nparts: not assigned), edited in place."""
+    nc = W.shape[0]
+    indptr, indices, data = W.indptr, W.indices, W.data
+    hot = sp.csr_matrix((np.ones(nc), (np.arange(nc), np.minimum(blk, nparts))), shape=(nc, nparts + 1))
+    M = np.asarray((W @ hot).todense())                             # M[c, g]: weight between cluster c and block g
+    swaps = 0
+    again = True
+    while again and swaps < max_swaps:
+        again = False
+        for a in range(nparts):
+            for b in range(a + 1, nparts):
+                while swaps < max_swaps:
+                    ca = np.flatnonzero((blk == a) & movable)
+                    cb = np.flatnonzero((blk == b) & movable)
+                    if len(ca) == 0 or len(cb) == 0:
+                        break
+                    Da = M[ca, b] - M[ca, a]
+                    Db = M[cb, a] - M[cb, b]
+                    # the best pair among the few best of either side (the pair's own link counts against it twice)
+                    ta = ca[np.argsort(-Da, kind='stable')[:8]]
+                    tb = cb[np.argsort(-Db, kind='stable')[:8]]
+                    link = np.asarray(W[ta][:, tb].todense())
+                    gain = (M[ta, b] - M[ta, a])[:, None] + (M[tb, a] - M[tb, b])[None, :] - 2.0 * link
+                    i, j = np.unravel_index(np.argmax(gain), gain.shape)
+                    if gain[i, j] <= 1e-9:
+                        break
+                    c, d = int(ta[i]), int(tb[j])
+                    for x, src, dst in ((c, a, b), (d, b, a)):
+                        nb = indices[indptr[x]:indptr[x + 1]]
+                        w = data[indptr[x]:indptr[x + 1]]
+                        M[nb, src] -= w
+                        M[nb, dst] += w
+                        blk[x] = dst
+                    swaps += 1
+                    again = True
+    return swaps
+
+
+def partition_order(A, nparts, B=None, refine=True, compare=True):
     """A cell order whose `nparts` contiguous blocks of ceil(n / nparts) cells make good row blocks for a sharded run
     (the state rows of foreign neighbours are what the ranks exchange between diffusion steps):
     order[i] = caller's index of the i-th cell.
@@ -90,9 +149,15 @@ def partition_order(A, nparts, B=None):
     The clusters of the library's cluster order (512 cells that share neighbours) are merged into communities of at most
     one block -- heaviest normalised link first, Kruskal with a size cap, so that what is tightly linked ends up
     together and populations are not cut while anything lighter can be -- and the communities are packed whole into the
-    blocks, best fit, largest first; what fits nowhere is poured into the room that is left, in cluster order.  On the
-    benchmark's generator (2M cells, 20 populations, eight blocks) the rows a block must send drop from 12-77 % of the
-    block (the caller's order; 28-71 % for the plain cluster order) to 3-22 %, the edges cut from 20 % to 3.3 %.
+    blocks, largest first, each into the block it has the most edges to among those with room (none: best fit); what
+    fits nowhere is poured into the room that is left, in cluster order.  `refine`: pairs of clusters are then exchanged
+    between blocks while that lowers the number of edges between blocks (`_swap_refine`).  `compare`: the result is kept
+    only if its busiest block sends fewer rows than the busiest block of the caller's order (`block_traffic`) -- a
+    dataset that arrives sorted by population is best cut where it is -- otherwise the caller's order is returned.
+    On the benchmark's generator (20 populations, cells sorted by population), rows sent by the busiest block / by all
+    blocks (`block_traffic`): 2M cells, 8 blocks: 192k / 966k -> 76k / 392k (edges cut 20 % -> 3.3 %); 4 blocks: 118k /
+    373k -> 90k / 199k; 1M cells, 8 blocks: 97k / 483k -> 67k / 431k; 1M cells in 4 blocks and 200k cells: the caller's
+    order is kept.  A dataset whose cells come in random order: every row is wanted elsewhere before, 10-35 % after.
     Host work, once per dataset, before `dist.shard`; deterministic (every rank computes the same order)."""
     A = sp.csr_matrix(A)
     n = A.shape[0]
@@ -107,7 +172,8 @@ def partition_order(A, nparts, B=None):
     nc = -(-n // B)
     csize = np.full(nc, B, dtype=np.int64)
     csize[-1] = n - B * (nc - 1)
-    W = sp.triu(cluster_graph(A, base, B), k=1).tocoo()
+    Wfull = cluster_graph(A, base, B)
+    W = sp.triu(Wfull, k=1).tocoo()
     score = W.data / np.sqrt(csize[W.row].astype(np.float64) * csize[W.col])
     parent = np.arange(nc, dtype=np.int64)
     size = csize.copy()
@@ -128,22 +194,34 @@ def partition_order(A, nparts, B=None):
     lab_c = np.unique(np.array([find(x) for x in range(nc)]), return_inverse=True)[1]
     ncomp = int(lab_c.max()) + 1
     sizes = np.bincount(lab_c, weights=csize, minlength=ncomp).astype(np.int64)
+    # edges between communities, for the choice of the block
+    hot = sp.csr_matrix((np.ones(nc), (np.arange(nc), lab_c)), shape=(nc, ncomp))
+    Wc = (hot.T @ Wfull @ hot).tocsr()
     room = np.full(nparts, cap, dtype=np.int64)
     room[-1] = n - cap * (nparts - 1)
     home = np.full(ncomp, -1, dtype=np.int64)
     for c in np.argsort(-sizes, kind='stable'):
         fits = np.flatnonzero(room >= sizes[c])
         if len(fits):
-            g = fits[np.argmin(room[fits])]          # best fit: the fullest block that still takes it
+            nb = Wc.indices[Wc.indptr[c]:Wc.indptr[c + 1]]
+            wt = Wc.data[Wc.indptr[c]:Wc.indptr[c + 1]]
+            placed = home[nb] >= 0
+            pull = np.bincount(home[nb[placed]], weights=wt[placed], minlength=nparts)[fits]
+            if pull.max() > 0:
+                g = fits[np.argmax(pull)]            # the block it shares the most edges with
+            else:
+                g = fits[np.argmin(room[fits])]      # best fit: the fullest block that still takes it
             home[c] = g
             room[g] -= sizes[c]
-    # the sequence of clusters: block by block its whole communities (each in cluster order), the others poured into
-    # what room is left, in cluster order
     cl_home = home[lab_c]
-    seq_key = np.where(cl_home >= 0, cl_home, nparts)
-    cl_seq = np.lexsort((np.arange(nc), lab_c, seq_key))
-    whole = cl_seq[seq_key[cl_seq] < nparts]
-    split = cl_seq[seq_key[cl_seq] == nparts]
+    blk = np.where(cl_home >= 0, cl_home, nparts).astype(np.int64)
+    if refine:
+        _swap_refine(Wfull.tocsr(), blk, (blk < nparts) & (csize == B), nparts)
+    # the sequence of clusters: block by block its clusters (community by community, each in cluster order), the others
+    # poured into what room is left, in cluster order
+    cl_seq = np.lexsort((np.arange(nc), lab_c, blk))
+    whole = cl_seq[blk[cl_seq] < nparts]
+    split = cl_seq[blk[cl_seq] == nparts]
     # cells: clusters may straddle the fill line of a block, so the pouring is done cell by cell
     def cells_of(clusters):
         if len(clusters) == 0:
@@ -152,7 +230,7 @@ def partition_order(A, nparts, B=None):
     out = np.empty(n, dtype=np.int64)
     pour = cells_of(split)
     o = take = 0
-    wh_home = cl_home[whole]
+    wh_home = blk[whole]
     for g in range(nparts):
         mine = cells_of(whole[wh_home == g])
         size_g = min(cap, n - g * cap)
@@ -163,6 +241,8 @@ def partition_order(A, nparts, B=None):
         o += need
         take += need
     assert o == n and take == len(pour)
+    if compare and block_traffic(A, None, nparts).max() <= block_traffic(A, out, nparts).max():
+        return np.arange(n, dtype=np.int64)
     return out
 
 

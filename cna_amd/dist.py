@@ -161,7 +161,9 @@ def shard(data, rank=None, nranks=None, partition=None):
     ``partition``: which cells form the blocks.  None / False: the caller's order is cut into contiguous blocks.
     True: the cells are first put into ``cna_amd._order.partition_order(A, nranks)`` -- whole populations of the
     graph packed into the blocks -- so that a block's cells have few neighbours outside it (the rows exchanged
-    between diffusion steps); every rank computes the same order.  An index array: that order.  The
+    between diffusion steps) -- unless the busiest block of the caller's own order sends no more rows than
+    the busiest of those (a dataset that arrives sorted by population), then the caller's order is kept ('always': never
+    kept); every rank computes the same order.  An index array: that order.  The
     block keeps the caller's ``obs`` index, so per-cell results are matched by name as before.  (The analysis is then
     that of the dataset with its cells renumbered: every row still adds its neighbours in the caller's order, the
     column sums add their rows in the new one -- results agree with the unpartitioned run to rounding, ~1e-15.)  Pass the result to
@@ -183,7 +185,10 @@ def shard(data, rank=None, nranks=None, partition=None):
     if partition is not None and partition is not False and nranks > 1:
         import numpy as np
         from . import _order
-        order = _order.partition_order(A, nranks) if partition is True else np.asarray(partition, dtype=np.int64)
+        if partition is True or (isinstance(partition, str) and partition == 'always'):
+            order = _order.partition_order(A, nranks, compare=partition is True)
+        else:
+            order = np.asarray(partition, dtype=np.int64)
         if len(order) != n or len(np.unique(order)) != n:
             raise ValueError('partition must be a permutation of the cells')
         mine = order[r0:r1]

@@ -302,7 +302,7 @@ def _partition_shard_worker(rank, world, seg, name, q):
         from cna_amd.engine import Engine
         from helpers import load_case
         case = load_case(name)
-        part = dist.shard(case['data'], rank, world, partition=True)   # whole populations of the graph per block
+        part = dist.shard(case['data'], rank, world, partition='always')   # whole populations of the graph per block
         eng = Engine(device=0, rank=rank, nranks=world, shm=(seg, 8 << 20))
         res = cna.tl.association(part, case['y'], case['sid_name'], batches=case['batches'], covs=case['covs'],
                                  donorids=case['donorids'], return_full=True, engine=eng, **case['call'])
@@ -407,7 +407,7 @@ def test_sharded_inputs_on_one_gpu(name, world):
 
 @pytest.mark.parametrize('name,world', [('c01_plain_f32', 2), ('c12_batchy_qc', 4), ('c03_covs_batches', 3)])
 def test_sharded_inputs_partitioned_by_population_on_one_gpu(name, world):
-    """dist.shard(..., partition=True) through the HIP path: each rank's block is made of whole populations of the
+    """dist.shard(..., partition='always') through the HIP path: each rank's block is made of whole populations of the
     graph (_order.partition_order), the cells renumbered accordingly.  Per-cell results, matched by cell name, and the
     sample-level results are the reference's (integers exact, floats to 1e-5: the column sums add their rows in
     another order); every rank reports the same sample-level results.  The gloo twin of this test is

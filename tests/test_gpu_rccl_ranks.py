@@ -40,7 +40,7 @@ def _worker(rank, world, port, name, partition, overlap, q):
         case = load_case(name)
         assert dist.init_from_env() == (rank, world)           # rank 0's id over the Unix-domain socket
         eng = get_engine()
-        part = dist.shard(case['data'], rank, world, partition=partition)
+        part = dist.shard(case['data'], rank, world, partition='always' if partition else None)
         res = cna.tl.association(part, case['y'], case['sid_name'], batches=case['batches'], covs=case['covs'],
                                  donorids=case['donorids'], return_full=True, **case['call'])
         out = dict(p=res.p, k=int(res.k), kept=res.kept, num=res.fdrs.num_detected.values, fdr=res.fdrs.fdr.values,

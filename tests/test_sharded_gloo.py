@@ -184,7 +184,7 @@ def _partition_worker(rank, world, port, name, q):
     from fake_engine import FakeEngine, GlooColl
     from helpers import load_case
     case = load_case(name)
-    part = dist.shard(case['data'], rank, world, partition=True)     # whole populations of the graph per block
+    part = dist.shard(case['data'], rank, world, partition='always')     # whole populations of the graph per block
     eng = FakeEngine(GlooColl(), order='rcm')
     res = cna.tl.association(part, case['y'], case['sid_name'], batches=case['batches'], covs=case['covs'],
                              donorids=case['donorids'], return_full=True, engine=eng, **case['call'])
@@ -199,7 +199,7 @@ def _partition_worker(rank, world, port, name, q):
 
 @pytest.mark.parametrize('name,world', [('c01_plain_f32', 2), ('c12_batchy_qc', 4)])
 def test_sharded_inputs_partitioned_by_population(name, world):
-    """dist.shard(..., partition=True): the blocks are made of whole populations of the graph
+    """dist.shard(..., partition='always'): the blocks are made of whole populations of the graph
     (_order.partition_order) instead of contiguous runs of the caller's cells.  The analysis is the reference's on the
     renumbered dataset: per-cell results matched by cell name, sample-level results equal on every rank and equal to
     the golden values (integers exact, floats to 1e-5; the column sums add their rows in another order: rounding)."""
@@ -276,4 +276,14 @@ def test_partition_order_packs_populations():
         assert boundary(np.arange(n), G) > 0.9                           # a random order: every row is wanted elsewhere
         assert boundary(o, G) < 0.6 * boundary(_order.cluster_order(A, 512), G)
         assert boundary(o, G) < max(0.35, 1.3 * sorted_by_population), (G, boundary(o, G), sorted_by_population)
+        # block_traffic counts what the halo plan sends: distinct (row, peer block) pairs
+        tr = _order.block_traffic(A, o, G)
+        assert tr.shape == (G,) and boundary(o, G) * n <= tr.sum() <= (G - 1) * boundary(o, G) * n + 1
+        assert tr.max() < 0.5 * _order.block_traffic(A, None, G).max()
     assert np.array_equal(_order.partition_order(A, 1), _order.cluster_order(A, 512))
+    # a dataset that arrives sorted by population and is cut between populations keeps its own order ...
+    two = sp.block_diag([A0[:100][:, :100], A0[:100][:, :100]]).tocsr()
+    assert np.array_equal(_order.partition_order(two, 2), np.arange(200))
+    # ... unless asked otherwise
+    forced = _order.partition_order(two, 2, compare=False)
+    assert sorted(forced.tolist()) == list(range(200))
