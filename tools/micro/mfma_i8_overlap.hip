@@ -9,7 +9,7 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
-template <int KIND>
+template <int KIND, int NV = 0>
 __global__ __launch_bounds__(512) void k(int do_mfma, int do_valu, int iters, int* out, unsigned long long* clk) {
   const int wv = threadIdx.x >> 6;
   const unsigned long long t0 = __builtin_readcyclecounter(), r0 = wall_clock64();
@@ -34,6 +34,36 @@ __global__ __launch_bounds__(512) void k(int do_mfma, int do_valu, int iters, in
       }
     }
     res = c0[0] + c1[1] + c2[2] + c3[3] + (int)(x + y + z + w);
+  } else if (KIND == 2 || KIND == 3 || KIND == 4) {
+    // one wave per SIMD: MFMA (KIND 2 only), NV INDEPENDENT vector instructions (8 chains of fma / med3, which do not
+    // pack), MFMA, ... fenced so that the order stays
+    if (wv >= 4 && KIND != 4) return;                  // KIND 4: two such waves per SIMD
+    v16i c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    float x[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) x[q] = threadIdx.x + q;
+    const float lo = (float)do_valu, hi = 1e30f * do_valu;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        if (KIND == 2 || KIND == 4) {
+          if (m == 0) c0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c0, 0, 0, 0);
+          if (m == 1) c1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c1, 0, 0, 0);
+          if (m == 2) c2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c2, 0, 0, 0);
+          if (m == 3) c3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c3, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+          const int q = (m * NV + u) & 7;
+          x[q] = (u & 1) ? __builtin_amdgcn_fmed3f(x[q], lo, hi) : fmaf(x[q], 1.0000001f, lo);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    float sx = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sx += x[q];
+    res = c0[0] + c1[1] + c2[2] + c3[3] + (int)sx;
   } else if (wv < 4) {
     if (!do_mfma) return;
     v16i c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
@@ -59,13 +89,13 @@ __global__ __launch_bounds__(512) void k(int do_mfma, int do_valu, int iters, in
   if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = __builtin_readcyclecounter() - t0; clk[1] = wall_clock64() - r0; }
 }
 
-template <int KIND>
+template <int KIND, int NV = 0>
 void run(const char* what, int m, int v, int iters, int* out, unsigned long long* clk) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(512), 0, 0, m, v, iters, out, clk);
+  hipLaunchKernelGGL((k<KIND, NV>), dim3(256), dim3(512), 0, 0, m, v, iters, out, clk);
   hipEventRecord(e0);
-  hipLaunchKernelGGL(k<KIND>, dim3(256), dim3(512), 0, 0, m, v, iters, out, clk);
+  hipLaunchKernelGGL((k<KIND, NV>), dim3(256), dim3(512), 0, 0, m, v, iters, out, clk);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -84,6 +114,23 @@ int main() {
   run<1>("one wave/SIMD: mfma only", 1, 0, iters, out, clk);
   run<1>("one wave/SIMD: valu only (24 instr/it)", 0, 1, iters, out, clk);
   run<1>("one wave/SIMD: interleaved in one stream", 1, 1, iters, out, clk);
+  run<2, 0>("one wave/SIMD, fenced: mfma only", 1, 1, iters, out, clk);
+  run<2, 2>("one wave/SIMD, fenced: mfma + 2 valu each", 1, 1, iters, out, clk);
+  run<3, 2>("one wave/SIMD, fenced: 2 valu per slot, no mfma", 1, 1, iters, out, clk);
+  run<2, 4>("one wave/SIMD, fenced: mfma + 4 valu each", 1, 1, iters, out, clk);
+  run<3, 4>("one wave/SIMD, fenced: 4 valu per slot, no mfma", 1, 1, iters, out, clk);
+  run<2, 6>("one wave/SIMD, fenced: mfma + 6 valu each", 1, 1, iters, out, clk);
+  run<3, 6>("one wave/SIMD, fenced: 6 valu per slot, no mfma", 1, 1, iters, out, clk);
+  run<2, 8>("one wave/SIMD, fenced: mfma + 8 valu each", 1, 1, iters, out, clk);
+  run<3, 8>("one wave/SIMD, fenced: 8 valu per slot, no mfma", 1, 1, iters, out, clk);
+  run<2, 12>("one wave/SIMD, fenced: mfma + 12 valu each", 1, 1, iters, out, clk);
+  run<3, 12>("one wave/SIMD, fenced: 12 valu per slot, no mfma", 1, 1, iters, out, clk);
+  run<4, 0>("two waves/SIMD, fenced: mfma only", 1, 1, iters, out, clk);
+  run<4, 2>("two waves/SIMD, fenced: mfma + 2 valu each", 1, 1, iters, out, clk);
+  run<4, 4>("two waves/SIMD, fenced: mfma + 4 valu each", 1, 1, iters, out, clk);
+  run<4, 5>("two waves/SIMD, fenced: mfma + 5 valu each", 1, 1, iters, out, clk);
+  run<4, 6>("two waves/SIMD, fenced: mfma + 6 valu each", 1, 1, iters, out, clk);
+  run<4, 8>("two waves/SIMD, fenced: mfma + 8 valu each", 1, 1, iters, out, clk);
   const double ops = 256.0 * 4 * iters * 4.0 * 65536.0;
   printf("(4 MFMA waves per CU: %.3g integer ops per run)\n", ops);
   return 0;
