@@ -96,7 +96,10 @@ def _free_port():
 
 @pytest.mark.parametrize('name,world,partition,overlap', [
     ('c01_plain_f32', 2, None, True), ('c12_batchy_qc', 3, True, True), ('c03_covs_batches', 4, True, True),
-    ('c13_zero_variance', 2, None, False), ('c11_string_ids_null_y', 2, True, True)])
+    ('c13_zero_variance', 2, None, False), ('c11_string_ids_null_y', 2, True, True),
+    # the walk's stop rule and the batch-kurtosis loop take medians over the cells of all ranks; a float64 graph
+    ('c02_covs_autostop', 2, True, True), ('c05_ks_f64', 3, None, True), ('c16_ridge_loop', 2, True, False),
+    ('c14_selfweight_autostop_unsorted', 4, True, True)])
 def test_rccl_ranks_sharded_inputs(name, world, partition, overlap):
     """Every rank: its own block of cells (contiguous, or whole populations: partition=True), real RCCL between the ranks.
     Per-cell results matched by cell name and sample-level results are the reference's; every rank reports the same
