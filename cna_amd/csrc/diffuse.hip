@@ -670,6 +670,24 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
     const int cl = (base + lane < end) ? (int)a.sp_cnt[jl] : 0;
     const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
     int l = 0;
+    // (no neighbour of these 64 edges overflowed its pairs -- the rule on one GPU: the batches then carry no test for it)
+    if (__ballot(cl == SP_DENSE) == 0ull) {
+      for (; l + U <= cnt; l += U) {
+        int cc[U];
+        SpPair sp[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int j = __builtin_amdgcn_readlane(jl, l + u);
+          cc[u] = __builtin_amdgcn_readlane(cl, l + u);
+          if (lane < cc[u]) sp[u] = pairs[(int64_t)j * SP_CAP + lane];       // (used under the same condition only)
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const double av = readlane_d(al, l + u);
+          if (lane < cc[u]) lds_add(&acc[sp[u].col], mul_rn(av, sp[u].v));
+        }
+      }
+    }
     for (; l + U <= cnt; l += U) {
       int cc[U];
       SpPair sp[U];
