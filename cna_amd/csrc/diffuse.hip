@@ -625,16 +625,17 @@ __global__ __launch_bounds__(256) void k_nam_step_pair(StepArgs a) {
 // 2.13 against 1.93 at 1M x 100 -- 65 VGPRs, seven waves per SIMD)
 __device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
-// U, the edges of a batch whose pairs are in flight together: 6 (us per launch at 2M x 200 / 1M x 100, from the
+// U, the edges of a batch whose pairs are in flight together: 5 since round 4; before that 6 (us per launch at 2M x 200 / 1M x 100, from the
 // averages of profiles/r02_kbench_sparse_u.txt: U = 3: 4.41 / 2.12, 4: 4.20 / 2.03, 6: 4.10 / 1.95, 8: 4.37 / 2.10,
 // 12: 4.9 / 2.2, 16: 5.0 / 2.3; the ragged end of a row as one more, predicated batch instead of edge by edge:
-// slower at every U).  Round 3: the bank conflicts of the scatter are NOT what the step waits for -- with every lane
+// slower at every U).  Round 4, after the batches of edges without an overflowed neighbour got a loop of their own: U = 3:
+// 3.98 / 1.79 ms (2M x 200 / 1M x 100), 4: 3.86 / 1.71, 5: 3.85 / 1.67, 6: 4.02 / 1.67, 8: 4.39 / 1.96 -- five.  Round 3: the bank conflicts of the scatter are NOT what the step waits for -- with every lane
 // adding into its own column (conflict-free, wrong sums: a timing experiment) the launch goes from 4.45 to 4.25 ms at
 // 2M x 200, 1.86 -> 1.78 at 1M x 100; a pair order that spreads a row's columns over the banks
 // (tools/micro/lds_scatter_pattern.hip: 14.3 -> 11.7 clk per ds_add_f64, floor 7.4) is therefore not worth its
 // bookkeeping.  Counters (profiles/r03_pmc_summary_C4.txt): VALU 42 % and LDS 49 % of the cycles, 61 % of the wave
 // cycles waiting, 12.5 vector instructions per edge: no single unit is the limit.
-template <typename VT, int NQ2, int U = 6, int FL = 0>
+template <typename VT, int NQ2, int U = 5, int FL = 0>
 __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
   if (STEP_STOPPED(a)) return;
   extern __shared__ double sm[];
@@ -954,9 +955,9 @@ int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
 template <typename VT, int NQ2>
 int launch_step_sparse_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(double) * 4 * 128 * NQ2;
-  if (a.rows) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 6, 2>), grid, dim3(256), lds, st, a);
-  else if (a.sel_X) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 6, 1>), grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 6, 0>), grid, dim3(256), lds, st, a);
+  if (a.rows) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 2>), grid, dim3(256), lds, st, a);
+  else if (a.sel_X) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 1>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 0>), grid, dim3(256), lds, st, a);
   return 0;
 }
 
