@@ -505,6 +505,7 @@ bool null_i8_enabled() {
 bool null_i8_eligible(const cna_ctx* c, int P, int T, double cut0, double inv_step, double eps) {
   if (!null_i8_enabled()) return false;
   if (c->Nx > 256 || c->Nx < 2 || c->nx < 1) return false;
+  if (P > 65535 - 64 || T > 65535) return false;          // a queue entry packs the permutation and the bin into 16 bits each
   if (!(inv_step > 0.0) || !(eps < 0.05) || !(cut0 * inv_step > 2.0) || !(cut0 * inv_step + T < 5e4)) return false;
   const int KS = (c->Nx + 31) / 32;
   return i8_lds(KS, T) <= 160 * 1024 && c->nx < (int64_t)1 << 31;
