@@ -56,8 +56,11 @@ WORKLOADS = {
     # _association.py:194, _nam.py:64-68) and the demo's call with covariates AND batches (demo/demo.ipynb:149)
     'C3_default_nsteps': (1_000_000, 100, 30, None, 1000, 0),
     'C3_covs_batches': (1_000_000, 100, 30, 3, 1000, 2, 5),
+    # one rank's share of C4 on eight GPUs as a problem of its own (no exchange): what the kernels of a block take when
+    # the block is all there is -- the input of DESIGN.md 7's predicted timeline
+    'C4_block8': (250_000, 200, 30, 3, 1000, 0),
 }
-DEFAULT_STEPS = {'C2': (100, 60), 'C3': (20, 5), 'C4': (20, 5), 'C5': (20, 5), 'C3_default_nsteps': (10, 3),
+DEFAULT_STEPS = {'C4_block8': (50, 10), 'C2': (100, 60), 'C3': (20, 5), 'C4': (20, 5), 'C5': (20, 5), 'C3_default_nsteps': (10, 3),
                  'C3_covs_batches': (10, 3)}
 
 

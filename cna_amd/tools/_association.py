@@ -154,6 +154,41 @@ def _draw_null(y, batches, donorids, Nnull=1000, force_permute_all=False, seed=N
     return y, y_
 
 
+_TAIL_FIRST = True        # (measured against the sequential order at 200 000 x 50 and 250 000 x 200: DESIGN.md 6)
+_EIG_POOL = None
+
+
+def _eig_pool():
+    """One worker for LAPACK beside the per-cell pass of a small problem (its wrapper releases the GIL)."""
+    global _EIG_POOL
+    if _EIG_POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _EIG_POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix='cna-eig')
+    return _EIG_POOL
+
+
+def _fdr_tables(tail_sums, ranks, Nloc, thresholds):
+    """(fdr per threshold, first threshold at 5 %, at 10 %, running minimum) from the local null's sums
+    (_association.py:105-118, _stats.py:79-80)."""
+    fdr_5p_t = fdr_10p_t = None
+    with np.errstate(all='ignore'):
+        # mean over permutations of tails/ranks (_stats.py:79-80) from the per-threshold sums
+        fdr_vals = tail_sums / ranks / Nloc
+    # the reference takes np.min of a pandas Series (_association.py:111-118), which skips NaN (0/0 at
+    # thresholds nothing reaches); a table without a single finite entry fails there with an
+    # IndexError, and so does this
+    with np.errstate(invalid='ignore'), warnings.catch_warnings():
+        warnings.simplefilter('ignore', RuntimeWarning)          # all-NaN slice
+        fdr_min = np.nanmin(fdr_vals) if len(fdr_vals) else np.nan
+        if not fdr_min > 0.05:
+            fdr_5p_t = thresholds[np.flatnonzero(fdr_vals <= 0.05)[0]]
+        if not fdr_min > 0.1:
+            fdr_10p_t = thresholds[np.flatnonzero(fdr_vals <= 0.1)[0]]
+    with np.errstate(invalid='ignore'):
+        runmin = np.fmin.accumulate(fdr_vals)
+    return fdr_vals, fdr_5p_t, fdr_10p_t, runmin
+
+
 def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_progress=False,
                  npcs=None, n_cells=None, conditioned=False, null_source=None, maxabs=None, on_coef=None,
                  coef_first=False, coef_launched=False, full=False):
@@ -219,6 +254,13 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         pending = True
 
     tail_sums = ranks = num_detected = None
+    # Few cells (a block of a sharded run, the 200 000-cell configuration): the local null is over before LAPACK is, and
+    # what follows it on the host -- the FDR table, the per-cell columns -- does not need the eigenvectors.  Then LAPACK
+    # runs on a thread of its own and this one takes the null's results and the per-cell pass meanwhile; what the caller
+    # sees (values, warnings, progress text, which exception wins) keeps the reference's order.
+    tail_first = (local_test and coef_early and not coef_first and getattr(engine, 'n_global', 0) < _COEF_FIRST_CELLS
+                  and _TAIL_FIRST)
+    early_tail = None
     try:
         # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105), and the global F-tests of the
         # observed phenotype and every permutation (second stream), all under the local-null kernel
@@ -234,11 +276,34 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         pcs = GramPCs(G)
         if full:
             pcs.start()                                      # LAPACK's SVD beside the F-tests and the local null
-        Uk = _top_pcs(G, int(ks_arr.max()))
-        if Uk is None:
-            Uk = pcs.U[:, :int(ks_arr.max())]
-        _mark('pcs')
-        if coef_early:
+        if tail_first:
+            fut = _eig_pool().submit(_top_pcs, G, int(ks_arr.max()))
+            try:
+                on_coef(engine.percell_coef_wait())
+                tail_sums, ranks, num_detected = engine.null_local_fetch()
+                pending = False
+                _mark('null fetched')
+                try:
+                    early_tail = ('ok', _fdr_tables(tail_sums, ranks, Nloc, thresholds))
+                    early_tail += (engine.percell(thresholds, early_tail[1][3]),)
+                except Exception as exc:                     # raised where the sequential order meets it
+                    early_tail = ('error', exc)
+                _mark('percell done')
+            finally:
+                Uk = fut.result()
+            if Uk is None:
+                Uk = pcs.U[:, :int(ks_arr.max())]
+            _mark('pcs')
+            engine.global_test_launch(Uk, ks_arr, r)
+            best, pv, r2v = engine.global_test_fetch()
+        else:
+            Uk = _top_pcs(G, int(ks_arr.max()))
+            if Uk is None:
+                Uk = pcs.U[:, :int(ks_arr.max())]
+            _mark('pcs')
+        if tail_first:
+            pass
+        elif coef_early:
             engine.global_test_launch(Uk, ks_arr, r)         # second stream
             try:
                 if not coef_first:
@@ -251,7 +316,8 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         if pending:
             tail_sums, ranks, num_detected = engine.null_local_fetch()   # never leave a pass pending behind an exception
 
-    _mark('null fetched')
+    if not tail_first:
+        _mark('null fetched')
     if (best < 0).any():
         raise ValueError('All-NaN slice encountered')        # np.nanargmin in _minp_stats
     k, p, r2 = ks[best[0]], pv[0], r2v[0]
@@ -289,34 +355,26 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     fdr_5p_t = fdr_10p_t = None
     if local_test:
         print('computing neighborhood-level FDRs', file=out)
-        with np.errstate(all='ignore'):
-            # mean over permutations of tails/ranks (_stats.py:79-80) from the per-threshold sums
-            fdr_vals = tail_sums / ranks / Nloc
-        # the reference takes np.min of a pandas Series (_association.py:111-118), which skips NaN (0/0 at
-        # thresholds nothing reaches); a table without a single finite entry fails there with an
-        # IndexError, and so does this
-        with np.errstate(invalid='ignore'), warnings.catch_warnings():
-            warnings.simplefilter('ignore', RuntimeWarning)          # all-NaN slice
-            fdr_min = np.nanmin(fdr_vals) if len(fdr_vals) else np.nan
-            if not fdr_min > 0.05:
-                fdr_5p_t = thresholds[np.flatnonzero(fdr_vals <= 0.05)[0]]
-            if not fdr_min > 0.1:
-                fdr_10p_t = thresholds[np.flatnonzero(fdr_vals <= 0.1)[0]]
+        if early_tail is not None and early_tail[0] == 'error':
+            raise early_tail[1]
+        fdr_vals, fdr_5p_t, fdr_10p_t, runmin = early_tail[1] if early_tail is not None else \
+            _fdr_tables(tail_sums, ranks, Nloc, thresholds)
         res._defer('fdrs', lambda: pd.DataFrame({'threshold': thresholds, 'fdr': fdr_vals,
                                                  'num_detected': num_detected}))
     else:
         res.fdrs = None
 
     # data.obs columns (all cells) and, from them, the coefficients of the kept cells
-    if fdr_vals is not None:
-        with np.errstate(invalid='ignore'):
-            runmin = np.fmin.accumulate(fdr_vals)
+    if early_tail is not None:
+        coef_all, fdr_all = early_tail[2]
+    elif fdr_vals is not None:
         _mark('pre percell')
         coef_all, fdr_all = engine.percell(thresholds, runmin)
     else:
         coef_all, fdr_all = engine.percell(None, None)
 
-    _mark('percell done')
+    if early_tail is None:
+        _mark('percell done')
     res.__dict__.update({'p': pfinal, 'nullminps': nullminps, 'k': k, 'fdr_5p_t': fdr_5p_t,
                          'fdr_10p_t': fdr_10p_t, 'yresid_hat': yhat, 'ks': ks,
                          'r2': r2, 'r2_perpc': r2_perpc, 'nullr2_mean': nullr2s.mean(),

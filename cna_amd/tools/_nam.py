@@ -57,6 +57,37 @@ def _small_svd(G):
     return np.linalg.svd(G)
 
 
+_LAPACKE_DSYEVR = None
+
+
+def _lapacke_dsyevr():
+    """LAPACKE_dsyevr of the OpenBLAS that scipy itself loads, through ctypes: the same routine as
+    scipy.linalg.lapack.dsyevr -- whose f2py wrapper keeps the GIL for the whole call -- without the GIL, so that the
+    interpreter goes on beside it (`_association`: the per-cell pass of a small problem under LAPACK).  False when that
+    library is not to be found."""
+    global _LAPACKE_DSYEVR
+    if _LAPACKE_DSYEVR is None:
+        _LAPACKE_DSYEVR = False
+        try:
+            import ctypes as C
+            from scipy.linalg import lapack          # noqa: F401  (maps the library)
+            path = None
+            with open('/proc/self/maps') as f:
+                for line in f:
+                    if 'libscipy_openblas' in line and '64_' not in os.path.basename(line.split()[-1]):
+                        path = line.split()[-1]
+                        break
+            if path:
+                fn = C.CDLL(path).scipy_LAPACKE_dsyevr
+                fn.restype = C.c_int
+                fn.argtypes = [C.c_int, C.c_char, C.c_char, C.c_char, C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                               C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+                _LAPACKE_DSYEVR = fn
+        except Exception:
+            _LAPACKE_DSYEVR = False
+    return _LAPACKE_DSYEVR
+
+
 def _top_pcs(G, kmax):
     """The kmax leading eigenvectors of the samples x samples Gram matrix (columns, leading first), for the global
     F-tests.  Every statistic of _association.py:35-48 depends on the PCs only through squared projections -- not on
@@ -68,6 +99,18 @@ def _top_pcs(G, kmax):
         return None                                 # degenerate input: the caller takes the SVD (and its errors)
     # LAPACK's wrapper directly: scipy.linalg.eigh spends as long again on argument checks and a workspace query
     # (264 -> 208 us at 50 samples; the call sits on the critical path of a small analysis)
+    fn = _lapacke_dsyevr()
+    if fn:
+        import ctypes as C
+        a = np.array(G, dtype=np.float64, order='F')            # (destroyed by the routine)
+        w = np.empty(n)
+        z = np.empty((n, kmax), order='F')
+        isuppz = np.empty(2 * max(kmax, 1), dtype=np.int32)
+        mm = C.c_int(0)
+        info = fn(102, b'V', b'I', b'L', n, a.ctypes.data, n, 0.0, 0.0, n - kmax + 1, n, 0.0, C.addressof(mm),
+                  w.ctypes.data, z.ctypes.data, n, isuppz.ctypes.data)          # 102: column major
+        if info == 0 and mm.value == kmax:
+            return np.ascontiguousarray(z[:, ::-1])
     from scipy.linalg import lapack
     _, z, m, _, info = lapack.dsyevr(G, compute_v=1, range='I', il=n - kmax + 1, iu=n, lower=1, overwrite_a=0)
     if info != 0 or m != kmax:

@@ -55,6 +55,7 @@ def legacy_randn(m, num, clean=False):
     return out.reshape(m, num)          # a view of the reused buffer: consume before the next draw
 
 
+_MID_DRAW = 150_000
 _BIG_DRAW = 400_000          # draws x rows from which the threaded host helpers pay (200 samples x 10 000 permutations: 2M)
 _threads_set = False
 
@@ -204,9 +205,11 @@ def native_draw_start(B, Y, num, seed, threads=None):
     if len(members) < len(Y):
         table[:, 1:] = Yc[0]                  # rows of no level (NaN batch labels): upstream's src stays 0 there
     if threads is None:                        # large draws (10 000 permutations of 200 samples): normals and sorts on several threads
+        from .._order import usable_cpus
         if len(Y) * num >= _BIG_DRAW:
-            from .._order import usable_cpus
             threads = usable_cpus(16)
+        elif len(Y) * num >= _MID_DRAW:        # 200 samples x 1000 permutations: 2.1 ms on one thread, as long as the walk of
+            threads = usable_cpus(4)           # 250 000 cells -- a rank's block of the 2M problem on eight GPUs
         else:
             threads = 1
     np.random.seed(seed)
