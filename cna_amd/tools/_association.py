@@ -258,8 +258,9 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     # what follows it on the host -- the FDR table, the per-cell columns -- does not need the eigenvectors.  Then LAPACK
     # runs on a thread of its own and this one takes the null's results and the per-cell pass meanwhile; what the caller
     # sees (values, warnings, progress text, which exception wins) keeps the reference's order.
-    tail_first = (local_test and coef_early and not coef_first and getattr(engine, 'n_global', 0) < _COEF_FIRST_CELLS
-                  and _TAIL_FIRST)
+    # (the size of a rank's block, the same number on every rank)
+    block_cells = -(-int(getattr(engine, 'n_global', 0)) // max(1, int(getattr(engine, 'nranks', 1))))
+    tail_first = local_test and coef_early and not coef_first and block_cells < _COEF_FIRST_CELLS and _TAIL_FIRST
     early_tail = None
     try:
         # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105), and the global F-tests of the
