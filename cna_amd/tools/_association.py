@@ -114,7 +114,17 @@ _COEF_FIRST_CELLS = 500000
 # From this many cells on (and three or more steps) the walk's last step is queued after validation and planning, which
 # run under the first steps; it then knows what the selection pass will be asked for and does it on its way out
 # (compute_nam_and_reindex).  Below, the first steps are too short to hide the host work.
-_DEFER_LAST_CELLS = int(os.environ.get('CNA_DEFER_LAST_CELLS', '300000'))
+# (150 000: at 250 000 cells x 200 samples -- a rank's block of the 2M problem on eight GPUs -- the by-product saves the
+# selection pass, 4.23-4.48 -> 4.01-4.29 ms; at 200 000 x 50 it is neutral, 1.60 -> 1.58; it was 300 000 before round 4's
+# last day.)  Sharded inputs: the size of the largest block, the same number on every rank.
+_DEFER_LAST_CELLS = int(os.environ.get('CNA_DEFER_LAST_CELLS', '150000'))
+
+
+def _rule_cells(data, engine):
+    shard = getattr(data, 'uns', {}).get('cna_shard') if hasattr(data, 'uns') else None
+    if shard:
+        return -(-int(shard['n_global']) // max(1, int(getattr(engine, 'nranks', 1))))
+    return len(data.obs)
 
 
 def _host_copy(dst, src):
@@ -629,7 +639,7 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
             nam_queued = _nam_device(engine, data, sid_name, nsteps=nsteps, show_progress=False,
                                      codes_labels=(codes, labels, counts, token),
                                      defer_last=(nsteps is not None and nsteps >= 3 and kwargs.get('local_test', True)
-                                                 and len(data.obs) >= _DEFER_LAST_CELLS))
+                                                 and _rule_cells(data, engine) >= _DEFER_LAST_CELLS))
         except Exception as exc:             # noqa: BLE001 - re-raised below, after validation
             nam_error = exc
         finally:
