@@ -945,6 +945,15 @@ def _checker():
     return _check_pool
 
 
+def _forget_pools():
+    """In a forked child the worker threads of these pools do not exist; the next user makes new ones."""
+    global _reorder_workers, _check_pool
+    _reorder_workers = _check_pool = None
+
+
+if hasattr(os, 'register_at_fork'):
+    os.register_at_fork(after_in_child=_forget_pools)
+
 _default = None
 
 

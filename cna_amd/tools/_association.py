@@ -164,6 +164,15 @@ def _draw_null(y, batches, donorids, Nnull=1000, force_permute_all=False, seed=N
     return y, y_
 
 
+def _forget_pools():
+    """In a forked child the worker threads of these pools do not exist; the next user makes new ones."""
+    global _pool, _EIG_POOL
+    _pool = _EIG_POOL = None
+
+
+if hasattr(os, 'register_at_fork'):
+    os.register_at_fork(after_in_child=_forget_pools)
+
 _TAIL_FIRST = True        # (measured against the sequential order at 200 000 x 50 and 250 000 x 200: DESIGN.md 6)
 _EIG_POOL = None
 

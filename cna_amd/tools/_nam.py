@@ -123,6 +123,16 @@ def _top_pcs(G, kmax):
 _svd_workers = None
 
 
+def _forget_pools():
+    """In a forked child the worker thread of this pool does not exist; the next user makes a new one."""
+    global _svd_workers
+    _svd_workers = None
+
+
+if hasattr(os, 'register_at_fork'):
+    os.register_at_fork(after_in_child=_forget_pools)
+
+
 class GramPCs:
     """np.linalg.svd of the samples x samples Gram matrix (_nam.py:105; the LAPACK routine that defines the PC
     signs of the reference), computed when `U` / `svs` are first read -- or from start() on a worker thread,
