@@ -173,6 +173,7 @@ def _forget_pools():
 if hasattr(os, 'register_at_fork'):
     os.register_at_fork(after_in_child=_forget_pools)
 
+_TAIL_FIRST_SAMPLES = 128
 _TAIL_FIRST = True        # (measured against the sequential order at 200 000 x 50 and 250 000 x 200: DESIGN.md 6)
 _EIG_POOL = None
 
@@ -279,7 +280,10 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     # sees (values, warnings, progress text, which exception wins) keeps the reference's order.
     # (the size of a rank's block, the same number on every rank)
     block_cells = -(-int(getattr(engine, 'n_global', 0)) // max(1, int(getattr(engine, 'nranks', 1))))
-    tail_first = local_test and coef_early and not coef_first and block_cells < _COEF_FIRST_CELLS and _TAIL_FIRST
+    # (and LAPACK must be long enough to be worth it: 1.25 ms at 200 samples, 0.08 at 50, where the F-tests are better
+    # off under the local null as before)
+    tail_first = (local_test and coef_early and not coef_first and block_cells < _COEF_FIRST_CELLS and n >= _TAIL_FIRST_SAMPLES
+                  and _TAIL_FIRST)
     early_tail = None
     try:
         # PCA of the NAM: LAPACK SVD of the Gram matrix (_nam.py:105), and the global F-tests of the
