@@ -26,7 +26,8 @@ def usable_cpus(limit=None):
     """CPUs this process may really use: the cgroup v2 quota if there is one, else the affinity mask."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            quota, period = f.read().split()
         if quota != 'max':
             n = max(1, min(n, int(int(quota) / int(period))))
     except Exception:

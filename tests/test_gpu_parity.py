@@ -1612,3 +1612,77 @@ def test_device_knn_graph_builder_vs_host_builder(eng, n, d, k):
     common = A.multiply(B != 0) - B.multiply(A != 0)
     assert abs(common).max() < 1e-4
     assert abs(A.nnz - B.nnz) <= max(4, 0.001 * B.nnz)
+
+
+def test_small_block_many_samples_takes_the_per_cell_pass_under_lapack(eng, monkeypatch, capsys):
+    """Fewer than 500 000 cells and 128 samples or more: LAPACK's eigenvectors come from a thread of their own while the
+    main thread fetches the local null, builds the FDR table and runs the per-cell pass (_association.py: tail_first).
+    Same results, progress text and warnings as the sequential order; an error of the early per-cell pass surfaces where
+    the sequential order would meet it (after the global test), and a failing global test still wins over it."""
+    import warnings
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.tools import _association as A
+    data, meta = synth.make_dataset(30000, 160, k=15, seed=4)
+    kw = dict(Nnull=200, seed=2, nsteps=3, show_progress=True)
+    monkeypatch.setattr(eng, 'reuse_nam', False)
+    submits = []
+    real_pool = A._eig_pool
+
+    def counting_pool():
+        submits.append(1)
+        return real_pool()
+    monkeypatch.setattr(A, '_eig_pool', counting_pool)
+
+    def run():
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            res = cna.tl.association(data, meta['y'], 'id', return_full=True, engine=eng, **kw)
+        out = capsys.readouterr().out
+        return (res.p, int(res.k), res.ncorrs.values.copy(), res.fdrs.copy(), data.obs['coef'].values.copy(),
+                data.obs['coef_fdr'].values.copy(), res.fdr_5p_t, res.fdr_10p_t, out,
+                sorted(str(x.message) for x in w if not issubclass(x.category, ResourceWarning)))
+    monkeypatch.setattr(A, '_TAIL_FIRST', False)
+    run()                                                         # (data.obs has its columns from here on: same warnings)
+    monkeypatch.setattr(A, '_TAIL_FIRST', True)
+    a = run()
+    assert len(submits) == 1                                      # the path under test was taken
+    monkeypatch.setattr(A, '_TAIL_FIRST', False)
+    b = run()
+    assert len(submits) == 1
+    assert a[0] == b[0] and a[1] == b[1] and a[6] == b[6] and a[7] == b[7]
+    np.testing.assert_array_equal(a[2], b[2])
+    pd.testing.assert_frame_equal(a[3], b[3])
+    np.testing.assert_array_equal(a[4], b[4])
+    np.testing.assert_array_equal(a[5], b[5])
+    assert a[8] == b[8] and 'computing neighborhood-level FDRs' in a[8]
+    assert a[9] == b[9]
+
+    # an error in the early per-cell pass: reported, and only after the global test has had its say
+    monkeypatch.setattr(A, '_TAIL_FIRST', True)
+    real_percell, real_fetch = eng.percell, eng.global_test_fetch
+    order = []
+
+    def bad_percell(*args, **k):
+        order.append('percell')
+        raise FloatingPointError('per-cell pass')
+
+    def fetch(*args, **k):
+        order.append('global test')
+        return real_fetch(*args, **k)
+    monkeypatch.setattr(eng, 'percell', bad_percell)
+    monkeypatch.setattr(eng, 'global_test_fetch', fetch)
+    with pytest.raises(FloatingPointError, match='per-cell pass'):
+        cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+    assert order == ['percell', 'global test']
+
+    def bad_fetch(*args, **k):
+        real_fetch(*args, **k)
+        raise ArithmeticError('global test')
+    monkeypatch.setattr(eng, 'global_test_fetch', bad_fetch)
+    with pytest.raises(ArithmeticError, match='global test'):
+        cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+    monkeypatch.setattr(eng, 'percell', real_percell)
+    monkeypatch.setattr(eng, 'global_test_fetch', real_fetch)
+    capsys.readouterr()
+    assert cna.tl.association(data, meta['y'], 'id', engine=eng, **kw) == a[0]
