@@ -174,12 +174,12 @@ if hasattr(os, 'register_at_fork'):
     os.register_at_fork(after_in_child=_forget_pools)
 
 _TAIL_FIRST_SAMPLES = 128
-_TAIL_FIRST = True        # (measured against the sequential order at 200 000 x 50 and 250 000 x 200: DESIGN.md 6)
+_TAIL_FIRST = True        # (measured against the sequential order at 200 000 x 50 and 250 000 x 200: DESIGN.md 7 e)
 _EIG_POOL = None
 
 
 def _eig_pool():
-    """One worker for LAPACK beside the per-cell pass of a small problem (its wrapper releases the GIL)."""
+    """One worker for LAPACK beside the per-cell pass of a small problem (_nam._top_pcs calls it without the GIL)."""
     global _EIG_POOL
     if _EIG_POOL is None:
         from concurrent.futures import ThreadPoolExecutor
@@ -274,7 +274,7 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         pending = True
 
     tail_sums = ranks = num_detected = None
-    # Few cells (a block of a sharded run, the 200 000-cell configuration): the local null is over before LAPACK is, and
+    # Few cells and many samples (a rank's block of a sharded run): the local null is over before LAPACK is, and
     # what follows it on the host -- the FDR table, the per-cell columns -- does not need the eigenvectors.  Then LAPACK
     # runs on a thread of its own and this one takes the null's results and the per-cell pass meanwhile; what the caller
     # sees (values, warnings, progress text, which exception wins) keeps the reference's order.
