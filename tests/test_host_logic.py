@@ -278,3 +278,43 @@ def test_nam_cache_skips_the_walk_for_a_second_phenotype():
     data.obs['id'] = ids
     cna.tl.association(data, y2, 'id', engine=eng, nsteps=2, Nnull=50, seed=1)
     assert steps(eng) == 11
+
+
+def test_fdr_tables_follow_the_reference_lines():
+    """_association._fdr_tables against the statements of the reference (_association.py:105-118, _stats.py:79-80) on
+    tables with NaN entries (thresholds nothing reaches), tables that never get below 5 % / 10 %, and the all-NaN table,
+    which fails with the reference's IndexError."""
+    import pandas as pd
+    from cna_amd.tools._association import _fdr_tables
+    rs = np.random.RandomState(0)
+    thresholds = np.arange(0.05, 0.2, 0.2 / 400)
+    T = len(thresholds)
+    for case in range(6):
+        ranks = np.sort(rs.randint(0, 5000, T))[::-1].astype(np.int64)
+        tails = (ranks * rs.rand(T) * (0.02 if case % 2 else 0.5) * 100).astype(np.int64)
+        if case >= 2:
+            ranks[-(case * 7):] = 0
+            tails[-(case * 7):] = 0
+        if case == 5:
+            ranks[:] = 0
+            tails[:] = 0
+        Nloc = 100
+        with np.errstate(all='ignore'):
+            fdr = tails / ranks / Nloc
+        fdrs = pd.DataFrame({'threshold': thresholds, 'fdr': fdr})
+        want5 = want10 = None
+        if case == 5:
+            with pytest.raises(IndexError):
+                _fdr_tables(tails, ranks, Nloc, thresholds)
+            continue
+        # the reference: if np.min(fdrs.fdr) > 0.05: None else fdrs[fdrs.fdr <= 0.05].iloc[0].threshold
+        if not np.min(fdrs.fdr) > 0.05:
+            want5 = fdrs[fdrs.fdr <= 0.05].iloc[0].threshold
+        if not np.min(fdrs.fdr) > 0.1:
+            want10 = fdrs[fdrs.fdr <= 0.1].iloc[0].threshold
+        got, t5, t10, runmin = _fdr_tables(tails, ranks, Nloc, thresholds)
+        np.testing.assert_array_equal(got, fdr)
+        assert t5 == want5 and t10 == want10
+        # running minimum that skips NaN, as the per-cell lookup of _association.py:234-237 needs it
+        ref = np.array([np.nanmin(fdr[:i + 1]) if not np.isnan(fdr[:i + 1]).all() else np.nan for i in range(T)])
+        np.testing.assert_array_equal(runmin, ref)
