@@ -44,7 +44,13 @@ I8_MFMA_PEAK_TOPS = 5033.0   # dense i8 matrix: 2x the bf16 rate (guide: >= 4404
 # profiles/*_pmc_traffic.json: bytes = 2 * FETCH_SIZE KB + WRITE_SIZE KB; the factor 2 on FETCH_SIZE is the
 # guide's gfx950 correction, re-calibrated on k_ncorrs, which streams the matrix once).  Counted at the L2's
 # fabric side, i.e. Infinity-Cache hits included.  Only valid for the profiled workload on one GPU.
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")   # replaced by the r05 file once this round has its PMC passes
+
+METRIC = 'cells*permutations/sec end-to-end cna.tl.association'
+ARITHMETIC_I8 = ('f64 throughout (diffusion, QC, residualisation, Gram, F-tests); the local-null products '
+                 'as exact 24-bit fixed-point digits on the i8 matrix cores with an f64 recheck of every '
+                 'output within the error bound of a threshold (same integer counts as the f64 kernel)')
+DETAILS_FILE = os.path.join(ROOT, 'bench_details.json')
 
 WORKLOADS = {
     # name: (cells, samples, kNN k, nsteps, Nnull, covariates[, batches])
@@ -389,6 +395,173 @@ def workload_text(m, world, args):
                                                                    and not m['n_covs'] and not m.get('n_batches')) else ''))
 
 
+def cpu_reference_cost(synth, ns, N, k, nsteps, Nnull, n_covs, extrapolate_to=None):
+    """oracle/reference_cost.py -- the reference's own sequence of library calls (pandas frames, scipy csr.dot +
+    st.kurtosis per step, a Python loop over the permutations with st.f.sf, the materialised cells x Nnull null
+    matrix, np.histogram per null column, per-cell Series.apply; 1.04x the wall time of the real reference on
+    50k x 50 x 1000 in the build container) -- timed on `ns` cells of the generator (seed 0) on this box's host cores.
+    BLAS gets the cores the cgroup allows; everything else is single-threaded, as in the reference."""
+    from oracle import reference_cost as rc
+    sdata, smeta = synth.make_dataset(ns, N, k=k, seed=0, n_covs=n_covs)
+    # give the CPU path the cores this container may actually use (cgroup quota), not the
+    # host's core count: oversubscribed BLAS threads only get the process throttled
+    threads = usable_cpus()
+    blas = None
+    try:
+        from threadpoolctl import threadpool_limits, threadpool_info
+        limiter = threadpool_limits(limits=threads, user_api='blas')
+    except Exception:
+        import contextlib
+        limiter = contextlib.nullcontext()
+        threadpool_info = None
+    Pc = min(Nnull, 1000)
+    with limiter:
+        if threadpool_info is not None:
+            blas = max([int(i.get('num_threads', 1)) for i in threadpool_info() if i.get('user_api') == 'blas'] or [1])
+        t0 = time.perf_counter()
+        ref = rc.association(sdata, smeta['y'], 'id', covs=smeta.get('covs'), nsteps=nsteps, Nnull=Pc, seed=0)
+        t_cpu = time.perf_counter() - t0
+    st = ref['stages']
+    cpu = dict(value=round(ns * Pc / t_cpu, 1), unit='cell*perm/s', cores=int(threads), kind='port',
+               mode='reference-cost', seconds=round(t_cpu, 2), host_cpus=os.cpu_count(), blas_threads=blas, p_value=float(ref['p']),
+               stages_s={k_: round(v, 2) for k_, v in st.items()},
+               value_without_percell_apply=round(ns * Pc / max(t_cpu - st.get('percell_apply', 0.0), 1e-9), 1),
+               sample_short='reference-cost port on %d cells x %d samples, k=%d, nsteps=%s, Nnull=%d, same generator seed 0' % (ns, N, k, nsteps, Pc),
+               sample='oracle/reference_cost.py (the reference\'s own sequence of library calls: pandas frames, '
+                      'scipy csr.dot + st.kurtosis per step, a Python loop over the permutations with st.f.sf, the '
+                      'materialised cells x Nnull null matrix, np.histogram per null column, per-cell Series.apply; '
+                      '1.04x the wall time of the real reference on 50k x 50 x 1000 in the build container) on %d '
+                      'cells x %d samples, k=%d, nsteps=%s, Nnull=%d of the same generator (seed 0); BLAS threads as '
+                      'listed, everything else single-threaded as in the reference' % (ns, N, k, nsteps, Pc))
+    if extrapolate_to is not None and extrapolate_to != ns:
+        # every stage of the reference's cost profile is linear in the cell count at fixed samples and Nnull
+        # (SURVEY 6: the null loop's per-permutation cost does not depend on the cells, the rest is per cell):
+        # the sample's stage times scaled to the workload's cells.  EXTRAPOLATED, and labelled so.
+        scaled = {k_: (v if k_ == 'global_test' else v * extrapolate_to / ns) for k_, v in st.items()}
+        tot = sum(scaled.values())
+        cpu['extrapolated_to_workload'] = dict(cells=extrapolate_to, seconds=round(tot, 1),
+                                               stages_s={k_: round(v, 1) for k_, v in scaled.items()},
+                                               value=round(extrapolate_to * Pc / max(tot, 1e-9), 1))
+    return cpu
+
+
+def workload_short(m, world):
+    """<= 200 characters: what the step is, for the contract line (`workload_text` is the long form)."""
+    return ('%s: %d cells x %d samples, k=%d kNN (%.1f nnz/row, f32 CSR), nsteps=%s, Nnull=%d%s%s, local FDR on; '
+            'graph resident, walk recomputed every step' % (
+                m['name'], m['n'], m['N'], m['k'], m['nnz'] / m['n'], m['nsteps'], m['Nnull'],
+                ', %d covs' % m['n_covs'] if m['n_covs'] else '', ', %d batches' % m['n_batches'] if m.get('n_batches') else ''))[:200]
+
+
+def parallelism_text(m, world, args):
+    return 'cells sharded in %d row block(s)%s%s%s' % (
+        world, '' if world == 1 else ((', every rank holds its block of cells only (blocks: %s)' % (
+            'whole populations of the graph packed per block' if args.partition == 'populations' else "contiguous runs of the caller's order")) if m['sharded_inputs']
+                                      else ', dataset and per-cell results replicated on every rank'),
+        '' if m['halo'] is None else ', halo exchange %d/%d rows out/in on rank 0' % m['halo'],
+        ' [--comm shm: ranks share one GPU, plumbing check only]' if args.comm == 'shm' and world > 1 else '')
+
+
+def _roofline_short(r):
+    """The roofline object of the contract line.  `frac` is priced on SURVEY 8(d)'s bytes of the launch ALONE
+    (`frac_step_bytes` of the details); what the fused by-product adds is `frac_fused`."""
+    if not r:
+        return None
+    frac = r.get('frac_step_bytes', r.get('frac'))
+    out = dict(kernel=r.get('kernel'), bound=r.get('bound'), achieved=round(frac * r['peak'], 3) if frac is not None else None,
+               peak=r.get('peak'), unit=r.get('unit'), frac=frac, traffic=r.get('traffic'), avg_us=r.get('avg_us'))
+    if 'frac_step_bytes' in r:
+        out['frac_fused'] = r.get('frac')
+    return out
+
+
+def _cpu_short(c):
+    if not c:
+        return None
+    out = {k_: c.get(k_) for k_ in ('value', 'unit', 'cores', 'kind', 'mode', 'seconds', 'value_without_percell_apply') if k_ in c}
+    if c.get('sample_short'):
+        out['sample'] = c['sample_short']
+    if c.get('extrapolated_to_workload'):
+        e = c['extrapolated_to_workload']
+        out['extrapolated'] = dict(cells=e.get('cells'), seconds=e.get('seconds'), value=e.get('value'))
+    for k_ in ('stages_s', 'blas_threads', 'gpu_ms_per_step', 'gpu_over_cpu', 'p_value'):
+        if k_ in c:
+            out[k_] = c[k_]
+    return out
+
+
+def assemble_details(m, main_sum, cpu, cpu_c2, extra, world, steps, warmup, args):
+    """Everything this run measured (the side file); `contract_line` condenses it."""
+    return {
+        'metric': METRIC,
+        'value': main_sum['value'], 'unit': 'cell*perm/s', 'n_gpus': world, 'steps': steps,
+        'warmup': warmup, 'ms_per_step': main_sum['ms_per_step'], 'higher_is_better': True,
+        'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': workload_text(m, world, args), 'workload_short': workload_short(m, world),
+                   'parallelism': parallelism_text(m, world, args),
+                   'communicator': {'backend': m['comm'][0], 'nranks_reported_by_communicator': m['comm'][1],
+                                    'halo_rows_out_in_rank0': m['halo'],
+                                    'halo_exchange_overlaps_the_walk_step': bool(m.get('halo_comm')) or (m['comm'][0] == 'shm' and world > 1)},
+                   'arithmetic': ARITHMETIC_I8 if m.get('i8', (False,))[0] else 'f64 throughout',
+                   'p_value': m['p']},
+        'roofline': main_sum['roofline'],
+        'cpu_baseline': cpu,
+        'cpu_baseline_C2_full': cpu_c2,
+        'gpu_kernel_ms_per_step': main_sum['gpu_kernel_ms_per_step'],
+        'host_ms_per_step': main_sum['host_ms_per_step'],
+        'cold_first_call': main_sum['cold_first_call'],
+        'first_call_ms_incl_graph_h2d': main_sum['cold_first_call']['ms'],
+        'value_cold': main_sum['cold_first_call']['value'],      # the same metric on the first call (graph preparation + H2D included)
+        'dataset_gen_s': main_sum['dataset_gen_s'],
+        'kernels': main_sum['kernels'],
+        'other_configs': extra,
+    }
+
+
+def contract_line(d, details_file=None):
+    """The ONE stdout line of the bench contract, kept small (target <= 6 KB, tests/test_bench_line.py): the contract's
+    keys, `roofline`, `cpu_baseline`, and one {ms_per_step, value, roofline} triple per other configuration.  Everything
+    else (per-kernel tables of every configuration, notes, cold-call breakdown) is in `bench_details.json` / on stderr."""
+    cfg = d['config']
+    others = {}
+    for name, o in (d.get('other_configs') or {}).items():
+        if 'error' in o:
+            others[name] = dict(error=str(o['error'])[:120])
+            continue
+        r = o.get('roofline') or {}
+        others[name] = dict(ms_per_step=o.get('ms_per_step'), value=o.get('value'), steps=o.get('steps'),
+                            gpu_kernel_ms=o.get('gpu_kernel_ms_per_step'), host_ms=o.get('host_ms_per_step'),
+                            first_call_ms=(o.get('cold_first_call') or {}).get('ms'), p_value=o.get('p_value'),
+                            roofline=dict(kernel=r.get('kernel'), frac=r.get('frac_step_bytes', r.get('frac')), avg_us=r.get('avg_us')))
+    top = sorted((d.get('kernels') or {}).items(), key=lambda kv: -kv[1]['total_ms'])[:6]
+    steps = max(int(d['steps']), 1)
+    out = {k_: d[k_] for k_ in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                                'scaling', 'vs_baseline', 'dtype', 'data')}
+    comm = cfg.get('communicator') or {}
+    out['config'] = dict(workload=cfg.get('workload_short', cfg['workload'])[:200], parallelism=cfg['parallelism'][:200],
+                         arithmetic=('f64; local null as exact i8 digit products on the matrix cores + f64 recheck near cuts'
+                                     if cfg['arithmetic'] != 'f64 throughout' else 'f64 throughout')[:120],
+                         comm=comm.get('backend'), comm_ranks=comm.get('nranks_reported_by_communicator'),
+                         halo_rows_out_in=comm.get('halo_rows_out_in_rank0'),
+                         halo_overlaps_step=comm.get('halo_exchange_overlaps_the_walk_step'), p_value=cfg.get('p_value'))
+    out['roofline'] = _roofline_short(d.get('roofline'))
+    out['cpu_baseline'] = _cpu_short(d.get('cpu_baseline'))
+    if d.get('cpu_baseline_C2_full'):
+        out['cpu_baseline_C2_full'] = _cpu_short(d['cpu_baseline_C2_full'])
+    out['gpu_kernel_ms_per_step'] = d.get('gpu_kernel_ms_per_step')
+    out['host_ms_per_step'] = d.get('host_ms_per_step')
+    out['first_call_ms_incl_graph_h2d'] = d.get('first_call_ms_incl_graph_h2d')
+    out['value_cold'] = d.get('value_cold')
+    # the kernels that make the step, each with its own fraction of its own roof: {name: [ms per step, launches per step, frac]}
+    out['kernels_ms_per_step'] = {k_: [round(v['total_ms'] / steps, 3), round(v['launches'] / steps, 2),
+                                       v.get('frac_step_bytes', v.get('frac'))] for k_, v in top}
+    out['other_configs'] = others
+    out['details'] = os.path.basename(details_file or DETAILS_FILE) + ' (and stderr): per-kernel tables of every configuration'
+    line = json.dumps(out, separators=(',', ':'))
+    assert '\n' not in line
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -401,6 +574,9 @@ def main():
     ap.add_argument('--no-extra', action='store_true', help='N=1: skip the additional C5, C3 and C2 lines')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-sample-cells', type=int, default=150_000)
+    ap.add_argument('--no-cpu-c2-full', action='store_true',
+                    help='N=1: skip the reference-cost CPU run of the FULL C2 workload (~1-2 min of host time)')
+    ap.add_argument('--details', default=DETAILS_FILE, help='where the full per-kernel tables go (JSON)')
     ap.add_argument('--profile-host', default=None, help='write a cProfile of 3 extra steps to this file')
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'shm'],
                     help="shm: plumbing check of the N>1 path on ONE GPU (all ranks on device 0, gloo for the "
@@ -471,41 +647,8 @@ def main():
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import reference_cost as rc
-        ns = min(args.cpu_sample_cells, m['n'])
-        sdata, smeta = synth.make_dataset(ns, m['N'], k=m['k'], seed=0, n_covs=m['n_covs'])
-        # give the CPU path the cores this container may actually use (cgroup quota), not the
-        # host's core count: oversubscribed BLAS threads only get the process throttled
-        threads = usable_cpus()
-        try:
-            from threadpoolctl import threadpool_limits
-            limiter = threadpool_limits(limits=threads, user_api='blas')
-        except Exception:
-            import contextlib
-            limiter = contextlib.nullcontext()
-        Pc = min(m['Nnull'], 1000)
-        with limiter:
-            t0 = time.perf_counter()
-            ref = rc.association(sdata, smeta['y'], 'id', covs=smeta.get('covs'), nsteps=m['nsteps'], Nnull=Pc, seed=0)
-            t_cpu = time.perf_counter() - t0
-        st = ref['stages']
-        cpu = dict(value=round(ns * Pc / t_cpu, 1), unit='cell*perm/s', cores=int(threads), kind='port',
-                   mode='reference-cost', seconds=round(t_cpu, 2), host_cpus=os.cpu_count(), p_value=float(ref['p']),
-                   stages_s={k_: round(v, 2) for k_, v in st.items()},
-                   value_without_percell_apply=round(ns * Pc / max(t_cpu - st.get('percell_apply', 0.0), 1e-9), 1),
-                   # every stage of the reference's cost profile is linear in the cell count at fixed samples and Nnull
-                   # (the null loop's per-permutation cost does not depend on the cells, the rest is per cell):
-                   # the sample's stage times scaled to the workload's cells
-                   extrapolated_to_workload=dict(
-                       cells=m['n'], seconds=round(sum((v if k_ == 'global_test' else v * m['n'] / ns) for k_, v in st.items()), 1),
-                       stages_s={k_: round(v if k_ == 'global_test' else v * m['n'] / ns, 1) for k_, v in st.items()},
-                       value=round(m['n'] * Pc / max(sum((v if k_ == 'global_test' else v * m['n'] / ns) for k_, v in st.items()), 1e-9), 1)),
-                   sample='oracle/reference_cost.py (the reference\'s own sequence of library calls: pandas frames, '
-                          'scipy csr.dot + st.kurtosis per step, a Python loop over the permutations with st.f.sf, the '
-                          'materialised cells x Nnull null matrix, np.histogram per null column, per-cell Series.apply; '
-                          '1.04x the wall time of the real reference on 50k x 50 x 1000 in the build container) on %d '
-                          'cells x %d samples, k=%d, nsteps=%d, Nnull=%d of the same generator (seed 0); BLAS threads as '
-                          'listed, everything else single-threaded as in the reference' % (ns, m['N'], m['k'], m['nsteps'], Pc))
+        cpu = cpu_reference_cost(synth, min(args.cpu_sample_cells, m['n']), m['N'], m['k'], m['nsteps'], m['Nnull'], m['n_covs'],
+                                 extrapolate_to=m['n'])
     del m['data'], m['meta']
 
     extra = {}
@@ -520,37 +663,31 @@ def main():
             except Exception as e:                      # the extra lines never take the headline down
                 extra[name] = dict(error=repr(e))
 
-    out = {
-        'metric': 'cells*permutations/sec end-to-end cna.tl.association',
-        'value': main_sum['value'], 'unit': 'cell*perm/s', 'n_gpus': world, 'steps': steps,
-        'warmup': warmup, 'ms_per_step': main_sum['ms_per_step'], 'higher_is_better': True,
-        'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': workload_text(m, world, args),
-                   'parallelism': 'cells sharded in %d row block(s)%s%s%s' % (
-                       world, '' if world == 1 else ((', every rank holds its block of cells only (blocks: %s)' % (
-                           'whole populations of the graph packed per block' if args.partition == 'populations' else "contiguous runs of the caller's order")) if m['sharded_inputs']
-                                                     else ', dataset and per-cell results replicated on every rank'),
-                       '' if m['halo'] is None else ', halo exchange %d/%d rows out/in on rank 0' % m['halo'],
-                       ' [--comm shm: ranks share one GPU, plumbing check only]' if args.comm == 'shm' and world > 1 else ''),
-                   'communicator': {'backend': m['comm'][0], 'nranks_reported_by_communicator': m['comm'][1],
-                                    'halo_rows_out_in_rank0': m['halo'],
-                                    'halo_exchange_overlaps_the_walk_step': bool(m.get('halo_comm')) or (m['comm'][0] == 'shm' and world > 1)},
-                   'arithmetic': 'f64 throughout (diffusion, QC, residualisation, Gram, F-tests); the local-null products '
-                                 'as exact 24-bit fixed-point digits on the i8 matrix cores with an f64 recheck of every '
-                                 'output within the error bound of a threshold (same integer counts as the f64 kernel)'
-                                 if m.get('i8', (False,))[0] else 'f64 throughout',
-                   'p_value': m['p']},
-        'roofline': main_sum['roofline'],
-        'cpu_baseline': cpu,
-        'gpu_kernel_ms_per_step': main_sum['gpu_kernel_ms_per_step'],
-        'host_ms_per_step': main_sum['host_ms_per_step'],
-        'cold_first_call': main_sum['cold_first_call'],
-        'first_call_ms_incl_graph_h2d': main_sum['cold_first_call']['ms'],
-        'value_cold': main_sum['cold_first_call']['value'],      # the same metric on the first call (graph preparation + H2D included)
-        'dataset_gen_s': main_sum['dataset_gen_s'],
-        'kernels': main_sum['kernels'],
-        'other_configs': extra,
-    }
+    cpu_c2 = None
+    if world == 1 and not args.no_cpu_baseline and not args.no_cpu_c2_full and args.workload == 'C4':
+        # BASELINE.md 3 asks for the CPU path on a BASELINE configuration in full, in the same run: configs[1] (C2:
+        # 200k x 50, nsteps 3, Nnull 1000), no sampling, no extrapolation -- beside this run's C2 GPU time
+        n2, N2, k2, ns2, P2, c2 = WORKLOADS['C2'][:6]
+        try:
+            cpu_c2 = cpu_reference_cost(synth, n2, N2, k2, ns2, P2, c2)
+            g = extra.get('C2', {})
+            if g.get('ms_per_step'):
+                cpu_c2['gpu_ms_per_step'] = g['ms_per_step']
+                cpu_c2['gpu_over_cpu'] = round(cpu_c2['seconds'] * 1e3 / g['ms_per_step'], 1)
+                cpu_c2['same_p_value_as_gpu'] = bool(abs(cpu_c2['p_value'] - g.get('p_value', -1)) < 1e-12)
+        except Exception as e:
+            cpu_c2 = dict(error=repr(e))
+
+    details = assemble_details(m, main_sum, cpu, cpu_c2, extra, world, steps, warmup, args)
+    line = contract_line(details)
+    # the full tables (every kernel of every configuration, notes, stage times) go to a side file and to stderr; the
+    # ONE line on stdout stays small enough for any consumer (round 4's 20 KB line was not parsed by the driver)
+    try:
+        with open(args.details, 'w') as f:
+            json.dump(details, f, indent=1)
+    except OSError as e:
+        print('bench.py: could not write %s: %r' % (args.details, e), file=sys.stderr)
+    print('bench.py details: ' + json.dumps(details), file=sys.stderr)
     # the JSON line is the last thing this process writes: tear the communicators down first and
     # push out whatever the libraries (RCCL prints a version banner) still hold in C stdio buffers
     try:
@@ -563,7 +700,7 @@ def main():
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
-    sys.stdout.write(json.dumps(out) + '\n')
+    sys.stdout.write(line + '\n')
     sys.stdout.flush()              # (a normal exit follows: profilers attached to this process write at exit)
 
 
