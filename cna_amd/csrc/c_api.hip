@@ -694,22 +694,29 @@ static int ranged_last_step(cna_ctx* c, bool first, bool want_kurt, bool may_sto
   if ((*rc = dev_reserve(c, &g, &c->gram_cap, (int64_t)sizeof(double) * c->Nx * c->Nx)) != 0) return 1;
   c->gram_buf = (double*)g;
   hipStream_t W = c->stream;
-#define RL_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cna_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); *rc = (int)e_; return 1; } } while (0)
+  // an error from here on: close the profiling span that was opened and wait for what already sits on the Gram stream
+  // (nobody would otherwise: gram_pre_pending stays false, and the next writer of X or of the partial tiles must not
+  // find those kernels still reading them)
+  bool span_open = false;
+  int kid_of_span = CNA_K_NAM_STEP;
+  auto fail = [&]() { if (span_open) prof_end(c, kid_of_span, c->stream); (void)hipStreamSynchronize(c->gram_stream); return 1; };
+#define RL_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { cna_set_error(std::string(#expr) + ": " + hipGetErrorString(e_)); *rc = (int)e_; return fail(); } } while (0)
   const bool sparse_step = c->sp_cnt && c->steps_done == 1;
   const int kid = sparse_step ? CNA_K_NAM_STEP_SPARSE : CNA_K_NAM_STEP;
-  if (c->prof) prof_begin(c, kid, W);                     // one span over all ranges: the step as the other launches report it
+  kid_of_span = kid;
+  if (c->prof) { prof_begin(c, kid, W); span_open = true; }   // one span over all ranges: the step as the other launches report it
   int64_t b0 = 0;
   for (int r = 0; r < K; ++r) {
     const int64_t b1 = r + 1 == K ? c->n_local : (nunits * (r + 1) / K) * unit;
     if ((*rc = launch_nam_step(c, first, want_kurt, false, may_stop, false, nullptr, 0, b0, b1 - b0, W, false)) != 0) break;
-    if (r + 1 == K && c->prof) prof_end(c, kid, W);
+    if (r + 1 == K && span_open) { prof_end(c, kid, W); span_open = false; }
     RL_TRY(hipEventRecord(c->range_done, W));
     RL_TRY(hipStreamWaitEvent(c->gram_stream, c->range_done, 0));
     if ((*rc = gram_pre_range(c, b0, b1, c->gram_stream)) != 0) break;
     b0 = b1;
   }
-  if (*rc) return 1;
-  if ((*rc = gram_pre_finish(c, c->gram_buf, c->gram_stream)) != 0) return 1;
+  if (*rc) return fail();
+  if ((*rc = gram_pre_finish(c, c->gram_buf, c->gram_stream)) != 0) return fail();
   RL_TRY(hipEventRecord(c->gram_pre_done, c->gram_stream));
 #undef RL_TRY
   c->gram_pre = true;
@@ -1998,6 +2005,18 @@ int cna_null_local_fetch(cna_ctx* c, int64_t* tails_out, int64_t* tail_sums_out,
                          int64_t* num_detected_out) {
   CHECK_CTX(c);
   return null_local_collect(c, tails_out, tail_sums_out, ranks_out, num_detected_out);
+}
+
+// A pass that was launched and never collected (the caller raised between launch and fetch: a bad `ks`, a failed
+// draw, Ctrl-C): wait for its kernels, drop its results and the prepared half, so that the next analysis on this
+// context starts clean instead of failing with "still pending".  A no-op when nothing is pending.
+int cna_null_local_discard(cna_ctx* c) {
+  CHECK_CTX(c);
+  c->null_prepared = 0;
+  if (!c->null_pending) return 0;
+  c->null_pending = 0;
+  HIP_TRY(hipEventSynchronize(c->null_done));
+  return 0;
 }
 
 int cna_null_local_i8_stats(cna_ctx* c, int* used_out, int64_t* rechecked_out, int* fallback_out) {

@@ -284,10 +284,15 @@ extern "C" int cna_comm_selftest(cna_ctx* c, double timeout_s, int* halo_ok) {
   const double host[8] = {1, 1, 1, 1, 1, 1, 1, 1};
   HIP_TRY(hipMemcpy(buf, host, 64, hipMemcpyHostToDevice));
   ncclComm_t comm = (ncclComm_t)c->comm;
+  // a communicator that stopped answering cannot be destroyed (ncclCommDestroy would wait for it): on every timeout
+  // the split child goes first, then the parent, and the context forgets both before the error is returned
+  auto abort_both = [&]() {
+    if (c->comm_halo) { if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t)c->comm_halo); c->comm_halo = nullptr; }
+    if (c->comm) { if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t)c->comm); c->comm = nullptr; }
+  };
   NCCL_TRY(g_rccl.AllReduce(buf, buf, 1, ncclFloat64, ncclSum, comm, c->stream));
   if (poll_stream(c->stream, timeout_s) != 0) {
-    if (g_rccl.CommAbort) g_rccl.CommAbort(comm);
-    c->comm = nullptr;
+    abort_both();
     CNA_FAIL(CNA_ERCCL, "cna_comm_selftest: the first all-reduce did not finish in time");
   }
   int ok = 1;
@@ -305,7 +310,10 @@ extern "C" int cna_comm_selftest(cna_ctx* c, double timeout_s, int* halo_ok) {
   double flag = ok ? 0.0 : 1.0;
   HIP_TRY(hipMemcpy(buf + 4, &flag, 8, hipMemcpyHostToDevice));
   NCCL_TRY(g_rccl.AllReduce(buf + 4, buf + 4, 1, ncclFloat64, ncclMax, comm, c->stream));
-  if (poll_stream(c->stream, timeout_s) != 0) CNA_FAIL(CNA_ERCCL, "cna_comm_selftest: the second all-reduce did not finish in time");
+  if (poll_stream(c->stream, timeout_s) != 0) {
+    abort_both();
+    CNA_FAIL(CNA_ERCCL, "cna_comm_selftest: the second all-reduce did not finish in time");
+  }
   HIP_TRY(hipMemcpy(&flag, buf + 4, 8, hipMemcpyDeviceToHost));
   double sum = 0;
   HIP_TRY(hipMemcpy(&sum, buf, 8, hipMemcpyDeviceToHost));

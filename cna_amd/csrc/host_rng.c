@@ -81,6 +81,10 @@ CLONES static void candidates(const uint32_t* restrict w, int nc, double* restri
 
 #include <pthread.h>
 static int g_host_threads = 1;
+/* the library's draw thread runs with the count its request carries: an override of ITS OWN, so that it never races
+ * with cna_host_set_threads or with a draw on the caller's thread */
+static __thread int t_host_threads = 0;
+static inline int host_threads(void) { return t_host_threads > 0 ? t_host_threads : g_host_threads; }
 
 struct norm_job { const double *x1, *x2, *r2; double* out; int64_t n_out, a, b; };
 static void* norm_worker(void* arg) {
@@ -154,7 +158,7 @@ int cna_host_legacy_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss
     struct norm_job jobs[64];
     pthread_t th[64];
     int started[64];
-    int nt = g_host_threads;
+    int nt = host_threads();
     if (nt > 64) nt = 64;
     if (nt < 1 || pairs < (1 << 15)) nt = 1;
     for (int t = 0; t < nt; ++t) {
@@ -339,7 +343,7 @@ int cna_host_argsort_gather(const double* R, int m, int num, const double* y, do
   struct sort_job jobs[64];
   pthread_t th[64];
   int started[64];
-  int nt = g_host_threads;
+  int nt = host_threads();
   if (nt > 64) nt = 64;
   if (nt > num / 128) nt = num / 128;                    /* at least two blocks of 64 columns per thread */
   if ((int64_t)m * num < 32768) nt = 1;                  /* (a thread costs ~30 us to start) */
@@ -394,8 +398,7 @@ static int draw_run(const struct draw_req* q) {
   double* ysub = (double*)malloc(sizeof(double) * (size_t)(mmax > 0 ? mmax : 1));
   if (!R || !ysub) { free(R); free(ysub); return -1; }
   int rc = 0;
-  const int saved = g_host_threads;
-  g_host_threads = q->threads > 0 ? q->threads : 1;
+  t_host_threads = q->threads > 0 ? q->threads : 1;
   for (int l = 0; l < q->nlev && rc == 0; ++l) {
     const int64_t* mem = q->members + q->lev_off[l];
     const int ml = (int)(q->lev_off[l + 1] - q->lev_off[l]);
@@ -406,7 +409,7 @@ static int draw_run(const struct draw_req* q) {
     for (int i = 0; i < ml; ++i) ysub[i] = q->y[mem[i]];
     if (cna_host_argsort_gather(R, ml, q->num, ysub, q->out, q->ld_out, mem) != 0) rc = -1;
   }
-  g_host_threads = saved;
+  t_host_threads = 0;
   free(R); free(ysub);
   return rc;
 }

@@ -514,7 +514,7 @@ class Engine(_order.CellOrder):
         nz = C.c_int64(0)
         m = C.c_double(0.0)
         yv = None if y is None else _f64(y)
-        self._fused = None
+        self.null_local_discard()       # (a pass left behind by an analysis that raised after its launch)
         if yv is not None and fuse_null > 0:
             T, gq, cq, nl = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
             thr = np.empty(512)
@@ -716,6 +716,13 @@ class Engine(_order.CellOrder):
         ranks, numdet = np.empty(T, dtype=np.int64), np.empty(T, dtype=np.int64)
         check(self.lib.cna_null_local_fetch(self.h, None, ptr(sums), ptr(ranks), ptr(numdet)), 'cna_null_local_fetch')
         return sums, ranks, numdet
+
+    def null_local_discard(self):
+        """Drop a local-null pass that was launched (here or by the fused selection call) and never fetched -- the
+        caller raised in between -- and whatever else the fused call queued for an analysis that will not happen.
+        No-op when nothing is pending; called on the error paths of association() and before every new selection."""
+        self._fused = None
+        check(self.lib.cna_null_local_discard(self.h), 'cna_null_local_discard')
 
     def global_test(self, U, ks, r):
         """min-p F-test of every resident phenotype column -> (index into ks, p, r2) arrays."""

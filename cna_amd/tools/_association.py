@@ -304,8 +304,8 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
             fut = _eig_pool().submit(_top_pcs, G, int(ks_arr.max()))
             try:
                 on_coef(engine.percell_coef_wait())
+                pending = False                              # (the library clears its flag before it can fail)
                 tail_sums, ranks, num_detected = engine.null_local_fetch()
-                pending = False
                 _mark('null fetched')
                 try:
                     early_tail = ('ok', _fdr_tables(tail_sums, ranks, Nloc, thresholds))
@@ -336,9 +336,15 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
                 best, pv, r2v = engine.global_test_fetch()
         else:
             best, pv, r2v = engine.global_test(Uk, ks_arr, r)
-    finally:
-        if pending:
-            tail_sums, ranks, num_detected = engine.null_local_fetch()   # never leave a pass pending behind an exception
+    except BaseException:
+        if pending:                     # never leave a pass pending behind an exception -- and never hide that exception
+            try:
+                engine.null_local_fetch()
+            except Exception:           # noqa: BLE001
+                pass
+        raise
+    if pending:
+        tail_sums, ranks, num_detected = engine.null_local_fetch()
 
     if not tail_first:
         _mark('null fetched')
@@ -938,6 +944,12 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         _mark('obs written')
     except BaseException:
         roll_back()
+        # the fused selection call may have launched the local null before whatever raised (a `ks` too large for the
+        # cohort, a failed draw, an interrupt): collect and drop it, or every later call on this engine finds it pending
+        try:
+            engine.null_local_discard()
+        except Exception:               # noqa: BLE001 - the caller gets the error that brought us here
+            pass
         raise
     if fdr_all is None:
         # upstream has written data.obs[key_added] and then dereferences res.fdrs, which is None when

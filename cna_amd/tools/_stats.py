@@ -131,6 +131,7 @@ class NativeDraw:
 
     def __init__(self, lib, keep, table):
         self._lib, self._keep, self.table, self._done = lib, keep, table, False
+        self._state = None                           # (bit generator, address of its state, the worker's copy)
         self.flag = np.zeros(1, dtype=np.int32)      # 1: the worker has conditioned the phenotypes itself (then_condition)
         self._m = None
 
@@ -156,6 +157,13 @@ class NativeDraw:
         if not self._done:
             rc = self._lib.cna_host_draw_wait()
             self._done = True
+            if rc == 0 and self._state is not None:
+                # the worker advanced a COPY of the generator's state; numpy's own is written once, whole, under its lock
+                import ctypes as C
+                bg, addr, st = self._state
+                with bg.lock:
+                    C.memmove(addr, st, _MT_STATE_BYTES)
+            self._state = None
             self._keep = None
             if rc != 0:
                 raise MemoryError('cna_host_draw_wait: the permutation draw failed (%d)' % rc)
@@ -214,12 +222,45 @@ def native_draw_start(B, Y, num, seed, threads=None):
             threads = 1
     np.random.seed(seed)
     addr = bg.ctypes.state_address             # struct mt19937_state { uint32_t key[624]; int pos; }
-    rc = lib.cna_host_draw_start(addr, C.cast(addr + 624 * 4, C.POINTER(C.c_int)), Yc.ctypes.data, len(Y), int(num),
+    if not _mt_layout_ok(bg, addr):
+        return None
+    # The worker advances a copy of the freshly seeded state in memory this object owns; wait() writes it back under
+    # the generator's lock.  Whoever touches np.random in between sees a consistent generator (never a torn one), as
+    # with the reference's own interleaving of draws.
+    st = (C.c_uint32 * (_MT_STATE_BYTES // 4))()
+    with bg.lock:
+        C.memmove(st, addr, _MT_STATE_BYTES)
+    base = C.addressof(st)
+    rc = lib.cna_host_draw_start(base, C.cast(base + 624 * 4, C.POINTER(C.c_int)), Yc.ctypes.data, len(Y), int(num),
                                  len(off) - 1, off.ctypes.data, members.ctypes.data, table.ctypes.data + 8, num + 1,
                                  int(threads))
     if rc != 0:
         return None                            # (seeded, nothing drawn: the caller's own draw seeds again)
-    return NativeDraw(lib, (Yc, off, members, bg), table)
+    d = NativeDraw(lib, (Yc, off, members, bg, st), table)
+    d._state = (bg, addr, st)
+    return d
+
+
+_MT_STATE_BYTES = 624 * 4 + 4
+_mt_layout = None
+
+
+def _mt_layout_ok(bg, addr):
+    """Once per process: numpy's `struct mt19937_state { uint32_t key[624]; int pos; }` is where this module reads it
+    (the public `state` dict against the raw memory)."""
+    global _mt_layout
+    if _mt_layout is None:
+        import ctypes as C
+        try:
+            with bg.lock:
+                raw = (C.c_uint32 * 625).from_address(addr)
+                key = np.frombuffer(raw, dtype=np.uint32, count=624).copy()
+                pos = C.c_int.from_address(addr + 624 * 4).value
+            pub = bg.state['state']
+            _mt_layout = bool(int(pub['pos']) == pos and np.array_equal(np.asarray(pub['key'], dtype=np.uint32), key))
+        except Exception:                      # noqa: BLE001
+            _mt_layout = False
+    return _mt_layout
 
 
 def grouplevel_permutation(G, Y, num, clean=False):

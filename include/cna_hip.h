@@ -297,6 +297,10 @@ int  cna_null_local_launch(cna_ctx* ctx, int col0, int P, const double* edges, i
 int  cna_null_local_prepare(cna_ctx* ctx, int P, const double* edges, int T, int want_tails, const double* thr);
 int  cna_null_local_fetch(cna_ctx* ctx, int64_t* tails_out, int64_t* tail_sums_out,
                           int64_t* ranks_out, int64_t* num_detected_out /* both NULL unless thr was given */);
+/* Error path of _association.py:84-120 on the caller's side: a pass that was launched (cna_null_local_launch, or the
+ * fused selection call) and never fetched because the caller raised in between is waited for and dropped, together
+ * with a prepared half; the context is ready for the next analysis.  No-op when nothing is pending. */
+int  cna_null_local_discard(cna_ctx* ctx);
 /* Diagnostics of the last local-null pass that wanted only the sums over permutations (the
  * analysis): such a pass forms the products on the integer matrix cores (csrc/null_i8.hip: 24-bit
  * fixed point, exact int32 accumulation, outputs within the error bound of a cut recomputed in f64)

@@ -350,6 +350,9 @@ class FakeEngine(_order.CellOrder):
         out, self._pending = self._pending, None
         return out
 
+    def null_local_discard(self):
+        self._pending = None
+
     def global_test(self, U, ks, r):
         kix, p, r2 = orc.minp_stats(self._Y, self._M, np.asarray(U), np.asarray(ks), r)
         return kix.astype(np.int32), p, r2

@@ -1686,3 +1686,49 @@ def test_small_block_many_samples_takes_the_per_cell_pass_under_lapack(eng, monk
     monkeypatch.setattr(eng, 'global_test_fetch', real_fetch)
     capsys.readouterr()
     assert cna.tl.association(data, meta['y'], 'id', engine=eng, **kw) == a[0]
+
+
+def test_error_after_a_fused_null_launch_leaves_the_engine_usable(eng, monkeypatch):
+    """The fused selection call may launch the local null itself (the draw thread's flag says the phenotypes are on the
+    device).  An analysis that raises AFTER that launch and before its fetch -- `ks` too large for the cohort
+    (_association.py:29-33), a draw that fails, a conditioning that refuses -- must not leave the pass pending: the next
+    call on the same (process-wide) engine works and returns what a fresh engine returns."""
+    import cna_amd as cna
+    from cna_amd import synth
+    data, meta = synth.make_dataset(6000, 24, k=15, seed=5)
+    kw = dict(Nnull=100, seed=1, nsteps=3)
+    want = cna.tl.association(data, meta['y'], 'id', engine=eng, return_full=True, **kw)
+    coef = data.obs['coef'].values.copy()
+    # (1) ks too large: ValueError from the reference's own guard, raised after walk + selection
+    for bad in ([24], [30], [23]):
+        with pytest.raises(ValueError, match='Maximum number of PCs'):
+            cna.tl.association(data, meta['y'], 'id', engine=eng, ks=bad, **kw)
+        np.testing.assert_array_equal(data.obs['coef'].values, coef)
+        got = cna.tl.association(data, meta['y'], 'id', engine=eng, return_full=True, **kw)
+        assert got.p == want.p and got.k == want.k
+        np.testing.assert_array_equal(got.fdrs.num_detected.values, want.fdrs.num_detected.values)
+        np.testing.assert_array_equal(got.ncorrs.values, want.ncorrs.values)
+    # (2) a failure of the first consumer after the launch
+    real = eng.gram_fetch
+
+    def boom(*a, **k):
+        raise FloatingPointError('injected')
+    monkeypatch.setattr(eng, 'gram_fetch', boom)
+    with pytest.raises(FloatingPointError):
+        cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+    monkeypatch.setattr(eng, 'gram_fetch', real)
+    assert cna.tl.association(data, meta['y'], 'id', engine=eng, **kw) == want.p
+    # (3) the C entry point by itself: a launched pass, dropped; then nothing pending and the next prepare is accepted
+    thr = np.arange(0.01, 0.04, 0.0001)
+    edges = thr ** 2 - 1e-8 - 1e-5 * thr ** 2
+    eng.null_local_launch(1, 50, edges, thr)
+    eng.null_local_discard()
+    eng.null_local_discard()                                      # no-op
+    with pytest.raises(Exception, match='no local-null pass pending'):
+        eng.null_local_fetch()
+    eng.null_local_launch(1, 50, edges, thr)
+    a = eng.null_local_fetch()
+    eng.null_local_launch(1, 50, edges, thr)
+    b = eng.null_local_fetch()
+    for x, y in zip(a, b):
+        np.testing.assert_array_equal(x, y)
