@@ -135,6 +135,19 @@ def fuzzy_knn_graph(X, k=30, dtype=np.float32, workers=None, n_iter=40, builder=
     return A
 
 
+def graph_digest(A):
+    """sha256 over shape, indptr (as int64), indices (int32) and the value bytes of a CSR matrix: the identity of a
+    regenerated input (tests/golden/d02_config2.npz stores the digest instead of 64 MB of graph)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(np.asarray(A.shape, dtype=np.int64).tobytes())
+    h.update(np.ascontiguousarray(A.indptr, dtype=np.int64).tobytes())
+    h.update(np.ascontiguousarray(A.indices, dtype=np.int32).tobytes())
+    h.update(str(A.data.dtype).encode())
+    h.update(np.ascontiguousarray(A.data).tobytes())
+    return h.hexdigest()
+
+
 def assign_samples(cluster, n_samples, seed=0, skew=1.0):
     """Sample id per cell with a per-sample preference over clusters so the NAM
     carries signal.  Returns (sid int64[n], sample_cluster_props float64[N, K])."""
@@ -156,15 +169,16 @@ def assign_samples(cluster, n_samples, seed=0, skew=1.0):
 
 def make_dataset(n_cells, n_samples, k=30, seed=0, dim=8, n_clusters=20,
                  graph_dtype=np.float32, cluster_sorted=True, sid_name='id',
-                 sid_kind='int', signal=True, n_covs=0, n_batches=0):
-    """Build a CellData plus sample-level phenotype/covariates.
+                 sid_kind='int', signal=True, n_covs=0, n_batches=0, builder='auto'):
+    """Build a CellData plus sample-level phenotype/covariates.  ``builder``: see fuzzy_knn_graph ('cpu' gives the same
+    graph on every machine of this image, GPU or not -- what fixtures captured from the reference are regenerated with).
 
     Returns (data, meta) where meta has y (Series), covs (DataFrame|None),
     batches (Series|None), props, cluster.
     """
     X, cl = mixture_points(n_cells, dim=dim, n_clusters=n_clusters, seed=seed,
                            cluster_sorted=cluster_sorted)
-    A = fuzzy_knn_graph(X, k=k, dtype=graph_dtype)
+    A = fuzzy_knn_graph(X, k=k, dtype=graph_dtype, builder=builder)
     sid, props = assign_samples(cl, n_samples, seed=seed)
     labels = np.arange(n_samples)
     if sid_kind == 'str':

@@ -331,8 +331,67 @@ def run_demo_like():
                                                            out['fdr_num_detected'][0], os.path.getsize(path) / 1024))
 
 
+CONFIG2 = dict(n_cells=200_000, n_samples=50, k=30, seed=0)            # BASELINE.json configs[1]
+CONFIG2_CALL = dict(nsteps=3, Nnull=1000, seed=0)
+CONFIG2_EVERY = 100                                                     # cells-sized results: every 100th cell
+
+
+def run_config2():
+    """BASELINE.json configs[1] AT FULL SIZE through the reference itself: 200 000 cells x 50 samples, k = 30,
+    nsteps = 3, Nnull = 1000, seed 0 (about two minutes and ~10 GB here).  The inputs are NOT stored: they are
+    `synth.make_dataset(**CONFIG2, builder='cpu')`, regenerated wherever the fixture is used, and recognised by the
+    digest of the CSR arrays.  Stored: every sample-level result, the FDR table, the integer counts, and the
+    cells-sized results (nam, namresid, V, ncorrs, the two data.obs columns) for every 100th cell."""
+    import time
+    t0 = time.time()
+    data, meta = synth.make_dataset(builder='cpu', **CONFIG2)
+    A = data.obsp['connectivities']
+    t_gen = time.time() - t0
+    y = meta['y']
+    t0 = time.time()
+    with warnings.catch_warnings(record=True) as wlist:
+        warnings.simplefilter('always')
+        res = cna.tl.association(data, y, 'id', return_full=True, **CONFIG2_CALL)
+    t_ref = time.time() - t0
+    f = result_fields(res)
+    sub = np.arange(0, A.shape[0], CONFIG2_EVERY)
+    assert f['kept'].all()
+    out = dict(call=np.array(json.dumps(CONFIG2_CALL)), dataset=np.array(json.dumps(CONFIG2)),
+               graph_digest=np.array(synth.graph_digest(A)), nnz=np.int64(A.nnz), in_y=y.values,
+               sid_digest=np.array(__import__('hashlib').sha256(np.asarray(data.obs['id'].values, dtype=np.int64).tobytes()).hexdigest()))
+    out['warnings'] = np.array(json.dumps([str(w.message) for w in wlist if issubclass(w.category, UserWarning)]))
+    for key in ('p', 'k', 'ks', 'r', 'nullminps', 'M', 'svs', 'varexp', 'yresid', 'yresid_hat', 'beta',
+                'r2', 'r2_perpc', 'nullr2_mean', 'nullr2_std', 'fdr_threshold', 'fdr_fdr', 'fdr_num_detected',
+                'fdr_5p_t', 'fdr_10p_t', 'U'):
+        out[key] = f[key]
+    out['n_kept'] = np.int64(f['kept'].sum())
+    out['sub'] = sub
+    out['ncorrs_sub'] = f['ncorrs'][sub]
+    out['ncorrs_absmax'] = np.float64(np.abs(f['ncorrs']).max())
+    out['ncorrs_sum'] = np.float64(f['ncorrs'].sum())
+    out['nam_sub'] = f['nam'][:, sub]
+    out['namresid_sub'] = f['namresid'][:, sub]
+    out['V_sub'] = f['V'][sub]
+    out['obs_coef_sub'] = data.obs['coef'].values.astype(np.float64)[sub]
+    out['obs_coef_fdr_sub'] = data.obs['coef_fdr'].values.astype(np.float64)[sub]
+    out['obs_coef_fdr_below_1'] = np.int64((data.obs['coef_fdr'].values < 1).sum())
+    out['reference_seconds'] = np.float64(t_ref)
+    out['versions'] = np.array(json.dumps(dict(numpy=np.__version__, scipy=scipy.__version__, pandas=pd.__version__,
+                                               python=sys.version.split()[0], cna='0.2.3 (/root/reference)')))
+    path = os.path.join(HERE, 'd02_config2.npz')
+    np.savez_compressed(path, **out)
+    print('%-36s p=%.6g k=%d detected@first=%d  %.0f KB  (dataset %.0f s, reference %.0f s, graph %s)' % (
+        'd02_config2', out['p'], out['k'], out['fdr_num_detected'][0], os.path.getsize(path) / 1024, t_gen, t_ref,
+        str(out['graph_digest'])[:16]))
+
+
 def main():
     only = set(sys.argv[1:])
+    if 'd02_config2' in only:                      # two minutes and ~10 GB: only on request
+        run_config2()
+        only.discard('d02_config2')
+        if not only:
+            return
     if not only or 'd01_demo_like' in only:
         run_demo_like()
     if only == {'d01_demo_like'}:

@@ -203,3 +203,70 @@ def assert_matches_demo(out, z, tol, obs=None):
     if obs is not None:
         np.testing.assert_allclose(obs['coef'], z['obs_coef'], rtol=0, atol=tol * np.nanmax(np.abs(z['obs_coef'])))
         np.testing.assert_allclose(obs['coef_fdr'], z['obs_coef_fdr'], rtol=tol * 10, atol=1e-12)
+
+
+# --------------------------------------------------------------------------------------
+# d02_config2: BASELINE.json configs[1] at FULL size through the reference (tests/golden/make_golden.py:run_config2)
+def load_config2_case():
+    """The fixture holds results only; the inputs are regenerated here -- `synth.make_dataset(**dataset, builder='cpu')`,
+    the host builder (cKDTree + scipy.sparse: the same graph on every machine of this image) -- and recognised by the
+    digest of their CSR arrays and sample ids.  Returns dict(data, y, call, z, same_inputs)."""
+    import hashlib
+    from cna_amd import synth
+    z = np.load(os.path.join(GOLDEN_DIR, 'd02_config2.npz'))
+    ds = json.loads(z['dataset'].item())
+    data, meta = synth.make_dataset(builder='cpu', **ds)
+    A = data.obsp['connectivities']
+    same = (synth.graph_digest(A) == z['graph_digest'].item() and
+            hashlib.sha256(np.asarray(data.obs['id'].values, dtype=np.int64).tobytes()).hexdigest() == z['sid_digest'].item() and
+            np.array_equal(meta['y'].values, z['in_y']))
+    return dict(data=data, y=meta['y'], call=json.loads(z['call'].item()), z=z, same_inputs=bool(same))
+
+
+def assert_matches_config2(out, z, tol, obs=None, floors=None, exact_counts=True):
+    """out: dict with p, k, ks, r, n_kept, nullminps, svs, U, M, yresid, yresid_hat, r2, r2_perpc, nullr2_mean, nullr2_std,
+    ncorrs (all cells), nam / namresid (cells x samples or None), fdrs{threshold, fdr, num_detected}, fdr_5p_t, fdr_10p_t.
+    Integers exact, floats within `tol` relative (entry by entry with the golden floors for the cells-sized fields),
+    empirical FDRs within 10 tol (ratios of counts), PCs up to sign for the first k."""
+    sub = z['sub']
+    floors = floors or dict(nam=1e-12, ncorrs=2e-7, namresid=2e-7)
+    assert int(out['k']) == int(z['k']) and np.array_equal(out['ks'], z['ks']) and int(out['r']) == int(z['r'])
+    assert int(out['n_kept']) == int(z['n_kept'])
+    assert abs(float(out['p']) - float(z['p'])) < 1e-12
+    assert relerr(out['nullminps'], z['nullminps']) < tol * 10
+    assert relerr(out['svs'], z['svs']) < tol
+    assert relerr(out['M'], z['M']) < tol
+    assert relerr(out['yresid'], z['yresid']) < tol and relerr(out['yresid_hat'], z['yresid_hat']) < tol
+    for key in ('r2', 'nullr2_mean', 'nullr2_std'):
+        assert abs(float(out[key]) - float(z[key])) <= tol * abs(float(z[key])), key
+    assert relerr(out['r2_perpc'], z['r2_perpc']) < tol
+    kk = int(z['k'])
+    a, b = sign_align(out['U'], z['U'], kk)
+    assert relerr(a, b) < tol
+    nc = np.asarray(out['ncorrs'])
+    assert_elementwise(nc[sub], z['ncorrs_sub'], tol, floors['ncorrs'], 'ncorrs (every 100th cell)')
+    assert abs(np.abs(nc).max() - float(z['ncorrs_absmax'])) <= tol * float(z['ncorrs_absmax'])
+    if out.get('nam') is not None:
+        assert_elementwise(np.asarray(out['nam'])[sub].T, z['nam_sub'], tol, floors['nam'], 'nam (every 100th cell)')
+    if out.get('namresid') is not None:
+        assert_elementwise(np.asarray(out['namresid'])[sub].T, z['namresid_sub'], tol, floors['namresid'], 'namresid (every 100th cell)')
+    f = out['fdrs']
+    T = min(len(f['threshold']), len(z['fdr_threshold']))
+    assert T >= 300 and abs(len(f['threshold']) - len(z['fdr_threshold'])) <= 1
+    assert relerr(np.asarray(f['threshold'])[:T], z['fdr_threshold'][:T]) < tol
+    if exact_counts:
+        assert np.array_equal(np.asarray(f['num_detected'])[:T], z['fdr_num_detected'][:T])
+    else:
+        assert np.abs(np.asarray(f['num_detected'])[:T] - z['fdr_num_detected'][:T]).max() <= 3
+    np.testing.assert_allclose(np.asarray(f['fdr'])[:T], z['fdr_fdr'][:T], rtol=tol * 10, atol=1e-12, equal_nan=True)
+    for key in ('fdr_5p_t', 'fdr_10p_t'):
+        ref = float(z[key])
+        if np.isnan(ref):
+            assert out[key] is None
+        else:
+            assert out[key] is not None and abs(out[key] - ref) <= tol * abs(ref)
+    if obs is not None:
+        np.testing.assert_allclose(np.asarray(obs['coef'])[sub], z['obs_coef_sub'], rtol=0, atol=tol * float(z['ncorrs_absmax']))
+        np.testing.assert_allclose(np.asarray(obs['coef_fdr'])[sub], z['obs_coef_fdr_sub'], rtol=tol * 10, atol=1e-12)
+        if exact_counts:
+            assert int((np.asarray(obs['coef_fdr']) < 1).sum()) == int(z['obs_coef_fdr_below_1'])
