@@ -284,11 +284,14 @@ extern "C" int cna_comm_selftest(cna_ctx* c, double timeout_s, int* halo_ok) {
   const double host[8] = {1, 1, 1, 1, 1, 1, 1, 1};
   HIP_TRY(hipMemcpy(buf, host, 64, hipMemcpyHostToDevice));
   ncclComm_t comm = (ncclComm_t)c->comm;
-  // a communicator that stopped answering cannot be destroyed (ncclCommDestroy would wait for it): on every timeout
-  // the split child goes first, then the parent, and the context forgets both before the error is returned
+  // A communicator that stopped answering cannot be destroyed (ncclCommDestroy would wait for it), so after a timeout
+  // the context must not keep either handle: the main communicator is aborted, and the split child is DROPPED without a
+  // call into RCCL -- ncclCommAbort on the child of a communicator whose peer is stopped did not return in
+  // test_rccl_selftest_reports_a_silent_peer (measured, round 5).  A leaked handle in a process that is about to report
+  // the error and exit; comm_destroy then finds nothing it could hang on.
   auto abort_both = [&]() {
-    if (c->comm_halo) { if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t)c->comm_halo); c->comm_halo = nullptr; }
     if (c->comm) { if (g_rccl.CommAbort) g_rccl.CommAbort((ncclComm_t)c->comm); c->comm = nullptr; }
+    c->comm_halo = nullptr;
   };
   NCCL_TRY(g_rccl.AllReduce(buf, buf, 1, ncclFloat64, ncclSum, comm, c->stream));
   if (poll_stream(c->stream, timeout_s) != 0) {

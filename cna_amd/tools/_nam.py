@@ -88,15 +88,63 @@ def _lapacke_dsyevr():
     return _LAPACKE_DSYEVR
 
 
+# acceptance of the library's own eigen-solver (csrc/host_eig.c): residual and orthogonality at rounding level, and every
+# gap of the leading spectrum wide enough for the individual vectors to be defined to ~1e-10 (two backward-stable solvers
+# agree to ~eps ||G|| / gap); anything else is LAPACK's to decide
+_EIG_NATIVE = os.environ.get('CNA_EIG', 'native') != 'lapack'
+_EIG_RESID = 1e-12
+_EIG_GAP = 1e-6
+eig_stats = {'native': 0, 'lapack': 0}
+
+
+def _top_pcs_native(G, kmax):
+    """csrc/host_eig.c:cna_host_top_eig, accepted only with its evidence (see above); None -> the caller asks LAPACK."""
+    n = len(G)
+    if not _EIG_NATIVE or n < 8 or 4 * kmax > n or kmax + 1 > 256:
+        return None
+    try:
+        import ctypes as C
+        from .. import _ffi
+        fn = _ffi.load().cna_host_top_eig
+    except Exception:                           # noqa: BLE001
+        return None
+    Gc = np.ascontiguousarray(G, dtype=np.float64)
+    U = np.empty((n, kmax))
+    lam = np.empty(kmax + 1)
+    resid, ortho = C.c_double(0.0), C.c_double(0.0)
+    if fn(Gc.ctypes.data, n, kmax, U.ctypes.data, lam.ctypes.data, C.byref(resid), C.byref(ortho)) != 0:
+        return None
+    top = lam[0]
+    if not (top > 0 and np.isfinite(lam).all()):
+        return None
+    if not (resid.value <= _EIG_RESID * top and ortho.value <= _EIG_RESID):
+        return None
+    if not ((lam[:-1] - lam[1:]) > _EIG_GAP * top).all():
+        return None                             # a (near-)degenerate leading spectrum: individual vectors are LAPACK's choice
+    return U
+
+
 def _top_pcs(G, kmax):
     """The kmax leading eigenvectors of the samples x samples Gram matrix (columns, leading first), for the global
     F-tests.  Every statistic of _association.py:35-48 depends on the PCs only through squared projections -- not on
-    their signs -- so the tests need not wait for the sign-defining LAPACK SVD of _nam.py:105: LAPACK's dsyevr with
-    an index range (tridiagonalisation + the wanted eigenpairs) is ~3x shorter at 200 samples, and the SVD is left
-    to `GramPCs` (a worker thread, or whoever first reads a field that shows the signs).  Same subspaces to ~1e-13."""
+    their signs -- so the tests need not wait for the sign-defining LAPACK SVD of _nam.py:105, which is left to
+    `GramPCs` (a worker thread, or whoever first reads a field that shows the signs).  First choice: the library's own
+    checked solver for the leading pairs (csrc/host_eig.c; no LAPACK, no interpreter: 2-3x shorter than dsyevr at 200
+    samples); else LAPACK's dsyevr with an index range.  Same subspaces to ~1e-14 (tests/test_host_eig.py)."""
     n = len(G)
     if kmax >= n or not np.isfinite(G).all():
         return None                                 # degenerate input: the caller takes the SVD (and its errors)
+    U = _top_pcs_native(G, kmax)
+    if U is not None:
+        eig_stats['native'] += 1
+        return U
+    eig_stats['lapack'] += 1
+    return _top_pcs_lapack(G, kmax)
+
+
+def _top_pcs_lapack(G, kmax):
+    """LAPACK's dsyevr with an index range (tridiagonalisation + the wanted eigenpairs)."""
+    n = len(G)
     # LAPACK's wrapper directly: scipy.linalg.eigh spends as long again on argument checks and a workspace query
     # (264 -> 208 us at 50 samples; the call sits on the critical path of a small analysis)
     fn = _lapacke_dsyevr()

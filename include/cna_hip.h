@@ -467,6 +467,18 @@ int  cna_prof_reset(cna_ctx* ctx);
 int  cna_prof_get(cna_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
 const char* cna_kernel_name(int kernel_id);
 
+/* svd_nam's `np.linalg.svd(NAM.dot(NAM.T))` (_nam.py:105) as the global test consumes it (_association.py:35-48: the
+ * first k <= max(ks) vectors, through squared projections only): the k leading eigenpairs of the symmetric n x n matrix
+ * G (row-major) on the host -- Householder tridiagonalisation, bisection, inverse iteration (csrc/host_eig.c) -- with
+ * the evidence the caller needs to accept them or fall back to LAPACK: U_out n x k row-major (column t belongs to the
+ * t-th largest eigenvalue, sign arbitrary), lam_out the k + 1 largest eigenvalues, *resid_out / *ortho_out = largest
+ * residual and largest orthogonality defect of the eigenvectors of the tridiagonal stage (the one that can fail; the
+ * reflectors around it are orthogonal to rounding).  Returns 0; 1 = breakdown, 2 = bad arguments (k + 1 <= min(n, 260)),
+ * -1 = no memory.  Needs no context and no GPU. */
+int  cna_host_top_eig(const double* G, int n, int k, double* U_out, double* lam_out, double* resid_out, double* ortho_out);
+/* The same two figures measured on G itself: max_t ||G u_t - lam_t u_t||_inf, max |U^T U - I| (tests). */
+int  cna_host_eig_check(const double* G, int n, int k, const double* U, const double* lam, double* resid_out, double* ortho_out);
+
 #ifdef __cplusplus
 }
 #endif

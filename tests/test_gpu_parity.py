@@ -1700,8 +1700,9 @@ def test_error_after_a_fused_null_launch_leaves_the_engine_usable(eng, monkeypat
     want = cna.tl.association(data, meta['y'], 'id', engine=eng, return_full=True, **kw)
     coef = data.obs['coef'].values.copy()
     # (1) ks too large: ValueError from the reference's own guard, raised after walk + selection
-    for bad in ([24], [30], [23]):
-        with pytest.raises(ValueError, match='Maximum number of PCs'):
+    # ... and ks = [n - 1]: no degrees of freedom left, every p is NaN, np.nanargmin's ValueError as upstream -- AFTER the fetch
+    for bad, msg in (([24], 'Maximum number of PCs'), ([30], 'Maximum number of PCs'), ([23], 'All-NaN slice')):
+        with pytest.raises(ValueError, match=msg):
             cna.tl.association(data, meta['y'], 'id', engine=eng, ks=bad, **kw)
         np.testing.assert_array_equal(data.obs['coef'].values, coef)
         got = cna.tl.association(data, meta['y'], 'id', engine=eng, return_full=True, **kw)

@@ -17,10 +17,12 @@ for N, k in ((50, 4), (100, 8), (200, 16)):
         f(); t0 = time.perf_counter()
         for _ in range(reps): f()
         return (time.perf_counter() - t0) / reps * 1e3
-    ref = _nam._top_pcs(G, k)
+    ref = _nam._top_pcs_lapack(G, k)
+    assert _nam._top_pcs_native(G, k) is not None
     v0 = np.ones(N) / np.sqrt(N)
     res = {
-        'LAPACKE dsyevr I (ctypes)': t(lambda: _nam._top_pcs(G, k)),
+        'native (csrc/host_eig.c, checked)': t(lambda: _nam._top_pcs_native(G, k)),
+        'LAPACKE dsyevr I (ctypes)': t(lambda: _nam._top_pcs_lapack(G, k)),
         'f2py dsyevr I': t(lambda: lapack.dsyevr(G, compute_v=1, range='I', il=N - k + 1, iu=N, lower=1)),
         'f2py dsyevd': t(lambda: lapack.dsyevd(G, compute_v=1, lower=1)),
         'f2py dsyevx I': t(lambda: lapack.dsyevx(G, compute_v=1, range='I', il=N - k + 1, iu=N, lower=1)),
@@ -28,5 +30,7 @@ for N, k in ((50, 4), (100, 8), (200, 16)):
         'eigsh k (ARPACK, tol 0)': t(lambda: eigsh(G, k=k, which='LA', v0=v0, tol=0)),
     }
     w, v = eigsh(G, k=k, which='LA', v0=v0, tol=0)
+    Un = _nam._top_pcs_native(G, k)
+    print('   native vs dsyevr projector difference %.1e' % np.abs(ref @ ref.T - Un @ Un.T).max())
     P1 = ref @ ref.T; P2 = v @ v.T
     print(N, k, '  '.join('%s %.3f ms' % kv for kv in res.items()), ' | projector difference ARPACK vs dsyevr %.1e' % np.abs(P1 - P2).max())
