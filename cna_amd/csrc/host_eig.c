@@ -22,10 +22,13 @@
  * signs come from LAPACK's SVD, `GramPCs`).  No threads, no shared state: re-entrant (the work space is per thread). */
 #include <float.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
-#ifndef CLONES
+#ifdef CNA_NO_CLONES          /* sanitizer builds: an ifunc resolver runs before the sanitizer's runtime is up */
+#define CLONES
+#elif !defined(CLONES)
 #define CLONES __attribute__((target_clones("avx512f", "fma", "default")))
 #endif
 #define MAXT 260                    /* most eigenpairs asked for at once (k + 1 <= n / 4 + 1 <= 257) */
@@ -380,6 +383,11 @@ static void check_pairs(const double* G, int n, int k, const double* Y, const do
   *ortho_out = omax;
 }
 
+static pthread_key_t g_ws_key;
+static int g_ws_key_ok = 0;
+static pthread_once_t g_ws_once = PTHREAD_ONCE_INIT;
+static void ws_make_key(void) { g_ws_key_ok = pthread_key_create(&g_ws_key, free) == 0; }
+
 /* G: n x n symmetric, row-major (only its lower triangle is read for the decomposition; all of it for the check).
  * U_out: n x k row-major, column t = eigenvector of the t-th LARGEST eigenvalue.  lam_out: k + 1 values, the k leading
  * eigenvalues and the next one (for the caller's gap test; k + 1 <= n).  resid_out: max_t ||T y_t - lam_t y_t||_inf and
@@ -397,6 +405,8 @@ int cna_host_top_eig(const double* G, int n, int k, double* U_out, double* lam_o
     free(t_buf);
     t_buf = (double*)malloc(sizeof(double) * need);
     t_cap = t_buf ? need : 0;
+    pthread_once(&g_ws_once, ws_make_key);          /* ... and goes when the thread does */
+    if (g_ws_key_ok) pthread_setspecific(g_ws_key, t_buf);
   }
   double* A = t_buf;
   if (!A) return -1;

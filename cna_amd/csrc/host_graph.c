@@ -131,7 +131,9 @@ int cna_host_copy(void* dst, const void* src, int64_t nbytes, int nthreads) {
  * which follows it (2 bytes per cell cross PCIe instead of 8, and none of them after the null) */
 struct expand_job { double* d; const uint16_t* b; size_t n; const double* tab; int T; };
 /* branch-free: a 1024-entry table t2[h] = 1 for h = 0 (and beyond T), runmin[h - 1] otherwise */
+#ifndef CNA_NO_CLONES          /* (sanitizer builds: no ifunc resolvers) */
 __attribute__((target_clones("avx2", "default")))
+#endif
 static void expand_span(double* d, const uint16_t* b, size_t n, const double* t2) {
   for (size_t i = 0; i < n; ++i) d[i] = t2[b[i] & 1023u];
 }
@@ -437,7 +439,7 @@ static void* co_worker(void* arg) {
     pthread_barrier_wait(&sh->bar);
     if (t == 0) {                                           /* the next round's frontier (its order does not matter) */
       int64_t tot = 0;
-      for (int k = 0; k < T; ++k) { memcpy(sh->frontier + tot, sh->next[k], 4 * (size_t)sh->nnext[k]); tot += sh->nnext[k]; }
+      for (int k = 0; k < T; ++k) { if (sh->nnext[k]) memcpy(sh->frontier + tot, sh->next[k], 4 * (size_t)sh->nnext[k]); tot += sh->nnext[k]; }   /* (a thread that found nothing has no list yet: memcpy(_, NULL, 0) is undefined) */
       sh->nfront = sh->failed ? 0 : tot;
     }
     pthread_barrier_wait(&sh->bar);

@@ -28,7 +28,11 @@
 #define LOWER_MASK 0x7fffffffu
 
 #if defined(__x86_64__) && defined(__GNUC__) && !defined(__clang__)
+#ifdef CNA_NO_CLONES          /* sanitizer builds: an ifunc resolver runs before the sanitizer's runtime is up */
+#define CLONES
+#else
 #define CLONES __attribute__((target_clones("avx2", "default")))
+#endif
 #else
 #define CLONES
 #endif

@@ -17,7 +17,9 @@ if ncov: kw['covs'] = meta['covs']
 if nbat: kw['batches'] = meta['batches']
 if os.environ.get('TRACE_NSTEPS') == 'None': kw['nsteps'] = None
 if os.environ.get('TRACE_PIN'): eng.pin_graph(data.obsp['connectivities'])
-for _ in range(4): cna.tl.association(data, meta['y'], 'id', **kw)
+cna.tl.association(data, meta['y'], 'id', **kw)
+if getattr(eng, 'reorder_pending', lambda: False)(): eng.wait_reorder()        # the call that adopts the device order is not the one traced
+for _ in range(6): cna.tl.association(data, meta['y'], 'id', **kw)
 ev = []
 for name in dir(Engine):
     if name.startswith('_') or name in ('block', 'prof', 'close'): continue
