@@ -295,7 +295,7 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
     return dict(name=name, n=n, N=N, k=k, nsteps=nsteps, Nnull=Nnull, n_covs=n_covs, n_batches=n_batches, nnz=nnz, wA=wA, dt=dt, t_cold=t_cold, i8=i8,
                 t_gen=t_gen, prof=prof, p=p_last, t_adopt=t_adopt, n_loc=n_loc, nnz_loc=nnz_loc, halo=getattr(eng, 'halo', None),
                 sharded_inputs=sharded_inputs, data=data, meta=meta, kw=kw, steps=steps, warmup=warmup, comm=eng.comm_info(),
-                halo_comm=getattr(eng, 'halo_comm', False))
+                halo_comm=getattr(eng, 'halo_comm', False), dev_bytes=int(eng.device_bytes()))
 
 
 def kernel_table(m, world):
@@ -501,6 +501,7 @@ def assemble_details(m, main_sum, cpu, cpu_c2, extra, world, steps, warmup, args
                    'parallelism': parallelism_text(m, world, args),
                    'communicator': {'backend': m['comm'][0], 'nranks_reported_by_communicator': m['comm'][1],
                                     'halo_rows_out_in_rank0': m['halo'],
+                                    'device_bytes_rank0': m.get('dev_bytes'),       # everything the library holds on rank 0's GPU (cna_ctx_device_bytes)
                                     'halo_exchange_overlaps_the_walk_step': bool(m.get('halo_comm')) or (m['comm'][0] == 'shm' and world > 1)},
                    'arithmetic': ARITHMETIC_I8 if m.get('i8', (False,))[0] else 'f64 throughout',
                    'p_value': m['p']},
@@ -543,6 +544,7 @@ def contract_line(d, details_file=None):
                                      if cfg['arithmetic'] != 'f64 throughout' else 'f64 throughout')[:120],
                          comm=comm.get('backend'), comm_ranks=comm.get('nranks_reported_by_communicator'),
                          halo_rows_out_in=comm.get('halo_rows_out_in_rank0'),
+                         device_gb_rank0=None if comm.get('device_bytes_rank0') is None else round(comm['device_bytes_rank0'] / 1e9, 3),
                          halo_overlaps_step=comm.get('halo_exchange_overlaps_the_walk_step'), p_value=cfg.get('p_value'))
     out['roofline'] = _roofline_short(d.get('roofline'))
     out['cpu_baseline'] = _cpu_short(d.get('cpu_baseline'))

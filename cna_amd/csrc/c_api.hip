@@ -377,10 +377,14 @@ int cna_fetch_colsums(cna_ctx* c, double* out) {
   return 0;
 }
 
+static int64_t state_rows(const cna_ctx* c) { return c->t_compact ? c->t_rows : c->n_pad; }
+
 static int ensure_T(cna_ctx* c, int ld) {
   // + 64 doubles: the gather kernel lets lanes past the row width read into the following row
-  const int64_t need = (int64_t)sizeof(double) * (c->n_pad * ld + 64);
-  if (need > c->t_cap || !c->T[0]) {
+  const int64_t need = (int64_t)sizeof(double) * (state_rows(c) * ld + 64);
+  // (a buffer left over from a much larger row space -- the graph's halo plan came after a first allocation -- goes:
+  // the point of the compact row space is the memory)
+  if (need > c->t_cap || !c->T[0] || (c->t_compact && c->t_cap > need + need / 2 + (1 << 20))) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 2; ++i) {
       if (c->T[i]) dev_free(c, c->T[i], (size_t)c->t_cap);
@@ -411,22 +415,25 @@ static int ensure_sparse_state(cna_ctx* c) {
   if (!want) {
     if (c->sp_cnt) {
       HIP_TRY(hipStreamSynchronize(c->stream));
-      dev_free(c, c->sp_pair, 16 * 64 * (size_t)c->sp_rows);
+      dev_free(c, c->sp_pair, 16 * 64 * (size_t)c->sp_pair_rows);
       dev_free(c, c->sp_cnt, (size_t)c->sp_rows);
       c->sp_pair = c->sp_cnt = nullptr;
-      c->sp_rows = 0;
+      c->sp_rows = c->sp_pair_rows = 0;
     }
     return 0;
   }
-  if (c->sp_cnt && c->sp_rows == c->n_pad) return 0;
+  // compact row space: counts for every row of the state (halo rows stay "dense"), pairs for this rank's own rows only
+  const int64_t cnt_rows = state_rows(c), pair_rows = c->t_compact ? std::max<int64_t>(c->n_local, 1) : c->n_pad;
+  if (c->sp_cnt && c->sp_rows == cnt_rows && c->sp_pair_rows == pair_rows) return 0;
   if (c->sp_cnt) {
     HIP_TRY(hipStreamSynchronize(c->stream));
-    dev_free(c, c->sp_pair, 16 * 64 * (size_t)c->sp_rows);
+    dev_free(c, c->sp_pair, 16 * 64 * (size_t)c->sp_pair_rows);
     dev_free(c, c->sp_cnt, (size_t)c->sp_rows);
     c->sp_pair = c->sp_cnt = nullptr;
   }
-  c->sp_rows = c->n_pad;
-  CNA_TRY(dev_alloc(c, &c->sp_pair, 16 * 64 * (size_t)c->sp_rows));   // 64 = SP_CAP records of 16 bytes (diffuse.hip)
+  c->sp_rows = cnt_rows;
+  c->sp_pair_rows = pair_rows;
+  CNA_TRY(dev_alloc(c, &c->sp_pair, 16 * 64 * (size_t)c->sp_pair_rows));   // 64 = SP_CAP records of 16 bytes (diffuse.hip)
   CNA_TRY(dev_alloc(c, &c->sp_cnt, (size_t)c->sp_rows));
   // every row "dense" (255 = SP_DENSE) until a first step of this rank says otherwise: rows of other ranks stay so
   HIP_TRY(hipMemsetAsync(c->sp_cnt, 0xff, (size_t)c->sp_rows, c->stream));
@@ -489,6 +496,15 @@ int cna_restart_nam(cna_ctx* c) {
 }
 
 static void halo_clear(cna_ctx* c) {
+  if (c->idx_t) dev_free(c, c->idx_t, sizeof(int32_t) * std::max<int64_t>(c->idx_t_n, 1));
+  c->idx_t = nullptr;
+  c->idx_t_n = 0;
+  if (c->t_compact) {          // the state's row space changes: whatever is in it is void
+    c->t_compact = false;
+    c->t_rows = 0;
+    c->t_valid = false;
+    c->cellinfo_valid = false;
+  }
   if (c->halo_send_idx) dev_free(c, c->halo_send_idx, sizeof(int64_t) * std::max<int64_t>(c->halo_ns, 1));
   if (c->halo_recv_idx) dev_free(c, c->halo_recv_idx, sizeof(int64_t) * std::max<int64_t>(c->halo_nr, 1));
   c->halo_send_idx = c->halo_recv_idx = nullptr;
@@ -546,6 +562,36 @@ int cna_set_halo(cna_ctx* c, const int64_t* send_rows, const int64_t* send_count
     if (!c->halo_e1) HIP_TRY(hipEventCreateWithFlags(&c->halo_e1, hipEventDisableTiming));
     if (!c->halo_e2) HIP_TRY(hipEventCreateWithFlags(&c->halo_e2, hipEventDisableTiming));
   }
+  // State for local + halo rows only: the rows this rank receives are the ONLY foreign rows its graph block
+  // references (that is what the plan is), so the state needs n_local + nr rows, not n_global -- and what arrives can land
+  // in the tail directly, in the order it is sent.  The walk steps read the graph through column indices renumbered
+  // into that row space (one pass, here).  CNA_COMPACT_STATE=0 keeps the global row space (A/B, tests).
+  {
+    const char* e = getenv("CNA_COMPACT_STATE");
+    bool ascending = true;
+    for (int64_t k = 1; k < nr && ascending; ++k) ascending = recv_rows[k] > recv_rows[k - 1];
+    for (int64_t k = 0; k < nr && ascending; ++k) ascending = recv_rows[k] < c->row0 || recv_rows[k] >= c->row0 + c->n_local;
+    if (!(e && atoi(e) == 0) && ascending && c->n_local + nr < ((int64_t)1 << 31)) {
+      CNA_TRY(dev_alloc(c, (void**)&c->idx_t, sizeof(int32_t) * std::max<int64_t>(c->nnz, 1)));
+      c->idx_t_n = c->nnz;
+      int bad = 0;
+      CNA_TRY(launch_remap_indices(c, c->halo_recv_idx, nr, c->idx_t, &bad));
+      if (bad) {
+        dev_free(c, c->idx_t, sizeof(int32_t) * std::max<int64_t>(c->idx_t_n, 1));
+        c->idx_t = nullptr;
+        c->idx_t_n = 0;
+        CNA_FAIL(CNA_EINVAL, "cna_set_halo: the graph block references rows that are neither local nor in the receive list");
+      }
+      c->t_compact = true;
+      c->t_rows = c->n_local + nr;
+      c->t_valid = false;
+      c->cellinfo_valid = false;
+      if (c->sid) {                      // (a plan that arrives after cna_set_samples: size the buffers for the new row space)
+        CNA_TRY(ensure_T(c, c->ld));
+        CNA_TRY(ensure_sparse_state(c));
+      }
+    }
+  }
   return 0;
 }
 
@@ -557,6 +603,13 @@ static int exchange_state(cna_ctx* c, double* T, hipStream_t st = nullptr) {
   if (c->halo_on) {
     const int ld = c->t_ld;
     CNA_TRY(dev_reserve(c, &c->halo_sbuf, &c->halo_sbuf_cap, 8 * std::max<int64_t>(c->halo_ns, 1) * ld));
+    if (c->t_compact) {
+      // the rows that arrive ARE the tail of the state, in the order of the receive list: no staging, no scatter
+      CNA_TRY(launch_pack_rows(c, T, c->halo_send_idx, c->halo_ns, ld, (double*)c->halo_sbuf, st));
+      if (c->halo_ns + c->halo_nr > 0)
+        CNA_TRY(comm_halo_exchange(c, (const double*)c->halo_sbuf, T + c->n_local * (int64_t)ld, ld, st));
+      return 0;
+    }
     CNA_TRY(dev_reserve(c, &c->halo_rbuf, &c->halo_rbuf_cap, 8 * std::max<int64_t>(c->halo_nr, 1) * ld));
     CNA_TRY(launch_pack_rows(c, T + c->row0 * ld, c->halo_send_idx, c->halo_ns, ld, (double*)c->halo_sbuf, st));
     if (c->halo_ns + c->halo_nr > 0)
@@ -755,7 +808,7 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
     const int ld = c->t_ld;
     double* Tn = c->T[c->t_cur ^ 1];
     CNA_TRY(dev_reserve(c, &c->halo_sbuf, &c->halo_sbuf_cap, 8 * std::max<int64_t>(c->halo_ns, 1) * ld));
-    CNA_TRY(dev_reserve(c, &c->halo_rbuf, &c->halo_rbuf_cap, 8 * std::max<int64_t>(c->halo_nr, 1) * ld));
+    if (!c->t_compact) CNA_TRY(dev_reserve(c, &c->halo_rbuf, &c->halo_rbuf_cap, 8 * std::max<int64_t>(c->halo_nr, 1) * ld));
     CNA_TRY(launch_nam_step(c, first, want_kurt != 0, true, may_stop != 0, false, c->halo_rows_b, c->halo_nb));
     HIP_TRY(hipEventRecord(c->halo_e1, c->stream));
     CNA_TRY(launch_nam_step(c, first, want_kurt != 0, true, may_stop != 0, false, c->halo_rows_i, c->halo_ni));

@@ -113,7 +113,15 @@ struct cna_ctx {
   int64_t cellinfo_cap = 0;
   bool cellinfo_valid = false;
 
-  // ---- diffusion state: scaled state T = s/colsums for all global rows (neighbour gathers)
+  // ---- diffusion state: scaled state T = s/colsums.  Rows: every global row (one rank; the all-gather exchange), or --
+  // with the halo exchange (t_compact, round 5; SURVEY 8e: "GPU g owns rows ... of A and of S") -- this rank's n_local
+  // rows followed by the halo rows in the order of halo_recv_idx; the walk steps then read the graph through idx_t,
+  // the column indices renumbered into that row space.
+  bool t_compact = false;
+  int64_t t_rows = 0;            // rows of T (and of sp_cnt) when compact
+  int32_t* idx_t = nullptr;      // nnz: column indices in the compact row space
+  int64_t idx_t_n = 0;
+  int64_t sp_pair_rows = 0;      // rows of sp_pair (pairs exist for this rank's own rows only when compact)
   double* T[2] = {nullptr, nullptr};
   int64_t t_cap = 0;  // doubles allocated per buffer
   int t_cur = 0, t_width = 0, t_ld = 0, steps_done = 0;
@@ -285,6 +293,9 @@ int dev_reserve(cna_ctx* c, void** p, int64_t* cap_bytes, int64_t need_bytes);
 // ---- collectives (comm.hip)
 inline bool comm_active(const cna_ctx* c) { return c->comm != nullptr || c->shm != nullptr; }
 int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t doubles_per_row, hipStream_t st = nullptr);
+// column indices of the local graph block -> rows of the compact state (cna_ctx::t_compact): own rows 0 .. n_local - 1, the
+// rows of the ascending receive list behind them; *bad = 1 when an index is neither (diffuse.hip)
+int launch_remap_indices(cna_ctx* c, const int64_t* recv_rows_dev, int64_t nr, int32_t* out, int* bad);
 int launch_pack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst, hipStream_t st = nullptr);
 int launch_unpack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst, hipStream_t st = nullptr);
 int comm_allreduce_f64_sum(cna_ctx* c, double* buf, size_t count);

@@ -758,6 +758,39 @@ __global__ void k_cellinfo(const double* __restrict__ colsum, const int32_t* __r
   }
 }
 
+// The same records for the rows of the compact state (cna_ctx::t_compact): row t is this rank's row row0 + t, or the
+// (t - n_local)-th row of the receive list.
+__global__ void k_cellinfo_compact(const double* __restrict__ colsum, const int32_t* __restrict__ sid, int64_t row0, int64_t n_local,
+                                   const int64_t* __restrict__ recv_rows, int64_t t_rows, CellInfo* __restrict__ info) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < t_rows) {
+    const int64_t i = t < n_local ? row0 + t : recv_rows[t - n_local];
+    CellInfo ci;
+    ci.inv_colsum = __ddiv_rn(1.0, colsum[i]);
+    ci.sid = sid[i];
+    ci.pad = 0;
+    info[t] = ci;
+  }
+}
+
+// Column indices (global rows) -> rows of the compact state: a local column is its row in the block, any other column its
+// position in the ascending receive list, behind the block.  *bad: some index is neither (the halo plan does not cover
+// the graph block -- cna_set_halo refuses it).
+__global__ void k_remap_idx(const int32_t* __restrict__ idx, int64_t nnz, int64_t row0, int64_t n_local,
+                            const int64_t* __restrict__ recv_rows, int64_t nr, int32_t* __restrict__ out, int* __restrict__ bad) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = idx[e];
+    if (j >= row0 && j < row0 + n_local) { out[e] = (int32_t)(j - row0); continue; }
+    int64_t lo = 0, hi = nr;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (recv_rows[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    if (lo < nr && recv_rows[lo] == j) out[e] = (int32_t)(n_local + lo);
+    else { out[e] = 0; *bad = 1; }
+  }
+}
+
 // ---- column sums, deterministic: colsums = A.sum(axis=0) (_nam.py:28) --------------------------------
 // scipy sums a CSR over axis 0 by walking the rows in ascending order and adding every entry into its
 // column's accumulator: column j receives its entries in ascending (row, position in row) order.  In
@@ -963,7 +996,7 @@ int launch_step_sparse_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t s
 
 // two rows per wave when a row fits a half-wave and byte offsets into the state fit 32 bits
 static bool step_takes_pairs(const cna_ctx* c, bool first, bool sparse, int ld) {
-  return !first && !sparse && ld <= 64 && c->n_pad * (int64_t)ld * 8 < (int64_t)4 << 30 &&
+  return !first && !sparse && ld <= 64 && (c->t_compact ? c->t_rows : c->n_pad) * (int64_t)ld * 8 < (int64_t)4 << 30 &&
          !getenv("CNA_STEP_WIDE");            // (test_two_rows_per_wave_step_matches_wave_per_row compares the two kernels)
 }
 // consecutive workgroups (4 rows each, 8 for the two-rows-per-wave kernel) one XCD takes per turn
@@ -1032,6 +1065,22 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in, hipStream_t st) 
 
 }  // namespace
 
+int launch_remap_indices(cna_ctx* c, const int64_t* recv_rows_dev, int64_t nr, int32_t* out, int* bad) {
+  *bad = 0;
+  if (c->nnz == 0) return 0;
+  int* flag = nullptr;
+  HIP_TRY(hipMalloc(&flag, sizeof(int)));
+  struct Free { int* p; ~Free() { (void)hipFree(p); } } free_flag{flag};
+  HIP_TRY(hipMemsetAsync(flag, 0, sizeof(int), c->stream));
+  const unsigned grid = (unsigned)std::min<int64_t>((c->nnz + 255) / 256, 65536);
+  hipLaunchKernelGGL(k_remap_idx, dim3(grid), dim3(256), 0, c->stream, c->indices, c->nnz, c->row0, c->n_local, recv_rows_dev, nr,
+                     out, flag);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(bad, flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int launch_colsum(cna_ctx* c) {
   ProfScope ps(c, CNA_K_COLSUM);
   HIP_TRY(hipMemsetAsync(c->colsum, 0, sizeof(double) * c->n_pad, c->stream));
@@ -1094,10 +1143,15 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
   hipStream_t st = st_in ? st_in : c->stream;
   if (first && !c->cellinfo_valid) {
     void* p = c->cellinfo;
-    CNA_TRY(dev_reserve(c, &p, &c->cellinfo_cap, (int64_t)sizeof(CellInfo) * c->n_global));
+    const int64_t rows = c->t_compact ? c->t_rows : c->n_global;
+    CNA_TRY(dev_reserve(c, &p, &c->cellinfo_cap, (int64_t)sizeof(CellInfo) * std::max<int64_t>(rows, 1)));
     c->cellinfo = p;
-    hipLaunchKernelGGL(k_cellinfo, dim3((unsigned)((c->n_global + 255) / 256)), dim3(256), 0, st, c->colsum,
-                       c->sid, c->n_global, (CellInfo*)c->cellinfo);
+    if (c->t_compact)
+      hipLaunchKernelGGL(k_cellinfo_compact, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, c->colsum, c->sid, c->row0,
+                         c->n_local, c->halo_recv_idx, rows, (CellInfo*)c->cellinfo);
+    else
+      hipLaunchKernelGGL(k_cellinfo, dim3((unsigned)((c->n_global + 255) / 256)), dim3(256), 0, st, c->colsum,
+                         c->sid, c->n_global, (CellInfo*)c->cellinfo);
     HIP_TRY(hipGetLastError());
     c->cellinfo_valid = true;
   }
@@ -1118,6 +1172,15 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
   a.n_local = rows ? n_rows : c->n_local;
   a.rows = rows;
   a.row0 = c->row0;
+  if (c->t_compact) {
+    // compact row space: the state, the pairs and the cell records are numbered from this rank's first row, and the
+    // graph is read through the renumbered column indices; the two arrays that stay global (column sums, per-cell
+    // statistic) are handed over shifted by row0 -- the kernels see a block that starts at row 0
+    a.idx = c->idx_t;
+    a.row0 = 0;
+    a.colsum = c->colsum + c->row0;
+    a.stat = c->stat ? c->stat + c->row0 : nullptr;
+  }
   a.width = c->t_width;
   a.ld = c->t_ld;
   a.w = c->self_weight;
@@ -1171,8 +1234,10 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
 int launch_scale_rows(cna_ctx* c, const double* s_local, double* t_global, int m, int ld) {
   const int64_t tot = c->n_local * ld;
   if (tot == 0) return 0;
+  // (compact row space: the block's rows are the first rows of the state)
   hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, c->stream,
-                     s_local, c->colsum, t_global, c->dense_s, c->n_local, c->row0, m, ld);
+                     s_local, c->t_compact ? c->colsum + c->row0 : c->colsum, t_global, c->dense_s, c->n_local,
+                     c->t_compact ? (int64_t)0 : c->row0, m, ld);
   HIP_TRY(hipGetLastError());
   return 0;
 }

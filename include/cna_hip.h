@@ -87,7 +87,11 @@ int  cna_comm_selftest(cna_ctx* ctx, double timeout_s, int* halo_ok);
  * destination rank (send_counts[nranks]); recv_rows = GLOBAL row indices this rank's cells
  * reference outside its block, grouped by owner rank (recv_counts[nranks]); the lists of two
  * peers must mirror each other.  NULL counts (and every cna_graph_upload) switch back to the
- * all-gather.  The walk itself is the reference's (_nam.py:31-34); only the data motion differs. */
+ * all-gather.  The walk itself is the reference's (_nam.py:31-34); only the data motion differs.
+ * With ascending recv_rows that cover every foreign column of the block (the plan of cna_amd._order.halo_plan) the
+ * diffusion state then holds n_local + sum(recv_counts) rows instead of n_global -- this rank's rows and, behind them,
+ * the rows it receives, which land there directly (a rank owns its rows of A and of S); a block that
+ * references a row outside both is refused (CNA_EINVAL).  CNA_COMPACT_STATE=0 keeps the global row space. */
 int  cna_set_halo(cna_ctx* ctx, const int64_t* send_rows, const int64_t* send_counts,
                   const int64_t* recv_rows, const int64_t* recv_counts);
 

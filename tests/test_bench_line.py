@@ -25,7 +25,7 @@ def stub_measurement(name, steps):
     return dict(name=name, n=n, N=N, k=k, nsteps=nsteps, Nnull=Nnull, n_covs=n_covs, n_batches=n_batches, nnz=int(40.23 * n), wA=4,
                 dt=0.0178123456 * steps, t_cold=0.1084321, i8=(True, 75192, False), t_gen=5.04321, prof=prof, p=0.000999000999000999,
                 t_adopt=0.0828765, n_loc=n, nnz_loc=int(40.23 * n), halo=(123456, 234567), sharded_inputs=True, steps=steps, warmup=5,
-                comm=('rccl', 8), halo_comm=True, kw={})
+                comm=('rccl', 8), halo_comm=True, kw={}, dev_bytes=20123456789)
 
 
 def build_line(world=1):

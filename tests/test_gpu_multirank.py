@@ -195,6 +195,8 @@ def _sparse_worker(rank, world, seg, q):
                    sparse=prof.get('nam_step_sparse', (0, 0))[1], dense=prof.get('nam_step', (0, 0))[1],
                    select=prof.get('select', (0, 0))[1], fdr=res.fdrs.fdr.values, num=res.fdrs.num_detected.values)
         out['nam'] = res.nam.values           # (last: with the selection by-product the raw NAM is one more dense launch)
+        out['bytes'] = eng.device_bytes()
+        out['rows'] = (eng.row0, eng.n_local)
         eng.close()
         q.put((rank, out))
     except BaseException as e:
@@ -249,6 +251,50 @@ def test_compressed_second_step_across_ranks(world, defer, monkeypatch):
         np.testing.assert_allclose(g['fdr'], one['fdr'], rtol=1e-9, atol=1e-13, equal_nan=True)
         assert g['k'] == one['k'] and g['p'] == pytest.approx(one['p'], rel=1e-12)
         np.testing.assert_allclose(g['ncorrs'], one['ncorrs'], rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_state_for_local_and_halo_rows_only(world, monkeypatch):
+    """a rank owns its rows of the graph AND of the state.  With the halo exchange the diffusion state holds
+    this rank's rows followed by the rows it receives (csrc/c_api.hip:cna_set_halo, `t_compact`), the walk reads the graph
+    through column indices renumbered into that row space, and what arrives lands in the tail directly.  Same bits as the
+    global row space (CNA_COMPACT_STATE=0) and as one GPU; and the device memory of a rank shrinks with the block."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    results = {}
+    for mode in ('1', '0'):
+        monkeypatch.setenv('CNA_COMPACT_STATE', mode)
+        q = ctx.Queue()
+        seg = 'cna_ct_%d_%s_%d' % (os.getpid(), mode, world)
+        procs = [ctx.Process(target=_sparse_worker, args=(r, world, seg, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = {}
+        try:
+            for _ in range(world):
+                r, out = q.get(timeout=240)
+                assert not isinstance(out, str), out
+                got[r] = out
+        finally:
+            for p in procs:
+                p.join(timeout=30)
+                if p.is_alive():
+                    p.kill()
+        results[mode] = got
+    for r in range(world):
+        a, b = results['1'][r], results['0'][r]
+        assert a['halo'] is not None and a['halo'][1] > 0 and a['halo'] == b['halo']
+        np.testing.assert_array_equal(a['nam'], b['nam'])
+        np.testing.assert_array_equal(a['num'], b['num'])
+        np.testing.assert_array_equal(a['ncorrs'], b['ncorrs'])
+        np.testing.assert_array_equal(a['fdr'], b['fdr'])
+        assert a['p'] == b['p'] and a['k'] == b['k'] and a['sparse'] == b['sparse'] and a['dense'] == b['dense']
+        # the state (two buffers of 8 x 120 bytes per row) and the pairs (1 KB per row) are what a rank holds per cell of
+        # the whole problem in the global row space: 9000 rows there, n_local + halo here
+        n_state = a['rows'][1] + a['halo'][1]
+        saved = b['bytes'] - a['bytes']
+        want = (9000 - n_state) * 2 * 8 * 120 + (9000 - a['rows'][1]) * 1024
+        assert saved > 0.8 * want, (saved, want, a['bytes'], b['bytes'])
 
 
 def _shard_worker(rank, world, seg, name, q):
