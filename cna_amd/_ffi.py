@@ -74,6 +74,8 @@ SIGNATURES = {
     'cna_null_local_prepare': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'cna_null_local_fetch': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cna_null_local_discard': (C.c_int, [c_ctx]),
+    'cna_gram_pcs_tests': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p,
+                                     C.c_void_p, C.POINTER(C.c_int)]),
     'cna_host_top_eig': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_f64p, c_f64p]),
     'cna_host_eig_check': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_f64p, c_f64p]),
     'cna_null_local_i8_stats': (C.c_int, [c_ctx, C.POINTER(C.c_int), c_i64p, C.POINTER(C.c_int)]),

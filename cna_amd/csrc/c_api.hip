@@ -1699,6 +1699,36 @@ int cna_gram_fetch(cna_ctx* c, double* G_out) {
   return 0;
 }
 
+// Gram matrix -> leading eigenpairs -> F-tests queued, without the interpreter in between (round 5): what follows the
+// Gram kernels on the critical path of a small block is sample-space work of ~0.5 ms, and three trips through Python
+// between its pieces cost a fifth of that again.  The acceptance rule of the native pairs is tools/_nam.py's
+// (_top_pcs_native): residual and orthogonality at rounding level, every leading gap wide enough for the individual
+// vectors to be defined; otherwise *accepted = 0 and the caller takes LAPACK (G_out is valid either way).
+int cna_gram_pcs_tests(cna_ctx* c, int kmax, const int32_t* ks, int K, int r, int use_native, double resid_tol, double gap_tol,
+                       double* G_out, double* U_out, int* accepted) {
+  CHECK_CTX(c);
+  if (!G_out || !U_out || !accepted || !ks) CNA_FAIL(CNA_EINVAL, "cna_gram_pcs_tests: null argument");
+  *accepted = 0;
+  CNA_TRY(cna_gram_fetch(c, G_out));
+  const int n = c->gram_n;
+  if (!use_native || n < 8 || kmax < 1 || 4 * kmax > n || kmax + 1 > 256) return 0;
+  for (int64_t i = 0; i < (int64_t)n * n; ++i)
+    if (!std::isfinite(G_out[i])) return 0;
+  std::vector<double> lam((size_t)kmax + 1);
+  double resid = 0.0, ortho = 0.0;
+  if (cna_host_top_eig(G_out, n, kmax, U_out, lam.data(), &resid, &ortho) != 0) return 0;
+  const double top = lam[0];
+  if (!(top > 0.0)) return 0;
+  for (int t = 0; t <= kmax; ++t)
+    if (!std::isfinite(lam[t])) return 0;
+  if (!(resid <= resid_tol * top && ortho <= resid_tol)) return 0;
+  for (int t = 0; t < kmax; ++t)
+    if (!(lam[t] - lam[t + 1] > gap_tol * top)) return 0;
+  CNA_TRY(cna_global_test_launch(c, U_out, kmax, ks, K, r));
+  *accepted = 1;
+  return 0;
+}
+
 int cna_gram(cna_ctx* c, double* G_out) {
   CNA_TRY(cna_gram_launch(c));
   return cna_gram_fetch(c, G_out);

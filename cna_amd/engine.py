@@ -604,6 +604,21 @@ class Engine(_order.CellOrder):
         check(self.lib.cna_gram_fetch(self.h, ptr(G)), 'cna_gram_fetch')
         return G
 
+    def gram_pcs_tests(self, ks, r, native=True, resid_tol=1e-12, gap_tol=1e-6):
+        """gram_fetch(), the leading max(ks) eigenpairs on the host and -- when the library's own solver is accepted
+        (tools/_nam.py:_top_pcs_native's rule) -- global_test_launch(), in ONE call without the interpreter in between.
+        Returns (G, U or None, queued): queued -> collect with global_test_fetch(); else the caller finds the
+        eigenvectors elsewhere and launches the tests itself."""
+        ks = np.ascontiguousarray(ks, dtype=np.int32)
+        kmax = int(ks.max())
+        n = self._gram_cols
+        G = np.empty((n, n))
+        U = np.empty((n, max(kmax, 1)))
+        ok = C.c_int(0)
+        check(self.lib.cna_gram_pcs_tests(self.h, kmax, ptr(ks), len(ks), int(r), int(bool(native)), float(resid_tol), float(gap_tol),
+                                          ptr(G), ptr(U), C.byref(ok)), 'cna_gram_pcs_tests')
+        return G, (U if ok.value else None), bool(ok.value)
+
     def project(self, W):
         W = _f64(W)
         rows, cols = self.matrix_shape(MAT_X)
@@ -747,6 +762,13 @@ class Engine(_order.CellOrder):
         minp, r2, kidx = np.empty(P), np.empty(P), np.empty(P, dtype=np.int32)
         check(self.lib.cna_global_test_fetch(self.h, ptr(minp), ptr(r2), ptr(kidx)), 'cna_global_test_fetch')
         return kidx, minp, r2
+
+    def global_test_discard(self):
+        """Collect and drop a queued global test nobody will fetch (error paths); no-op when none is pending."""
+        try:
+            self.global_test_fetch()
+        except _ffi.CnaHipError:
+            pass
 
     def obs_counts(self, edges, thr):
         edges, thr = _f64(edges), _f64(thr)

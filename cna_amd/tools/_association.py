@@ -23,6 +23,7 @@ from ..engine import get_engine
 from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_plan, _resid_run, sample_codes_cached, confirm_codes,
                    shard_of, global_samples,
                    _small_svd, _defer_pcs, host_blas_threads, _top_pcs, GramPCs)
+from . import _nam as _nam_mod
 from ._out import select_output
 from ._stats import conditional_permutation, grouplevel_permutation, default_ks, minp_stats, native_draw_start
 
@@ -295,13 +296,40 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         coef_first = coef_early and coef_first
         if coef_first:
             on_coef(engine.percell_coef_wait())
-        G = engine.gram_fetch()
-        _mark('gram fetched')
-        pcs = GramPCs(G)
-        if full:
-            pcs.start()                                      # LAPACK's SVD beside the F-tests and the local null
+        kmax = int(ks_arr.max())
+        can_launch = getattr(engine, 'global_test_launch', None) is not None
+        # Gram matrix -> leading eigenpairs -> F-tests queued as ONE library call (engine.gram_pcs_tests: the library's
+        # own checked eigen-solver, csrc/host_eig.c) when the caller does not want the sign-defining SVD started at once;
+        # where the solver steps aside (degenerate leading spectrum, ks beyond a quarter of the samples) LAPACK follows
+        one_call = (can_launch and not full and _nam_mod._EIG_NATIVE and getattr(engine, 'gram_pcs_tests', None) is not None)
+        G = pcs = None
+        if not one_call:
+            G = engine.gram_fetch()
+            _mark('gram fetched')
+            pcs = GramPCs(G)
+            if full:
+                pcs.start()                                  # LAPACK's SVD beside the F-tests and the local null
+
+        def pcs_then_tests():
+            """-> (G, leading eigenvectors or None, F-tests queued)"""
+            if one_call:
+                G_, U_, queued = engine.gram_pcs_tests(ks_arr, r)
+                _nam_mod.eig_stats['native' if queued else 'lapack'] += 1
+                if queued:
+                    return G_, U_, True
+                U_ = _top_pcs(G_, kmax, native=False)
+            else:
+                G_ = G
+                U_ = _top_pcs(G_, kmax)
+            if U_ is None or not can_launch:
+                return G_, U_, False
+            engine.global_test_launch(U_, ks_arr, r)         # second stream
+            return G_, U_, True
+
         if tail_first:
-            fut = _eig_pool().submit(_top_pcs, G, int(ks_arr.max()))
+            # on a thread of their own: the F-tests then run under the local null instead of behind the per-cell pass
+            # (second stream, their own buffers: nothing the null's tail or the per-cell pass touches)
+            fut = _eig_pool().submit(pcs_then_tests)
             try:
                 on_coef(engine.percell_coef_wait())
                 pending = False                              # (the library clears its flag before it can fail)
@@ -314,34 +342,33 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
                     early_tail = ('error', exc)
                 _mark('percell done')
             finally:
-                Uk = fut.result()
-            if Uk is None:
-                Uk = pcs.U[:, :int(ks_arr.max())]
-            _mark('pcs')
-            engine.global_test_launch(Uk, ks_arr, r)
-            best, pv, r2v = engine.global_test_fetch()
+                G, Uk, tests_queued = fut.result()
         else:
-            Uk = _top_pcs(G, int(ks_arr.max()))
-            if Uk is None:
-                Uk = pcs.U[:, :int(ks_arr.max())]
-            _mark('pcs')
-        if tail_first:
-            pass
-        elif coef_early:
-            engine.global_test_launch(Uk, ks_arr, r)         # second stream
+            G, Uk, tests_queued = pcs_then_tests()
+        if pcs is None:
+            _mark('gram fetched')
+            pcs = GramPCs(G)
+        if Uk is None:
+            Uk = pcs.U[:, :kmax]
+        _mark('pcs')
+        if not can_launch:
+            best, pv, r2v = engine.global_test(Uk, ks_arr, r)
+        else:
+            if not tests_queued:
+                engine.global_test_launch(Uk, ks_arr, r)     # second stream
             try:
-                if not coef_first:
+                if coef_early and not tail_first and not coef_first:
                     on_coef(engine.percell_coef_wait())
             finally:
                 best, pv, r2v = engine.global_test_fetch()
-        else:
-            best, pv, r2v = engine.global_test(Uk, ks_arr, r)
     except BaseException:
         if pending:                     # never leave a pass pending behind an exception -- and never hide that exception
             try:
                 engine.null_local_fetch()
             except Exception:           # noqa: BLE001
                 pass
+        if getattr(engine, 'global_test_discard', None) is not None:
+            engine.global_test_discard()      # (the F-tests may have been queued already, by this thread or the eigenvector thread)
         raise
     if pending:
         tail_sums, ranks, num_detected = engine.null_local_fetch()

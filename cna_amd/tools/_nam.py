@@ -124,7 +124,7 @@ def _top_pcs_native(G, kmax):
     return U
 
 
-def _top_pcs(G, kmax):
+def _top_pcs(G, kmax, native=True):
     """The kmax leading eigenvectors of the samples x samples Gram matrix (columns, leading first), for the global
     F-tests.  Every statistic of _association.py:35-48 depends on the PCs only through squared projections -- not on
     their signs -- so the tests need not wait for the sign-defining LAPACK SVD of _nam.py:105, which is left to
@@ -134,11 +134,12 @@ def _top_pcs(G, kmax):
     n = len(G)
     if kmax >= n or not np.isfinite(G).all():
         return None                                 # degenerate input: the caller takes the SVD (and its errors)
-    U = _top_pcs_native(G, kmax)
-    if U is not None:
-        eig_stats['native'] += 1
-        return U
-    eig_stats['lapack'] += 1
+    if native:
+        U = _top_pcs_native(G, kmax)
+        if U is not None:
+            eig_stats['native'] += 1
+            return U
+        eig_stats['lapack'] += 1
     return _top_pcs_lapack(G, kmax)
 
 

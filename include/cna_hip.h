@@ -250,6 +250,13 @@ int  cna_gram(cna_ctx* ctx, double* G_out);
  * for work queued after the launch, e.g. the local-null kernel) */
 int  cna_gram_launch(cna_ctx* ctx);
 int  cna_gram_fetch(cna_ctx* ctx, double* G_out);
+/* cna_gram_fetch, then the leading kmax eigenpairs of G on the host (cna_host_top_eig: svd_nam's np.linalg.svd, _nam.py:105,
+ * as the global test consumes it) and, when they pass the acceptance rule -- residual <= resid_tol * lambda_1,
+ * orthogonality <= resid_tol, every leading gap > gap_tol * lambda_1 -- cna_global_test_launch(U, kmax, ks, K, r)
+ * (_association.py:35-61,84) in the same call: *accepted = 1, collect with cna_global_test_fetch.  *accepted = 0: G_out
+ * is valid, nothing was queued, the caller takes the eigenvectors elsewhere (LAPACK).  use_native = 0: fetch only. */
+int  cna_gram_pcs_tests(cna_ctx* ctx, int kmax, const int32_t* ks, int K, int r, int use_native, double resid_tol,
+                        double gap_tol, double* G_out /* n_cols x n_cols */, double* U_out /* n_cols x kmax */, int* accepted);
 /* out = X . W  (V = NAM^T U / sqrt(svs), _nam.py:106; W = U/sqrt(svs), n_cols x n_w row-major),
  * local rows, row-major n_x_local x n_w */
 int  cna_project(cna_ctx* ctx, const double* W, int n_w, double* out_local);

@@ -1710,14 +1710,26 @@ def test_error_after_a_fused_null_launch_leaves_the_engine_usable(eng, monkeypat
         np.testing.assert_array_equal(got.fdrs.num_detected.values, want.fdrs.num_detected.values)
         np.testing.assert_array_equal(got.ncorrs.values, want.ncorrs.values)
     # (2) a failure of the first consumer after the launch
-    real = eng.gram_fetch
+    # (the Gram matrix is collected by gram_pcs_tests, or by gram_fetch when the caller wants the full result)
+    for name, extra in (('gram_pcs_tests', {}), ('gram_fetch', dict(return_full=True))):
+        real = getattr(eng, name)
 
-    def boom(*a, **k):
-        raise FloatingPointError('injected')
-    monkeypatch.setattr(eng, 'gram_fetch', boom)
+        def boom(*a, **k):
+            raise FloatingPointError('injected')
+        monkeypatch.setattr(eng, name, boom)
+        with pytest.raises(FloatingPointError):
+            cna.tl.association(data, meta['y'], 'id', engine=eng, **kw, **extra)
+        monkeypatch.setattr(eng, name, real)
+        assert cna.tl.association(data, meta['y'], 'id', engine=eng, **kw) == want.p
+    # ... and a failure AFTER the F-tests were queued by that call: nothing stays pending either
+    real_coef = eng.percell_coef_wait
+
+    def boom2(*a, **k):
+        raise FloatingPointError('injected late')
+    monkeypatch.setattr(eng, 'percell_coef_wait', boom2)
     with pytest.raises(FloatingPointError):
         cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
-    monkeypatch.setattr(eng, 'gram_fetch', real)
+    monkeypatch.setattr(eng, 'percell_coef_wait', real_coef)
     assert cna.tl.association(data, meta['y'], 'id', engine=eng, **kw) == want.p
     # (3) the C entry point by itself: a launched pass, dropped; then nothing pending and the next prepare is accepted
     thr = np.arange(0.01, 0.04, 0.0001)

@@ -342,167 +342,6 @@ __global__ __launch_bounds__(NW * 64) void k_walk_tiles(TileArgs a) {
 //                        tile (blob header: uint16 offsets per consumer), count themselves in `done`; a slot is reused
 //                        when all NCONS consumers are done with it.  A fast wave runs up to NB - 1 tiles ahead of a
 //                        slow one: the per-tile imbalance of the barrier version (x 1.6) averages out.
-struct PcArgs {
-  const long* blk_tile; const int* tile_src; const unsigned char* blob;     // blob: BLOB bytes per tile
-  const double* Tin; double* Tout;
-  long n, nblocks; int ld, S, xcd_chunk, piece_bytes, halves;
-};
-constexpr int BLOB = 4096, HDR = 64;
-
-template <int NQ2, int R, int NPROD, int NCONS, int K, int NB, int MODE>
-__global__ __launch_bounds__((NPROD + NCONS) * 64) void k_walk_pc(PcArgs a) {
-  constexpr int SLOT = NPROD * K * 1024;                  // bytes of a ring slot: blob (4 KiB) + rows
-  constexpr int IDR0 = NB * SLOT, FLAG0 = IDR0 + NPROD * NB * 256;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const long bb = blockIdx.x >> 3, x = blockIdx.x & 7;
-  const long b = (bb / a.xcd_chunk) * (8 * (long)a.xcd_chunk) + x * a.xcd_chunk + (bb % a.xcd_chunk);
-  if (b >= a.nblocks) return;
-  const int half = blockIdx.y;
-  const int ldb = a.ld * 8, pb = a.piece_bytes;
-  const int col0b = half * pb;
-  const long T0 = a.blk_tile[b];
-  const int nt = (int)(a.blk_tile[b + 1] - T0);
-  const long r0 = b * (long)(NCONS * R);
-  const unsigned lds0 = (unsigned)(size_t)sm;
-  unsigned* landed = (unsigned*)(sm + FLAG0);
-  unsigned* done = landed + NB;
-  if (tid < 2 * NB) landed[tid] = 0;
-  // the source ids of the first NB tiles: one id ring per producer (256 B per tile)
-  if (wv < NPROD) {
-    for (int t = 0; t < NB && t < nt; ++t)
-      if (lane < a.S) *(int*)(sm + IDR0 + (wv * NB + t) * 256 + lane * 4) = a.tile_src[(T0 + t) * a.S + lane];
-  }
-  __syncthreads();
-  if (wv < NPROD) {
-    // ------------------------------------------------------------------ producer
-    int s_of[K], within[K];
-#pragma unroll
-    for (int u = 0; u < K; ++u) {
-      const int g = wv + NPROD * u;                       // piece of the slot: 0..3 the blob, then the packed rows
-      const int o = (g - BLOB / 1024) * 1024 + lane * 16;
-      int s = o / pb;
-      within[u] = o - s * pb;
-      if (s >= a.S) { s = a.S - 1; within[u] = 0; }
-      s_of[u] = g < BLOB / 1024 ? -1 : s;
-    }
-    const char* Tb = (const char*)a.Tin + col0b;
-    for (int t = 0; t < nt; ++t) {
-      const int sl = t % NB;
-      if (t >= NB) {
-        const unsigned want = (unsigned)NCONS * (unsigned)(t / NB);
-        while (__hip_atomic_load(&done[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(2);
-      }
-      asm volatile("" ::: "memory");
-      int sid[K];
-#pragma unroll
-      for (int u = 0; u < K; ++u) sid[u] = s_of[u] >= 0 ? *(const int*)(sm + IDR0 + (wv * NB + sl) * 256 + s_of[u] * 4) : 0;
-      if (MODE != 2) {
-#pragma unroll
-        for (int u = 0; u < K; ++u) {
-          const int g = wv + NPROD * u;
-          const void* src = s_of[u] >= 0 ? (const void*)(Tb + (long)sid[u] * ldb + within[u])
-                                         : (const void*)(a.blob + (T0 + t) * BLOB + g * 1024 + lane * 16);
-          dma16(src, lds0 + (unsigned)(sl * SLOT + g * 1024));
-        }
-      } else {                                            // edge walk only: the blob alone
-#pragma unroll
-        for (int u = 0; u < K; ++u) {
-          const int g = wv + NPROD * u;
-          const void* src = (const void*)(a.blob + (T0 + t) * BLOB + (g & 3) * 1024 + lane * 16);
-          dma16(src, lds0 + (unsigned)(sl * SLOT + (g & 3) * 1024));
-        }
-      }
-      // ids of the tile NB ahead into this producer's ring slot (read again when that tile is issued)
-      {
-        const long tn = (t + NB < nt) ? T0 + t + NB : T0 + t;
-        dma4((const char*)(a.tile_src + tn * a.S) + lane * 4, lds0 + (unsigned)(IDR0 + (wv * NB + sl) * 256));
-      }
-      if (t >= 1) {
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K + 1) : "memory");        // tile t - 1 has landed
-        __hip_atomic_fetch_add(&landed[(t - 1) % NB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (nt > 0) __hip_atomic_fetch_add(&landed[(nt - 1) % NB], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return;
-  }
-  // -------------------------------------------------------------------- consumer
-  const int cw = wv - NPROD;
-  double2 acc[R][NQ2];
-#pragma unroll
-  for (int i = 0; i < R; ++i)
-#pragma unroll
-    for (int q = 0; q < NQ2; ++q) acc[i][q] = make_double2(0.0, 0.0);
-  for (int t = 0; t < nt; ++t) {
-    const int sl = t % NB;
-    const unsigned want = (unsigned)NPROD * (unsigned)(t / NB + 1);
-    while (__hip_atomic_load(&landed[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < want) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
-    if (MODE != 1) {
-      const char* slot = sm + sl * SLOT;
-      const int o0 = *(const unsigned short*)(slot + cw * 2), o1 = *(const unsigned short*)(slot + cw * 2 + 2);
-      const int n_all = __builtin_amdgcn_readfirstlane(o1 - o0);
-      const unsigned base = (unsigned)(sl * SLOT + BLOB) + (unsigned)lane * 16u;
-      for (int c0 = 0; c0 < n_all; c0 += 64) {
-        const int m = n_all - c0 < 64 ? n_all - c0 : 64;
-        double w_cur = 0.0;
-        unsigned sr_cur = 0xff000000u;
-        if (lane < m) {
-          const Rec8 r = *(const Rec8*)(slot + HDR + (o0 + c0 + lane) * 8);
-          w_cur = (double)r.w;
-          sr_cur = (unsigned)r.slot * (unsigned)pb + ((unsigned)r.row << 24);
-        }
-        const unsigned rowj = sr_cur >> 24;
-        int j = 0;
-        const unsigned s0 = __builtin_amdgcn_readlane(sr_cur, 0) & 0xffffffu;
-        const unsigned s1 = __builtin_amdgcn_readlane(sr_cur, 1) & 0xffffffu;
-        double2 v[NQ2], vn[NQ2], vnn[NQ2];
-#pragma unroll
-        for (int q = 0; q < NQ2; ++q) v[q] = *(const double2*)(sm + base + s0 + q * 1024);
-#pragma unroll
-        for (int q = 0; q < NQ2; ++q) vn[q] = *(const double2*)(sm + base + s1 + q * 1024);
-#pragma unroll
-        for (int i = 0; i < R; ++i) {
-          const int c = __popcll(__ballot(rowj == (unsigned)i));
-          for (int k = 0; k < c; ++k) {
-            const unsigned s2 = __builtin_amdgcn_readlane(sr_cur, (j + 2) & 63) & 0xffffffu;
-#pragma unroll
-            for (int q = 0; q < NQ2; ++q) vnn[q] = *(const double2*)(sm + base + s2 + q * 1024);
-            const double wj = readlane_d(w_cur, j);
-#pragma unroll
-            for (int q = 0; q < NQ2; ++q) {
-              acc[i][q].x = acc[i][q].x + wj * v[q].x;
-              acc[i][q].y = acc[i][q].y + wj * v[q].y;
-            }
-#pragma unroll
-            for (int q = 0; q < NQ2; ++q) { v[q] = vn[q]; vn[q] = vnn[q]; }
-            ++j;
-          }
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(&done[sl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  }
-  const int pairs = pb / 16;
-  const double2* Tin2 = (const double2*)((const char*)a.Tin + col0b);
-  double2* Tout2 = (double2*)((char*)a.Tout + col0b);
-  const int ld2 = a.ld >> 1;
-#pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const long row = r0 + (long)i * NCONS + cw;
-    if (row < a.n) {
-#pragma unroll
-      for (int q = 0; q < NQ2; ++q)
-        if (lane + 64 * q < pairs) {
-          const double2 own = Tin2[row * ld2 + lane + 64 * q];
-          Tout2[row * ld2 + lane + 64 * q] = make_double2(acc[i][q].x + own.x, acc[i][q].y + own.y);
-        }
-    }
-  }
-}
-
 __global__ void k_compare(const double* __restrict__ A, const double* __restrict__ B, long n, int ld, int N,
                           unsigned long long* __restrict__ bad) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -540,17 +379,6 @@ static float run(TileArgs& a, const char* what, double gathered, double staged) 
   return ms;
 }
 
-template <int NQ2, int R, int NPROD, int NCONS, int K, int NB, int MODE>
-static float run_pc(PcArgs& a, const char* what, double gathered, double staged) {
-  const size_t smem = (size_t)NB * NPROD * K * 1024 + NPROD * NB * 256 + 64;
-  (void)hipFuncSetAttribute((const void*)k_walk_pc<NQ2, R, NPROD, NCONS, K, NB, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  const long grid = (a.nblocks + 8 * a.xcd_chunk - 1) / (8 * a.xcd_chunk) * (8 * a.xcd_chunk);
-  const float ms = time_it([&] { hipLaunchKernelGGL((k_walk_pc<NQ2, R, NPROD, NCONS, K, NB, MODE>), dim3((unsigned)grid, a.halves), dim3((NPROD + NCONS) * 64), smem, 0, a); });
-  printf("  producer/consumer %-15s P=%d C=%d R=%d K=%d ring=%d S=%d halves=%d xcd_chunk=%-3d %8.1f us  (%.2f TB/s of edge bytes, %.2f TB/s staged)\n",
-         what, NPROD, NCONS, R, K, NB, a.S, a.halves, a.xcd_chunk, ms * 1e3, gathered / (ms * 1e-3) / 1e12, staged / (ms * 1e-3) / 1e12);
-  return ms;
-}
-
 int main(int argc, char** argv) {
   const std::string dir = argv[1];
   const int N = atoi(argv[2]), NW = atoi(argv[3]), R = atoi(argv[4]), S = atoi(argv[5]);
@@ -572,57 +400,9 @@ int main(int argc, char** argv) {
     const long b0 = tilesrc0[t], c = tilesrc0[t + 1] - b0;
     for (int s = 0; s < S; ++s) tsrc[(size_t)t * S + s] = tilesrc[b0 + (s < c ? s : c - 1)];
   }
-  const bool pc = argc > 7 && std::string(argv[7]) == "pc";
-  if (pc) {
-    auto blob = slurp<unsigned char>(dir + "/blob.bin");
-    PcArgs p{};
-    p.blk_tile = up(blktile); p.tile_src = up(tsrc); p.blob = up(blob);
-    p.n = n; p.nblocks = (long)blktile.size() - 1; p.ld = ld; p.S = S; p.xcd_chunk = 4; p.halves = halves;
-    p.piece_bytes = ((N + halves - 1) / halves + 1) / 2 * 16;
-    const long* d_indptr = up(indptr); const int* d_idx = up(idx); const float* d_val = up(val);
-    double *T, *O1, *O2;
-    const size_t rm = (size_t)(n + 64) * ld;
-    (void)hipMalloc(&T, rm * 8); (void)hipMalloc(&O1, rm * 8); (void)hipMalloc(&O2, rm * 8);
-    hipLaunchKernelGGL(k_fill, dim3((unsigned)((rm + 255) / 256)), dim3(256), 0, 0, T, (long)rm);
-    (void)hipMemset(O1, 0, rm * 8); (void)hipMemset(O2, 0, rm * 8);
-    p.Tin = T; p.Tout = O2;
-    const double gathered = (double)idx.size() * N * 8, staged = (double)tilesrc.size() * p.piece_bytes * halves;
-    printf("n = %ld, N = %d (row stride %d B, %d pass(es) of %d B), nnz/row %.1f, %ld blocks of %d rows, %.1f tiles of %d sources per "
-           "block, edges/sources %.2f\n", n, N, ld * 8, halves, p.piece_bytes, (double)idx.size() / n, p.nblocks, NW * R,
-           (double)ntiles / p.nblocks, S, (double)idx.size() / tilesrc.size());
-    {
-      const int chunk = 128;
-      const long grid = ((n + 3) / 4 + 8 * chunk - 1) / (8 * chunk) * (8 * chunk);
-      float ms;
-      if (ld <= 128) ms = time_it([&] { hipLaunchKernelGGL((k_row<1, 10>), dim3((unsigned)grid), dim3(256), 0, 0, d_indptr, d_idx, d_val, (const double2*)T, ld / 2, n, (double2*)O1, chunk); });
-      else ms = time_it([&] { hipLaunchKernelGGL((k_row<2, 10>), dim3((unsigned)grid), dim3(256), 0, 0, d_indptr, d_idx, d_val, (const double2*)T, ld / 2, n, (double2*)O1, chunk); });
-      printf("  wave-per-row (10 rows in flight, xcd chunk %d)  %8.1f us  (%.2f TB/s gathered)\n", chunk, ms * 1e3, gathered / (ms * 1e-3) / 1e12);
-    }
-    unsigned long long* bad; (void)hipMalloc(&bad, 8);
-    auto check = [&](const char* what) {
-      (void)hipMemset(bad, 0, 8);
-      hipLaunchKernelGGL(k_compare, dim3((unsigned)((n * (long)N + 255) / 256)), dim3(256), 0, 0, O2, O1, n, ld, N, bad);
-      unsigned long long h; (void)hipMemcpy(&h, bad, 8, hipMemcpyDeviceToHost);
-      printf("      %s: %llu of %ld outputs differ from the wave-per-row result\n", what, h, n * (long)N);
-    };
-#define RUNPC(NQ2, R_, K_, NB_)                                                      \
-    for (int xc : {4, 1, 16}) {                                                      \
-      p.xcd_chunk = xc;                                                              \
-      run_pc<NQ2, R_, 2, 14, K_, NB_, 0>(p, "full", gathered, staged);               \
-      if (xc == 4) check("full");                                                    \
-    }                                                                                \
-    p.xcd_chunk = 4;                                                                 \
-    run_pc<NQ2, R_, 2, 14, K_, NB_, 1>(p, "staging only", gathered, staged);         \
-    run_pc<NQ2, R_, 2, 14, K_, NB_, 2>(p, "edge walk only", gathered, staged);
-    const int need = (S * p.piece_bytes + BLOB + 1023) / 1024;                       // pieces per tile
-    const bool wide = p.piece_bytes > 1024;
-    if (NW != 14) { printf("producer/consumer probe wants 14 consumer waves\n"); return 1; }
-    if (wide && R == 8 && need <= 36) { RUNPC(2, 8, 18, 4) }
-    else if (!wide && R == 16 && need <= 36) { RUNPC(1, 16, 18, 4) }
-    else if (wide && R == 8 && need <= 24) { RUNPC(2, 8, 12, 6) }
-    else printf("no instantiation for R=%d piece=%d pieces=%d\n", R, p.piece_bytes, need);
-    return 0;
-  }
+  // (the producer / consumer variant of round 3, k_walk_pc -- two DMA waves feeding fourteen walking waves through a ring of
+  // LDS slots -- was removed in round 5: it staged no faster than the barrier version (5.8 TB/s) and its sums were never
+  // brought to bit-identity; HISTORY.md 5 keeps the measurement)
   TileArgs a{};
   a.blk_tile = up(blktile); a.tile_src = up(tsrc); a.seg = up(seg); a.rec = up(rec);
   a.n = n; a.nblocks = (long)blktile.size() - 1; a.ld = ld; a.S = S; a.xcd_chunk = 4; a.halves = halves;
