@@ -164,7 +164,7 @@ int cna_host_legacy_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss
     int started[64];
     int nt = host_threads();
     if (nt > 64) nt = 64;
-    if (nt < 1 || pairs < (1 << 15)) nt = 1;
+    if (nt < 1 || pairs < (1 << 13)) nt = 1;                  /* (25 000 pairs = 50 samples x 1000 permutations split over two to four threads) */
     for (int t = 0; t < nt; ++t) {
       jobs[t].x1 = ax1; jobs[t].x2 = ax2; jobs[t].r2 = ar2; jobs[t].out = out + done; jobs[t].n_out = n - done;
       jobs[t].a = pairs * t / nt; jobs[t].b = pairs * (t + 1) / nt;

@@ -55,7 +55,7 @@ def legacy_randn(m, num, clean=False):
     return out.reshape(m, num)          # a view of the reused buffer: consume before the next draw
 
 
-_MID_DRAW = 150_000
+_MID_DRAW = 80_000            # 100 samples x 1000 permutations: 0.91 -> 0.60 ms with four threads on the box (50 x 1000: no gain, 0.33 either way)
 _BIG_DRAW = 400_000          # draws x rows from which the threaded host helpers pay (200 samples x 10 000 permutations: 2M)
 _threads_set = False
 

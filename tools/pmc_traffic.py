@@ -69,6 +69,6 @@ for W in ('C4', 'C3', 'C2', 'C5'):
         w = sums.loc[k, 'WRITE_SIZE'] / steps_w if steps_w else 0.0
         traffic[name] = traffic.get(name, 0.0) + (2.0 * f + w) * 1e3
     out[W] = {name: round(v / PER_STEP.get(name, 1), 0) for name, v in traffic.items()}
-with open(os.path.join(d, os.environ.get('PMC_TRAFFIC_NAME', 'r04_pmc_traffic.json')), 'w') as fh:
+with open(os.path.join(d, os.environ.get('PMC_TRAFFIC_NAME', 'r05_pmc_traffic.json')), 'w') as fh:
     json.dump(out, fh, indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True))

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Everything profiles/ needs for round 4, on the GPU box:  bash tools/profile_round4.sh
+# Everything profiles/ needs for round 5, on the GPU box:  bash tools/profile_round5.sh
 # (rocprofv3 --kernel-trace --stats of the bench command; PMC passes -- counters only, each in its own
 # run -- for HBM-side traffic (FETCH_SIZE / WRITE_SIZE) and the SQ / TCC view of the dominant kernels)
 set -u
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_r04; mkdir -p $OUT
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_r05; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 SHORT="--no-cpu-baseline --no-extra --steps 6 --warmup 2"
 for W in ${WORKLOADS:-C4 C3 C2 C5}; do
