@@ -548,8 +548,9 @@ def contract_line(d, details_file=None):
                          halo_overlaps_step=comm.get('halo_exchange_overlaps_the_walk_step'), p_value=cfg.get('p_value'))
     out['roofline'] = _roofline_short(d.get('roofline'))
     out['cpu_baseline'] = _cpu_short(d.get('cpu_baseline'))
-    if d.get('cpu_baseline_C2_full'):
-        out['cpu_baseline_C2_full'] = _cpu_short(d['cpu_baseline_C2_full'])
+    for key in ('cpu_baseline_C2_full', 'cpu_baseline_C3_full'):
+        if d.get(key):
+            out[key] = _cpu_short(d[key])
     out['gpu_kernel_ms_per_step'] = d.get('gpu_kernel_ms_per_step')
     out['host_ms_per_step'] = d.get('host_ms_per_step')
     out['first_call_ms_incl_graph_h2d'] = d.get('first_call_ms_incl_graph_h2d')
@@ -578,6 +579,7 @@ def main():
     ap.add_argument('--cpu-sample-cells', type=int, default=150_000)
     ap.add_argument('--no-cpu-c2-full', action='store_true',
                     help='N=1: skip the reference-cost CPU run of the FULL C2 workload (~1-2 min of host time)')
+    ap.add_argument('--cpu-full', default='C2', help='N=1: BASELINE configurations whose FULL workload the reference-cost CPU path runs (C2, C3)')
     ap.add_argument('--details', default=DETAILS_FILE, help='where the full per-kernel tables go (JSON)')
     ap.add_argument('--profile-host', default=None, help='write a cProfile of 3 extra steps to this file')
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'shm'],
@@ -666,21 +668,30 @@ def main():
                 extra[name] = dict(error=repr(e))
 
     cpu_c2 = None
-    if world == 1 and not args.no_cpu_baseline and not args.no_cpu_c2_full and args.workload == 'C4':
+    cpu_full = {}
+    if world == 1 and not args.no_cpu_baseline and not args.no_cpu_c2_full:
         # BASELINE.md 3 asks for the CPU path on a BASELINE configuration in full, in the same run: configs[1] (C2:
-        # 200k x 50, nsteps 3, Nnull 1000), no sampling, no extrapolation -- beside this run's C2 GPU time
-        n2, N2, k2, ns2, P2, c2 = WORKLOADS['C2'][:6]
-        try:
-            cpu_c2 = cpu_reference_cost(synth, n2, N2, k2, ns2, P2, c2)
-            g = extra.get('C2', {})
-            if g.get('ms_per_step'):
-                cpu_c2['gpu_ms_per_step'] = g['ms_per_step']
-                cpu_c2['gpu_over_cpu'] = round(cpu_c2['seconds'] * 1e3 / g['ms_per_step'], 1)
-                cpu_c2['same_p_value_as_gpu'] = bool(abs(cpu_c2['p_value'] - g.get('p_value', -1)) < 1e-12)
-        except Exception as e:
-            cpu_c2 = dict(error=repr(e))
+        # 200k x 50, nsteps 3, Nnull 1000), no sampling, no extrapolation -- beside this run's GPU time of the same
+        # configuration.  (--cpu-full C2,C3 adds configs[2]: minutes of host time and ~30 GB, not in the default run.)
+        for wname in [w for w in args.cpu_full.split(',') if w]:
+            if wname not in ('C2', 'C3') or not (args.workload == 'C4' or args.workload == wname):
+                continue
+            n2, N2, k2, ns2, P2, c2 = WORKLOADS[wname][:6]
+            try:
+                one = cpu_reference_cost(synth, n2, N2, k2, ns2, P2, c2)
+                g = main_sum if args.workload == wname else extra.get(wname, {})
+                if g.get('ms_per_step'):
+                    one['gpu_ms_per_step'] = g['ms_per_step']
+                    one['gpu_over_cpu'] = round(one['seconds'] * 1e3 / g['ms_per_step'], 1)
+                    one['same_p_value_as_gpu'] = bool(abs(one['p_value'] - g.get('p_value', -1)) < 1e-12)
+            except Exception as e:
+                one = dict(error=repr(e))
+            cpu_full[wname] = one
+        cpu_c2 = cpu_full.get('C2')
 
     details = assemble_details(m, main_sum, cpu, cpu_c2, extra, world, steps, warmup, args)
+    if cpu_full.get('C3'):
+        details['cpu_baseline_C3_full'] = cpu_full['C3']
     line = contract_line(details)
     # the full tables (every kernel of every configuration, notes, stage times) go to a side file and to stderr; the
     # ONE line on stdout stays small enough for any consumer (round 4's 20 KB line was not parsed by the driver)
