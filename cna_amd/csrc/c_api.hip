@@ -226,7 +226,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   if (c->pair_buf) { (void)hipFree(c->pair_buf); c->pair_buf = nullptr; }
   prof_flush(c);
   comm_destroy(c);
-  void* bufs[] = {c->i8_buf, c->xq, c->xq_scale, c->coef_dev, c->proj, c->sp_pair, c->sp_cnt, c->null_part, c->rp16_buf, c->halo_send_idx, c->halo_recv_idx, c->halo_rows_b, c->halo_rows_i, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+  void* bufs[] = {c->idx_t, c->i8_buf, c->xq, c->xq_scale, c->coef_dev, c->proj, c->sp_pair, c->sp_cnt, c->null_part, c->rp16_buf, c->halo_send_idx, c->halo_recv_idx, c->halo_rows_b, c->halo_rows_i, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
                   c->nam, c->X, c->X2, c->resid_f, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf, c->gram_part, c->bins_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);

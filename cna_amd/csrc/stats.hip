@@ -92,19 +92,48 @@ __global__ __launch_bounds__(256) void k_cond_gemm(const double* __restrict__ M,
 // per column: mean and standard deviation (ddof = 1) over the N rows, then the division -- one thread per
 // column, consecutive threads on consecutive columns (coalesced), rows walked in order (two passes, like
 // pandas / numpy: mean first, then squared deviations)
+// (round 5: the three passes fetch eight rows ahead of the sequential adds -- the loop was one exposed memory latency per
+// row: 279 us for 200 x 1001 at C4, 465 us at 10 001 columns; the order of the additions is unchanged)
 __global__ __launch_bounds__(256) void k_cond_scale(double* __restrict__ Z, int N, int P, int ldy) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
+  double* __restrict__ z = Z + p;
+  constexpr int U = 8;
   double s = 0.0;
-  for (int i = 0; i < N; ++i) s += Z[(size_t)i * ldy + p];
+  int i = 0;
+  for (; i + U <= N; i += U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = z[(size_t)(i + u) * ldy];
+#pragma unroll
+    for (int u = 0; u < U; ++u) s += v[u];
+  }
+  for (; i < N; ++i) s += z[(size_t)i * ldy];
   const double mean = s / (double)N;
   double ss = 0.0;
-  for (int i = 0; i < N; ++i) {
-    const double d = Z[(size_t)i * ldy + p] - mean;
+  for (i = 0; i + U <= N; i += U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = z[(size_t)(i + u) * ldy];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double d = v[u] - mean;
+      ss += d * d;
+    }
+  }
+  for (; i < N; ++i) {
+    const double d = z[(size_t)i * ldy] - mean;
     ss += d * d;
   }
   const double sd = sqrt(ss / (double)(N - 1));
-  for (int i = 0; i < N; ++i) Z[(size_t)i * ldy + p] /= sd;
+  for (i = 0; i + U <= N; i += U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = z[(size_t)(i + u) * ldy];
+#pragma unroll
+    for (int u = 0; u < U; ++u) z[(size_t)(i + u) * ldy] = v[u] / sd;
+  }
+  for (; i < N; ++i) z[(size_t)i * ldy] /= sd;
 }
 
 // ---- global F-tests of every column (_association.py:35-61,84) ------------------------------------------
