@@ -336,7 +336,18 @@ CONFIG2_CALL = dict(nsteps=3, Nnull=1000, seed=0)
 CONFIG2_EVERY = 100                                                     # cells-sized results: every 100th cell
 
 
-def run_config2():
+CONFIG3 = dict(n_cells=1_000_000, n_samples=100, k=30, seed=0)          # BASELINE.json configs[2]
+CONFIG3_EVERY = 1000
+
+
+def run_config3():
+    """BASELINE.json configs[2] (1M cells x 100 samples, the "HBM roofline run") at full size through the reference: ~15
+    minutes and ~40 GB in the build container.  Same layout as d02 (results only; every 1000th cell of the cells-sized
+    fields)."""
+    run_config2(CONFIG3, CONFIG3_EVERY, 'd03_config3')
+
+
+def run_config2(dataset=None, every=None, name='d02_config2'):
     """BASELINE.json configs[1] AT FULL SIZE through the reference itself: 200 000 cells x 50 samples, k = 30,
     nsteps = 3, Nnull = 1000, seed 0 (about two minutes and ~10 GB here).  The inputs are NOT stored: they are
     `synth.make_dataset(**CONFIG2, builder='cpu')`, regenerated wherever the fixture is used, and recognised by the
@@ -344,7 +355,9 @@ def run_config2():
     cells-sized results (nam, namresid, V, ncorrs, the two data.obs columns) for every 100th cell."""
     import time
     t0 = time.time()
-    data, meta = synth.make_dataset(builder='cpu', **CONFIG2)
+    dataset = dataset or CONFIG2
+    every = every or CONFIG2_EVERY
+    data, meta = synth.make_dataset(builder='cpu', **dataset)
     A = data.obsp['connectivities']
     t_gen = time.time() - t0
     y = meta['y']
@@ -354,9 +367,9 @@ def run_config2():
         res = cna.tl.association(data, y, 'id', return_full=True, **CONFIG2_CALL)
     t_ref = time.time() - t0
     f = result_fields(res)
-    sub = np.arange(0, A.shape[0], CONFIG2_EVERY)
+    sub = np.arange(0, A.shape[0], every)
     assert f['kept'].all()
-    out = dict(call=np.array(json.dumps(CONFIG2_CALL)), dataset=np.array(json.dumps(CONFIG2)),
+    out = dict(call=np.array(json.dumps(CONFIG2_CALL)), dataset=np.array(json.dumps(dataset)),
                graph_digest=np.array(synth.graph_digest(A)), nnz=np.int64(A.nnz), in_y=y.values,
                sid_digest=np.array(__import__('hashlib').sha256(np.asarray(data.obs['id'].values, dtype=np.int64).tobytes()).hexdigest()))
     out['warnings'] = np.array(json.dumps([str(w.message) for w in wlist if issubclass(w.category, UserWarning)]))
@@ -378,10 +391,10 @@ def run_config2():
     out['reference_seconds'] = np.float64(t_ref)
     out['versions'] = np.array(json.dumps(dict(numpy=np.__version__, scipy=scipy.__version__, pandas=pd.__version__,
                                                python=sys.version.split()[0], cna='0.2.3 (/root/reference)')))
-    path = os.path.join(HERE, 'd02_config2.npz')
+    path = os.path.join(HERE, name + '.npz')
     np.savez_compressed(path, **out)
     print('%-36s p=%.6g k=%d detected@first=%d  %.0f KB  (dataset %.0f s, reference %.0f s, graph %s)' % (
-        'd02_config2', out['p'], out['k'], out['fdr_num_detected'][0], os.path.getsize(path) / 1024, t_gen, t_ref,
+        name, out['p'], out['k'], out['fdr_num_detected'][0], os.path.getsize(path) / 1024, t_gen, t_ref,
         str(out['graph_digest'])[:16]))
 
 
@@ -390,6 +403,11 @@ def main():
     if 'd02_config2' in only:                      # two minutes and ~10 GB: only on request
         run_config2()
         only.discard('d02_config2')
+        if not only:
+            return
+    if 'd03_config3' in only:                      # a quarter of an hour and ~40 GB: only on request
+        run_config3()
+        only.discard('d03_config3')
         if not only:
             return
     if not only or 'd01_demo_like' in only:

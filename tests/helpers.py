@@ -207,13 +207,13 @@ def assert_matches_demo(out, z, tol, obs=None):
 
 # --------------------------------------------------------------------------------------
 # d02_config2: BASELINE.json configs[1] at FULL size through the reference (tests/golden/make_golden.py:run_config2)
-def load_config2_case():
-    """The fixture holds results only; the inputs are regenerated here -- `synth.make_dataset(**dataset, builder='cpu')`,
+def load_config2_case(name='d02_config2'):
+    """(also d03_config3 = configs[2], same layout.)  The fixture holds results only; the inputs are regenerated here -- `synth.make_dataset(**dataset, builder='cpu')`,
     the host builder (cKDTree + scipy.sparse: the same graph on every machine of this image) -- and recognised by the
     digest of their CSR arrays and sample ids.  Returns dict(data, y, call, z, same_inputs)."""
     import hashlib
     from cna_amd import synth
-    z = np.load(os.path.join(GOLDEN_DIR, 'd02_config2.npz'))
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
     ds = json.loads(z['dataset'].item())
     data, meta = synth.make_dataset(builder='cpu', **ds)
     A = data.obsp['connectivities']

@@ -62,3 +62,40 @@ def test_config2_matches_the_f64_oracle_at_full_size(case, result):
     np.testing.assert_allclose(res.fdrs.fdr.values[:T], ref['fdrs']['fdr'][:T], rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(case['data'].obs['coef'].values, ref['obs_coef'], rtol=0, atol=1e-10 * np.abs(ref['obs_coef']).max())
     np.testing.assert_allclose(case['data'].obs['coef_fdr'].values, ref['obs_coef_fdr'], rtol=1e-9, atol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] (1M cells x 100 samples, the "HBM roofline run") against the reference's own run at full size
+# (tests/golden/d03_config3.npz; a quarter of an hour and ~40 GB of the reference in the build container)
+@pytest.fixture(scope='module')
+def case3():
+    import os
+    from helpers import GOLDEN_DIR
+    if not os.path.exists(os.path.join(GOLDEN_DIR, 'd03_config3.npz')):
+        pytest.skip('no d03_config3 fixture')
+    return load_config2_case('d03_config3')
+
+
+def test_config3_matches_the_reference_run(case3):
+    import warnings
+    import cna_amd as cna
+    from cna_amd.engine import get_engine
+    z, data = case3['z'], case3['data']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        res = cna.tl.association(data, case3['y'], 'id', return_full=True, engine=get_engine(), **case3['call'])
+    sub = z['sub']
+    out = dict(p=res.p, k=res.k, ks=res.ks, r=res.r, n_kept=int(res.kept.sum()), nullminps=res.nullminps,
+               svs=res.namresid_svs.values, U=res.namresid_sampleXpc.values, M=res.M.values, yresid=res.yresid.values,
+               yresid_hat=res.yresid_hat, r2=res.r2, r2_perpc=res.r2_perpc, nullr2_mean=res.nullr2_mean, nullr2_std=res.nullr2_std,
+               ncorrs=res.ncorrs.values, nam=None, namresid=None,
+               fdrs=dict(threshold=res.fdrs.threshold.values, fdr=res.fdrs.fdr.values, num_detected=res.fdrs.num_detected.values),
+               fdr_5p_t=res.fdr_5p_t, fdr_10p_t=res.fdr_10p_t)
+    assert_matches_config2(out, z, 1e-5, obs=dict(coef=data.obs['coef'].values, coef_fdr=data.obs['coef_fdr'].values),
+                           exact_counts=case3['same_inputs'])
+    # the cells-sized frames on the fixture's cells only (800 MB each in full)
+    from helpers import assert_elementwise
+    nam_sub = res.nam.values[:, sub]
+    assert_elementwise(nam_sub, z['nam_sub'], 1e-5, 1e-12, 'nam (every 1000th cell)')
+    assert_elementwise(res.namresid.values[:, sub], z['namresid_sub'], 1e-5, 2e-7, 'namresid (every 1000th cell)')
+    assert case3['same_inputs'], 'results agree, but the regenerated inputs are not bit-identical to the fixture\'s'
