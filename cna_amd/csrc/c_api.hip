@@ -482,7 +482,8 @@ int cna_restart_nam(cna_ctx* c) {
   CHECK_CTX(c);
   AUTO_FINISH(c);
   if (!c->sid || !c->counts) CNA_FAIL(CNA_ESTATE, "cna_restart_nam needs cna_set_samples first");
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  // (no wait for the stream here: the new walk is queued behind whatever still runs on it, and ensure_T waits by itself
+  // in the one case that needs it, a reallocation -- the wait cost 20-40 us at the front of every call)
   CNA_TRY(ensure_T(c, c->ld));
   c->t_width = c->N;
   c->t_ld = c->ld;
