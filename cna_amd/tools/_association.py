@@ -214,7 +214,7 @@ def _fdr_tables(tail_sums, ranks, Nloc, thresholds):
 
 def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_progress=False,
                  npcs=None, n_cells=None, conditioned=False, null_source=None, maxabs=None, on_coef=None,
-                 coef_first=False, coef_launched=False, full=False):
+                 coef_first=False, coef_launched=False, full=False, on_fdr=None):
     """Body of the reference's ``_association`` (_association.py:24-129) against the
     residualised NAM held by ``engine`` (cells x samples), whose Gram-matrix kernels have been
     queued.  ``res`` is the namespace from the residualisation (M, r), ``y`` / ``y_`` the
@@ -340,6 +340,8 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
                 try:
                     early_tail = ('ok', _fdr_tables(tail_sums, ranks, Nloc, thresholds))
                     early_tail += (engine.percell(thresholds, early_tail[1][3]),)
+                    if on_fdr is not None:                   # the FDR column into the frame while the eigenvectors are on
+                        on_fdr(early_tail[2][1])             # their way (put back if the test then fails)
                 except Exception as exc:                     # raised where the sequential order meets it
                     early_tail = ('error', exc)
                 _mark('percell done')
@@ -898,6 +900,7 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                     del data.obs[fdr_key]
             early_coef.pop('fdr_view', None)
             early_coef.pop('fdr_touched', None)
+            early_coef.pop('fdr_done', None)
             early_coef.pop('values', None)
 
     def write_coef_early(coef):
@@ -920,8 +923,18 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
                                                                   min(8, usable_cpus(8)))
         _mark('coef column written')
 
+    def write_fdr_early(fdr):
+        # (small-block schedule: the per-cell pass is done before the eigenvectors are; same rules as the coefficient column)
+        if 'values' not in early_coef or early_coef.get('fdr_view') is not None or fdr is None:
+            return
+        confirm_graph()
+        early_coef['written'] = early_coef['fdr_touched'] = True
+        data.obs[fdr_key] = fdr
+        early_coef['fdr_done'] = True
+
     try:
         coef_all, fdr_all, pcs = _association(engine, res, y_std, None, ks=ks, Nnull=Nnull, full=return_full,
+                                                 on_fdr=write_fdr_early,
                                                  local_test=kwargs.get('local_test', True),
                                                  show_progress=show_progress, npcs=npcs, n_cells=engine.x_rows_global,
                                                  null_source=drawn,
@@ -962,6 +975,8 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         early = fdr_copied_early()
         if fdr_all is None:
             pass                                              # local_test=False: see below
+        elif early_coef.pop('fdr_done', False) and fdr_key in data.obs:
+            pass                                              # written while the eigenvectors were computed
         elif early and view is not None and fdr_key in data.obs and np.shares_memory(data.obs[fdr_key].values, view):
             pass                                              # filled by the helper thread under the SVD
         elif (view is not None and isinstance(fdr_all, np.ndarray) and fdr_all.dtype == np.float64 and fdr_all.flags.c_contiguous

@@ -1682,6 +1682,23 @@ def test_small_block_many_samples_takes_the_per_cell_pass_under_lapack(eng, monk
     monkeypatch.setattr(eng, 'global_test_fetch', bad_fetch)
     with pytest.raises(ArithmeticError, match='global test'):
         cna.tl.association(data, meta['y'], 'id', engine=eng, **kw)
+    # both per-cell columns reach the frame BEFORE the global test in this schedule (the coefficient column under the local
+    # null, the FDR column while the eigenvectors are computed): a test that then fails puts both back
+    monkeypatch.setattr(eng, 'percell', real_percell)
+    y2 = pd.Series(np.random.RandomState(7).randn(len(meta['y'])), index=meta['y'].index)
+    seen = {}
+
+    def bad_fetch2(*args, **k):
+        seen['coef'] = data.obs['coef'].values.copy()
+        seen['fdr'] = data.obs['coef_fdr'].values.copy()
+        real_fetch(*args, **k)
+        raise ArithmeticError('global test')
+    monkeypatch.setattr(eng, 'global_test_fetch', bad_fetch2)
+    with pytest.raises(ArithmeticError, match='global test'):
+        cna.tl.association(data, y2, 'id', engine=eng, **kw)
+    assert not np.array_equal(seen['coef'], a[4]) and not np.array_equal(seen['fdr'], a[5])    # written early ...
+    np.testing.assert_array_equal(data.obs['coef'].values, a[4])                                 # ... and put back
+    np.testing.assert_array_equal(data.obs['coef_fdr'].values, a[5])
     monkeypatch.setattr(eng, 'percell', real_percell)
     monkeypatch.setattr(eng, 'global_test_fetch', real_fetch)
     capsys.readouterr()
