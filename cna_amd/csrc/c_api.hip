@@ -238,7 +238,6 @@ int cna_ctx_destroy(cna_ctx* c) {
   if (c->coef_ready) (void)hipEventDestroy(c->coef_ready);
   if (c->gt_done) (void)hipEventDestroy(c->gt_done);
   if (c->stage_done) (void)hipEventDestroy(c->stage_done);
-  if (c->sel_done) (void)hipEventDestroy(c->sel_done);
   if (c->h_gt) (void)hipHostFree(c->h_gt);
   if (c->coef_copied) (void)hipEventDestroy(c->coef_copied);
   if (c->null_done) (void)hipEventDestroy(c->null_done);
@@ -1401,31 +1400,9 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
   }
   unsigned long long h = 0;
   double m = 0.0;
-  // Small blocks with many samples (a rank's share of a sharded run: fewer than 500 000 cells per rank, 128 samples or
-  // more -- the regime of _association.py's tail_first): what the step then waits for longest is Gram -> eigenpairs ->
-  // F-tests, so the Gram kernels go out NOW, before the host has seen the two counters -- which leave through the copy
-  // stream behind an event instead of waiting for the main stream to drain.  If a cell turns out to have zero variance
-  // the matrix is simply not used (the caller redoes the selection and the product).  Every rank decides alike.
-  bool spec = false;
-  if (gram_too && y && !fused && !(byp && gram_pre_was) && c->Nx >= 128 && c->Nx <= 1024 &&
-      c->n_global / std::max(c->nranks, 1) < 500000) {
-    if (!c->sel_done) HIP_TRY(hipEventCreateWithFlags(&c->sel_done, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(c->sel_done, c->stream));
-    const bool xv = c->x_valid;
-    c->x_valid = true;
-    const int rc = cna_gram_launch(c);
-    c->x_valid = xv;
-    if (rc != 0) return rc;
-    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->sel_done, 0));
-    HIP_TRY(hipMemcpyAsync(&h, nz, 8, hipMemcpyDeviceToHost, c->copy_stream));
-    HIP_TRY(hipMemcpyAsync(&m, mb, 8, hipMemcpyDeviceToHost, c->copy_stream));
-    HIP_TRY(hipStreamSynchronize(c->copy_stream));
-    spec = true;
-  } else {
-    HIP_TRY(hipMemcpyAsync(&h, nz, 8, hipMemcpyDeviceToHost, c->stream));
-    if (y) HIP_TRY(hipMemcpyAsync(&m, mb, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-  }
+  HIP_TRY(hipMemcpyAsync(&h, nz, 8, hipMemcpyDeviceToHost, c->stream));
+  if (y) HIP_TRY(hipMemcpyAsync(&m, mb, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   if (n_zero_out) *n_zero_out = (int64_t)h;
   if (max_abs_out) *max_abs_out = m;
   c->x_valid = true;
@@ -1438,9 +1415,7 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
   c->x_ident = !keep_idx && in_place && rk == 0 && h == 0 && Nx == c->N && nx == c->n_local;
   c->coef_early = false;
   c->fdr_inline = false;
-  if (spec) {
-    *gram_too = true;                            // queued above, right behind the kernel that made X
-  } else if (fused) {                            // what cna_gram_launch does after its kernels
+  if (fused) {                                   // what cna_gram_launch does after its kernels
     CNA_TRY(comm_allreduce_f64_sum(c, c->gram_buf, (size_t)Nx * Nx));
     HIP_TRY(hipEventRecord(c->gram_done, c->stream));
     c->gram_n = Nx;

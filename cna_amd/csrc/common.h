@@ -200,7 +200,6 @@ struct cna_ctx {
   void* h_gt = nullptr;           // pinned staging of cna_global_test_launch / _fetch: U, ks | minp, r2, kidx
   int64_t h_gt_cap = 0;
   hipEvent_t gt_done = nullptr;
-  hipEvent_t sel_done = nullptr;     // the selection pass's two counters are final (their copy leaves on the copy stream: select_standardized_impl)
   hipEvent_t stage_done = nullptr;   // uploads out of h_res' staging tail (cna_null_local_prepare) have been issued and finished
   int gt_pending_P = 0;           // > 0: a launched global test waits to be fetched (its number of columns)
   int64_t gt_off_out = 0;
