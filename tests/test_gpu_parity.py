@@ -1762,3 +1762,39 @@ def test_error_after_a_fused_null_launch_leaves_the_engine_usable(eng, monkeypat
     b = eng.null_local_fetch()
     for x, y in zip(a, b):
         np.testing.assert_array_equal(x, y)
+
+
+def test_zero_variance_cells_with_many_samples(eng, orc):
+    """140 samples (the by-product / small-block schedules) and cells of zero variance -- a far-away blob whose only sample
+    has no phenotype: whatever the fused selection call queued for "no zero variance" must not be used; results as the
+    oracle's, the cells dropped (_association.py:182-185); the next analysis on the engine is unaffected."""
+    import cna_amd as cna
+    from cna_amd import synth
+    data, meta = synth.make_dataset(8000, 140, k=15, seed=9)
+    A = sp.csr_matrix(data.obsp['connectivities'])
+    n, n_iso = A.shape[0], 25
+    rs = np.random.RandomState(7)
+    B = sp.random(n_iso, n_iso, density=0.6, random_state=rs, format='csr', dtype=np.float64)
+    B = B + B.T
+    B.setdiag(0)
+    B.eliminate_zeros()
+    B.data = np.clip(B.data, 0.05, 1.0)
+    A2 = sp.block_diag([A, B.astype(A.dtype)], format='csr')
+    A2.sort_indices()
+    obs = pd.DataFrame({'id': np.concatenate([data.obs['id'].values, np.repeat(140, n_iso)])},
+                       index=pd.Index(['cell_%d' % i for i in range(n + n_iso)], name='cell'))
+    d2 = type('D', (), {'obs': obs, 'obsp': {'connectivities': A2}, 'uns': {}})()
+    y = pd.concat([meta['y'], pd.Series([np.nan], index=[140])])
+    kw = dict(nsteps=3, Nnull=100, seed=3)
+    res = cna.tl.association(d2, y, 'id', return_full=True, engine=eng, **kw)
+    ref = orc.association(d2, y, 'id', mode='f64', **kw)
+    assert (~res.kept).sum() == n_iso and np.array_equal(res.kept, ref['kept'])
+    assert int(res.k) == ref['k'] and res.p == ref['p']
+    assert relerr(res.ncorrs.values, ref['ncorrs']) < 1e-10
+    assert relerr(res.namresid_svs.values, ref['svs']) < 1e-10
+    T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
+    assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T])
+    # ... and the very next analysis (no zero variance)
+    res2 = cna.tl.association(data, meta['y'], 'id', return_full=True, engine=eng, **kw)
+    ref2 = orc.association(data, meta['y'], 'id', mode='f64', **kw)
+    assert res2.p == ref2['p'] and int(res2.k) == ref2['k'] and relerr(res2.namresid_svs.values, ref2['svs']) < 1e-10
