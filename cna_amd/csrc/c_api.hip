@@ -266,7 +266,7 @@ int cna_ctx_sync(cna_ctx* c) {
 
 int cna_ctx_device_bytes(cna_ctx* c, int64_t* bytes) {
   if (!c || !bytes) CNA_FAIL(CNA_EINVAL, "null argument");
-  *bytes = c->dev_bytes;
+  *bytes = c->dev_bytes.load();
   return 0;
 }
 

@@ -67,7 +67,7 @@ struct cna_ctx {
   std::atomic<int> null_pending{0};   // (read by the helper thread's cna_percell_fdr_copy_early, like the four flags below)
   int64_t gram_cap = 0;
   int gram_n = 0;
-  int64_t dev_bytes = 0;
+  std::atomic<int64_t> dev_bytes{0};   // (two host threads may reserve buffers of one context at once: the F-tests from the eigenvector thread)
   std::recursive_mutex alloc_mu;   // dev_alloc / dev_free / dev_reserve (two host threads may share the context)
 
   // ---- communicator
