@@ -2,6 +2,7 @@
 """Walk kernels under different device cell orders and XCD chunk sizes:
     kbench_order.py n_cells n_samples   (prints us per launch of nam_first / nam_step)"""
 import os, sys, time
+os.environ['CNA_REORDER_ASYNC'] = '0'      # read when cna_amd.engine is imported: the order under test must be the one the kernels run in
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from cna_amd import synth
