@@ -1798,3 +1798,36 @@ def test_zero_variance_cells_with_many_samples(eng, orc):
     res2 = cna.tl.association(data, meta['y'], 'id', return_full=True, engine=eng, **kw)
     ref2 = orc.association(data, meta['y'], 'id', mode='f64', **kw)
     assert res2.p == ref2['p'] and int(res2.k) == ref2['k'] and relerr(res2.namresid_svs.values, ref2['svs']) < 1e-10
+
+
+def test_small_block_schedule_is_reproducible_over_many_calls(eng, monkeypatch):
+    """Two host threads drive one context in the small-block schedule (the eigenvector thread fetches the Gram matrix,
+    solves and queues the F-tests while the main thread collects the local null and runs the per-cell pass; the library's
+    draw thread conditions the phenotypes beside both).  300 analyses of two phenotypes in turn: every one returns the
+    bits of its first run."""
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.tools import _association as A
+    from cna_amd.tools import _nam as NM
+    assert A._TAIL_FIRST
+    data, meta = synth.make_dataset(30000, 160, k=15, seed=11)
+    monkeypatch.setattr(eng, 'reuse_nam', False)
+    ys = [meta['y'], pd.Series(np.random.RandomState(5).randn(160), index=meta['y'].index)]
+    kw = dict(Nnull=200, seed=4, nsteps=3)
+    import warnings
+    first = {}
+    native0 = NM.eig_stats['native']
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        for it in range(300):
+            j = it & 1
+            p = cna.tl.association(data, ys[j], 'id', engine=eng, **kw)
+            got = (p, data.obs['coef'].values.copy(), data.obs['coef_fdr'].values.copy())
+            if j not in first:
+                first[j] = got
+                continue
+            assert got[0] == first[j][0], it
+            np.testing.assert_array_equal(got[1], first[j][1])
+            np.testing.assert_array_equal(got[2], first[j][2])
+    assert NM.eig_stats['native'] - native0 == 300        # the library's own eigen-solver every time, on the helper thread
+    assert first[0][0] != first[1][0] or not np.array_equal(first[0][1], first[1][1])
