@@ -32,7 +32,26 @@ def usable_cpus(limit=None):
             n = max(1, min(n, int(int(quota) / int(period))))
     except Exception:
         pass
+    # several ranks on one node (one process per GPU) share that allowance: every rank's helper threads -- the draw,
+    # the content hash, the cluster order, the column copies -- take their share, not all of it (eight ranks x four
+    # draw threads on a 16-CPU allowance made the draw, identical on every rank, the longest item of a rank's step)
+    n = max(1, n // ranks_on_this_node())
     return n if limit is None else max(1, min(n, int(limit)))
+
+
+def ranks_on_this_node():
+    """Processes of this job on this node: the launcher's LOCAL_WORLD_SIZE, else what cna_amd.dist was told (one node), else 1."""
+    try:
+        k = int(os.environ.get('LOCAL_WORLD_SIZE', '0'))
+        if k >= 1:
+            return k
+    except ValueError:
+        pass
+    try:
+        from . import dist
+        return max(1, int(dist.current().get('nranks', 1) or 1))
+    except Exception:
+        return 1
 
 
 DEFAULT_CLUSTER = 512
