@@ -17,7 +17,8 @@ by torch.distributed.run, or self-spawned when `--gpus N` is given to a plain `p
 SAME 2M x 200 problem is sharded over the ranks by row blocks of cells (strong scaling, BASELINE.json's
 "sharded over 8 x MI355X"); `--scaling weak` keeps the per-GPU block fixed instead.  At N = 1 two more
 lines ride along in the same JSON object (`other_configs`): configs[4] ("C5": C4 + 5 covariates, Nnull = 10000),
-configs[2] ("C3", 1M x 100) and configs[1] ("C2", 200k x 50).
+configs[2] ("C3", 1M x 100), configs[1] ("C2", 200k x 50), two reference call shapes at C3 and "C4_block8" (250k x 200: one
+rank's share of C4 on eight GPUs as a problem of its own -- the input of DESIGN.md 7's scaling estimate).
 
 Prints ONE JSON line on rank 0 (see the repo's bench contract) with two extra objects:
   roofline     for the kernel that dominates the timed region (HIP-event timed in this run)
@@ -657,7 +658,7 @@ def main():
 
     extra = {}
     if world == 1 and not args.no_extra and args.workload == 'C4':
-        for name in ('C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches'):
+        for name in ('C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches', 'C4_block8'):
             st_, wu_ = DEFAULT_STEPS[name]
             try:
                 mm = time_workload(name, args, rank, world, st_, wu_)

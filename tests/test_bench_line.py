@@ -33,11 +33,11 @@ def build_line(world=1):
     m = stub_measurement('C4', 20)
     main_sum = bench.summary(m, world, 20)
     extra = {}
-    for name in ('C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches'):
+    for name in ('C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches', 'C4_block8'):
         st = bench.DEFAULT_STEPS[name][0]
         mm = stub_measurement(name, st)
         extra[name] = dict(workload=bench.workload_text(mm, world, args), steps=st, warmup=3, **bench.summary(mm, world, st))
-    extra['C4_block8'] = dict(error=repr(RuntimeError('x' * 1000)))
+    extra['C6_failed'] = dict(error=repr(RuntimeError('x' * 1000)))
     stages = dict(nam=43.71, resid_svd=9.31, global_test=0.64, local_test=16.04, percell_apply=143.21)
     cpu = dict(value=9025360.1, unit='cell*perm/s', cores=16, kind='port', mode='reference-cost', seconds=16.62, host_cpus=256,
                blas_threads=16, p_value=0.000999000999000999, stages_s=stages, value_without_percell_apply=25517190.4,
@@ -68,9 +68,9 @@ def test_contract_line_is_small_and_loads():
     for key in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert key in d['cpu_baseline'], key
     assert d['cpu_baseline_C2_full']['seconds'] and 'extrapolated' not in d['cpu_baseline_C2_full']
-    assert set(d['other_configs']) == {'C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches', 'C4_block8'}
+    assert set(d['other_configs']) == {'C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches', 'C4_block8', 'C6_failed'}
     for name, o in d['other_configs'].items():
-        if name != 'C4_block8':
+        if name != 'C6_failed':
             assert o['ms_per_step'] > 0 and o['value'] > 0 and 'frac' in o['roofline']
 
 
