@@ -175,7 +175,6 @@ if hasattr(os, 'register_at_fork'):
     os.register_at_fork(after_in_child=_forget_pools)
 
 _TAIL_FIRST_SAMPLES = 128
-_EARLY_FDR_STORAGE = True
 _TAIL_FIRST = True        # (measured against the sequential order at 200 000 x 50 and 250 000 x 200: DESIGN.md 7 e)
 _EIG_POOL = None
 
@@ -909,16 +908,14 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         early_coef['written'] = True
         data.obs[key_added] = coef
         early_coef['values'] = data.obs[key_added].values
-        if big or _EARLY_FDR_STORAGE:
+        if big:
             # the FDR column's storage as well (the frame takes a private copy of whatever it is given: 16 MB at 2M
-            # cells): made now, under a kernel, and filled in place at the end by a (threaded) copy -- at any size: the
-            # frame's bookkeeping for a new column is ~50 us whatever its length, and here the GPU is busy anyway
+            # cells): made now, under a kernel, and filled in place at the end by a threaded copy
             data.obs[fdr_key] = np.empty(len(data.obs))
-            early_coef['fdr_touched'] = True                     # (roll_back puts the column back whatever happens next)
             view = data.obs[fdr_key].values
             if view.dtype == np.float64 and view.flags.c_contiguous and view.flags.writeable:
                 early_coef['fdr_view'] = view
-                if big and _EARLY_FDR and hasattr(engine, 'percell_fdr_copy_early'):
+                if _EARLY_FDR and hasattr(engine, 'percell_fdr_copy_early'):
                     # the column follows the local null on the device and the host still has the SVD and the
                     # F-tests in front of it: the helper thread waits for the column and fills the storage
                     from .._order import usable_cpus
@@ -928,19 +925,11 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
 
     def write_fdr_early(fdr):
         # (small-block schedule: the per-cell pass is done before the eigenvectors are; same rules as the coefficient column)
-        if 'values' not in early_coef or fdr is None:
+        if 'values' not in early_coef or early_coef.get('fdr_view') is not None or fdr is None:
             return
         confirm_graph()
-        view = early_coef.get('fdr_view')
-        if view is not None:
-            if early_coef.get('fdr_job') is not None or not (isinstance(fdr, np.ndarray) and fdr.dtype == np.float64 and
-                                                               fdr.shape == view.shape and fdr_key in data.obs and
-                                                               np.shares_memory(data.obs[fdr_key].values, view)):
-                return
-            _host_copy(view, np.ascontiguousarray(fdr))
-        else:
-            early_coef['written'] = early_coef['fdr_touched'] = True
-            data.obs[fdr_key] = fdr
+        early_coef['written'] = early_coef['fdr_touched'] = True
+        data.obs[fdr_key] = fdr
         early_coef['fdr_done'] = True
 
     try:
