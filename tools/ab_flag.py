@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-process A/B of a module-level switch of cna_amd.tools._association on repeated association() calls:
-    ab_flag.py FLAG [cells=200000] [samples=50] [calls=300] [rounds=4]
+    ab_flag.py [MODULE:]FLAG [cells=200000] [samples=50] [calls=300] [rounds=4]
 alternates FLAG = True / False in rounds, prints ms per call of every round (box-to-box noise is 10x the effects looked for)."""
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,8 +9,9 @@ import numpy as np
 import cna_amd as cna
 from cna_amd import synth
 from cna_amd.engine import get_engine
-from cna_amd.tools import _association as A
-flag = sys.argv[1]
+from cna_amd.tools import _association, _nam, _stats
+modname, _, flag = sys.argv[1].rpartition(':')
+A = {'': _association, '_association': _association, '_nam': _nam, '_stats': _stats}[modname]
 n, N = int(sys.argv[2]) if len(sys.argv) > 2 else 200000, int(sys.argv[3]) if len(sys.argv) > 3 else 50
 calls, rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 300, int(sys.argv[5]) if len(sys.argv) > 5 else 4
 cna.tune_host_allocator()
