@@ -318,3 +318,21 @@ def test_fdr_tables_follow_the_reference_lines():
         # running minimum that skips NaN, as the per-cell lookup of _association.py:234-237 needs it
         ref = np.array([np.nanmin(fdr[:i + 1]) if not np.isnan(fdr[:i + 1]).all() else np.nan for i in range(T)])
         np.testing.assert_array_equal(runmin, ref)
+
+
+def test_helper_threads_take_their_ranks_share_of_the_cpu_allowance(monkeypatch):
+    """Several ranks on one node share the node's CPU allowance: every helper (draw, hash, cluster order, copies) asks
+    cna_amd._order.usable_cpus, which divides by the launcher's LOCAL_WORLD_SIZE (or what cna_amd.dist was told)."""
+    from cna_amd import _order, dist
+    monkeypatch.delenv('LOCAL_WORLD_SIZE', raising=False)
+    monkeypatch.setattr(dist, '_cfg', {})
+    alone = _order.usable_cpus()
+    assert alone >= 1 and _order.ranks_on_this_node() == 1
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    assert _order.ranks_on_this_node() == 8
+    assert _order.usable_cpus() == max(1, alone // 8) and _order.usable_cpus(4) == max(1, min(4, alone // 8))
+    monkeypatch.delenv('LOCAL_WORLD_SIZE')
+    monkeypatch.setattr(dist, '_cfg', dict(rank=1, nranks=4))
+    assert _order.ranks_on_this_node() == 4 and _order.usable_cpus() == max(1, alone // 4)
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', 'garbage')
+    assert _order.ranks_on_this_node() == 4
