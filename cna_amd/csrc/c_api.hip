@@ -812,7 +812,12 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
     if (!c->t_compact) CNA_TRY(dev_reserve(c, &c->halo_rbuf, &c->halo_rbuf_cap, 8 * std::max<int64_t>(c->halo_nr, 1) * ld));
     CNA_TRY(launch_nam_step(c, first, want_kurt != 0, true, may_stop != 0, false, c->halo_rows_b, c->halo_nb));
     HIP_TRY(hipEventRecord(c->halo_e1, c->stream));
-    CNA_TRY(launch_nam_step(c, first, want_kurt != 0, true, may_stop != 0, false, c->halo_rows_i, c->halo_ni));
+    // (the interior rows: nobody else reads their state after the FIRST step -- this rank's second step takes its local
+    // neighbours from their pairs -- so their dense rows, 8N bytes each, are not written: only rows that overflow the pairs)
+    c->sp_dense_interior_off = first;
+    const int rc_int = launch_nam_step(c, first, want_kurt != 0, true, may_stop != 0, false, c->halo_rows_i, c->halo_ni);
+    c->sp_dense_interior_off = false;
+    CNA_TRY(rc_int);
     HIP_TRY(hipStreamWaitEvent(c->halo_stream, c->halo_e1, 0));
     CNA_TRY(exchange_state(c, Tn, c->halo_stream));
     HIP_TRY(hipEventRecord(c->halo_e2, c->halo_stream));

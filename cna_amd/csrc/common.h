@@ -121,6 +121,7 @@ struct cna_ctx {
   int64_t t_rows = 0;            // rows of T (and of sp_cnt) when compact
   int32_t* idx_t = nullptr;      // nnz: column indices in the compact row space
   int64_t idx_t_n = 0;
+  bool sp_dense_interior_off = false;   // set around the launch over the rows no other rank asked for (cna_nam_step)
   int64_t sp_pair_rows = 0;      // rows of sp_pair (pairs exist for this rank's own rows only when compact)
   double* T[2] = {nullptr, nullptr};
   int64_t t_cap = 0;  // doubles allocated per buffer

@@ -1188,7 +1188,7 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
   a.write_t = write_t;
   a.write_nam = write_nam;
   a.stop = c->auto_stop;
-  a.sp_keep_dense = (c->nranks > 1 || c->halo_on) ? 1 : 0;
+  a.sp_keep_dense = ((c->nranks > 1 || c->halo_on) && !c->sp_dense_interior_off) ? 1 : 0;
   // compressed state: written by the first step, read by the second (sample indicators only)
   const bool sp = c->sp_cnt && !dense && (first || c->steps_done == 1);
   a.sp_pair = sp ? (SpPair*)c->sp_pair : nullptr;
