@@ -163,6 +163,14 @@ static int ragged_gather(cna_ctx* c, const double* src_dev, int64_t count_local,
   return 0;
 }
 
+// the main stream waits for an exchange still in flight on the halo stream (see cna_nam_step); no-op when none is
+int halo_settle(cna_ctx* c) {
+  if (!c->halo_wait_pending) return 0;
+  c->halo_wait_pending = false;
+  HIP_TRY(hipStreamWaitEvent(c->stream, c->halo_e2, 0));
+  return 0;
+}
+
 extern "C" {
 
 const char* cna_last_error(void) { return g_err.c_str(); }
@@ -226,7 +234,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   if (c->pair_buf) { (void)hipFree(c->pair_buf); c->pair_buf = nullptr; }
   prof_flush(c);
   comm_destroy(c);
-  void* bufs[] = {c->idx_t, c->i8_buf, c->xq, c->xq_scale, c->coef_dev, c->proj, c->sp_pair, c->sp_cnt, c->null_part, c->rp16_buf, c->halo_send_idx, c->halo_recv_idx, c->halo_rows_b, c->halo_rows_i, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
+  void* bufs[] = {c->halo_rows_safe, c->halo_rows_need, c->idx_t, c->i8_buf, c->xq, c->xq_scale, c->coef_dev, c->proj, c->sp_pair, c->sp_cnt, c->null_part, c->rp16_buf, c->halo_send_idx, c->halo_recv_idx, c->halo_rows_b, c->halo_rows_i, c->halo_sbuf, c->halo_rbuf, c->orig_idx, c->indptr, c->indices, c->data, c->colsum, c->sid, c->counts, c->T[0], c->T[1], c->dense_s,
                   c->nam, c->X, c->X2, c->resid_f, c->keep_store, c->stat, c->ncorrs, c->scratch, c->scratch2, c->cellinfo, c->zc, c->gt, c->gram_tiles_ptr, c->gram_buf, c->gram_part, c->bins_dev};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
@@ -259,6 +267,7 @@ int cna_ctx_destroy(cna_ctx* c) {
 int cna_ctx_sync(cna_ctx* c) {
   CHECK_CTX(c);
   AUTO_FINISH(c);
+  CNA_TRY(halo_settle(c));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (c->gram_stream && c->gram_pre_pending) HIP_TRY(hipStreamSynchronize(c->gram_stream));
   return 0;
@@ -386,6 +395,7 @@ static int ensure_T(cna_ctx* c, int ld) {
   // the point of the compact row space is the memory)
   if (need > c->t_cap || !c->T[0] || (c->t_compact && c->t_cap > need + need / 2 + (1 << 20))) {
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->halo_wait_pending && c->halo_stream) { HIP_TRY(hipStreamSynchronize(c->halo_stream)); c->halo_wait_pending = false; }
     for (int i = 0; i < 2; ++i) {
       if (c->T[i]) dev_free(c, c->T[i], (size_t)c->t_cap);
       c->T[i] = nullptr;
@@ -497,6 +507,12 @@ int cna_restart_nam(cna_ctx* c) {
 }
 
 static void halo_clear(cna_ctx* c) {
+  if (c->halo_wait_pending && c->halo_stream) (void)hipStreamSynchronize(c->halo_stream);     // (nothing may still write into buffers about to go)
+  c->halo_wait_pending = false;
+  if (c->halo_rows_safe) dev_free(c, c->halo_rows_safe, sizeof(int32_t) * std::max<int64_t>(c->halo_nsafe, 1));
+  if (c->halo_rows_need) dev_free(c, c->halo_rows_need, sizeof(int32_t) * std::max<int64_t>(c->halo_nneed, 1));
+  c->halo_rows_safe = c->halo_rows_need = nullptr;
+  c->halo_nsafe = c->halo_nneed = 0;
   if (c->idx_t) dev_free(c, c->idx_t, sizeof(int32_t) * std::max<int64_t>(c->idx_t_n, 1));
   c->idx_t = nullptr;
   c->idx_t_n = 0;
@@ -562,6 +578,24 @@ int cna_set_halo(cna_ctx* c, const int64_t* send_rows, const int64_t* send_count
     if (!c->halo_stream) HIP_TRY(hipStreamCreateWithFlags(&c->halo_stream, hipStreamNonBlocking));
     if (!c->halo_e1) HIP_TRY(hipEventCreateWithFlags(&c->halo_e1, hipEventDisableTiming));
     if (!c->halo_e2) HIP_TRY(hipEventCreateWithFlags(&c->halo_e2, hipEventDisableTiming));
+  }
+  // the rows that read no foreign row, and the rest (from the graph block itself: no symmetry assumed)
+  if (c->n_local > 0) {
+    unsigned char* fl = nullptr;
+    HIP_TRY(hipMalloc(&fl, (size_t)c->n_local));
+    struct Free { unsigned char* p; ~Free() { (void)hipFree(p); } } free_fl{fl};
+    CNA_TRY(launch_rows_need_halo(c, fl));
+    std::vector<unsigned char> hf((size_t)c->n_local);
+    HIP_TRY(hipMemcpyAsync(hf.data(), fl, (size_t)c->n_local, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<int32_t> rs, rn;
+    for (int64_t r = 0; r < c->n_local; ++r) (hf[(size_t)r] ? rn : rs).push_back((int32_t)r);
+    c->halo_nsafe = (int64_t)rs.size();
+    c->halo_nneed = (int64_t)rn.size();
+    CNA_TRY(dev_alloc(c, (void**)&c->halo_rows_safe, sizeof(int32_t) * std::max<int64_t>(c->halo_nsafe, 1)));
+    CNA_TRY(dev_alloc(c, (void**)&c->halo_rows_need, sizeof(int32_t) * std::max<int64_t>(c->halo_nneed, 1)));
+    if (c->halo_nsafe) HIP_TRY(hipMemcpy(c->halo_rows_safe, rs.data(), sizeof(int32_t) * c->halo_nsafe, hipMemcpyHostToDevice));
+    if (c->halo_nneed) HIP_TRY(hipMemcpy(c->halo_rows_need, rn.data(), sizeof(int32_t) * c->halo_nneed, hipMemcpyHostToDevice));
   }
   // State for local + halo rows only: the rows this rank receives are the ONLY foreign rows its graph block
   // references (that is what the plan is), so the state needs n_local + nr rows, not n_global -- and what arrives can land
@@ -801,8 +835,21 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
   const char* ov = getenv("CNA_HALO_OVERLAP");
   // (RCCL: only with a communicator of the halo stream's own, cna_comm_init; the shared-memory test backend stages
   // through the host and has no such constraint)
-  const bool overlap = may_continue && c->halo_on && c->halo_stream && c->halo_nb > 0 && c->halo_ni > 0 && !(ov && atoi(ov) == 0) &&
-                       (c->shm || c->comm_halo);
+  const bool overlap_ok = c->halo_on && c->halo_stream && !(ov && atoi(ov) == 0) && (c->shm || c->comm_halo);
+  const bool overlap = may_continue && overlap_ok && c->halo_nb > 0 && c->halo_ni > 0;
+  // Round 5: the main stream no longer waits for an exchange where it is queued (halo_wait_pending) but where its rows
+  // are first needed.  A step that reads a state walks the rows WITHOUT a foreign neighbour first -- under the exchange that
+  // brings the foreign rows -- then waits, then walks the rest; its own exchange starts when both are done and is in turn
+  // hidden under the next step's safe rows (the last step included: row list and selection by-product combine).  The
+  // first step reads no state: the rows other ranks asked for first, their exchange beside the interior.
+  const bool two_lists = overlap_ok && c->halo_nsafe > 0 && c->halo_nneed > 0;
+  auto walk_safe_then_rest = [&](bool wt) -> int {
+    c->halo_safe_launch = true;
+    int rc2 = launch_nam_step(c, first, want_kurt != 0, wt, may_stop != 0, false, c->halo_rows_safe, c->halo_nsafe);
+    c->halo_safe_launch = false;
+    if (rc2 == 0) rc2 = launch_nam_step(c, first, want_kurt != 0, wt, may_stop != 0, false, c->halo_rows_need, c->halo_nneed);
+    return rc2;
+  };
   if (overlap) {
     c->byp_arm = false;
     c->byp_skip_nam = false;
@@ -810,24 +857,32 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
     double* Tn = c->T[c->t_cur ^ 1];
     CNA_TRY(dev_reserve(c, &c->halo_sbuf, &c->halo_sbuf_cap, 8 * std::max<int64_t>(c->halo_ns, 1) * ld));
     if (!c->t_compact) CNA_TRY(dev_reserve(c, &c->halo_rbuf, &c->halo_rbuf_cap, 8 * std::max<int64_t>(c->halo_nr, 1) * ld));
-    CNA_TRY(launch_nam_step(c, first, want_kurt != 0, true, may_stop != 0, false, c->halo_rows_b, c->halo_nb));
-    HIP_TRY(hipEventRecord(c->halo_e1, c->stream));
-    // (the interior rows: nobody else reads their state after the FIRST step -- this rank's second step takes its local
-    // neighbours from their pairs -- so their dense rows, 8N bytes each, are not written: only rows that overflow the pairs)
-    c->sp_dense_interior_off = first;
-    const int rc_int = launch_nam_step(c, first, want_kurt != 0, true, may_stop != 0, false, c->halo_rows_i, c->halo_ni);
-    c->sp_dense_interior_off = false;
-    CNA_TRY(rc_int);
+    if (first || !two_lists) {
+      CNA_TRY(launch_nam_step(c, first, want_kurt != 0, true, may_stop != 0, false, c->halo_rows_b, c->halo_nb));
+      HIP_TRY(hipEventRecord(c->halo_e1, c->stream));
+      // (the interior rows: nobody else reads their state after the FIRST step -- this rank's second step takes its local
+      // neighbours from their pairs -- so their dense rows, 8N bytes each, are not written: only rows that overflow the pairs)
+      c->sp_dense_interior_off = first;
+      const int rc_int = launch_nam_step(c, first, want_kurt != 0, true, may_stop != 0, false, c->halo_rows_i, c->halo_ni);
+      c->sp_dense_interior_off = false;
+      CNA_TRY(rc_int);
+    } else {
+      CNA_TRY(walk_safe_then_rest(true));
+      HIP_TRY(hipEventRecord(c->halo_e1, c->stream));
+    }
     HIP_TRY(hipStreamWaitEvent(c->halo_stream, c->halo_e1, 0));
     CNA_TRY(exchange_state(c, Tn, c->halo_stream));
     HIP_TRY(hipEventRecord(c->halo_e2, c->halo_stream));
-    HIP_TRY(hipStreamWaitEvent(c->stream, c->halo_e2, 0));
+    c->halo_wait_pending = true;                 // (halo_settle: before the first launch that reads those rows, before any collective)
     c->t_cur ^= 1;
     c->lazy_steps_before = c->steps_done;
   } else {
     int rc_step = 0;
-    if (!(arm && ranged_last_step(c, first, want_kurt != 0, may_stop != 0, &rc_step) == 1))
+    if (!first && !may_continue && c->halo_wait_pending && two_lists && !c->auto_stop && gram_overlap_ranges() < 2) {
+      rc_step = walk_safe_then_rest(false);     // the walk's last step: safe rows under the last exchange, then the rest
+    } else if (!(arm && ranged_last_step(c, first, want_kurt != 0, may_stop != 0, &rc_step) == 1)) {
       rc_step = launch_nam_step(c, first, want_kurt != 0, may_continue != 0, may_stop != 0, false);
+    }
     c->byp_arm = false;
     c->byp_skip_nam = false;
     CNA_TRY(rc_step);

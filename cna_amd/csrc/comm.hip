@@ -363,6 +363,9 @@ static int allreduce(cna_ctx* c, void* buf, size_t count, ncclDataType_t dt, ncc
   }
   if (c->nranks == 1 && !c->comm) return 0;
   if (!c->comm) CNA_FAIL(CNA_ESTATE, "multi-rank context without cna_comm_init");
+  // (never a collective of the main communicator beside an exchange still in flight on the halo communicator: two
+  // communicators active at once on one device may deadlock across ranks)
+  CNA_TRY(halo_settle(c));
   ProfScope ps(c, CNA_K_ALLGATHER);
   NCCL_TRY(g_rccl.AllReduce(buf, buf, count, dt, op, (ncclComm_t)c->comm, c->stream));
   return 0;
@@ -380,6 +383,7 @@ int comm_allgather_bytes(cna_ctx* c, const void* send, void* recv, size_t bytes_
     return 0;
   }
   if (!c->comm) CNA_FAIL(CNA_ESTATE, "multi-rank context without cna_comm_init");
+  CNA_TRY(halo_settle(c));
   ProfScope ps(c, CNA_K_ALLGATHER);
   NCCL_TRY(g_rccl.AllGather(send, recv, bytes_per_rank, ncclInt8, (ncclComm_t)c->comm, c->stream));
   return 0;

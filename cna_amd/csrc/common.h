@@ -121,6 +121,13 @@ struct cna_ctx {
   int64_t t_rows = 0;            // rows of T (and of sp_cnt) when compact
   int32_t* idx_t = nullptr;      // nnz: column indices in the compact row space
   int64_t idx_t_n = 0;
+  // rows of the block that read NO foreign state row (safe) / at least one (need): a step can walk the safe rows while the
+  // exchange that feeds it is still in flight (halo_wait_pending: recorded in halo_e2, the main stream has not waited yet)
+  int32_t* halo_rows_safe = nullptr;
+  int32_t* halo_rows_need = nullptr;
+  int64_t halo_nsafe = 0, halo_nneed = 0;
+  bool halo_wait_pending = false;
+  bool halo_safe_launch = false;        // set around a launch over halo_rows_safe (launch_nam_step then does not wait)
   bool sp_dense_interior_off = false;   // set around the launch over the rows no other rank asked for (cna_nam_step)
   int64_t sp_pair_rows = 0;      // rows of sp_pair (pairs exist for this rank's own rows only when compact)
   double* T[2] = {nullptr, nullptr};
@@ -296,6 +303,10 @@ inline bool comm_active(const cna_ctx* c) { return c->comm != nullptr || c->shm 
 int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64_t doubles_per_row, hipStream_t st = nullptr);
 // column indices of the local graph block -> rows of the compact state (cna_ctx::t_compact): own rows 0 .. n_local - 1, the
 // rows of the ascending receive list behind them; *bad = 1 when an index is neither (diffuse.hip)
+// the main stream waits for an exchange still in flight on the halo stream (c_api.hip); no-op when none is
+int halo_settle(cna_ctx* c);
+// flags[row] = 1 when the row's graph block references a column outside [row0, row0 + n_local) (diffuse.hip)
+int launch_rows_need_halo(cna_ctx* c, unsigned char* flags_dev);
 int launch_remap_indices(cna_ctx* c, const int64_t* recv_rows_dev, int64_t nr, int32_t* out, int* bad);
 int launch_pack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst, hipStream_t st = nullptr);
 int launch_unpack_rows(cna_ctx* c, const double* src, const int64_t* idx, int64_t nrows, int ld, double* dst, hipStream_t st = nullptr);

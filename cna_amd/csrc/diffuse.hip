@@ -773,6 +773,19 @@ __global__ void k_cellinfo_compact(const double* __restrict__ colsum, const int3
   }
 }
 
+// flags[row] = the row has a neighbour outside this rank's block (its step needs rows another rank sends)
+__global__ void k_rows_need_halo(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx, int64_t n_local, int64_t row0,
+                                 unsigned char* __restrict__ flags) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_local) return;
+  unsigned char f = 0;
+  for (int64_t e = indptr[r]; e < indptr[r + 1] && !f; ++e) {
+    const int64_t j = idx[e];
+    f = (j < row0 || j >= row0 + n_local) ? 1 : 0;
+  }
+  flags[r] = f;
+}
+
 // Column indices (global rows) -> rows of the compact state: a local column is its row in the block, any other column its
 // position in the ascending receive list, behind the block.  *bad: some index is neither (the halo plan does not cover
 // the graph block -- cna_set_halo refuses it).
@@ -979,7 +992,8 @@ int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
   // (resident workgroups per CU, limited by a dynamic LDS allocation: 6 -> 5 changes nothing, 4 costs 4.5 %, 2 costs 47 %:
   // profiles/r04_ab_gram_overlap.txt)
   const size_t pad = 0;
-  if (a.rows) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 2>), grid, dim3(256), pad, st, a);
+  if (a.rows && a.sel_X) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 3>), grid, dim3(256), pad, st, a);   // (row list AND by-product: the last step of a sharded walk, in two launches)
+  else if (a.rows) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 2>), grid, dim3(256), pad, st, a);
   else if (a.sel_X) hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 1>), grid, dim3(256), pad, st, a);
   else hipLaunchKernelGGL((k_nam_step<VT, NQ2, U, 0>), grid, dim3(256), pad, st, a);
   return 0;
@@ -988,7 +1002,8 @@ int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
 template <typename VT, int NQ2>
 int launch_step_sparse_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(double) * 4 * 128 * NQ2;
-  if (a.rows) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 2>), grid, dim3(256), lds, st, a);
+  if (a.rows && a.sel_X) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 3>), grid, dim3(256), lds, st, a);
+  else if (a.rows) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 2>), grid, dim3(256), lds, st, a);
   else if (a.sel_X) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 1>), grid, dim3(256), lds, st, a);
   else hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 0>), grid, dim3(256), lds, st, a);
   return 0;
@@ -1064,6 +1079,14 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in, hipStream_t st) 
 }
 
 }  // namespace
+
+int launch_rows_need_halo(cna_ctx* c, unsigned char* flags_dev) {
+  if (c->n_local == 0) return 0;
+  hipLaunchKernelGGL(k_rows_need_halo, dim3((unsigned)((c->n_local + 255) / 256)), dim3(256), 0, c->stream, c->indptr, c->indices,
+                     c->n_local, c->row0, flags_dev);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
 
 int launch_remap_indices(cna_ctx* c, const int64_t* recv_rows_dev, int64_t nr, int32_t* out, int* bad) {
   *bad = 0;
@@ -1141,6 +1164,9 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
                     int64_t n_rows, int64_t base, int64_t count, hipStream_t st_in, bool timed) {
   if (c->n_local == 0 || (rows && n_rows == 0) || count == 0) return 0;
   hipStream_t st = st_in ? st_in : c->stream;
+  // an exchange of the input state may still be in flight on the halo stream: every launch waits for it, except the one
+  // over the rows that read no foreign row (cna_nam_step)
+  if (!first && !c->halo_safe_launch) CNA_TRY(halo_settle(c));
   if (first && !c->cellinfo_valid) {
     void* p = c->cellinfo;
     const int64_t rows = c->t_compact ? c->t_rows : c->n_global;
