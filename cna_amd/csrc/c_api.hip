@@ -836,7 +836,9 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
   // (RCCL: only with a communicator of the halo stream's own, cna_comm_init; the shared-memory test backend stages
   // through the host and has no such constraint)
   const bool overlap_ok = c->halo_on && c->halo_stream && !(ov && atoi(ov) == 0) && (c->shm || c->comm_halo);
-  const bool overlap = may_continue && overlap_ok && c->halo_nb > 0 && c->halo_ni > 0;
+  // (NOT a function of this rank's own row counts: a rank nobody asks for rows, or one without interior rows, takes the
+  // same path with an empty launch -- which communicator carries the exchange must be the same decision on every rank)
+  const bool overlap = may_continue && overlap_ok;
   // Round 5: the main stream no longer waits for an exchange where it is queued (halo_wait_pending) but where its rows
   // are first needed.  A step that reads a state walks the rows WITHOUT a foreign neighbour first -- under the exchange that
   // brings the foreign rows -- then waits, then walks the rest; its own exchange starts when both are done and is in turn
