@@ -25,6 +25,7 @@ SIGNATURES = {
     'cna_ctx_destroy': (C.c_int, [c_ctx]),
     'cna_ctx_sync': (C.c_int, [c_ctx]),
     'cna_ctx_device_bytes': (C.c_int, [c_ctx, c_i64p]),
+    'cna_set_state_f32': (C.c_int, [c_ctx, C.c_int]),
     'cna_comm_unique_id': (C.c_int, [C.c_void_p]),
     'cna_comm_init': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_void_p]),
     'cna_graph_upload': (C.c_int, [c_ctx, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,

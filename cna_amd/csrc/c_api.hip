@@ -220,6 +220,7 @@ int cna_ctx_create(int device, cna_ctx** out) {
     cna_set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
     return (int)e;
   }
+  if (const char* sf = getenv("CNA_STATE_F32")) c->state_f32_mode = atoi(sf) != 0;
   *out = c;
   return 0;
 }
@@ -276,6 +277,14 @@ int cna_ctx_sync(cna_ctx* c) {
 int cna_ctx_device_bytes(cna_ctx* c, int64_t* bytes) {
   if (!c || !bytes) CNA_FAIL(CNA_EINVAL, "null argument");
   *bytes = c->dev_bytes.load();
+  return 0;
+}
+
+int cna_set_state_f32(cna_ctx* c, int on) {
+  CHECK_CTX(c);
+  // takes effect at the next step that writes the state: every buffer carries its own format (t_f32), so a walk in
+  // progress stays consistent; the caller decides what a NAM already on the device is worth (engine.set_state_f32)
+  c->state_f32_mode = on != 0;
   return 0;
 }
 
@@ -479,6 +488,7 @@ int cna_set_samples(cna_ctx* c, const int32_t* codes, int n_samples, const doubl
   c->t_width = c->N;
   c->t_ld = c->ld;
   c->t_cur = 0;
+  c->t_f32[0] = c->t_f32[1] = false;
   c->steps_done = 0;
   c->t_valid = false;
   c->nam_valid = false; c->nam_lazy = false;
@@ -498,6 +508,7 @@ int cna_restart_nam(cna_ctx* c) {
   c->t_width = c->N;
   c->t_ld = c->ld;
   c->t_cur = 0;
+  c->t_f32[0] = c->t_f32[1] = false;
   c->steps_done = 0;
   c->t_valid = false;
   c->nam_valid = false; c->nam_lazy = false;
@@ -1141,6 +1152,7 @@ int cna_dense_load(cna_ctx* c, const double* s_local, int m) {
   c->t_width = m;
   c->t_ld = ld;
   c->t_cur = 0;
+  c->t_f32[0] = c->t_f32[1] = false;
   CNA_TRY(launch_scale_rows(c, (const double*)c->scratch, c->T[0], m, ld));
   CNA_TRY(exchange_state(c, c->T[0]));
   HIP_TRY(hipStreamSynchronize(c->stream));

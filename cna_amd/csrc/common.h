@@ -134,6 +134,11 @@ struct cna_ctx {
   int64_t t_cap = 0;  // doubles allocated per buffer
   int t_cur = 0, t_width = 0, t_ld = 0, steps_done = 0;
   bool t_valid = false;
+  // opt-in (cna_set_state_f32): the scaled state BETWEEN two steps of a walk is stored in 4 bytes per entry
+  // (sums still run in f64).  Halves what the dense step gathers; the NAM then equals the f64 one to ~1e-7 relative
+  // instead of bit for bit.  t_f32[i]: what T[i] holds right now.
+  bool state_f32_mode = false;
+  bool t_f32[2] = {false, false};
   double* dense_s = nullptr;  // unscaled local state of the dense diffusion (n_local x t_ld)
   int64_t dense_cap = 0;
 

@@ -69,6 +69,8 @@ struct StepArgs {
   unsigned long long* sel_nz;   // [0] rows of zero variance, [1] bits of max |coefficient| (NaN pattern if any is NaN)
   int sel_ldx, sel_Kp;
   int skip_nam;             // with the by-product: the raw NAM is not stored (c_api.hip:need_nam materialises it on demand)
+  // 4-byte state between steps (common.h:state_f32_mode); host-side dispatch only: the kernels are instantiated per format
+  int in32, out32;
 };
 #define STEP_STOPPED(a) ((a).stop != nullptr && __builtin_nontemporal_load((a).stop) != 0)
 // One 16-byte record per non-zero: the second step then fetches an edge's whole neighbour row with ONE
@@ -106,6 +108,10 @@ struct ColStride1 {   // one double per lane: col = lane + 64*k
 };
 struct ColPair {      // double2 per lane: cols 2*(lane + 64*(k/2)) + (k&1)
   __device__ static int col(int lane, int k) { return 2 * (lane + 64 * (k >> 1)) + (k & 1); }
+};
+
+struct ColQuad {      // four adjacent columns per lane (4-byte state: one float4): cols 4*(lane + 64*(k/4)) + (k&3)
+  __device__ static int col(int lane, int k) { return 4 * (lane + 64 * (k >> 2)) + (k & 3); }
 };
 
 // What rows.hip:k_select_std16 makes of a NAM row when every cell and every sample stays and nothing is regressed out
@@ -194,21 +200,104 @@ __device__ __forceinline__ void select_tail(const StepArgs& a, int64_t row, int 
   }
 }
 
+// The same statements for the four-columns-per-lane layout of k_nam_step32 (ColQuad).  A lane holds four adjacent bytes of
+// each digit plane, so the planes are stored as dwords without the exchange between neighbouring lanes.
+template <int NV>
+__device__ __forceinline__ void select_tail_quad(const StepArgs& a, int64_t row, int lane, double (&x)[NV]) {
+  const double n = (double)a.width;
+  double sum = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) sum += x[k];
+  const double avg0 = wave_sum(sum) / n;
+  bool flat = true;
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (ColQuad::col(lane, k) < a.width) flat = flat && (avg0 - x[k] == 0.0);
+  if (__all(flat) && lane == 0) atomicAdd(a.sel_nz, 1ull);
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+    if (ColQuad::col(lane, k) < a.width) x[k] -= avg0;
+  double s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) s2 += x[k];
+  const double avg = wave_sum(s2) / n;
+  double ss = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (ColQuad::col(lane, k) < a.width) {
+      const double d = avg - x[k];
+      ss += d * d;
+    }
+  }
+  const double sd = sqrt(wave_sum(ss) / (n - 1.0));
+  double dot = 0.0, amax = 0.0;
+  double* __restrict__ dst = a.sel_X + row * a.sel_ldx;
+#pragma unroll
+  for (int k = 0; k < NV; k += 2) {
+    const int c0 = ColQuad::col(lane, k);
+    const double x0 = c0 < a.width ? __ddiv_rn(x[k], sd) : 0.0;
+    const double x1 = c0 + 1 < a.width ? __ddiv_rn(x[k + 1], sd) : 0.0;
+    x[k] = x0;
+    x[k + 1] = x1;
+    if (c0 < a.width) dot += a.sel_y[c0] * x0;
+    if (c0 + 1 < a.width) dot += a.sel_y[c0 + 1] * x1;
+    amax = fmax(amax, fmax(fabs(x0), fabs(x1)));
+    if (c0 + 1 < a.sel_ldx) *(double2*)(dst + c0) = make_double2(x0, x1);
+  }
+  if (a.sel_xq) {
+    const double rmax = wave_max_d(amax);
+    const double inv = rmax > 0.0 ? I8_QMAX / rmax : 0.0;
+    unsigned char* rq = a.sel_xq + (size_t)row * 3 * a.sel_Kp;
+#pragma unroll
+    for (int k = 0; k < NV; k += 4) {
+      unsigned h0 = 0, h1 = 0, h2 = 0;                      // this lane's four bytes of each plane
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const double v = x[k + j] * inv;
+        const int qi = v == v ? (int)rint(v) : 0;
+        const int q1 = (qi + 128) >> 8;
+        h0 |= ((unsigned)qi & 255u) << (8 * j);
+        h1 |= ((unsigned)q1 & 255u) << (8 * j);
+        h2 |= ((unsigned)((q1 + 128) >> 8) & 255u) << (8 * j);
+      }
+      const int c0 = ColQuad::col(lane, k);
+      if (c0 < a.sel_Kp) {
+        *(unsigned*)(rq + c0) = h0;
+        *(unsigned*)(rq + a.sel_Kp + c0) = h1;
+        *(unsigned*)(rq + 2 * a.sel_Kp + c0) = h2;
+      }
+    }
+    const double l1 = rmax > 0.0 ? n * (I8_QMAX / rmax) + n : 0.0;
+    if (lane == 0) a.sel_xscale[row] = make_double2(rmax, l1);
+  }
+  const double v = wave_sum(dot) / n;
+  if (lane == 0) {
+    a.sel_nc[row] = v;
+    const unsigned long long bits = v != v ? 0x7ff8000000000000ull : (unsigned long long)__double_as_longlong(fabs(v));
+    if (bits > __builtin_nontemporal_load(a.sel_nz + 1)) atomicMax(a.sel_nz + 1, bits);
+  }
+}
+
 // FL: what a launch's instantiation compiles in -- bit 0: the selection by-product (select_tail; the last step of a
-// walk with a hint), bit 1: a row list (halo overlap).  Kept out of the plain instantiations on purpose: the fields
+// walk with a hint), bit 1: a row list (halo overlap), bit 2: the scaled state is written in 4 bytes per entry.  Kept out of the plain instantiations on purpose: the fields
 // they need are kernel arguments that stay live in scalar registers across the gather loop, and the compressed second
 // step lost 9 % (4.09 -> 4.45 ms at 2M x 200) when it carried them.
 template <int NV, typename CM, int FL = 0>
 __device__ __forceinline__ void finish_row(const StepArgs& a, int64_t row, int64_t grow, int lane,
                                            const double (&s)[NV]) {
   constexpr bool BYP = (FL & 1) != 0;
+  constexpr bool T32 = (FL & 4) != 0;
   const double cs = a.colsum[grow];
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int col = CM::col(lane, k);
     if (col < a.ld) {
       const bool in = col < a.width;
-      if (a.write_t) a.Tout[grow * a.ld + col] = in ? __ddiv_rn(s[k], cs) : 0.0;
+      if constexpr (T32) {
+        if (a.write_t) ((float*)a.Tout)[grow * a.ld + col] = in ? (float)__ddiv_rn(s[k], cs) : 0.0f;
+      } else {
+        if (a.write_t) a.Tout[grow * a.ld + col] = in ? __ddiv_rn(s[k], cs) : 0.0;
+      }
       if (a.dense_out) a.dense_out[row * a.ld + col] = in ? s[k] : 0.0;
     }
   }
@@ -245,6 +334,9 @@ __device__ __forceinline__ void finish_row(const StepArgs& a, int64_t row, int64
     }
     if constexpr (BYP && std::is_same<CM, ColPair>::value) {
       if (a.sel_X) select_tail<NV>(a, row, lane, x);
+    }
+    if constexpr (BYP && std::is_same<CM, ColQuad>::value) {
+      if (a.sel_X) select_tail_quad<NV>(a, row, lane, x);
     }
   }
 }
@@ -478,6 +570,82 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
     s[2 * q + 1] = add_rn(acc[q].y, mul_rn(a.w, own.y));
   }
   finish_row<2 * NQ2, ColPair, FL>(a, row, grow, lane, s);
+}
+
+// The same step on a state stored in 4 bytes per entry (cna_set_state_f32): a lane owns FOUR adjacent columns and one
+// 16-byte load fetches them; every entry is widened to f64 before the same unfused multiply and add, in the same CSR
+// order.  Half the bytes per edge through the vector L1 and from behind the L2 -- the two limits of k_nam_step.
+template <typename VT, int NQ4, int U = 8, int FL = 0>
+__global__ __launch_bounds__(256) void k_nam_step32(StepArgs a) {
+  if (STEP_STOPPED(a)) return;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row = my_row(wv, a.xcd_chunk);
+  if (row >= a.n_local) return;
+  const int64_t grow = a.row0 + row;
+  const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
+  const float4* __restrict__ Tin = (const float4*)a.Tin;
+  const int ld4 = a.ld >> 2;
+  // lanes past the row width fetch the row's first 16 bytes (same cache line as lane 0's) and their sums are never read
+  // (finish_row looks at columns below ld only): with the load under a condition the compiler puts the widening to f64
+  // next to it and waits for every row before it asks for the next one
+  unsigned off[NQ4];
+#pragma unroll
+  for (int q = 0; q < NQ4; ++q) off[q] = lane + 64 * q < ld4 ? (unsigned)(lane + 64 * q) : 0u;
+  double acc[NQ4][4];
+#pragma unroll
+  for (int q = 0; q < NQ4; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[q][i] = 0.0;
+  auto add_row = [&](int q, double av, const float4& t) {
+    acc[q][0] = add_rn(acc[q][0], mul_rn(av, (double)t.x));
+    acc[q][1] = add_rn(acc[q][1], mul_rn(av, (double)t.y));
+    acc[q][2] = add_rn(acc[q][2], mul_rn(av, (double)t.z));
+    acc[q][3] = add_rn(acc[q][3], mul_rn(av, (double)t.w));
+  };
+  for (int64_t base = start; base < end; base += 64) {
+    int jl;
+    double al;
+    load_edges<VT>(a, base, end, lane, jl, al);
+    const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+    int l = 0;
+    for (; l + U <= cnt; l += U) {
+      float4 t[U][NQ4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int j = __builtin_amdgcn_readlane(jl, l + u);
+        const float4* __restrict__ rowp = Tin + (int64_t)j * ld4;
+#pragma unroll
+        for (int q = 0; q < NQ4; ++q) t[u][q] = rowp[off[q]];
+      }
+      // (all U rows requested before the first is consumed: left alone the scheduler starts widening row 0 after three
+      // requests and waits for each of them with vmcnt(0))
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double av = readlane_d(al, l + u);
+#pragma unroll
+        for (int q = 0; q < NQ4; ++q) add_row(q, av, t[u][q]);
+      }
+    }
+    for (; l < cnt; ++l) {                       // ragged tail
+      const int j = __builtin_amdgcn_readlane(jl, l);
+      const double av = readlane_d(al, l);
+      const float4* __restrict__ rowp = Tin + (int64_t)j * ld4;
+#pragma unroll
+      for (int q = 0; q < NQ4; ++q) add_row(q, av, rowp[off[q]]);
+    }
+  }
+  double s[4 * NQ4];
+#pragma unroll
+  for (int q = 0; q < NQ4; ++q) {
+    const float4 own = Tin[grow * ld4 + off[q]];
+    s[4 * q] = add_rn(acc[q][0], mul_rn(a.w, (double)own.x));
+    s[4 * q + 1] = add_rn(acc[q][1], mul_rn(a.w, (double)own.y));
+    s[4 * q + 2] = add_rn(acc[q][2], mul_rn(a.w, (double)own.z));
+    s[4 * q + 3] = add_rn(acc[q][3], mul_rn(a.w, (double)own.w));
+  }
+  finish_row<4 * NQ4, ColQuad, FL>(a, row, grow, lane, s);
 }
 
 // Narrow states (ld <= 64 columns, i.e. at most 32 column pairs): TWO destination rows per wave, one
@@ -999,9 +1167,25 @@ int launch_step_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
   return 0;
 }
 
+template <typename VT, int NQ4, int U = 8>
+int launch_step32_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
+  if (a.rows) CNA_FAIL(CNA_ESTATE, "4-byte state with a row list");          // (launch_nam_step never produces one)
+  if (a.sel_X && a.out32) hipLaunchKernelGGL((k_nam_step32<VT, NQ4, U, 5>), grid, dim3(256), 0, st, a);
+  else if (a.sel_X) hipLaunchKernelGGL((k_nam_step32<VT, NQ4, U, 1>), grid, dim3(256), 0, st, a);
+  else if (a.out32) hipLaunchKernelGGL((k_nam_step32<VT, NQ4, U, 4>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_nam_step32<VT, NQ4, U, 0>), grid, dim3(256), 0, st, a);
+  return 0;
+}
+
 template <typename VT, int NQ2>
 int launch_step_sparse_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(double) * 4 * 128 * NQ2;
+  if (a.out32) {
+    if (a.rows) CNA_FAIL(CNA_ESTATE, "4-byte state with a row list");
+    if (a.sel_X) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 5>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 4>), grid, dim3(256), lds, st, a);
+    return 0;
+  }
   if (a.rows && a.sel_X) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 3>), grid, dim3(256), lds, st, a);
   else if (a.rows) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 2>), grid, dim3(256), lds, st, a);
   else if (a.sel_X) hipLaunchKernelGGL((k_nam_step_sparse<VT, NQ2, 5, 1>), grid, dim3(256), lds, st, a);
@@ -1052,17 +1236,26 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in, hipStream_t st) 
     }
   } else if (a.sp_cnt) {
     switch ((a.ld / 2 + 63) / 64) {
-      case 1: launch_step_sparse_t<VT, 1>(c, a, grid, st); break;
-      case 2: launch_step_sparse_t<VT, 2>(c, a, grid, st); break;
-      case 3: launch_step_sparse_t<VT, 3>(c, a, grid, st); break;
-      case 4: launch_step_sparse_t<VT, 4>(c, a, grid, st); break;
-      case 5: case 6: launch_step_sparse_t<VT, 6>(c, a, grid, st); break;
-      default: launch_step_sparse_t<VT, 8>(c, a, grid, st); break;
+      case 1: CNA_TRY((launch_step_sparse_t<VT, 1>(c, a, grid, st))); break;
+      case 2: CNA_TRY((launch_step_sparse_t<VT, 2>(c, a, grid, st))); break;
+      case 3: CNA_TRY((launch_step_sparse_t<VT, 3>(c, a, grid, st))); break;
+      case 4: CNA_TRY((launch_step_sparse_t<VT, 4>(c, a, grid, st))); break;
+      case 5: case 6: CNA_TRY((launch_step_sparse_t<VT, 6>(c, a, grid, st))); break;
+      default: CNA_TRY((launch_step_sparse_t<VT, 8>(c, a, grid, st))); break;
     }
   } else if (pair) {
+    if (a.in32 || a.out32) CNA_FAIL(CNA_ESTATE, "4-byte state with the two-rows-per-wave step");
     if (a.rows) hipLaunchKernelGGL((k_nam_step_pair<VT, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_nam_step_pair<VT, 0>), grid, dim3(256), 0, st, a);
+  } else if (a.in32) {
+    switch ((a.ld / 4 + 63) / 64) {
+      case 1: CNA_TRY((launch_step32_t<VT, 1, 8>(c, a, grid, st))); break;
+      case 2: CNA_TRY((launch_step32_t<VT, 2, 8>(c, a, grid, st))); break;
+      case 3: CNA_TRY((launch_step32_t<VT, 3, 4>(c, a, grid, st))); break;
+      default: CNA_TRY((launch_step32_t<VT, 4, 4>(c, a, grid, st))); break;
+    }
   } else {
+    if (a.out32) CNA_FAIL(CNA_ESTATE, "4-byte state out of the 8-byte dense step");
     switch ((a.ld / 2 + 63) / 64) {
       case 1: launch_step_t<VT, 1>(c, a, grid, st); break;
       // 129 ... 256 columns: ten rows in flight (7.82 -> 7.69 ms at 2M x 200; 9: the same, 11 / 12: as 8); with the
@@ -1215,6 +1408,13 @@ int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool w
   a.write_nam = write_nam;
   a.stop = c->auto_stop;
   a.sp_keep_dense = ((c->nranks > 1 || c->halo_on) && !c->sp_dense_interior_off) ? 1 : 0;
+  // 4-byte state between steps (opt-in, one rank): written by the compressed second step and by every later step that is
+  // not known to be the last, read by k_nam_step32.  The first step, narrow states (two rows per wave), the dense
+  // diffusion and sharded walks (the exchange moves 8-byte rows) keep 8 bytes.
+  a.in32 = (!first && c->t_f32[c->t_cur]) ? 1 : 0;
+  a.out32 = (write_t && !first && !dense && c->state_f32_mode && c->nranks == 1 && !c->halo_on && !c->t_compact && c->t_ld > 64 &&
+             !rows && (sparse_step || a.in32)) ? 1 : 0;
+  if (write_t) c->t_f32[c->t_cur ^ 1] = a.out32 != 0;
   // compressed state: written by the first step, read by the second (sample indicators only)
   const bool sp = c->sp_cnt && !dense && (first || c->steps_done == 1);
   a.sp_pair = sp ? (SpPair*)c->sp_pair : nullptr;

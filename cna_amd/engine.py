@@ -91,6 +91,18 @@ class Engine(_order.CellOrder):
     def sync(self):
         check(self.lib.cna_ctx_sync(self.h), 'cna_ctx_sync')
 
+    def set_state_f32(self, on=True):
+        """Opt-in: keep the diffusion state between two steps of a walk in 4 bytes per entry (one rank, more than 64
+        samples; sums, NAM and everything downstream stay float64).  Halves what the dense step gathers; the NAM then
+        agrees with the default walk to ~1e-7 relative instead of bit for bit (reference: float64 `s` between the
+        iterations of `_nam.py:31-34`).  A NAM held on the device from the other format is forgotten."""
+        on = bool(on)
+        if on != getattr(self, '_state_f32', None):
+            check(self.lib.cna_set_state_f32(self.h, int(on)), 'cna_set_state_f32')
+            self._state_f32 = on
+            self._nam_sig = None
+        return self
+
     def device_bytes(self):
         b = C.c_int64(0)
         check(self.lib.cna_ctx_device_bytes(self.h, C.byref(b)), 'cna_ctx_device_bytes')

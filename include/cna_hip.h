@@ -62,6 +62,12 @@ int  cna_ctx_destroy(cna_ctx* ctx);
 int  cna_ctx_sync(cna_ctx* ctx);
 /* bytes of device memory currently held by the context */
 int  cna_ctx_device_bytes(cna_ctx* ctx, int64_t* bytes);
+/* Opt-in storage format of the diffusion state BETWEEN two steps of a walk (reference: the float64 `s` of
+   _nam.py:31-34 between iterations of diffuse_stepwise): on != 0 keeps it in 4 bytes per entry from the second step on
+   (one rank, more than 64 samples; anything else keeps 8 bytes).  Sums, the NAM and everything after it stay float64;
+   the NAM then agrees with the 8-byte walk to ~1e-7 relative instead of bit for bit.  Default off (env CNA_STATE_F32=1
+   turns it on at context creation). */
+int  cna_set_state_f32(cna_ctx* ctx, int on);
 
 /* ---- multi-GPU (RCCL over xGMI) ------------------------------------------------------ */
 /* rank 0 creates a 128-byte id and ships it to the other ranks by any host channel */

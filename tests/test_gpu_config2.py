@@ -77,13 +77,17 @@ def case3():
 
 
 def test_config3_matches_the_reference_run(case3):
+    from cna_amd.engine import get_engine
+    check_config3_against_the_reference(case3, get_engine())
+
+
+def check_config3_against_the_reference(case3, engine):
     import warnings
     import cna_amd as cna
-    from cna_amd.engine import get_engine
     z, data = case3['z'], case3['data']
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        res = cna.tl.association(data, case3['y'], 'id', return_full=True, engine=get_engine(), **case3['call'])
+        res = cna.tl.association(data, case3['y'], 'id', return_full=True, engine=engine, **case3['call'])
     sub = z['sub']
     out = dict(p=res.p, k=res.k, ks=res.ks, r=res.r, n_kept=int(res.kept.sum()), nullminps=res.nullminps,
                svs=res.namresid_svs.values, U=res.namresid_sampleXpc.values, M=res.M.values, yresid=res.yresid.values,
@@ -99,3 +103,4 @@ def test_config3_matches_the_reference_run(case3):
     assert_elementwise(nam_sub, z['nam_sub'], 1e-5, 1e-12, 'nam (every 1000th cell)')
     assert_elementwise(res.namresid.values[:, sub], z['namresid_sub'], 1e-5, 2e-7, 'namresid (every 1000th cell)')
     assert case3['same_inputs'], 'results agree, but the regenerated inputs are not bit-identical to the fixture\'s'
+    return res
