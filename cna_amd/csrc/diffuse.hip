@@ -525,24 +525,26 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
   double2 acc[NQ2];
 #pragma unroll
   for (int q = 0; q < NQ2; ++q) acc[q] = make_double2(0.0, 0.0);
-  for (int64_t base = start; base < end; base += 64) {
-    int jl;
-    double al;
-    load_edges<VT>(a, base, end, lane, jl, al);
-    const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
-    int l = 0;
-    for (; l + U <= cnt; l += U) {
-      double2 t[U][NQ2];
+  // B neighbour rows requested together, then added one by one in CSR order.  PAD: the last, partial batch of a row --
+  // its missing rows are requested from the row's own state (wanted next anyway) and never added: one memory latency for
+  // the rest of a row instead of one per edge (the rows of a kNN graph have ~40 edges: with U = 8 a row waited for five
+  // batches and 3.5 single rows)
+  auto batch = [&](auto bc, auto pc, int jl, double al, int l0, int nvalid) {
+    constexpr int B = decltype(bc)::value;
+    constexpr bool PAD = decltype(pc)::value;
+    double2 t[B][NQ2];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int j = __builtin_amdgcn_readlane(jl, l + u);
-        const double2* __restrict__ rowp = Tin + (int64_t)j * ld2;
+    for (int u = 0; u < B; ++u) {
+      int64_t j = __builtin_amdgcn_readlane(jl, (l0 + u) & 63);
+      if (PAD && u >= nvalid) j = grow;
+      const double2* __restrict__ rowp = Tin + j * ld2;
 #pragma unroll
-        for (int q = 0; q < NQ2; ++q) t[u][q] = act[q] ? rowp[off[q]] : make_double2(0.0, 0.0);
-      }
+      for (int q = 0; q < NQ2; ++q) t[u][q] = act[q] ? rowp[off[q]] : make_double2(0.0, 0.0);
+    }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double av = readlane_d(al, l + u);
+    for (int u = 0; u < B; ++u) {
+      if (!PAD || u < nvalid) {              // (uniform; not a `break`: the batch must unroll completely or t[] goes to scratch)
+        const double av = readlane_d(al, (l0 + u) & 63);
 #pragma unroll
         for (int q = 0; q < NQ2; ++q) {
           acc[q].x = add_rn(acc[q].x, mul_rn(av, t[u][q].x));
@@ -550,17 +552,17 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
         }
       }
     }
-    for (; l < cnt; ++l) {                       // ragged tail
-      const int j = __builtin_amdgcn_readlane(jl, l);
-      const double av = readlane_d(al, l);
-      const double2* __restrict__ rowp = Tin + (int64_t)j * ld2;
-#pragma unroll
-      for (int q = 0; q < NQ2; ++q) {
-        const double2 t = act[q] ? rowp[off[q]] : make_double2(0.0, 0.0);
-        acc[q].x = add_rn(acc[q].x, mul_rn(av, t.x));
-        acc[q].y = add_rn(acc[q].y, mul_rn(av, t.y));
-      }
-    }
+  };
+  for (int64_t base = start; base < end; base += 64) {
+    int jl;
+    double al;
+    load_edges<VT>(a, base, end, lane, jl, al);
+    const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+    int l = 0;
+    for (; l + U <= cnt; l += U) batch(std::integral_constant<int, U>{}, std::false_type{}, jl, al, l, U);
+    const int rem = cnt - l;
+    if (rem > (U + 1) / 2) batch(std::integral_constant<int, U>{}, std::true_type{}, jl, al, l, rem);
+    else if (rem > 0) batch(std::integral_constant<int, (U + 1) / 2>{}, std::true_type{}, jl, al, l, rem);
   }
   double s[2 * NQ2];
 #pragma unroll
@@ -597,11 +599,39 @@ __global__ __launch_bounds__(256) void k_nam_step32(StepArgs a) {
   for (int q = 0; q < NQ4; ++q)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[q][i] = 0.0;
+  // (fused: nothing here is bit-identical to the 8-byte walk anyway.  Measured at 2M x 200, HISTORY.md "Round 5": 5.5 ms;
+  // with the arithmetic removed 5.3 ms -- 800-byte rows touch 7.25 lines of 128 bytes, the vector L1 passes ~30 bytes of
+  // LINES per clock --; with every gather aimed at one resident row 4.6 ms: both sides are within 15 % of the launch)
   auto add_row = [&](int q, double av, const float4& t) {
-    acc[q][0] = add_rn(acc[q][0], mul_rn(av, (double)t.x));
-    acc[q][1] = add_rn(acc[q][1], mul_rn(av, (double)t.y));
-    acc[q][2] = add_rn(acc[q][2], mul_rn(av, (double)t.z));
-    acc[q][3] = add_rn(acc[q][3], mul_rn(av, (double)t.w));
+    acc[q][0] = __builtin_fma(av, (double)t.x, acc[q][0]);
+    acc[q][1] = __builtin_fma(av, (double)t.y, acc[q][1]);
+    acc[q][2] = __builtin_fma(av, (double)t.z, acc[q][2]);
+    acc[q][3] = __builtin_fma(av, (double)t.w, acc[q][3]);
+  };
+  // (batches as in k_nam_step: the partial batch at the end of a row asks for the row's own state in its empty slots)
+  auto batch = [&](auto bc, auto pc, int jl, double al, int l0, int nvalid) {
+    constexpr int B = decltype(bc)::value;
+    constexpr bool PAD = decltype(pc)::value;
+    float4 t[B][NQ4];
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      int64_t j = __builtin_amdgcn_readlane(jl, (l0 + u) & 63);
+      if (PAD && u >= nvalid) j = grow;
+      const float4* __restrict__ rowp = Tin + j * ld4;
+#pragma unroll
+      for (int q = 0; q < NQ4; ++q) t[u][q] = rowp[off[q]];
+    }
+    // (all rows requested before the first is consumed: left alone the scheduler starts widening row 0 after three
+    // requests and waits for each of them with vmcnt(0))
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      if (!PAD || u < nvalid) {
+        const double av = readlane_d(al, (l0 + u) & 63);
+#pragma unroll
+        for (int q = 0; q < NQ4; ++q) add_row(q, av, t[u][q]);
+      }
+    }
   };
   for (int64_t base = start; base < end; base += 64) {
     int jl;
@@ -609,43 +639,97 @@ __global__ __launch_bounds__(256) void k_nam_step32(StepArgs a) {
     load_edges<VT>(a, base, end, lane, jl, al);
     const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
     int l = 0;
-    for (; l + U <= cnt; l += U) {
-      float4 t[U][NQ4];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int j = __builtin_amdgcn_readlane(jl, l + u);
-        const float4* __restrict__ rowp = Tin + (int64_t)j * ld4;
-#pragma unroll
-        for (int q = 0; q < NQ4; ++q) t[u][q] = rowp[off[q]];
-      }
-      // (all U rows requested before the first is consumed: left alone the scheduler starts widening row 0 after three
-      // requests and waits for each of them with vmcnt(0))
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const double av = readlane_d(al, l + u);
-#pragma unroll
-        for (int q = 0; q < NQ4; ++q) add_row(q, av, t[u][q]);
-      }
-    }
-    for (; l < cnt; ++l) {                       // ragged tail
-      const int j = __builtin_amdgcn_readlane(jl, l);
-      const double av = readlane_d(al, l);
-      const float4* __restrict__ rowp = Tin + (int64_t)j * ld4;
-#pragma unroll
-      for (int q = 0; q < NQ4; ++q) add_row(q, av, rowp[off[q]]);
-    }
+    for (; l + U <= cnt; l += U) batch(std::integral_constant<int, U>{}, std::false_type{}, jl, al, l, U);
+    const int rem = cnt - l;
+    if (rem > (U + 1) / 2) batch(std::integral_constant<int, U>{}, std::true_type{}, jl, al, l, rem);
+    else if (rem > 0) batch(std::integral_constant<int, (U + 1) / 2>{}, std::true_type{}, jl, al, l, rem);
   }
   double s[4 * NQ4];
 #pragma unroll
   for (int q = 0; q < NQ4; ++q) {
     const float4 own = Tin[grow * ld4 + off[q]];
-    s[4 * q] = add_rn(acc[q][0], mul_rn(a.w, (double)own.x));
-    s[4 * q + 1] = add_rn(acc[q][1], mul_rn(a.w, (double)own.y));
-    s[4 * q + 2] = add_rn(acc[q][2], mul_rn(a.w, (double)own.z));
-    s[4 * q + 3] = add_rn(acc[q][3], mul_rn(a.w, (double)own.w));
+    s[4 * q] = __builtin_fma(a.w, (double)own.x, acc[q][0]);
+    s[4 * q + 1] = __builtin_fma(a.w, (double)own.y, acc[q][1]);
+    s[4 * q + 2] = __builtin_fma(a.w, (double)own.z, acc[q][2]);
+    s[4 * q + 3] = __builtin_fma(a.w, (double)own.w, acc[q][3]);
   }
   finish_row<4 * NQ4, ColQuad, FL>(a, row, grow, lane, s);
+}
+
+// ... and for rows of at most 128 columns (32 lanes of four): TWO edges of the row per wave instruction, one per
+// half-wave -- the instruction stream per edge (one load, four widenings, four fused multiply-adds) is what bounds the
+// kernel above, and a 100-column row leaves 39 of its 64 lanes idle.  Lanes 0-31 take the even edges of a batch, lanes
+// 32-63 the odd ones (index and weight reach them through the LDS crossbar, ds_bpermute: no VALU time); the two partial
+// sums of a column meet at the end.  Byte offsets into the state are 32 bits wide (launch_step_q checks).
+__device__ __forceinline__ double bperm_d(int byte_idx, double v) {
+  const int lo = __builtin_amdgcn_ds_bpermute(byte_idx, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(byte_idx, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+template <typename VT, int U = 8, int FL = 0>
+__global__ __launch_bounds__(256) void k_nam_step32h(StepArgs a) {
+  if (STEP_STOPPED(a)) return;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row = my_row(wv, a.xcd_chunk);
+  if (row >= a.n_local) return;
+  const int64_t grow = a.row0 + row;
+  const int64_t start = uniform64(a.indptr[row]), end = uniform64(a.indptr[row + 1]);
+  const char* __restrict__ Tin = (const char*)a.Tin;
+  const int half = lane >> 5, hl = lane & 31;
+  const unsigned row_bytes = (unsigned)a.ld * 4u;
+  const unsigned off = (hl < (a.ld >> 2) ? (unsigned)hl : 0u) * 16u;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  auto add_row = [&](double av, const float4& t) {
+    acc[0] = __builtin_fma(av, (double)t.x, acc[0]);
+    acc[1] = __builtin_fma(av, (double)t.y, acc[1]);
+    acc[2] = __builtin_fma(av, (double)t.z, acc[2]);
+    acc[3] = __builtin_fma(av, (double)t.w, acc[3]);
+  };
+  // B PAIRS of edges requested together (see k_nam_step: the partial batch at the end of a row costs one latency)
+  auto batch = [&](auto bc, auto pc, int jl, double al, int p0, int nvalid) {
+    constexpr int B = decltype(bc)::value;
+    constexpr bool PAD = decltype(pc)::value;
+    float4 t[B];
+    double av[B];
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      const int src = 4 * ((2 * (p0 + u) + half) & 63);
+      unsigned j = (unsigned)__builtin_amdgcn_ds_bpermute(src, jl);
+      av[u] = bperm_d(src, al);
+      if (PAD && u >= nvalid) j = (unsigned)grow;
+      t[u] = *(const float4*)(Tin + (size_t)(j * row_bytes + off));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < B; ++u) {
+      if (!PAD || u < nvalid) add_row(av[u], t[u]);
+    }
+  };
+  for (int64_t base = start; base < end; base += 64) {
+    int jl;
+    double al;
+    load_edges<VT>(a, base, end, lane, jl, al);            // (lanes past the end: neighbour 0 with weight 0)
+    const int cnt = (int)((end - base) < 64 ? (end - base) : 64);
+    const int npair = (cnt + 1) >> 1;
+    int p = 0;
+    for (; p + U <= npair; p += U) batch(std::integral_constant<int, U>{}, std::false_type{}, jl, al, p, U);
+    const int rem = npair - p;
+    if (rem > (U + 1) / 2) batch(std::integral_constant<int, U>{}, std::true_type{}, jl, al, p, rem);
+    else if (rem > 0) batch(std::integral_constant<int, (U + 1) / 2>{}, std::true_type{}, jl, al, p, rem);
+  }
+  // the odd edges' sums join the even edges' (lane l <- lane l + 32), then the row's own term
+  double s[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s[i] = acc[i] + bperm_d(4 * ((lane + 32) & 63), acc[i]);
+  const float4 own = *(const float4*)(Tin + ((size_t)grow * row_bytes + off));
+  s[0] = __builtin_fma(a.w, (double)own.x, s[0]);
+  s[1] = __builtin_fma(a.w, (double)own.y, s[1]);
+  s[2] = __builtin_fma(a.w, (double)own.z, s[2]);
+  s[3] = __builtin_fma(a.w, (double)own.w, s[3]);
+  // (lanes 32-63 now hold copies of columns 4 hl ...: finish_row reads a lane's columns as 4 lane + k, i.e. >= 128 >= ld
+  // for them, and skips them)
+  finish_row<4, ColQuad, FL>(a, row, grow, lane, s);
 }
 
 // Narrow states (ld <= 64 columns, i.e. at most 32 column pairs): TWO destination rows per wave, one
@@ -1177,6 +1261,20 @@ int launch_step32_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
   return 0;
 }
 
+#ifndef CNA_STEP32_U          // rows (row pairs) in flight per wave of the 4-byte steps; experiments: make EXTRA=-DCNA_STEP32_U=12
+#define CNA_STEP32_U 8
+#endif
+template <typename VT>
+int launch_step32h_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
+  if (a.rows) CNA_FAIL(CNA_ESTATE, "4-byte state with a row list");
+  constexpr int U = CNA_STEP32_U;
+  if (a.sel_X && a.out32) hipLaunchKernelGGL((k_nam_step32h<VT, U, 5>), grid, dim3(256), 0, st, a);
+  else if (a.sel_X) hipLaunchKernelGGL((k_nam_step32h<VT, U, 1>), grid, dim3(256), 0, st, a);
+  else if (a.out32) hipLaunchKernelGGL((k_nam_step32h<VT, U, 4>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_nam_step32h<VT, U, 0>), grid, dim3(256), 0, st, a);
+  return 0;
+}
+
 template <typename VT, int NQ2>
 int launch_step_sparse_t(cna_ctx* c, const StepArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = sizeof(double) * 4 * 128 * NQ2;
@@ -1248,8 +1346,11 @@ int launch_step_q(cna_ctx* c, bool first, const StepArgs& a_in, hipStream_t st) 
     if (a.rows) hipLaunchKernelGGL((k_nam_step_pair<VT, 2>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_nam_step_pair<VT, 0>), grid, dim3(256), 0, st, a);
   } else if (a.in32) {
-    switch ((a.ld / 4 + 63) / 64) {
-      case 1: CNA_TRY((launch_step32_t<VT, 1, 8>(c, a, grid, st))); break;
+    const bool halves = a.ld <= 128 && (c->t_compact ? c->t_rows : c->n_pad) * (int64_t)a.ld * 4 < (int64_t)4 << 30 &&
+                        !getenv("CNA_STEP32_WIDE");          // (tests compare the two kernels)
+    if (halves) CNA_TRY((launch_step32h_t<VT>(c, a, grid, st)));
+    else switch ((a.ld / 4 + 63) / 64) {
+      case 1: CNA_TRY((launch_step32_t<VT, 1, CNA_STEP32_U>(c, a, grid, st))); break;
       case 2: CNA_TRY((launch_step32_t<VT, 2, 8>(c, a, grid, st))); break;
       case 3: CNA_TRY((launch_step32_t<VT, 3, 4>(c, a, grid, st))); break;
       default: CNA_TRY((launch_step32_t<VT, 4, 4>(c, a, grid, st))); break;

@@ -165,3 +165,25 @@ def test_zero_variance_cells_on_the_four_byte_state(eng32):
     assert relerr(res.ncorrs.values, ref['ncorrs']) < 1e-5
     T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
     assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T])
+
+
+@pytest.mark.parametrize('N,nsteps', [(100, 3), (128, 4), (97, 3)])
+def test_two_edges_per_wave_step_agrees_with_the_wave_per_edge_step(eng32, monkeypatch, N, nsteps):
+    """At most 128 columns: k_nam_step32h sums a row's even and odd edges in the two halves of a wave and joins them at
+    the end -- another order of the same float64 additions than k_nam_step32's (CNA_STEP32_WIDE=1): 1e-13, not bits."""
+    import cna_amd as cna
+    from cna_amd import synth
+    data, meta = synth.make_dataset(7000, N, k=15, seed=N)
+    out = []
+    for wide in ('', '1'):
+        if wide:
+            monkeypatch.setenv('CNA_STEP32_WIDE', wide)
+        else:
+            monkeypatch.delenv('CNA_STEP32_WIDE', raising=False)
+        eng32._nam_sig = None
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            frame, keep = cna.tl.nam(data, 'id', nsteps=nsteps, engine=eng32)
+        out.append(frame.values.copy())
+    assert relerr(out[0], out[1]) < 1e-13 and np.abs(out[0] - out[1]).max() > 0
+    assert (np.abs(out[0] - out[1]) <= 1e-12 * np.abs(out[1])).all()
