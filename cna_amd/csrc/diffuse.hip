@@ -940,24 +940,6 @@ __global__ __launch_bounds__(256) void k_nam_step_sparse(StepArgs a) {
           if (lane < cc[u]) lds_add(&acc[sp[u].col], mul_rn(av, sp[u].v));
         }
       }
-      if (l < cnt) {
-        // the partial batch at the end of the row: its empty slots take no pairs (count 0) -- one memory latency for the
-        // rest of the row instead of one per edge, same products in the same order
-        int cc[U];
-        SpPair sp[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int j = __builtin_amdgcn_readlane(jl, (l + u) & 63);
-          cc[u] = l + u < cnt ? __builtin_amdgcn_readlane(cl, (l + u) & 63) : 0;
-          if (lane < cc[u]) sp[u] = pairs[(int64_t)j * SP_CAP + lane];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const double av = readlane_d(al, (l + u) & 63);
-          if (lane < cc[u]) lds_add(&acc[sp[u].col], mul_rn(av, sp[u].v));
-        }
-        l = cnt;
-      }
     }
     for (; l + U <= cnt; l += U) {
       int cc[U];
