@@ -390,7 +390,7 @@ def summary(m, world, steps):
                                      call_that_adopts_the_device_order_ms=None if m.get('t_adopt') is None else round(m['t_adopt'] * 1e3, 1),
                                      note='first call: graph H2D over PCIe (in the caller\'s cell order when the graph is large: '
                                           'the device order is computed on a host thread beside it and adopted by a later call, '
-                                          'whose time -- a second upload -- is listed too), column sums, first-use allocations, one analysis'),
+                                          'whose time -- the resident graph renumbered on the device -- is listed too), column sums, first-use allocations, one analysis'),
                 dataset_gen_s=round(m['t_gen'], 1), p_value=m['p'])
 
 

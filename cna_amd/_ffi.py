@@ -35,6 +35,7 @@ SIGNATURES = {
     'cna_comm_init_shm': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_char_p, C.c_int64]),
     'cna_set_halo': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cna_set_cell_order': (C.c_int, [c_ctx, C.c_void_p]),
+    'cna_graph_reorder': (C.c_int, [c_ctx, C.c_void_p]),
     'cna_set_local_view': (C.c_int, [c_ctx, C.c_int]),
     'cna_colsums': (C.c_int, [c_ctx, C.c_double]),
     'cna_fetch_colsums': (C.c_int, [c_ctx, C.c_void_p]),

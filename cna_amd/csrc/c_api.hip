@@ -364,6 +364,44 @@ int cna_set_cell_order(cna_ctx* c, const int64_t* orig_index) {
   return 0;
 }
 
+int cna_graph_reorder(cna_ctx* c, const int64_t* perm) {
+  CHECK_CTX(c);
+  AUTO_FINISH(c);
+  if (!c->indptr || !perm) CNA_FAIL(CNA_ESTATE, "cna_graph_reorder before cna_graph_upload");
+  if (c->nranks != 1 || c->halo_on || c->local_view || c->n_local != c->n_global || c->n_pad != c->n_global)
+    CNA_FAIL(CNA_ESTATE, "cna_graph_reorder: one rank holding the whole graph only");
+  if (c->orig_idx) CNA_FAIL(CNA_ESTATE, "cna_graph_reorder: the resident graph already has a device cell order");
+  CNA_TRY(halo_settle(c));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->gram_stream && c->gram_pre_pending) HIP_TRY(hipStreamSynchronize(c->gram_stream));
+  const int64_t n = c->n_global;
+  int64_t* pd = nullptr;
+  CNA_TRY(dev_alloc(c, (void**)&pd, sizeof(int64_t) * n));
+  hipError_t e = hipMemcpyAsync(pd, perm, sizeof(int64_t) * n, hipMemcpyHostToDevice, c->stream);
+  int rc = e == hipSuccess ? graph_reorder_device(c, pd) : (int)e;
+  if (rc) {
+    (void)hipStreamSynchronize(c->stream);
+    dev_free(c, pd, sizeof(int64_t) * n);
+    if (e != hipSuccess) cna_set_error(hipGetErrorString(e));
+    return rc;
+  }
+  c->orig_idx = pd;                       // (what cna_set_cell_order would have uploaded)
+  HIP_TRY(hipMemsetAsync(c->stat, 0, sizeof(double) * c->n_pad, c->stream));
+  // everything that hangs on the order of the cells goes, as after an upload; the column sums and the sample codes were
+  // permuted with the graph and stay
+  c->cellinfo_valid = false;
+  c->t_valid = false;
+  c->nam_valid = false; c->nam_lazy = false;
+  c->x_valid = false;
+  c->xq_valid = false; c->byp_valid = false; c->x_ident = false; c->gram_pre = false;
+  c->ncorrs_valid = false;
+  c->coef_early = false;
+  c->fdr_inline = false;
+  c->steps_done = 0;
+  c->t_f32[0] = c->t_f32[1] = false;
+  return 0;
+}
+
 int cna_set_local_view(cna_ctx* c, int on) {
   CHECK_CTX(c);
   HIP_TRY(hipStreamSynchronize(c->stream));

@@ -323,6 +323,7 @@ int comm_allgather_bytes(cna_ctx* c, const void* send, void* recv, size_t bytes_
 // ---- kernel launchers
 // diffuse.hip
 int launch_colsum(cna_ctx* c);
+int graph_reorder_device(cna_ctx* c, const int64_t* perm_dev);
 int launch_add_scalar(cna_ctx* c, double* v, int64_t n, double s);
 int launch_nam_step(cna_ctx* c, bool first, bool want_kurt, bool write_t, bool write_nam, bool dense,
                     const int32_t* rows = nullptr, int64_t n_rows = 0,       // rows: this launch's rows of the block (null: all)

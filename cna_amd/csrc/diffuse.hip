@@ -1442,6 +1442,130 @@ int launch_colsum(cna_ctx* c) {
   return 0;
 }
 
+// ---- the resident graph into another cell order, on the device (cna_graph_reorder) --------------------------------
+namespace {
+__global__ void k_perm_inverse(const int64_t* __restrict__ perm, int64_t n, int32_t* __restrict__ inv, int* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t p = perm[i];
+  if (p < 0 || p >= n) { atomicExch(bad, 1); return; }
+  inv[p] = (int32_t)i;
+}
+// a permutation iff every position is what the inverse says of its own cell (two positions naming one cell: one of them is not)
+__global__ void k_perm_check(const int64_t* __restrict__ perm, int64_t n, const int32_t* __restrict__ inv, int* __restrict__ bad) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t p = perm[i];
+  if (p < 0 || p >= n || inv[p] != (int32_t)i) atomicExch(bad, 1);
+}
+__global__ void k_perm_degrees(const int64_t* __restrict__ indptr, const int64_t* __restrict__ perm, int64_t n,
+                               unsigned int* __restrict__ deg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) deg[i] = (unsigned int)(indptr[perm[i] + 1] - indptr[perm[i]]);
+}
+// one wave per new row: the entries of the old row in their old order, columns renamed (what _order.permuted_rows does
+// on the host: the order of the terms of every row sum, hence every result, is unchanged)
+template <typename VT>
+__global__ __launch_bounds__(256) void k_perm_rows(const int64_t* __restrict__ indptr, const int32_t* __restrict__ idx,
+                                                   const VT* __restrict__ val, const int64_t* __restrict__ perm,
+                                                   const int32_t* __restrict__ inv, int64_t n,
+                                                   const int64_t* __restrict__ new_indptr, int32_t* __restrict__ new_idx,
+                                                   VT* __restrict__ new_val) {
+  const int lane = threadIdx.x & 63;
+  const int64_t nw = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += nw) {
+    const int64_t src = perm[row];
+    const int64_t s0 = indptr[src], cnt = indptr[src + 1] - s0, d0 = new_indptr[row];
+    for (int64_t e = lane; e < cnt; e += 64) {
+      new_idx[d0 + e] = inv[idx[s0 + e]];
+      new_val[d0 + e] = val[s0 + e];
+    }
+  }
+}
+template <typename T>
+__global__ void k_perm_gather(const T* __restrict__ src, const int64_t* __restrict__ perm, int64_t n, T* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[perm[i]];
+}
+}  // namespace
+
+// perm_dev[i] = the row of the resident graph that becomes row i (one rank, whole graph resident, n_pad == n).  Replaces
+// indptr / indices / data, permutes the column sums (keyed by the caller's row ids when they were formed: the same bits
+// in any order) and the sample codes.  The caller (c_api.hip) resets what hangs on the order.
+int graph_reorder_device(cna_ctx* c, const int64_t* perm_dev) {
+  const int64_t n = c->n_global, nnz = c->nnz;
+  const size_t vb = c->data_f64 ? 8 : 4;
+  const int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+  const int64_t b_inv = round_up64(4 * n, 256), b_deg = round_up64(4 * n, 256), b_tiles = round_up64(8 * ntiles, 256);
+  const size_t tmp_bytes = (size_t)(b_inv + b_deg + b_tiles + 256);
+  void* tmp = nullptr;
+  int64_t* nip = nullptr;
+  int32_t* nix = nullptr;
+  void* nval = nullptr;
+  double* ncs = nullptr;
+  int32_t* nsid = nullptr;
+  auto drop = [&]() {
+    (void)hipStreamSynchronize(c->stream);
+    if (tmp) dev_free(c, tmp, tmp_bytes);
+    if (nip) dev_free(c, nip, sizeof(int64_t) * (n + 1));
+    if (nix) dev_free(c, nix, sizeof(int32_t) * nnz);
+    if (nval) dev_free(c, nval, vb * nnz);
+    if (ncs) dev_free(c, ncs, sizeof(double) * c->n_pad);
+    if (nsid) dev_free(c, nsid, sizeof(int32_t) * n);
+  };
+  int rc = dev_alloc(c, &tmp, tmp_bytes);
+  if (!rc) rc = dev_alloc(c, (void**)&nip, sizeof(int64_t) * (n + 1));
+  if (!rc) rc = dev_alloc(c, (void**)&nix, sizeof(int32_t) * nnz);
+  if (!rc) rc = dev_alloc(c, &nval, vb * nnz);
+  if (!rc && c->have_colsum) rc = dev_alloc(c, (void**)&ncs, sizeof(double) * c->n_pad);
+  if (!rc && c->sid && c->sid_n == n) rc = dev_alloc(c, (void**)&nsid, sizeof(int32_t) * n);
+  if (rc) { drop(); return rc; }
+  int32_t* inv = (int32_t*)tmp;
+  unsigned int* deg = (unsigned int*)((char*)tmp + b_inv);
+  unsigned long long* tiles = (unsigned long long*)((char*)tmp + b_inv + b_deg);
+  int* bad = (int*)((char*)tmp + b_inv + b_deg + b_tiles);
+  hipStream_t st = c->stream;
+  const unsigned g_n = (unsigned)((n + 255) / 256);
+  hipError_t e = hipMemsetAsync(inv, 0xff, (size_t)b_inv, st);
+  if (e == hipSuccess) e = hipMemsetAsync(bad, 0, 4, st);
+  if (e != hipSuccess) { drop(); HIP_TRY(e); }
+  hipLaunchKernelGGL(k_perm_inverse, dim3(g_n), dim3(256), 0, st, perm_dev, n, inv, bad);
+  hipLaunchKernelGGL(k_perm_check, dim3(g_n), dim3(256), 0, st, perm_dev, n, (const int32_t*)inv, bad);
+  int bad_h = 0;
+  e = hipMemcpyAsync(&bad_h, bad, 4, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { drop(); HIP_TRY(e); }
+  if (bad_h) { drop(); CNA_FAIL(CNA_EINVAL, "cna_graph_reorder: not a permutation of the cells"); }
+  hipLaunchKernelGGL(k_perm_degrees, dim3(g_n), dim3(256), 0, st, c->indptr, perm_dev, n, deg);
+  hipLaunchKernelGGL(k_scan_tiles, dim3((unsigned)ntiles), dim3(256), 0, st, deg, n, tiles);
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(1024), 0, st, tiles, ntiles);
+  hipLaunchKernelGGL(k_scan_finish, dim3((unsigned)ntiles), dim3(256), 0, st, deg, n, tiles, (unsigned long long*)nip);
+  const unsigned g_rows = (unsigned)std::min<int64_t>((n + 3) / 4, 65536);
+  if (c->data_f64)
+    hipLaunchKernelGGL(k_perm_rows<double>, dim3(g_rows), dim3(256), 0, st, c->indptr, c->indices, (const double*)c->data, perm_dev,
+                       (const int32_t*)inv, n, (const int64_t*)nip, nix, (double*)nval);
+  else
+    hipLaunchKernelGGL(k_perm_rows<float>, dim3(g_rows), dim3(256), 0, st, c->indptr, c->indices, (const float*)c->data, perm_dev,
+                       (const int32_t*)inv, n, (const int64_t*)nip, nix, (float*)nval);
+  if (ncs) hipLaunchKernelGGL(k_perm_gather<double>, dim3(g_n), dim3(256), 0, st, (const double*)c->colsum, perm_dev, n, ncs);
+  if (nsid) hipLaunchKernelGGL(k_perm_gather<int32_t>, dim3(g_n), dim3(256), 0, st, (const int32_t*)c->sid, perm_dev, n, nsid);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { drop(); HIP_TRY(e); }
+  // swap in
+  dev_free(c, c->indptr, sizeof(int64_t) * (n + 1));
+  dev_free(c, c->indices, sizeof(int32_t) * nnz);
+  dev_free(c, c->data, vb * nnz);
+  c->indptr = nip; c->indices = nix; c->data = nval;
+  nip = nullptr; nix = nullptr; nval = nullptr;
+  if (ncs) { dev_free(c, c->colsum, sizeof(double) * c->n_pad); c->colsum = ncs; ncs = nullptr; }
+  if (nsid) {
+    (void)hipMemcpyAsync(c->sid, nsid, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, st);      // (sid keeps its buffer: sized elsewhere)
+  }
+  drop();
+  return 0;
+}
+
 int launch_add_scalar(cna_ctx* c, double* v, int64_t n, double s) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_add_scalar, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, v, n, s);

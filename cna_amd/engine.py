@@ -170,10 +170,9 @@ class Engine(_order.CellOrder):
             perm = _order.locality_order(A)
             if perm is None:
                 return None
-            n = A.shape[0]
-            indptr, indices, data = _order.permuted_rows(A, perm, 0, n)
-            # (the content the order was made from: adopted only if the matrix still hashes to it)
-            return perm, indptr, indices, data, self._full_hash(A)
+            # (the content the order was made from: adopted only if the matrix still hashes to it.  The renumbered rows
+            # themselves are made on the device from the resident copy: cna_graph_reorder)
+            return np.ascontiguousarray(perm, dtype=np.int64), self._full_hash(A)
         box['future'] = _reorder_pool().submit(job)
         self._reorder = box
 
@@ -190,10 +189,10 @@ class Engine(_order.CellOrder):
             out = box['future'].result()
         except Exception:                      # noqa: BLE001 - the caller's order stays
             return None
-        if out is None or out[4] != self._graph_hash:
+        if out is None or out[1] != self._graph_hash:
             return None                        # edited in place since: the next content check uploads it afresh
         pinned = self._pinned is not None and self._pinned[0]() is A and self._pinned[1] == self._buffers(A)
-        if not pinned and self._full_hash(A) != out[4]:
+        if not pinned and self._full_hash(A) != out[1]:
             return None                        # ... or edited after the order was made (an unpinned matrix is hashed in full, as always)
         return out
 
@@ -263,11 +262,19 @@ class Engine(_order.CellOrder):
         key = quick
         if staged is not None:
             # the device cell order computed beside the first analyses of this graph (see below) has arrived: the
-            # graph goes to the device again, now in that order; everything per cell follows as after any upload
-            n = A.shape[0]
-            r0, r1 = self.block(n)
-            perm, indptr, indices, data, full = staged
-            order = perm[r0:r1]
+            # resident copy is renumbered ON THE DEVICE (the rows keep the order of their entries: same bits as an upload
+            # of the renumbered graph, without the second trip over PCIe); column sums and sample codes move with it,
+            # everything else per cell follows as after any upload
+            perm, full = staged
+            check(self.lib.cna_graph_reorder(self.h, ptr(perm)), 'cna_graph_reorder')
+            self.perm = perm
+            self._keep_dev = None
+            self._kept_order_cache = None
+            self._x_is_selection = False
+            self._graph_key = key
+            self._graph_hash = full
+            self._pending_check = None
+            return True
         elif shard is None:
             n = A.shape[0]
             r0, r1 = self.block(n)

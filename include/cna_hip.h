@@ -115,6 +115,12 @@ int  cna_graph_upload(cna_ctx* ctx, int64_t n_global, int64_t row0, int64_t n_lo
  * caller's numbering; every other per-cell array crosses the ABI in library row order.  NULL
  * (and every cna_graph_upload) resets to the identity. */
 int  cna_set_cell_order(cna_ctx* ctx, const int64_t* orig_index);
+/* The resident graph into another cell order WITHOUT a second trip over PCIe (one rank holding the whole graph, resident
+ * in the caller's order): perm[i] = caller's cell that becomes row i (n_global entries, a permutation -- checked).  Same
+ * state afterwards as cna_graph_upload of the renumbered rows followed by cna_set_cell_order(perm), except that the column
+ * sums and the sample codes are carried over (permuted), not dropped: rows keep the order of their entries, so every
+ * result keeps its bits (reference: results do not depend on the order of the cells, _nam.py:25-34). */
+int  cna_graph_reorder(cna_ctx* ctx, const int64_t* perm);
 /* Sharded callers (one process per GPU, each holding only the cells of its row block -- the layout
  * SURVEY.md 8(e) asks for; the reference has no counterpart, its AnnData is whole): with the local
  * view on, every per-cell array that leaves the library covers this rank's n_local rows only --

@@ -658,8 +658,8 @@ def test_results_do_not_depend_on_device_cell_order(monkeypatch):
 
 def test_large_graph_is_analysed_first_and_reordered_beside_it(monkeypatch):
     """A graph of 100 000 cells or more goes to the device in the caller's order; the cluster order is computed on a
-    host thread meanwhile and adopted -- a second upload -- by the first later call that finds it done
-    (engine.ensure_graph).  The first result, the adopting call's and a later one's are the same analysis: NAM bit for
+    host thread meanwhile and adopted -- the resident copy renumbered on the device, cna_graph_reorder -- by the first
+    later call that finds it done (engine.ensure_graph).  The first result, the adopting call's and a later one's are the same analysis: NAM bit for
     bit, the rest to rounding (the Gram sum runs over the cells in another order); an in-place edit of the matrix
     between the calls is still seen (the order computed from the old content is dropped)."""
     import cna_amd as cna
@@ -709,6 +709,83 @@ def test_large_graph_is_analysed_first_and_reordered_beside_it(monkeypatch):
             fresh.close()
     finally:
         e.close()
+
+
+def test_graph_reordered_on_the_device_equals_an_upload_in_that_order(monkeypatch):
+    """cna_graph_reorder (the adoption of the device order by a graph that is already resident) against the other way to
+    the same state: an upload of the rows renumbered on the host (CNA_REORDER_ASYNC off).  Same permutation, same column
+    sums and the same analysis, every field bit for bit; what is not a permutation is refused and leaves the graph alone."""
+    import ctypes as C
+    import cna_amd as cna
+    from cna_amd import synth, engine as eng_mod
+    from cna_amd.engine import Engine
+    monkeypatch.setattr(eng_mod, '_REORDER_ASYNC_CELLS', 20000)
+    data, meta = synth.make_dataset(40000, 110, k=15, seed=8, cluster_sorted=False, n_covs=1)
+    kw = dict(Nnull=150, seed=2, nsteps=3, covs=meta['covs'], return_full=True)
+
+    def fields(res, d):
+        return dict(p=res.p, k=int(res.k), nam=res.nam.values.copy(), ncorrs=res.ncorrs.values.copy(), fdr=res.fdrs.values.copy(),
+                    namresid=res.namresid.values.copy(), coef=d.obs['coef'].values.copy(), coef_fdr=d.obs['coef_fdr'].values.copy(),
+                    nullminps=np.asarray(res.nullminps).copy())
+    a, b = Engine(device=0), Engine(device=0)
+    a.reuse_nam = b.reuse_nam = False
+    try:
+        first = fields(cna.tl.association(data, meta['y'], 'id', engine=a, **kw), data)
+        assert a.perm is None and a.reorder_pending()
+        cs_before = a.fetch_colsums()
+        a.wait_reorder()
+        class Spy:                                       # counts the uploads the adopting call makes
+            def __init__(self, lib):
+                self._lib, self.uploads = lib, 0
+
+            def __getattr__(self, k):
+                f = getattr(self._lib, k)
+                if k != 'cna_graph_upload':
+                    return f
+
+                def counted(*x):
+                    self.uploads += 1
+                    return f(*x)
+                return counted
+        spy = a.lib = Spy(a.lib)
+        second = fields(cna.tl.association(data, meta['y'], 'id', engine=a, **kw), data)
+        assert a.perm is not None and spy.uploads == 0                 # adopted without a second upload
+        a.lib = spy._lib
+        monkeypatch.setattr(eng_mod, '_REORDER_ASYNC', False)
+        ref = fields(cna.tl.association(data, meta['y'], 'id', engine=b, **kw), data)
+        assert np.array_equal(a.perm, b.perm)
+        np.testing.assert_array_equal(a.fetch_colsums(), b.fetch_colsums())
+        np.testing.assert_array_equal(a.fetch_colsums(), cs_before)    # (caller's order both times)
+        for key in ref:
+            np.testing.assert_array_equal(second[key], ref[key], err_msg=key)
+        np.testing.assert_array_equal(first['nam'], ref['nam'])        # (before the adoption: the same walk, other Gram order)
+        # the entry point itself: refusals
+        lib = eng_mod._ffi.load()
+        n = len(a.perm)
+        assert lib.cna_graph_reorder(a.h, np.arange(n, dtype=np.int64).ctypes.data) != 0       # already has a device order
+        c = Engine(device=0)
+        try:
+            monkeypatch.setattr(eng_mod, '_REORDER_ASYNC', True)
+            monkeypatch.setattr(eng_mod, '_REORDER_ASYNC_CELLS', 10 ** 9)
+            monkeypatch.setenv('CNA_REORDER', '0')
+            c.ensure_graph(data.obsp['connectivities'])
+            bad = np.arange(n, dtype=np.int64)
+            bad[5] = 7                                                 # two positions name cell 7
+            assert lib.cna_graph_reorder(c.h, bad.ctypes.data) != 0 and b'permutation' in lib.cna_last_error()
+            bad[5] = n
+            assert lib.cna_graph_reorder(c.h, bad.ctypes.data) != 0
+            c.colsums(1)
+            np.testing.assert_array_equal(c.fetch_colsums(), cs_before)      # the graph is as it was
+            rs = np.random.RandomState(0)
+            perm = rs.permutation(n).astype(np.int64)
+            assert lib.cna_graph_reorder(c.h, perm.ctypes.data) == 0
+            c.perm = perm
+            np.testing.assert_array_equal(c.fetch_colsums(), cs_before)      # permuted with the graph, back in the caller's order
+        finally:
+            c.close()
+    finally:
+        a.close()
+        b.close()
 
 
 def test_ordered_fetch_on_device_equals_host_reorder(monkeypatch):
