@@ -30,7 +30,7 @@ def bench_name(k):
 
 
 out = {}
-for W in ('C4', 'C3', 'C2', 'C5'):
+for W in os.environ.get('PMC_WORKLOADS', 'C4,C3,C2,C5').split(','):
     frames = []
     for f in sorted(glob.glob('%s/*_%s_counter_collection.csv' % (d, W)) + glob.glob('%s/*/*_%s_counter_collection.csv' % (d, W))):
         df = pd.read_csv(f)
