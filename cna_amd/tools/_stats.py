@@ -158,9 +158,11 @@ class NativeDraw:
             rc = self._lib.cna_host_draw_wait()
             self._done = True
             if rc == 0 and self._state is not None:
-                # the worker advanced a COPY of the generator's state; numpy's own is written once, whole, under its lock
+                # the worker advanced a COPY of a freshly seeded state; numpy's own generator is seeded and written here,
+                # once, whole, under its lock (np.random.seed(seed) + the draws: where the reference leaves it)
                 import ctypes as C
-                bg, addr, st = self._state
+                bg, addr, st, seed = self._state
+                np.random.seed(seed)                  # (also drops a cached second normal, as the reference's call does)
                 with bg.lock:
                     C.memmove(addr, st, _MT_STATE_BYTES)
             self._state = None
@@ -168,6 +170,15 @@ class NativeDraw:
             if rc != 0:
                 raise MemoryError('cna_host_draw_wait: the permutation draw failed (%d)' % rc)
         return self.table
+
+    def abandon(self):
+        """Collect the worker and forget what it drew: numpy's generator is left exactly as it was found (a draw that
+        was started before the inputs were validated, on inputs that turned out not to be the ones to permute)."""
+        self._state = None
+        try:
+            self.wait()
+        except Exception:                      # noqa: BLE001
+            pass
 
     def __del__(self):                         # the worker writes into buffers this object keeps alive
         try:
@@ -177,9 +188,11 @@ class NativeDraw:
 
 
 def native_draw_start(B, Y, num, seed, threads=None):
-    """Seed numpy's global generator (np.random.seed(seed), _association.py:15-16) and start
-    conditional_permutation(B, Y, num) on the library's host thread; None when the shape is not covered (the caller
-    then draws as before, from the generator as this function found it: nothing is consumed before the decision)."""
+    """Start conditional_permutation(B, Y, num) of a generator seeded with `seed` (np.random.seed(seed),
+    _association.py:15-16) on the library's host thread; None when the shape is not covered (the caller then draws as
+    before).  numpy's global generator is not touched before wait(): the worker runs on a copy of the state a PRIVATE
+    RandomState has after seed(seed) -- so a draw may be started before the inputs are validated and dropped again
+    (NativeDraw.abandon) without a trace."""
     import ctypes as C
     if seed is None or num < 2 or num % 2 or len(Y) < 1 or len(B) != len(Y):
         return None
@@ -220,29 +233,37 @@ def native_draw_start(B, Y, num, seed, threads=None):
             threads = usable_cpus(4)           # 250 000 cells -- a rank's block of the 2M problem on eight GPUs
         else:
             threads = 1
-    np.random.seed(seed)
     addr = bg.ctypes.state_address             # struct mt19937_state { uint32_t key[624]; int pos; }
     if not _mt_layout_ok(bg, addr):
         return None
-    # The worker advances a copy of the freshly seeded state in memory this object owns; wait() writes it back under
-    # the generator's lock.  Whoever touches np.random in between sees a consistent generator (never a torn one), as
-    # with the reference's own interleaving of draws.
+    # The worker advances a copy of a freshly seeded state in memory this object owns; wait() seeds numpy's generator
+    # and writes the copy into it under its lock.  Whoever touches np.random in between sees a consistent generator
+    # (never a torn one).
     st = (C.c_uint32 * (_MT_STATE_BYTES // 4))()
-    with bg.lock:
-        C.memmove(st, addr, _MT_STATE_BYTES)
+    try:
+        with _private_lock:
+            _private_rs.seed(seed)             # (legacy seeding, the same routine np.random.seed runs; raises on a bad seed)
+            pbg = _private_rs._bit_generator
+            with pbg.lock:
+                C.memmove(st, pbg.ctypes.state_address, _MT_STATE_BYTES)
+    except (TypeError, ValueError):
+        return None                            # np.random.seed(seed) in the caller's own draw reports it
     base = C.addressof(st)
     rc = lib.cna_host_draw_start(base, C.cast(base + 624 * 4, C.POINTER(C.c_int)), Yc.ctypes.data, len(Y), int(num),
                                  len(off) - 1, off.ctypes.data, members.ctypes.data, table.ctypes.data + 8, num + 1,
                                  int(threads))
     if rc != 0:
-        return None                            # (seeded, nothing drawn: the caller's own draw seeds again)
+        return None                            # (nothing drawn, numpy's generator untouched: the caller's own draw seeds it)
     d = NativeDraw(lib, (Yc, off, members, bg, st), table)
-    d._state = (bg, addr, st)
+    d._state = (bg, addr, st, seed)
     return d
 
 
 _MT_STATE_BYTES = 624 * 4 + 4
 _mt_layout = None
+import threading as _threading
+_private_lock = _threading.Lock()
+_private_rs = np.random.RandomState(0)         # seeded per draw under _private_lock; never handed out
 
 
 def _mt_layout_ok(bg, addr):
