@@ -575,8 +575,8 @@ __global__ __launch_bounds__(256) void k_nam_step(StepArgs a) {
 }
 
 // The same step on a state stored in 4 bytes per entry (cna_set_state_f32): a lane owns FOUR adjacent columns and one
-// 16-byte load fetches them; every entry is widened to f64 before the same unfused multiply and add, in the same CSR
-// order.  Half the bytes per edge through the vector L1 and from behind the L2 -- the two limits of k_nam_step.
+// 16-byte load fetches them; every entry is widened to f64 and enters a fused multiply-add, in the same CSR order.
+// Half the bytes per edge through the vector L1 and from behind the L2 -- the two limits of k_nam_step.
 template <typename VT, int NQ4, int U = 8, int FL = 0>
 __global__ __launch_bounds__(256) void k_nam_step32(StepArgs a) {
   if (STEP_STOPPED(a)) return;
