@@ -187,3 +187,36 @@ def test_two_edges_per_wave_step_agrees_with_the_wave_per_edge_step(eng32, monke
         out.append(frame.values.copy())
     assert relerr(out[0], out[1]) < 1e-13 and np.abs(out[0] - out[1]).max() > 0
     assert (np.abs(out[0] - out[1]) <= 1e-12 * np.abs(out[1])).all()
+
+
+def test_config4_size_integers_equal_the_default_path(eng32):
+    """BASELINE.json configs[3] at full size (2M cells x 200 samples, Nnull 1000): the analysis on the 4-byte state against
+    the default one on the same inputs -- p, k, the kept cells and every `num_detected` identical; FDR thresholds,
+    coefficients and per-cell FDRs within 1e-5; a 20 000-cell slice of the NAM within 3e-7 entry by entry."""
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.engine import get_engine
+    data, meta = synth.make_dataset(2_000_000, 200, k=30, seed=0)
+    kw = dict(nsteps=3, Nnull=1000, seed=0, return_full=True)
+    out = {}
+    for name, e in (('f64', get_engine()), ('f32', eng32)):
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            res = cna.tl.association(data, meta['y'], 'id', engine=e, **kw)
+        sl = np.arange(0, 2_000_000, 100)
+        out[name] = dict(p=res.p, k=int(res.k), nd=res.fdrs.num_detected.values.copy(), fdr=res.fdrs.fdr.values.copy(),
+                         t5=res.fdr_5p_t, t10=res.fdr_10p_t, coef=data.obs['coef'].values.copy(),
+                         coef_fdr=data.obs['coef_fdr'].values.copy(), nam=res.nam.values[:, sl].copy(),
+                         nullminps=np.asarray(res.nullminps).copy(), kept=int(res.kept.sum()))
+        del res
+    a, b = out['f64'], out['f32']
+    assert a['p'] == b['p'] and a['k'] == b['k'] and a['kept'] == b['kept']
+    assert np.array_equal(a['nd'], b['nd'])
+    for key in ('t5', 't10'):                        # (thresholds are fractions of max |coefficient|: floats)
+        np.testing.assert_allclose(b[key], a[key], rtol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(b['fdr'], a['fdr'], rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(b['nullminps'], a['nullminps'], rtol=1e-5)
+    assert np.abs(b['coef'] - a['coef']).max() <= 1e-5 * np.abs(a['coef']).max()
+    np.testing.assert_allclose(b['coef_fdr'], a['coef_fdr'], rtol=1e-4, atol=1e-12, equal_nan=True)
+    err = np.abs(a['nam'] - b['nam'])
+    assert (err <= 3e-7 * np.abs(a['nam']) + 1e-300).all() and err.max() > 0
