@@ -150,6 +150,15 @@ class Engine(_order.CellOrder):
         arr = np.ascontiguousarray(arr)
         return int(self.lib.cna_host_hash64(ptr(arr), arr.nbytes, self._host_threads if threads is None else threads))
 
+    def graph_resident(self, A):
+        """Cheap and conservative: True when A is, by object and buffers, the matrix whose copy is on the device (whether
+        its content still is what went up is ensure_graph's business)."""
+        try:
+            return (self._graph_key is not None and self._graph_ref is not None and self._graph_ref() is A
+                    and self._graph_key[:len(self._ident(A))] == self._ident(A))
+        except Exception:                      # noqa: BLE001
+            return False
+
     def pin_graph(self, A):
         """Promise that the connectivities matrix A will not be edited in place while it is resident:
         later calls then recognise it without hashing all of it (what a loop over many phenotypes of

@@ -17,11 +17,12 @@ import warnings
 
 import numpy as np
 import pandas as pd
+import scipy.sparse as sp
 
 from .. import _ffi
 from ..engine import get_engine
 from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_plan, _resid_run, sample_codes_cached, confirm_codes,
-                   shard_of, global_samples,
+                   shard_of, global_samples, get_connectivity,
                    _small_svd, _defer_pcs, host_blas_threads, _top_pcs, GramPCs)
 from . import _nam as _nam_mod
 from ._out import select_output
@@ -49,6 +50,8 @@ _EARLY_WALK = True       # the walk queued before the (pandas) validation of the
 _EARLY_COEF = True       # (module constants, not environment switches: each was measured against its alternative --
 _EARLY_FDR = True        #  DESIGN.md 6 -- and tests that need the other side patch the attribute)
 _DRAW_THREAD = True
+_PREFETCH_GRAPH = os.environ.get('CNA_PREFETCH_GRAPH', '1') != '0'    # a new graph's upload beside the factorisation of the sample ids
+_PREFETCH_CELLS = 100_000
 _NATIVE_DRAW = os.environ.get('CNA_NATIVE_DRAW', '1') != '0'      # the draw on the library's host thread (0: the interpreter's helper thread, for A/B runs)
 _SWITCH_INTERVAL = 5e-5   # GIL hand-over between the helper thread and this one: 2.08 -> 1.86 ms per call at 200k cells (default interval: 5 ms)
 
@@ -652,6 +655,14 @@ class _StaleGraph(Exception):
     """The deferred content check found the resident graph out of date (engine.confirm_graph)."""
 
 
+def _prefetch_graph(engine, data):
+    try:
+        from ._nam import _prepare_graph
+        _prepare_graph(engine, data, 1)
+    except Exception:                          # noqa: BLE001 - the regular call meets the same problem and reports it
+        pass
+
+
 def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added, max_frac_pcs, nsteps,
                       show_progress, allow_low_sample_size, return_full, ridges, engine, **kwargs):
     out = select_output(show_progress)
@@ -666,12 +677,27 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     # factorise the per-cell sample ids once; validation and NAM construction share the result
     _mark('enter')
     sharded = shard_of(data) is not None
+    # A graph that is new to the device: its upload (PCIe) and column sums start on a helper thread now, beside the
+    # factorisation of the sample ids on this one (2M cells: 26 + 14 ms beside 11 ms) -- _nam_device below then finds
+    # the graph resident.  Whatever goes wrong there is left for that call to find and report where it always did.
+    prefetch = None
+    if _PREFETCH_GRAPH and not sharded and not show_progress and getattr(engine, 'nranks', 1) == 1 and hasattr(engine, 'graph_resident'):
+        try:
+            A0 = get_connectivity(data)
+            if (sp.isspmatrix_csr(A0) or isinstance(A0, getattr(sp, 'csr_array', ()))) and A0.shape[0] >= _PREFETCH_CELLS \
+                    and not engine.graph_resident(A0):
+                prefetch = _background().submit(_prefetch_graph, engine, data)
+        except Exception:                      # noqa: BLE001
+            prefetch = None
     # one GPU: the content hash of the ids is checked on a helper thread, like the graph's (confirm_graph below)
     defer_ids = (getattr(engine, '_defer_graph_check', False) and not sharded and getattr(engine, 'nranks', 1) == 1
                  and not getattr(engine, '_has_comm', False))
     codes, labels, counts, token = sample_codes_cached(data.obs[sid_name], defer=defer_ids)
     if sharded:      # this rank's cells only: agree with the other ranks on the samples and their sizes
         codes, labels, counts, token = global_samples(engine, codes, labels, counts, token)
+    if prefetch is not None:
+        prefetch.result()
+        _mark('graph prefetched')
     _mark('codes')
     # The walk needs the graph and the sample ids only: it is queued before the (pandas) validation of the
     # sample-level inputs, which then runs under it.  An error of the walk is held back until validation has

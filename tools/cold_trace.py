@@ -16,7 +16,8 @@ data, meta = synth.make_dataset(n, N, k=30, seed=0)
 warm, wmeta = synth.make_dataset(20000, 24, k=15, seed=1)
 eng = get_engine(); eng.reuse_nam = False
 kw = dict(nsteps=3, Nnull=1000, seed=0)
-cna.tl.association(warm, wmeta['y'], 'id', **kw)
+if not os.environ.get('COLD_PROCESS'):        # COLD_PROCESS=1: the very first call of the process is the traced one
+    cna.tl.association(warm, wmeta['y'], 'id', **kw)
 ev = []
 for name in dir(Engine):
     if name.startswith('_') or name in ('block', 'prof', 'close'): continue
