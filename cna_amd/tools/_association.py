@@ -692,12 +692,14 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     # one GPU: the content hash of the ids is checked on a helper thread, like the graph's (confirm_graph below)
     defer_ids = (getattr(engine, '_defer_graph_check', False) and not sharded and getattr(engine, 'nranks', 1) == 1
                  and not getattr(engine, '_has_comm', False))
-    codes, labels, counts, token = sample_codes_cached(data.obs[sid_name], defer=defer_ids)
+    try:
+        codes, labels, counts, token = sample_codes_cached(data.obs[sid_name], defer=defer_ids)
+    finally:
+        if prefetch is not None:               # (whatever happened here: nobody else touches the engine while the helper does)
+            prefetch.result()
+            _mark('graph prefetched')
     if sharded:      # this rank's cells only: agree with the other ranks on the samples and their sizes
         codes, labels, counts, token = global_samples(engine, codes, labels, counts, token)
-    if prefetch is not None:
-        prefetch.result()
-        _mark('graph prefetched')
     _mark('codes')
     # The walk needs the graph and the sample ids only: it is queued before the (pandas) validation of the
     # sample-level inputs, which then runs under it.  An error of the walk is held back until validation has
