@@ -1841,6 +1841,37 @@ def test_error_after_a_fused_null_launch_leaves_the_engine_usable(eng, monkeypat
         np.testing.assert_array_equal(x, y)
 
 
+def test_new_graph_is_uploaded_beside_the_sample_ids(monkeypatch):
+    """A graph of 100 000 cells or more that is new to the device goes up on a helper thread while this thread factorises
+    the sample ids (_association.py:_prefetch_graph).  Same results as without; a call that fails on the ids (no such
+    column) has still collected the helper -- the graph is resident, the engine usable."""
+    import cna_amd as cna
+    from cna_amd import synth
+    from cna_amd.engine import Engine
+    from cna_amd.tools import _association as A
+    data, meta = synth.make_dataset(120000, 40, k=15, seed=13)
+    kw = dict(nsteps=3, Nnull=100, seed=1, return_full=True)
+    outs = []
+    for on in (True, False):
+        monkeypatch.setattr(A, '_PREFETCH_GRAPH', on)
+        e = Engine(device=0)
+        try:
+            A._TRACE = []
+            if on:
+                with pytest.raises(KeyError):
+                    cna.tl.association(data, meta['y'], 'no_such_column', engine=e, **kw)
+                assert e.graph_resident(data.obsp['connectivities'])
+            res = cna.tl.association(data, meta['y'], 'id', engine=e, **kw)
+            marks = [m for m, _ in A._TRACE]
+            assert ('graph prefetched' in marks) == on
+            outs.append((res.p, int(res.k), res.ncorrs.values.copy(), res.fdrs.values.copy(), data.obs['coef_fdr'].values.copy()))
+        finally:
+            A._TRACE = None
+            e.close()
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
+
+
 def test_zero_variance_cells_with_many_samples(eng, orc):
     """140 samples (the by-product / small-block schedules) and cells of zero variance -- a far-away blob whose only sample
     has no phenotype: whatever the fused selection call queued for "no zero variance" must not be used; results as the
