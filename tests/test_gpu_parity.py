@@ -711,7 +711,8 @@ def test_large_graph_is_analysed_first_and_reordered_beside_it(monkeypatch):
         e.close()
 
 
-def test_graph_reordered_on_the_device_equals_an_upload_in_that_order(monkeypatch):
+@pytest.mark.parametrize('graph_dtype', [np.float32, np.float64])
+def test_graph_reordered_on_the_device_equals_an_upload_in_that_order(monkeypatch, graph_dtype):
     """cna_graph_reorder (the adoption of the device order by a graph that is already resident) against the other way to
     the same state: an upload of the rows renumbered on the host (CNA_REORDER_ASYNC off).  Same permutation, same column
     sums and the same analysis, every field bit for bit; what is not a permutation is refused and leaves the graph alone."""
@@ -721,6 +722,7 @@ def test_graph_reordered_on_the_device_equals_an_upload_in_that_order(monkeypatc
     from cna_amd.engine import Engine
     monkeypatch.setattr(eng_mod, '_REORDER_ASYNC_CELLS', 20000)
     data, meta = synth.make_dataset(40000, 110, k=15, seed=8, cluster_sorted=False, n_covs=1)
+    data.obsp['connectivities'] = data.obsp['connectivities'].astype(graph_dtype)
     kw = dict(Nnull=150, seed=2, nsteps=3, covs=meta['covs'], return_full=True)
 
     def fields(res, d):
