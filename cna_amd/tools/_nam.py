@@ -471,6 +471,9 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
         if codes_labels is None and engine.view_local:
             codes, labels, counts, token = global_samples(engine, codes, labels, counts, None)
     N = len(labels)
+    # (cells per sample, aligned with labels: _qc_device leaves samples without cells -- NaN rows of the NAM -- out of
+    # the batch means, as pandas' mean does in the reference)
+    engine._sample_counts = (np.asarray(counts), len(labels))
     # NAM cache: the NAM is a function of the graph, the per-cell sample ids, the
     # step rule and the self weight only -- not of the phenotype.  When the device still holds the
     # NAM of exactly these inputs (same resident graph, same id fingerprint, no walk started since),
@@ -568,6 +571,12 @@ def _qc_device(engine, labels, batches, show_progress=False):
     if len(np.unique(batches)) == 1:
         return np.repeat(True, engine.n)
     codes, nb = _batch_codes(batches, labels)
+    # A sample without cells (an unused category of a categorical id column) has a NaN row in the NAM (0/0, _nam.py:73);
+    # the reference's batch means are DataFrame.mean, which skips NaN (_nam.py:78-82): such a sample belongs to no batch
+    # here (fixture c19_unused_category_batches; found by tools/fuzz_vs_oracle.py)
+    held = getattr(engine, '_sample_counts', None)
+    if held is not None and held[1] == len(codes) and len(held[0]) == len(codes):
+        codes = np.where(held[0] > 0, codes, -1).astype(np.int32)
     engine.batch_kurtosis(_ffi.MAT_NAM, codes, nb)
     if not show_progress and hasattr(engine, 'stat_qc'):
         # median, threshold and the count of failing cells are formed on the device: when nobody fails (always, with

@@ -135,7 +135,12 @@ def batch_kurtosis(nam, batch_codes, n_batches):
     per-batch means of the cell's NAM entries.  nam is cells x samples."""
     means = np.empty((nam.shape[0], n_batches))
     for b in range(n_batches):
-        means[:, b] = nam[:, batch_codes == b].mean(axis=1)
+        part = nam[:, batch_codes == b]
+        # the reference takes DataFrame.mean, which skips NaN: a sample without cells (an unused category of a categorical
+        # id column: its NAM row is 0/0) does not count in its batch's mean (fixture c19_unused_category_batches)
+        ok = ~np.isnan(part)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            means[:, b] = np.where(ok, part, 0.0).sum(axis=1) / ok.sum(axis=1)
     return row_kurtosis(means) + 3.0
 
 

@@ -137,6 +137,13 @@ def build_cases():
     # covariates with a missing row, wider PC budget, auto-stopped walk, sample ids handed over unsorted
     base('c18_covs_nan_maxfrac', seed=17, N=28, gen=dict(n_covs=3, cluster_sorted=False),
          call=dict(Nnull=100, seed=17, max_frac_pcs=0.3), mutate='covs_nan', extras=('progress',))
+    # categorical sample ids with a category that has no cells (what subsetting an AnnData leaves behind): its NAM row is
+    # 0/0 = NaN; pandas' mean skips it in the batch means of _batch_kurtosis (_nam.py:78-82), and with the default stop
+    # rule the median kurtosis is NaN, so the walk runs to maxnsteps (_nam.py:59-68)
+    base('c19_unused_category_batches', seed=18, N=24, gen=dict(sid_kind='cat', n_batches=4),
+         call=dict(nsteps=3, Nnull=100, seed=18), mutate='unused_category', extras=('nam', 'progress'))
+    base('c20_unused_category_autostop', seed=19, N=22, gen=dict(sid_kind='cat'),
+         call=dict(Nnull=100, seed=19), mutate='unused_category', extras=('progress',))
     return cases
 
 
@@ -195,6 +202,11 @@ def run_case(case):
             pool = np.flatnonzero(b == (c % (b.max() + 1)))
             sid[members] = rs.choice(pool, size=len(members))
         data.obs[sid_name] = sid
+    elif mut == 'unused_category':
+        col = data.obs[sid_name]
+        codes = np.asarray(col.cat.codes).copy()
+        codes[codes == 5] = 6                                  # sample 5 keeps its category and its phenotype, not its cells
+        data.obs[sid_name] = pd.Categorical.from_codes(codes, categories=col.cat.categories)
     elif mut == 'isolated':
         data, lab = add_isolated_blob(data, meta)
         y = pd.concat([y, pd.Series([np.nan], index=pd.Index([lab]))])

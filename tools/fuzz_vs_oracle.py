@@ -1,0 +1,107 @@
+#!/usr/bin/env python3
+"""Differential run against the float64 oracle on random small problems: shapes, graph dtype, cell order, id kinds,
+covariates / batches / donor groups, NaNs in y and covariates, walk rule, ks, force_permute_all, local test on / off, odd
+and even permutation counts -- for a wall-clock budget.  Every case: k, p, kept cells and num_detected equal, NAM
+bit-identical, floats at 1e-9.  Not part of the suites (oracle time dominates); evidence under profiles/.
+    python tools/fuzz_vs_oracle.py [seconds=300] [seed=0]"""
+import os, sys, time, warnings, traceback
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+warnings.simplefilter('ignore')
+import numpy as np, pandas as pd
+import cna_amd as cna
+from cna_amd import synth
+from cna_amd.engine import get_engine
+from oracle import cna_oracle as orc
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+eng = get_engine()
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    d = np.abs(a - b)
+    return float(np.nanmax(d) / max(np.nanmax(np.abs(b)), 1e-300)) if d.size else 0.0
+
+
+t_end = time.time() + budget
+done = failed = raised_both = ties = 0
+kinds = {}
+fails = {}
+while time.time() < t_end:
+    n = int(rs.choice([900, 1500, 2500, 4000, 7000]))
+    N = int(rs.choice([12, 20, 33, 48, 64, 65, 90, 96, 97, 128, 130, 200, 257, 300]))
+    opts = dict(k=int(rs.choice([8, 15, 25])), seed=int(rs.randint(1 << 30)), graph_dtype=rs.choice([np.float32, np.float64]),
+                cluster_sorted=bool(rs.rand() < 0.5), sid_kind=str(rs.choice(['int', 'str', 'cat'])),
+                n_covs=int(rs.choice([0, 0, 1, 3])), n_batches=int(rs.choice([0, 0, 3, 6])))
+    data, meta = synth.make_dataset(n, N, **opts)
+    y = meta['y'].copy()
+    kw = dict(nsteps=rs.choice([None, 2, 3, 4]), Nnull=int(rs.choice([50, 101, 200])), seed=int(rs.randint(1000)))
+    if kw['nsteps'] is not None:
+        kw['nsteps'] = int(kw['nsteps'])
+    covs, batches, donor = meta['covs'], meta['batches'], None
+    tag = []
+    if rs.rand() < 0.2:
+        y.iloc[int(rs.randint(N))] = np.nan; tag.append('ynan')
+    if covs is not None and rs.rand() < 0.2:
+        covs = covs.copy(); covs.iloc[int(rs.randint(N)), 0] = np.nan; tag.append('covnan')
+    if batches is None and rs.rand() < 0.2 and N >= 20:
+        donor = pd.Series(np.arange(N) // 2, index=y.index); y[:] = np.repeat(rs.randn((N + 1) // 2), 2)[:N]; tag.append('donor')
+    if rs.rand() < 0.15:
+        kw['force_permute_all'] = True; tag.append('fpa')
+    if rs.rand() < 0.15:
+        kw['local_test'] = False; tag.append('nolocal')
+    if rs.rand() < 0.2:
+        kw['ks'] = [1, 2, 3]; tag.append('ks')
+    tag += ['N%d' % N, 'covs%d' % opts['n_covs'], 'b%d' % opts['n_batches'], 'steps%s' % kw['nsteps'], opts['sid_kind'], opts['graph_dtype'].__name__]
+    for t in tag:
+        kinds[t] = kinds.get(t, 0) + 1
+    ref = res = eref = eres = None
+    try:
+        ref = orc.association(data, y, 'id', covs=covs, batches=batches, donorids=donor, mode='f64', **kw)
+    except Exception as e:                       # noqa: BLE001
+        eref = e
+    try:
+        res = cna.tl.association(data, y, 'id', covs=covs, batches=batches, donorids=donor, return_full=True, engine=eng, **kw)
+    except Exception as e:                       # noqa: BLE001
+        eres = e
+    done += 1
+    try:
+        if not kw.get('local_test', True) and eref is None:
+            # the reference itself fails here (its epilogue reads res.fdrs, which is None without the local test:
+            # _association.py:233-236, fixture c07_no_local): the product must raise that very error
+            assert isinstance(eres, AttributeError) and "'loc'" in str(eres), ('local_test=False', repr(eres))
+            continue
+        if eref is not None or eres is not None:
+            assert eref is not None and eres is not None and type(eref) is type(eres), ('one side raised', repr(eref), repr(eres))
+            raised_both += 1
+            continue
+        assert int(res.k) == ref['k'] and res.p == ref['p'], ('k / p', res.k, ref['k'], res.p, ref['p'])
+        assert np.array_equal(res.kept, ref['kept']), 'kept'
+        assert np.array_equal(res.nam.values.T, ref['nam']), ('nam bits', relerr(res.nam.values.T, ref['nam']))
+        assert relerr(res.ncorrs.values, ref['ncorrs']) < 1e-9, 'ncorrs'
+        assert relerr(res.nullminps, ref['nullminps']) < 1e-7, 'nullminps'
+        if kw.get('local_test', True):
+            T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
+            assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T]), 'num_detected'
+            got, want = data.obs['coef_fdr'].values, ref['obs_coef_fdr']
+            bad = np.flatnonzero(~np.isclose(got, want, rtol=1e-8, atol=1e-13, equal_nan=True))
+            if len(bad):
+                # the look-up is a step function of |coefficient|: a cell within rounding of a threshold may take the
+                # neighbouring step (the two sides' coefficients differ in the last bits) -- nothing else may differ
+                thr = res.fdrs.threshold.values
+                c = np.abs(data.obs['coef'].values[bad])
+                near = np.abs(c[:, None] - thr[None, :]).min(axis=1) <= 1e-9 * thr.max()
+                assert near.all() and len(bad) <= 2, ('coef_fdr', len(bad), got[bad][:3], want[bad][:3])
+                ties += len(bad)
+    except Exception as exc:                     # noqa: BLE001
+        failed += 1
+        what = str(exc.args[0] if exc.args else exc)[:160]
+        fails.setdefault(what.split(',')[0][:60], []).append((done, n, tag, kw, what))
+for key, items in fails.items():
+    print('== %d x %s' % (len(items), key))
+    for it in items[:4]:
+        print('   case %d n=%d %s %r\n      %s' % it)
+print('%d cases in %.0f s: %d disagreements, %d raised the same exception on both sides, %d cells on a threshold took the neighbouring FDR step' % (done, budget, failed, raised_both, ties))
+print('coverage: ' + '  '.join('%s x%d' % kv for kv in sorted(kinds.items())))
+sys.exit(1 if failed else 0)
