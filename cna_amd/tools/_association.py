@@ -247,6 +247,13 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     # when nothing had to be regressed out)
     if maxabs is None:
         _, maxabs = engine.ncorrs(y, fetch=False)
+    if maxabs != maxabs:
+        # NaN coefficients: the residualised NAM holds NaNs (e.g. a sample without cells that the reference's
+        # positionally paired sample filter let through, fixtures f03 / f24) -- the reference has failed before it gets
+        # here, in the SVD of the Gram matrix (_nam.py:105, "SVD did not converge"): the same routine on the same matrix
+        _small_svd(engine.gram_fetch())
+        if local_test:
+            raise ValueError('arange: cannot compute length')     # (a finite Gram matrix after all: the reference's next stop, _association.py:99)
     pending = False
     coef_early = False
     thresholds = edges = None

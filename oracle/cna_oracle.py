@@ -411,9 +411,23 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
         raise ValueError('You are supplying phenotype information on fewer than 10 samples.')
     nm = nam(data, sid_name, batches=batches, nsteps=nsteps, mode=mode)
     labels, kept = nm['labels'], nm['keep'].copy()
+    # The filter above is what the reference forms (_association.py:153-160): when y and covs come in different orders,
+    # `y.isna() | covs.isna().any(axis=1)` is indexed by the SORTED UNION of the two indices, while `present` is an array
+    # in y's order -- the `&` pairs them by position.  From here on the reference uses that Series as a boolean indexer
+    # of frames indexed by y.index (NAM.reindex(y.index)[filter_samples], y[filter_samples], ...): pandas aligns it by
+    # LABEL (and refuses it when a label of the frame is missing in it).  Fixtures f02 / f03 / f24.
+    if isinstance(filt, pd.Series) and not filt.index.equals(y.index):
+        aligned = filt.reindex(y.index)
+        if aligned.isna().any():
+            raise pd.errors.IndexingError('Unalignable boolean Series provided as indexer (index of the boolean Series and of '
+                                          'the indexed object do not match).')
+        filt = aligned.astype(bool)
     # NAM.reindex(y.index)[filter_samples]: sample axis follows y.index order
     pos = labels.get_indexer(y.index[filt.values])
     X = nm['nam'][:, pos]
+    if (pos < 0).any():
+        X = X.copy()
+        X[:, pos < 0] = np.nan                                # a label the NAM does not have: reindex gives a NaN row
     sd = _std1(X, 1)
     zero = np.flatnonzero(sd == 0)
     nz = np.flatnonzero(kept)

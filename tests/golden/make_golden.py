@@ -144,7 +144,59 @@ def build_cases():
          call=dict(nsteps=3, Nnull=100, seed=18), mutate='unused_category', extras=('nam', 'progress'))
     base('c20_unused_category_autostop', seed=19, N=22, gen=dict(sid_kind='cat'),
          call=dict(Nnull=100, seed=19), mutate='unused_category', extras=('progress',))
+    # messy sample-level inputs, drawn at random (seeded): every input in an order of its own, NaNs, samples the data does
+    # not have, unused categories, donor groups, custom ks / ridges / max_frac_pcs -- what pandas' label alignment makes
+    # of them in the reference is pinned here case by case (tools/fuzz_oracle_vs_reference.py found the first of them)
+    for i in range(1, 29):
+        frs = np.random.RandomState(7000 + i)
+        N = int(frs.choice([11, 14, 20, 26]))
+        gen = dict(sid_kind=str(frs.choice(['int', 'str', 'cat'])), n_covs=int(frs.choice([0, 1, 2])),
+                   n_batches=int(frs.choice([0, 0, 3, 5])), cluster_sorted=bool(frs.rand() < 0.5))
+        call = dict(nsteps=[None, 2, 3][int(frs.randint(3))], Nnull=int(frs.choice([20, 50])), seed=100 + i)
+        base('f%02d_messy' % i, n=500, N=N, k=10, seed=200 + i, gen=gen, call=call, mutate='fuzz:%d' % (7000 + i))
     return cases
+
+
+def fuzz_inputs(seed, data, meta, sid_name, call):
+    """Seeded mutations of the sample-level inputs of one case -> (y, covs, batches, donorids); may edit data.obs and call."""
+    rs = np.random.RandomState(seed)
+    y, covs, batches, donor = meta['y'].copy(), meta['covs'], meta['batches'], None
+    N = len(y)
+    if rs.rand() < 0.3:
+        y.iloc[int(rs.randint(N))] = np.nan
+    if covs is not None and rs.rand() < 0.4:
+        covs = covs.copy()
+        covs.iloc[int(rs.randint(N)), 0] = np.nan
+    col = data.obs[sid_name]
+    if isinstance(col.dtype, pd.CategoricalDtype) and rs.rand() < 0.5:
+        codes = np.asarray(col.cat.codes).copy()
+        codes[codes == 2] = 3                                  # category 2 keeps its phenotype, not its cells
+        data.obs[sid_name] = pd.Categorical.from_codes(codes, categories=col.cat.categories)
+    if rs.rand() < 0.5:                                        # every sample-level input in an order of its own
+        y = y.iloc[rs.permutation(len(y))]
+        if covs is not None and rs.rand() < 0.6:
+            covs = covs.iloc[rs.permutation(len(covs))]
+        if batches is not None and rs.rand() < 0.6:
+            batches = batches.iloc[rs.permutation(len(batches))]
+    if rs.rand() < 0.25 and not isinstance(col.dtype, pd.CategoricalDtype) and np.asarray(col).dtype.kind in 'iu':
+        extra = pd.Index([5000, 5001])                         # phenotypes of samples the data does not have
+        y = pd.concat([y, pd.Series([0.3, -1.2], index=extra)])
+        if covs is not None:
+            covs = pd.concat([covs, pd.DataFrame(np.zeros((2, covs.shape[1])), index=extra, columns=covs.columns)])
+        if batches is not None:
+            batches = pd.concat([batches, pd.Series([0, 1], index=extra)])
+    if batches is None and rs.rand() < 0.25 and N >= 14:
+        donor = pd.Series(np.arange(len(y)) // 2, index=y.index)
+        y = pd.Series(np.repeat(rs.randn((len(y) + 1) // 2), 2)[:len(y)], index=y.index)
+    if rs.rand() < 0.2:
+        call['force_permute_all'] = True
+    if rs.rand() < 0.25:
+        call['ks'] = [int(v) for v in sorted(rs.choice([1, 2, 3, 4], size=2, replace=False))]
+    if rs.rand() < 0.2:
+        call['max_frac_pcs'] = float(rs.choice([0.05, 0.3, 0.5]))
+    if batches is not None and rs.rand() < 0.3:
+        call['ridges'] = [float(v) for v in rs.choice([1e3, 10.0, 1.0, 0.0], size=2, replace=False)]
+    return y, covs, batches, donor
 
 
 def run_case(case):
@@ -202,6 +254,9 @@ def run_case(case):
             pool = np.flatnonzero(b == (c % (b.max() + 1)))
             sid[members] = rs.choice(pool, size=len(members))
         data.obs[sid_name] = sid
+    elif mut is not None and mut.startswith('fuzz:'):
+        case['call'] = dict(case['call'])
+        y, covs, batches, donorids = fuzz_inputs(int(mut.split(':')[1]), data, meta, sid_name, case['call'])
     elif mut == 'unused_category':
         col = data.obs[sid_name]
         codes = np.asarray(col.cat.codes).copy()

@@ -16,6 +16,11 @@ def golden_names():
     return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, 'c*.npz')))
 
 
+def messy_names():
+    """Fixtures of randomly drawn messy sample-level inputs (tests/golden/make_golden.py: f??_messy)."""
+    return sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, 'f*.npz')))
+
+
 def _index(arr):
     return pd.Index(arr.tolist())
 
