@@ -573,7 +573,7 @@ def _qc_device(engine, labels, batches, show_progress=False):
     codes, nb = _batch_codes(batches, labels)
     # A sample without cells (an unused category of a categorical id column) has a NaN row in the NAM (0/0, _nam.py:73);
     # the reference's batch means are DataFrame.mean, which skips NaN (_nam.py:78-82): such a sample belongs to no batch
-    # here (fixture c19_unused_category_batches; found by tools/fuzz_vs_oracle.py)
+    # here (fixture c19_unused_category_batches; found by differential fuzzing)
     held = getattr(engine, '_sample_counts', None)
     if held is not None and held[1] == len(codes) and len(held[0]) == len(codes):
         codes = np.where(held[0] > 0, codes, -1).astype(np.int32)
