@@ -512,7 +512,7 @@ def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_si
 
 def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
                             show_progress, codes_labels=None, overlap=None, nam_queued=None, y_std=None,
-                            fuse_null=0, null_ready=None, **kwargs):
+                            fuse_null=0, null_ready=None, local_test=True, **kwargs):
     """Reference compute_nam_and_reindex (_association.py:175-191) on the device: build the NAM,
     QC it, put the sample axis in ``y.index`` order restricted to ``filter_samples``, drop the
     cells whose remaining entries have zero variance.  Leaves the selected NAM in the engine's
@@ -566,6 +566,14 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
             hint = y_std
         finish_walk(hint)
     kept = _qc_device(engine, labels, batches_qc, show_progress=show_progress)
+    if not kept.any():
+        # Every neighbourhood failed the QC (a NaN among the batch labels is enough: it is a level without members, its
+        # mean and with it every batch kurtosis NaN, _nam.py:78-99).  The reference goes on with a NAM of no columns
+        # and stops where the thresholds are formed from the largest of no coefficients (_association.py:99-102;
+        # fixtures f29 / f30): the same error from here, before anything is selected or written.
+        if local_test:
+            raise ValueError('arange: cannot compute length')
+        raise ValueError('no neighborhood passed the batch-kurtosis QC')
 
     nzero = -1
     if (plan is not None and plan.kind == 'identity' and finish_walk is None and y_std is not None
@@ -848,7 +856,7 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         kept, sample_index, colmap, batches, covs, donorids, filter_samples, plan = \
             compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
                                     show_progress, codes_labels=(codes, labels, counts, token), overlap=host_side,
-                                    nam_queued=nam_queued, y_std=y_std,
+                                    nam_queued=nam_queued, y_std=y_std, local_test=kwargs.get('local_test', True),
                                     fuse_null=min(1000, Nnull) if kwargs.get('local_test', True) and _FUSE else 0,
                                     # (the conditioned phenotypes of THIS call on the device before the selection is
                                     # asked for: that call then launches the local null itself)

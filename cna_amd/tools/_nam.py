@@ -571,6 +571,12 @@ def _qc_device(engine, labels, batches, show_progress=False):
     if len(np.unique(batches)) == 1:
         return np.repeat(True, engine.n)
     codes, nb = _batch_codes(batches, labels)
+    if (codes < 0).any():
+        # a NaN among the batch labels of the NAM's samples: np.unique makes it a level, `batches == nan` selects nobody,
+        # the mean of nobody is NaN and so is every neighbourhood's batch kurtosis (_nam.py:78-99) -- none is kept
+        print('throwing out neighborhoods with batch kurtosis >=', 6, file=out)
+        print('keeping', 0, 'neighborhoods', file=out)
+        return np.repeat(False, engine.n)
     # A sample without cells (an unused category of a categorical id column) has a NaN row in the NAM (0/0, _nam.py:73);
     # the reference's batch means are DataFrame.mean, which skips NaN (_nam.py:78-82): such a sample belongs to no batch
     # here (fixture c19_unused_category_batches; found by differential fuzzing)

@@ -384,9 +384,14 @@ def nam(data, sid_name, batches=None, nsteps=None, self_weight=1, mode='referenc
         keep, thr = np.ones(A.shape[0], dtype=bool), None
     else:
         b = batches.reindex(labels).values
-        ub = np.unique(b)
-        bc = np.searchsorted(ub, b)
-        keep, thr = qc_keep(info['nam'], bc, len(ub))
+        if pd.isna(b).any() and len(np.unique(batches)) > 1:
+            # a NaN label is a level of np.unique that `batches == b` never matches: the mean of its (no) members is NaN,
+            # every batch kurtosis NaN, no neighbourhood below the threshold (_nam.py:78-99; fixtures f29 / f30)
+            keep, thr = np.zeros(A.shape[0], dtype=bool), 6
+        else:
+            ub = np.unique(b)
+            bc = np.searchsorted(ub, b)
+            keep, thr = qc_keep(info['nam'], bc, len(ub))
     return dict(nam=info['nam'][keep], keep=keep, labels=labels, info=info, qc_threshold=thr)
 
 
@@ -411,6 +416,10 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
         raise ValueError('You are supplying phenotype information on fewer than 10 samples.')
     nm = nam(data, sid_name, batches=batches, nsteps=nsteps, mode=mode)
     labels, kept = nm['labels'], nm['keep'].copy()
+    if not kept.any() and kwargs.get('local_test', True):
+        # no neighbourhood left: the reference goes on with a NAM of no columns until the thresholds are formed from the
+        # largest of no coefficients (_association.py:99-102)
+        raise ValueError('arange: cannot compute length')
     # The filter above is what the reference forms (_association.py:153-160): when y and covs come in different orders,
     # `y.isna() | covs.isna().any(axis=1)` is indexed by the SORTED UNION of the two indices, while `present` is an array
     # in y's order -- the `&` pairs them by position.  From here on the reference uses that Series as a boolean indexer

@@ -154,6 +154,11 @@ def build_cases():
                    n_batches=int(frs.choice([0, 0, 3, 5])), cluster_sorted=bool(frs.rand() < 0.5))
         call = dict(nsteps=[None, 2, 3][int(frs.randint(3))], Nnull=int(frs.choice([20, 50])), seed=100 + i)
         base('f%02d_messy' % i, n=500, N=N, k=10, seed=200 + i, gen=gen, call=call, mutate='fuzz:%d' % (7000 + i))
+    # a NaN among the batch labels (garbage in; what the reference makes of it is still what a drop-in must make of it)
+    base('f29_nan_batch', n=500, N=20, k=10, seed=231, gen=dict(n_batches=3), call=dict(nsteps=3, Nnull=50, seed=31),
+         mutate='nan_batch')
+    base('f30_nan_batch_covs_autostop', n=500, N=14, k=10, seed=232, gen=dict(n_batches=5, n_covs=1, sid_kind='str'),
+         call=dict(Nnull=20, seed=32), mutate='nan_batch')
     return cases
 
 
@@ -257,6 +262,9 @@ def run_case(case):
     elif mut is not None and mut.startswith('fuzz:'):
         case['call'] = dict(case['call'])
         y, covs, batches, donorids = fuzz_inputs(int(mut.split(':')[1]), data, meta, sid_name, case['call'])
+    elif mut == 'nan_batch':
+        batches = batches.astype(float).copy()
+        batches.iloc[4] = np.nan
     elif mut == 'unused_category':
         col = data.obs[sid_name]
         codes = np.asarray(col.cat.codes).copy()
