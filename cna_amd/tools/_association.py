@@ -538,8 +538,13 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     sample_index = y.index[positions]
     colmap = labels.get_indexer(sample_index)
     if (colmap < 0).any():
-        raise ValueError('the sample filter selects samples that have no cells in data; ' +
-                         'make sure y, covs, batches and donorids share one index order')
+        # The filter selects a sample the data has no cells of -- the reference's filter pairs `y.isna() | covs.isna()`
+        # (indexed by the sorted union of the two indices) with `y.index.isin(...)` (in y's order) BY POSITION
+        # (_association.py:153-160), so inputs in different orders can let such a sample through.  Its row of
+        # NAM.reindex(y.index) is NaN, the residualised NAM is NaN throughout, and the reference stops in the SVD of the
+        # Gram matrix (_nam.py:105) with numpy's message -- the same error here (cause: y, covs, batches and donorids that
+        # do not share one index order).
+        raise np.linalg.LinAlgError('SVD did not converge')
     batches = batches.reindex(y.index)
     covs = covs.reindex(y.index) if covs is not None else None
     donorids = donorids.reindex(y.index) if donorids is not None else None
@@ -573,7 +578,9 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
         # fixtures f29 / f30): the same error from here, before anything is selected or written.
         if local_test:
             raise ValueError('arange: cannot compute length')
-        raise ValueError('no neighborhood passed the batch-kurtosis QC')
+        # (without the local test the reference gets as far as its epilogue, which reads the FDR table that was never made:
+        # _association.py:233-236, as in every call with local_test=False)
+        raise AttributeError("'NoneType' object has no attribute 'loc'")
 
     nzero = -1
     if (plan is not None and plan.kind == 'identity' and finish_walk is None and y_std is not None

@@ -159,6 +159,10 @@ def build_cases():
          mutate='nan_batch')
     base('f30_nan_batch_covs_autostop', n=500, N=14, k=10, seed=232, gen=dict(n_batches=5, n_covs=1, sid_kind='str'),
          call=dict(Nnull=20, seed=32), mutate='nan_batch')
+    # integer ids, one sample of y has no cells, y in an order of its own and covs in another: the reference's positionally
+    # paired filter lets the sample without cells through and the analysis dies in the SVD of a NaN Gram matrix
+    base('f31_absent_sample_let_through', n=500, N=20, k=10, seed=233, gen=dict(n_covs=1),
+         call=dict(nsteps=3, Nnull=50, seed=33), mutate='absent_misaligned')
     return cases
 
 
@@ -262,6 +266,11 @@ def run_case(case):
     elif mut is not None and mut.startswith('fuzz:'):
         case['call'] = dict(case['call'])
         y, covs, batches, donorids = fuzz_inputs(int(mut.split(':')[1]), data, meta, sid_name, case['call'])
+    elif mut == 'absent_misaligned':
+        sid = np.asarray(data.obs[sid_name]).copy()
+        sid[sid == 5] = 6
+        data.obs[sid_name] = sid
+        y = y.iloc[np.random.RandomState(3).permutation(len(y))]    # (label 5 lands on position 15: the filter drops sample 15 and keeps 5)
     elif mut == 'nan_batch':
         batches = batches.astype(float).copy()
         batches.iloc[4] = np.nan

@@ -47,6 +47,24 @@ while time.time() < t_end:
         covs = covs.copy(); covs.iloc[int(rs.randint(N)), 0] = np.nan; tag.append('covnan')
     if batches is None and rs.rand() < 0.2 and N >= 20:
         donor = pd.Series(np.arange(N) // 2, index=y.index); y[:] = np.repeat(rs.randn((N + 1) // 2), 2)[:N]; tag.append('donor')
+    if opts['sid_kind'] == 'cat' and rs.rand() < 0.3:
+        col = data.obs['id']; codes = np.asarray(col.cat.codes).copy(); codes[codes == 2] = 3
+        data.obs['id'] = pd.Categorical.from_codes(codes, categories=col.cat.categories); tag.append('unused')
+    if donor is None and rs.rand() < 0.3:                  # every sample-level input in an order of its own
+        y = y.iloc[rs.permutation(len(y))]; tag.append('yperm')
+        if covs is not None and rs.rand() < 0.5:
+            covs = covs.iloc[rs.permutation(len(covs))]; tag.append('covperm')
+        if batches is not None and rs.rand() < 0.5:
+            batches = batches.iloc[rs.permutation(len(batches))]; tag.append('bperm')
+    if donor is None and rs.rand() < 0.15 and opts['sid_kind'] == 'int':
+        extra = pd.Index([5000, 5001]); tag.append('yextra')
+        y = pd.concat([y, pd.Series([0.3, -1.2], index=extra)])
+        if covs is not None:
+            covs = pd.concat([covs, pd.DataFrame(np.zeros((2, covs.shape[1])), index=extra, columns=covs.columns)])
+        if batches is not None:
+            batches = pd.concat([batches, pd.Series([0, 1], index=extra)])
+    if batches is not None and rs.rand() < 0.05:
+        batches = batches.astype(float).copy(); batches.iloc[int(rs.randint(len(batches)))] = np.nan; tag.append('batchnan')
     if rs.rand() < 0.15:
         kw['force_permute_all'] = True; tag.append('fpa')
     if rs.rand() < 0.15:
