@@ -30,13 +30,22 @@ DEFAULT_RIDGES = [1e5, 1e4, 1e3, 1e2, 1e1, 1e0, 1e-1, 1e-2, 1e-3, 1e-4, 0]
 
 
 # --------------------------------------------------------------------------- diffusion
+def _as_f64(A):
+    """The same CSR with float64 values, entry for entry: `A.astype(float64)` would also SORT the indices of a row and SUM
+    duplicate entries of a graph that is not in canonical form -- another order of the same sums than the reference's
+    `a.dot(...)`, which walks the stored entries as they are (found by tools/fuzz_graphs.py)."""
+    if A.data.dtype == np.float64:
+        return A
+    return sp.csr_matrix((A.data.astype(np.float64), A.indices, A.indptr), shape=A.shape)
+
+
 def column_sums(A, self_weight=1, mode='reference'):
     """colsums = A.sum(axis=0) + self_weight   (_nam.py:28).
 
     scipy sums a CSR over axis 0 in the matrix dtype, accumulating each column in
     ascending row order; the python-int self weight does not upcast float32."""
     if mode == 'f64':
-        A = A.astype(np.float64)
+        A = _as_f64(A)
     return np.asarray(A.sum(axis=0)).ravel() + self_weight
 
 
@@ -47,7 +56,7 @@ def diffusion_step(A, s, colsums, self_weight=1, first_onehot=False, mode='refer
     float32 graph the reference then evaluates the SpMM in float32 and the self term in
     float64 (bool/f32 -> f32, int*bool/f32 -> f64)."""
     if mode == 'f64':
-        A64 = A.astype(np.float64)
+        A64 = _as_f64(A)
         c = colsums.astype(np.float64)[:, None]
         s = s.astype(np.float64)
         return A64.dot(s / c) + self_weight * s / c
