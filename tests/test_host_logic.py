@@ -13,12 +13,12 @@ import pytest
 
 import cna_amd as cna
 from fake_engine import FakeEngine
-from helpers import golden_names, load_case, run_product, assert_matches_golden, relerr
+from helpers import messy_names, golden_names, load_case, run_product, assert_matches_golden, relerr
 
 NAMES = golden_names()
 
 
-ORDERS = [(n, None) for n in NAMES] + [(n, 'rcm') for n in NAMES] + \
+ORDERS = [(n, None) for n in NAMES] + [(n, 'rcm') for n in NAMES] + [(n, None) for n in messy_names()] + \
          [(n, 'random') for n in ('c01_plain_f32', 'c03_covs_batches', 'c12_batchy_qc', 'c13_zero_variance')]
 
 
@@ -32,14 +32,20 @@ def test_association_host_logic(name, order):
     if z['raised'].item():
         assert err is not None and type(err).__name__ == z['raised'].item().split(':')[0]
         assert str(err) == z['raised'].item().split(': ', 1)[1]
-        np.testing.assert_allclose(case['data'].obs['coef'].values, z['obs_coef'], rtol=0,
-                                   atol=1e-5 * np.nanmax(np.abs(z['obs_coef'])), equal_nan=True)
+        if 'obs_coef' in z:
+            np.testing.assert_allclose(case['data'].obs['coef'].values, z['obs_coef'], rtol=0,
+                                       atol=1e-5 * np.nanmax(np.abs(z['obs_coef'])), equal_nan=True)
+        else:
+            assert 'coef' not in case['data'].obs
         return
     assert err is None, repr(err)
     assert_matches_golden(res, case['data'], z, name=name)
     import json
-    ref_msgs = [m for m in json.loads(z['warnings'].item()) if 'already exists' not in m]
-    assert [m for m in msgs if 'already exists' not in m] == ref_msgs
+    # (pandas' own remark about the reference's misaligned boolean indexer -- "Boolean Series key will be reindexed" -- is
+    # an artefact of its implementation, not a message of the analysis)
+    skip = ('already exists', 'Boolean Series key')
+    ref_msgs = [m for m in json.loads(z['warnings'].item()) if not any(t in m for t in skip)]
+    assert [m for m in msgs if not any(t in m for t in skip)] == ref_msgs
 
 
 def _numbers(text):
