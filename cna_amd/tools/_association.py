@@ -512,7 +512,7 @@ def check_inputs(data, y, sid_name, batches, covs, donorids, allow_low_sample_si
 
 def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
                             show_progress, codes_labels=None, overlap=None, nam_queued=None, y_std=None,
-                            fuse_null=0, null_ready=None, local_test=True, **kwargs):
+                            fuse_null=0, null_ready=None, local_test=True, ks=None, **kwargs):
     """Reference compute_nam_and_reindex (_association.py:175-191) on the device: build the NAM,
     QC it, put the sample axis in ``y.index`` order restricted to ``filter_samples``, drop the
     cells whose remaining entries have zero variance.  Leaves the selected NAM in the engine's
@@ -576,6 +576,16 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
         # mean and with it every batch kurtosis NaN, _nam.py:78-99).  The reference goes on with a NAM of no columns
         # and stops where the thresholds are formed from the largest of no coefficients (_association.py:99-102;
         # fixtures f29 / f30): the same error from here, before anything is selected or written.
+        # (... after the check of ks against the sample count, which comes first there: _association.py:29-33)
+        n_f = int(filter_samples.sum())
+        f_ = filter_samples.values.astype(bool)
+        r_f = _resid_plan(sample_index, covs[f_] if covs is not None else None, batches[f_] if batches is not None else None).r
+        ks_f = ks if ks is not None else default_ks(n_f)
+        if max(ks_f) + r_f >= n_f:
+            raise ValueError(
+                'Maximum number of PCs plus number of covariates must be less than n-1. ' +
+                f'Currently it is {max(ks_f)+r_f} while n is {n_f}. Either reduce the number of covariates ' +
+                'or reduce the number of PCs to consider using the optional argument ks=[...].')
         if local_test:
             raise ValueError('arange: cannot compute length')
         # (without the local test the reference gets as far as its epilogue, which reads the FDR table that was never made:
@@ -863,7 +873,7 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         kept, sample_index, colmap, batches, covs, donorids, filter_samples, plan = \
             compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, filter_samples, nsteps,
                                     show_progress, codes_labels=(codes, labels, counts, token), overlap=host_side,
-                                    nam_queued=nam_queued, y_std=y_std, local_test=kwargs.get('local_test', True),
+                                    nam_queued=nam_queued, y_std=y_std, local_test=kwargs.get('local_test', True), ks=ks,
                                     fuse_null=min(1000, Nnull) if kwargs.get('local_test', True) and _FUSE else 0,
                                     # (the conditioned phenotypes of THIS call on the device before the selection is
                                     # asked for: that call then launches the local null itself)

@@ -159,6 +159,9 @@ def build_cases():
          mutate='nan_batch')
     base('f30_nan_batch_covs_autostop', n=500, N=14, k=10, seed=232, gen=dict(n_batches=5, n_covs=1, sid_kind='str'),
          call=dict(Nnull=20, seed=32), mutate='nan_batch')
+    # ... and when ks is also too large for the samples left, the reference's check of ks speaks first (_association.py:29-33)
+    base('f32_nan_batch_ks_too_large', n=500, N=11, k=10, seed=234, gen=dict(n_batches=3), call=dict(nsteps=2, Nnull=50, seed=34, ks=[4, 9]),
+         mutate='nan_batch')
     # integer ids, one sample of y has no cells, y in an order of its own and covs in another: the reference's positionally
     # paired filter lets the sample without cells through and the analysis dies in the SVD of a NaN Gram matrix
     base('f31_absent_sample_let_through', n=500, N=20, k=10, seed=233, gen=dict(n_covs=1),
