@@ -235,6 +235,10 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
     n = len(y)
     if ks is None:
         ks = default_ks(n)
+    if isinstance(M, pd.DataFrame) and M.values.dtype == np.float64 and np.isnan(M.values.sum()):
+        # a projector with NaNs (a constant covariate: 0/0 when it is standardised, _nam.py:125): the reference has
+        # already failed, in the SVD of the residualised NAM (_nam.py:105), before it looks at ks
+        _small_svd(engine.gram_fetch())
     if max(ks) + r >= n:
         raise ValueError(
             'Maximum number of PCs plus number of covariates must be less than n-1. ' +

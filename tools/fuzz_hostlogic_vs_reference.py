@@ -76,18 +76,35 @@ while time.time() < t_end:
         kw['ridges'] = [float(v) for v in rs.choice([1e3, 10.0, 1.0, 0.0], size=2, replace=False)]; tag.append('ridges')
     if N < 10 and rs.rand() < 0.6:
         kw['allow_low_sample_size'] = True; tag.append('lowN')
+    if rs.rand() < 0.1:
+        kw['local_test'] = False; tag.append('nolocal')
+    if rs.rand() < 0.1:
+        kw['Nnull'] = int(rs.choice([1001, 1200])); tag.append('bigNnull')
+    if covs is not None and rs.rand() < 0.1:
+        covs = covs.copy(); covs.iloc[:, 0] = 1.0; tag.append('constcov')
+    if batches is not None and rs.rand() < 0.15:
+        batches = batches.map(lambda v: 'b%s' % v if v == v else v); tag.append('strbatch')
+    if rs.rand() < 0.1:
+        y = y.round().astype(int) if not y.isna().any() else y; tag.append('inty')
+    if donor is not None and rs.rand() < 0.3:
+        y = y.copy(); y.iloc[0] += 1.0; tag.append('donor_inconsistent')
+    progress = rs.rand() < 0.3
+    if progress:
+        tag.append('progress')
     d2 = type('D', (), {})(); d2.obs = data.obs.copy(); d2.obsp = data.obsp; d2.uns = {}
     a = b = ea = eb = None
     try:
-        with contextlib.redirect_stdout(io.StringIO()):
-            a = ref.tl.association(d2, y, 'id', covs=covs, batches=batches, donorids=donor, return_full=True, **kw)
+        buf_a = io.StringIO()
+        with contextlib.redirect_stdout(buf_a):
+            a = ref.tl.association(d2, y, 'id', covs=covs, batches=batches, donorids=donor, return_full=True, show_progress=progress, **kw)
     except Exception as e:                       # noqa: BLE001
         ea = e
     d3 = type('D', (), {})(); d3.obs = data.obs.copy(); d3.obsp = data.obsp; d3.uns = {}
     try:
-        with contextlib.redirect_stdout(io.StringIO()):
+        buf_b = io.StringIO()
+        with contextlib.redirect_stdout(buf_b):
             b = cna_new.tl.association(d3, y, 'id', covs=covs, batches=batches, donorids=donor, return_full=True,
-                                       engine=FakeEngine(), **kw)
+                                       engine=FakeEngine(), show_progress=progress, **kw)
     except Exception as e:                       # noqa: BLE001
         eb = e
     done += 1
@@ -106,6 +123,9 @@ while time.time() < t_end:
             print('nullminps max diff', d.max(), 'at', int(d.argmax()), a.nullminps[d.argmax()], b.nullminps[d.argmax()], 'count > 1e-9:', int((d > 1e-9).sum()))
             print('yresid diff', np.abs(a.yresid - b.yresid.values if hasattr(b.yresid, 'values') else a.yresid - b.yresid).max())
             print('svs', a.namresid_svs.values[:5], b.namresid_svs.values[:5])
+            T_ = min(len(a.fdrs), len(b.fdrs)); dd = a.fdrs.num_detected.values[:T_] - b.fdrs.num_detected.values[:T_]
+            print('len fdrs', len(a.fdrs), len(b.fdrs), 'num_detected diffs at', np.flatnonzero(dd)[:10], dd[np.flatnonzero(dd)[:10]], 'thr', a.fdrs.threshold.values[np.flatnonzero(dd)[:3]], b.fdrs.threshold.values[np.flatnonzero(dd)[:3]])
+            nc_a = np.sort(np.abs(a.ncorrs.values)); nc_b = np.sort(np.abs(b.ncorrs.values)); print('max |ncorrs| rel diff', np.abs(nc_a - nc_b).max() / nc_a.max())
         break
     try:
         if ea is not None or eb is not None:
@@ -113,6 +133,9 @@ while time.time() < t_end:
             assert type(ea) is type(eb) and str(ea) == str(eb), ('exceptions differ', repr(ea)[:120], repr(eb)[:120])
             both += 1
             continue
+        import re as _re
+        mask = lambda t: _re.sub(r'[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?|nan|inf', '#', t)
+        assert mask(buf_a.getvalue()) == mask(buf_b.getvalue()), ('stdout', buf_a.getvalue()[-300:], buf_b.getvalue()[-300:])
         assert int(a.k) == int(b.k) and abs(a.p - b.p) < 1e-12, ('k / p', a.k, b.k, a.p, b.p)
         assert np.array_equal(a.kept, b.kept), ('kept', int(a.kept.sum()), int(b.kept.sum()))
         assert list(a.nam.index) == list(b.nam.index), 'sample order of res.nam'
