@@ -52,7 +52,10 @@ def _worker(rank, world, seg, name, halo, q):
 
 
 @pytest.mark.parametrize('name,world,halo', [('c12_batchy_qc', 2, True), ('c03_covs_batches', 3, True),
-                                             ('c13_zero_variance', 2, False), ('c01_plain_f32', 4, True)])
+                                             ('c13_zero_variance', 2, False), ('c01_plain_f32', 4, True),
+                                             # messy sample-level inputs (orders of their own, NaNs, an unused category)
+                                             ('f02_messy', 2, True), ('f12_messy', 3, True), ('f06_messy', 2, False),
+                                             ('c19_unused_category_batches', 2, True)])
 def test_sharded_hip_path_on_one_gpu(name, world, halo):
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
