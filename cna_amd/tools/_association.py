@@ -541,14 +541,7 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
     positions = pd.Series(np.arange(len(y)), index=y.index)[filter_samples].values
     sample_index = y.index[positions]
     colmap = labels.get_indexer(sample_index)
-    if (colmap < 0).any():
-        # The filter selects a sample the data has no cells of -- the reference's filter pairs `y.isna() | covs.isna()`
-        # (indexed by the sorted union of the two indices) with `y.index.isin(...)` (in y's order) BY POSITION
-        # (_association.py:153-160), so inputs in different orders can let such a sample through.  Its row of
-        # NAM.reindex(y.index) is NaN, the residualised NAM is NaN throughout, and the reference stops in the SVD of the
-        # Gram matrix (_nam.py:105) with numpy's message -- the same error here (cause: y, covs, batches and donorids that
-        # do not share one index order).
-        raise np.linalg.LinAlgError('SVD did not converge')
+    absent_selected = bool((colmap < 0).any())            # (dealt with after the QC, where the reference meets it)
     batches = batches.reindex(y.index)
     covs = covs.reindex(y.index) if covs is not None else None
     donorids = donorids.reindex(y.index) if donorids is not None else None
@@ -595,6 +588,14 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
         # (without the local test the reference gets as far as its epilogue, which reads the FDR table that was never made:
         # _association.py:233-236, as in every call with local_test=False)
         raise AttributeError("'NoneType' object has no attribute 'loc'")
+    if absent_selected:
+        # The filter selects a sample the data has no cells of -- the reference's filter pairs `y.isna() | covs.isna()`
+        # (indexed by the sorted union of the two indices) with `y.index.isin(...)` (in y's order) BY POSITION
+        # (_association.py:153-160), so inputs in different orders can let such a sample through.  Its row of
+        # NAM.reindex(y.index) is NaN, the residualised NAM is NaN throughout, and the reference stops in the SVD of the
+        # Gram matrix (_nam.py:105) with numpy's message -- the same error here (cause: y, covs, batches and donorids that
+        # do not share one index order).
+        raise np.linalg.LinAlgError('SVD did not converge')
 
     nzero = -1
     if (plan is not None and plan.kind == 'identity' and finish_walk is None and y_std is not None
