@@ -256,8 +256,9 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
         # positionally paired sample filter let through, fixtures f03 / f24) -- the reference has failed before it gets
         # here, in the SVD of the Gram matrix (_nam.py:105, "SVD did not converge"): the same routine on the same matrix
         _small_svd(engine.gram_fetch())
-        if local_test:
-            raise ValueError('arange: cannot compute length')     # (a finite Gram matrix after all: the reference's next stop, _association.py:99)
+        # a finite Gram matrix after all: then it is the phenotype that is NaN (a constant y: 0/0 when it is standardised,
+        # _association.py:22), and the reference's next stop is the argmin over its all-NaN p-values (_association.py:55)
+        raise ValueError('All-NaN slice encountered')
     pending = False
     coef_early = False
     thresholds = edges = None

@@ -162,6 +162,8 @@ def build_cases():
     # ... and when ks is also too large for the samples left, the reference's check of ks speaks first (_association.py:29-33)
     base('f32_nan_batch_ks_too_large', n=500, N=11, k=10, seed=234, gen=dict(n_batches=3), call=dict(nsteps=2, Nnull=50, seed=34, ks=[4, 9]),
          mutate='nan_batch')
+    # a constant phenotype: 0/0 when it is standardised, every p-value NaN, the reference stops at their argmin
+    base('f33_constant_phenotype', n=500, N=14, k=10, seed=235, call=dict(nsteps=2, Nnull=50, seed=35), mutate='constant_y')
     # integer ids, one sample of y has no cells, y in an order of its own and covs in another: the reference's positionally
     # paired filter lets the sample without cells through and the analysis dies in the SVD of a NaN Gram matrix
     base('f31_absent_sample_let_through', n=500, N=20, k=10, seed=233, gen=dict(n_covs=1),
@@ -274,6 +276,8 @@ def run_case(case):
         sid[sid == 5] = 6
         data.obs[sid_name] = sid
         y = y.iloc[np.random.RandomState(3).permutation(len(y))]    # (label 5 lands on position 15: the filter drops sample 15 and keeps 5)
+    elif mut == 'constant_y':
+        y = pd.Series(np.full(len(y), 2.0), index=y.index)
     elif mut == 'nan_batch':
         batches = batches.astype(float).copy()
         batches.iloc[4] = np.nan

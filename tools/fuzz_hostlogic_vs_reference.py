@@ -107,6 +107,30 @@ while time.time() < t_end:
                                        engine=FakeEngine(), show_progress=progress, **kw)
     except Exception as e:                       # noqa: BLE001
         eb = e
+    # cna.tl.nam on the same inputs (the public function: frame layout, QC mask, self weight)
+    if rs.rand() < 0.3:
+        sw = float(rs.choice([1, 1, 0.5, 2]))
+        na = nb_ = en = enb = None
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                na = ref.tl.nam(d2, 'id', batches=batches, nsteps=kw['nsteps'], self_weight=sw)
+        except Exception as e:                   # noqa: BLE001
+            en = e
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                nb_ = cna_new.tl.nam(d3, 'id', batches=batches, nsteps=kw['nsteps'], self_weight=sw, engine=FakeEngine())
+        except Exception as e:                   # noqa: BLE001
+            enb = e
+        try:
+            if en is not None or enb is not None:
+                assert en is not None and enb is not None and type(en) is type(enb) and str(en) == str(enb), ('tl.nam exceptions', repr(en)[:100], repr(enb)[:100])
+            else:
+                assert np.array_equal(np.asarray(na[1]), np.asarray(nb_[1])), 'tl.nam keep'
+                assert list(na[0].index) == list(nb_[0].index) and list(na[0].columns) == list(nb_[0].columns), 'tl.nam labels'
+                assert relerr(na[0].values, nb_[0].values) < 1e-6, ('tl.nam values', relerr(na[0].values, nb_[0].values))
+        except Exception as exc:                 # noqa: BLE001
+            what = str(exc.args[0] if exc.args else exc)[:200]
+            fails.setdefault(what.split(',')[0][:50], []).append((done, n, tag + ['sw%s' % sw], kw, opts['seed'], what))
     done += 1
     if os.environ.get('FUZZ_DEBUG_CASE') and done == int(os.environ['FUZZ_DEBUG_CASE']):
         print('case', done, n, N, opts, kw, tag)
