@@ -29,7 +29,7 @@ done = failed = raised_both = ties = 0
 kinds = {}
 fails = {}
 while time.time() < t_end:
-    n = int(rs.choice([900, 1500, 2500, 4000, 7000]))
+    n = int(rs.choice([int(v) for v in os.environ.get('FUZZ_CELLS', '900,1500,2500,4000,7000').split(',')]))      # FUZZ_CELLS=30000,120000: the paths of large inputs (device order adopted later, graph prefetch)
     N = int(rs.choice([12, 20, 33, 48, 64, 65, 90, 96, 97, 128, 130, 200, 257, 300]))
     opts = dict(k=int(rs.choice([8, 15, 25])), seed=int(rs.randint(1 << 30)), graph_dtype=rs.choice([np.float32, np.float64]),
                 cluster_sorted=bool(rs.rand() < 0.5), sid_kind=str(rs.choice(['int', 'str', 'cat'])),
