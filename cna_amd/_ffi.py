@@ -105,6 +105,10 @@ SIGNATURES = {
     'cna_host_draw_start': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
     'cna_host_draw_wait': (C.c_int, []),
+    'cna_host_draw_join': (C.c_int, []),
+    'cna_assoc_begin': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int]),
+    'cna_assoc_finish': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),
+    'cna_assoc_run': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'cna_host_draw_then_condition': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'cna_global_test_launch': (C.c_int, [c_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     'cna_global_test_fetch': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -131,6 +135,30 @@ SIGNATURES = {
 }
 
 MAT_NAM, MAT_X, MAT_PROJ = 0, 1, 2
+ASSOC_DONE, ASSOC_GENERAL, ASSOC_NEED_PCS, ASSOC_STALE = 0, 1, 2, 3
+ASSOC_MAXT = 512
+
+
+class AssocArgs(C.Structure):
+    """struct cna_assoc_args (include/cna_hip.h)"""
+    _fields_ = [('colmap', C.c_void_p), ('n_sel', C.c_int32), ('r', C.c_int32), ('y', C.c_void_p), ('M', C.c_void_p),
+                ('resid_C', C.c_void_p), ('resid_W', C.c_void_p), ('ks', C.c_void_p), ('K', C.c_int32), ('Nnull', C.c_int32),
+                ('table', C.c_void_p), ('draw_pending', C.c_int32), ('conditioned', C.c_int32), ('use_native_eig', C.c_int32),
+                ('coef_first', C.c_int32), ('resid_tol', C.c_double), ('gap_tol', C.c_double), ('coef_dst', C.c_void_p),
+                ('fdr_dst', C.c_void_p), ('n_dst', C.c_int64), ('copy_threads', C.c_int32), ('n_verify', C.c_int32),
+                ('verify_ptr', C.c_void_p * 4), ('verify_bytes', C.c_int64 * 4), ('verify_hash', C.c_uint64 * 4),
+                ('verify_threads', C.c_int32), ('reserved', C.c_int32),
+                ('G', C.c_void_p), ('U', C.c_void_p), ('minp', C.c_void_p), ('r2', C.c_void_p), ('kidx', C.c_void_p)]
+
+
+class AssocOut(C.Structure):
+    """struct cna_assoc_out (include/cna_hip.h)"""
+    _fields_ = [('status', C.c_int32), ('T', C.c_int32), ('eig_accepted', C.c_int32), ('null_fused', C.c_int32),
+                ('coef_in_dst', C.c_int32), ('fdr_in_dst', C.c_int32), ('n_zero', C.c_int64), ('max_abs', C.c_double),
+                ('coef_ptr', C.c_void_p), ('fdr_ptr', C.c_void_p), ('t_ms', C.c_double * 12),
+                ('thr', C.c_double * ASSOC_MAXT), ('fdr', C.c_double * ASSOC_MAXT), ('runmin', C.c_double * ASSOC_MAXT),
+                ('tail_sums', C.c_int64 * ASSOC_MAXT), ('ranks', C.c_int64 * ASSOC_MAXT), ('num_detected', C.c_int64 * ASSOC_MAXT)]
+
 KERNELS = ['colsum', 'nam_first', 'nam_step', 'batch_kurtosis', 'zero_variance', 'select', 'resid_xb',
            'standardize', 'gram', 'gram_reduce', 'ncorrs', 'null_local', 'obs_counts', 'percell_fdr',
            'project_xb', 'transpose', 'rccl', 'condition', 'global_test', 'nam_step_sparse']

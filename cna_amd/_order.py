@@ -22,16 +22,23 @@ import numpy as np
 import scipy.sparse as sp
 
 
+_allowance = None
+
+
 def usable_cpus(limit=None):
     """CPUs this process may really use: the cgroup v2 quota if there is one, else the affinity mask."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    try:
-        with open('/sys/fs/cgroup/cpu.max') as f:
-            quota, period = f.read().split()
-        if quota != 'max':
-            n = max(1, min(n, int(int(quota) / int(period))))
-    except Exception:
-        pass
+    global _allowance
+    if _allowance is None or _allowance[0] != os.getpid():
+        n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        try:
+            with open('/sys/fs/cgroup/cpu.max') as f:
+                quota, period = f.read().split()
+            if quota != 'max':
+                n = max(1, min(n, int(int(quota) / int(period))))
+        except Exception:
+            pass
+        _allowance = (os.getpid(), n)          # (read once per process: this sits on the path of every analysis)
+    n = _allowance[1]
     # several ranks on one node (one process per GPU) share that allowance: every rank's helper threads -- the draw,
     # the content hash, the cluster order, the column copies -- take their share, not all of it (eight ranks x four
     # draw threads on a 16-CPU allowance made the draw, identical on every rank, the longest item of a rank's step)

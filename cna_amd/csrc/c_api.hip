@@ -1593,15 +1593,17 @@ int cna_select_standardized_fused(cna_ctx* c, const int64_t* keep_idx, int64_t n
   double edges[512];
   int T = 0;
   if (null_P >= 1 && T_out && thr_out && !c->null_pending) T = cna_reference_thresholds(m, 512, thr_out, edges);
-  // the coefficient column first: its kernels and copy are short, and the host writes it into the caller's
-  // frame while the Gram kernel runs (behind the Gram kernel it would arrive when the host should already
-  // be in LAPACK)
+  // The Gram kernels first (round 6): every call issued here costs the host ~5 us and the device has nothing to do
+  // until the first kernel arrives -- 0.18 ms between the selection pass and the Gram kernel at 200 000 cells when the
+  // coefficient column's five calls went first (rocprofv3 --kernel-trace, profiles/r06_timeline_C2_*.txt).  Whoever
+  // consumes the Gram matrix (the eigenpairs) is the longer chain; the coefficient column (short kernels, a copy on
+  // its own stream) follows and still reaches the host under the local null.
+  if (!gram_done) CNA_TRY(cna_gram_launch(c));
+  if (gram_queued) *gram_queued = 1;
   if (T >= 1 && coef_queued && !((c->nranks > 1 || comm_active(c)) && !c->local_view)) {
     CNA_TRY(cna_percell_coef_launch(c));
     *coef_queued = 1;
   }
-  if (!gram_done) CNA_TRY(cna_gram_launch(c));
-  if (gram_queued) *gram_queued = 1;
   if (T < 1) return 0;
   CNA_TRY(null_local_prepare(c, null_P, edges, T, 0, thr_out));
   *T_out = T;

@@ -509,3 +509,14 @@ int cna_host_draw_wait(void) {
   pthread_mutex_unlock(&g_draw_mu);
   return rc;
 }
+
+/* as cna_host_draw_wait, but the request stays collectable: for a library-side consumer of the table (cna_assoc_finish)
+ * whose caller still collects the draw itself (it writes the generator state back) */
+int cna_host_draw_join(void) {
+  pthread_mutex_lock(&g_draw_mu);
+  if (g_draw_state == 0) { pthread_mutex_unlock(&g_draw_mu); return -2; }
+  while (!(g_draw_state == 3 && (g_then_state == 0 || g_then_state == 3))) pthread_cond_wait(&g_draw_cv, &g_draw_mu);
+  const int rc = g_draw_rc;
+  pthread_mutex_unlock(&g_draw_mu);
+  return rc;
+}

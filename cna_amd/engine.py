@@ -55,6 +55,9 @@ class Engine(_order.CellOrder):
         self._host_threads = _order.usable_cpus(8)
         self._colsum_w = None
         self._codes_token = self._codes_graph = None
+        self._assoc_out = None
+        self._zc_cols = 0
+        self._fused = None
         self.n = 0            # cells in the caller's view: all of them, or (view_local) this rank's block
         self.n_global = 0
         self.row0 = 0
@@ -251,6 +254,15 @@ class Engine(_order.CellOrder):
                 staged = self._take_reorder(A)
                 if staged is None:
                     return False
+        if (staged is None and defer == 'caller' and not pinned and self.nranks == 1 and not self._has_comm
+                and self._graph_key is not None and self._graph_ref is not None and self._graph_ref() is A
+                and getattr(self, '_reorder', None) is None):
+            # the caller has ALL of the matrix hashed while the device works (take_pending_graph: inside
+            # cna_assoc_finish): the probes of the quick key (six 64 KB windows: 0.1 ms) would tell it nothing more
+            ident = self._ident(A)
+            if self._graph_key[:len(ident)] == ident and self._graph_key[-1] == shard_key:
+                self._pending_check = ('caller', A)
+                return False
         quick = self._quick_key(A) + (shard_key,)
         full = None
         if staged is None and self._graph_key == quick and self._graph_ref is not None and self._graph_ref() is A:
@@ -258,6 +270,11 @@ class Engine(_order.CellOrder):
             if staged is not None:
                 pass
             elif pinned:
+                return False
+            elif defer == 'caller' and self.nranks == 1 and not self._has_comm:
+                # the caller has the three arrays hashed itself (take_pending_graph: inside cna_assoc_finish, while the
+                # device works); confirm_graph() still settles it if the caller never takes it
+                self._pending_check = ('caller', A)
                 return False
             elif defer and self.nranks == 1 and not self._has_comm:
                 self._pending_check = _checker().submit(self._full_hash, A)
@@ -360,12 +377,31 @@ class Engine(_order.CellOrder):
         the caller's graph (or nothing was deferred).  False: the matrix was edited in place since it went
         to the device; the resident copy is dropped and the caller has to redo its work."""
         fut, self._pending_check = self._pending_check, None
-        if fut is None or fut.result() == self._graph_hash:
+        if fut is None:
             return True
+        if isinstance(fut, tuple):
+            if self._full_hash(fut[1]) == self._graph_hash:
+                return True
+        elif fut.result() == self._graph_hash:
+            return True
+        self.drop_graph()
+        return False
+
+    def take_pending_graph(self):
+        """The deferred check of ensure_graph(defer='caller') as [(array, 64-bit hash its content must have)] x 3 for a
+        caller that has them verified elsewhere (and calls drop_graph() when that fails); else None."""
+        fut = self._pending_check
+        if not isinstance(fut, tuple) or self._graph_hash is None:
+            return None
+        self._pending_check = None
+        A = fut[1]
+        return [(np.ascontiguousarray(arr), h) for arr, h in zip((A.data, A.indices, A.indptr), self._graph_hash)]
+
+    def drop_graph(self):
+        """Forget the resident graph (its content is no longer what the caller holds): the next call uploads afresh."""
         self._graph_key = None
         self._graph_hash = None
         self._nam_sig = None
-        return False
 
     def colsums(self, self_weight=1):
         w = float(self_weight)
@@ -797,6 +833,101 @@ class Engine(_order.CellOrder):
             self.global_test_fetch()
         except _ffi.CnaHipError:
             pass
+
+    # ---------------------------------------------------------------- the fixed-shape analysis in two calls
+    def assoc_begin(self, nsteps, y_hint=None):
+        """Queue the walk of a fixed-shape analysis (cna_assoc_begin): `nsteps` steps (0: the NAM on the device is
+        kept), with `y_hint` the last step also does the selection pass (nam_select_hint).  Returns at once."""
+        yv = None if y_hint is None else _f64(y_hint)
+        check(self.lib.cna_assoc_begin(self.h, int(nsteps), ptr(yv), 0 if yv is None else len(yv)), 'cna_assoc_begin')
+        if yv is not None and nsteps >= 2:
+            self.x_epoch += 1             # (that step overwrites the working matrix: see nam_select_hint)
+
+    def assoc_finish(self, y, M, ks, Nnull, table, colmap=None, Cmat=None, W=None, draw_pending=False, conditioned=False,
+                     coef_dst=None, fdr_dst=None, coef_first=False, copy_threads=1, native_eig=True, resid_tol=1e-12,
+                     gap_tol=1e-6, run_steps=None, y_hint=None, verify=(), verify_threads=1):
+        """Selection (+ projector) -> Gram -> eigenpairs -> F-tests, conditioned phenotypes -> local null -> FDR table ->
+        per-cell columns, in ONE blocking library call (cna_assoc_finish; include/cna_hip.h).  Returns a dict: status,
+        n_zero, maxabs, thr, tail_sums, ranks, num_detected, fdr, runmin, G, U (None unless accepted), minp / r2 / kidx
+        (None when status is ASSOC_NEED_PCS), coef / fdr (views of pinned buffers, or the caller's own storage).
+        run_steps = nsteps: the walk is queued by the same call (cna_assoc_run = assoc_begin(nsteps, y_hint) + this)."""
+        a = _ffi.AssocArgs()
+        keep = []                                     # arrays the struct points to
+
+        def P(arr):
+            keep.append(arr)
+            return arr.ctypes.data
+        yv, Mv = _f64(y), _f64(M)
+        N = len(yv)
+        ksv = np.ascontiguousarray(ks, dtype=np.int32)
+        kmax = int(ksv.max())
+        P1 = int(Nnull) + 1
+        if Mv.shape != (N, N) or table.shape != (N, P1) or table.dtype != np.float64 or not table.flags.c_contiguous:
+            raise ValueError('assoc_finish: M must be N x N and table a C-contiguous float64 N x (Nnull + 1) matrix')
+        a.colmap = None if colmap is None else P(np.ascontiguousarray(colmap, dtype=np.int32))
+        a.n_sel, a.y, a.M = N, P(yv), P(Mv)
+        if Cmat is not None and W is not None and np.shape(Cmat)[1] > 0:
+            Cv, Wv = _f64(Cmat), _f64(W)
+            if Cv.shape[0] != N or Wv.shape != (Cv.shape[1], N):
+                raise ValueError('assoc_finish: C must be N x r and W r x N')
+            a.r, a.resid_C, a.resid_W = Cv.shape[1], P(Cv), P(Wv)
+        a.ks, a.K, a.Nnull = P(ksv), len(ksv), int(Nnull)
+        a.table = P(table)
+        a.draw_pending, a.conditioned = int(bool(draw_pending)), int(bool(conditioned))
+        a.use_native_eig, a.coef_first = int(bool(native_eig)), int(bool(coef_first))
+        a.resid_tol, a.gap_tol = float(resid_tol), float(gap_tol)
+        if coef_dst is not None and fdr_dst is not None:
+            a.coef_dst, a.fdr_dst, a.n_dst = coef_dst.ctypes.data, fdr_dst.ctypes.data, len(coef_dst)
+            keep += [coef_dst, fdr_dst]
+        a.copy_threads = int(copy_threads)
+        # verify: [(array, 64-bit content hash it must still have)], checked by the library while the device works
+        a.n_verify = len(verify)
+        for i, (arr, hv) in enumerate(verify):
+            a.verify_ptr[i], a.verify_bytes[i], a.verify_hash[i] = arr.ctypes.data, arr.nbytes, int(hv)
+            keep.append(arr)
+        a.verify_threads = int(verify_threads)
+        G, U = np.empty((N, N)), np.empty((N, max(kmax, 1)))
+        minp, r2, kidx = np.empty(P1), np.empty(P1), np.empty(P1, dtype=np.int32)
+        a.G, a.U, a.minp, a.r2, a.kidx = P(G), P(U), P(minp), P(r2), P(kidx)
+        if self._assoc_out is None:
+            o = _ffi.AssocOut()
+            raw = np.frombuffer(o, dtype=np.uint8)    # numpy views of the struct's arrays (a ctypes slice makes a list)
+            views = {f: raw[getattr(_ffi.AssocOut, f).offset:][:8 * _ffi.ASSOC_MAXT].view(np.float64 if f in ('thr', 'fdr', 'runmin') else np.int64)
+                     for f in ('thr', 'fdr', 'runmin', 'tail_sums', 'ranks', 'num_detected')}
+            self._assoc_out = (o, views)
+        o, ov = self._assoc_out
+        # bookkeeping of what the call replaces on the device, before it can fail half-way
+        self._fused = None
+        self._selection(None)
+        self.x_epoch += 1
+        self._gram_cols = N
+        self._zc_cols = P1
+        if run_steps is None:
+            check(self.lib.cna_assoc_finish(self.h, C.byref(a), C.byref(o)), 'cna_assoc_finish')
+        else:
+            hv = None if y_hint is None else _f64(y_hint)
+            check(self.lib.cna_assoc_run(self.h, int(run_steps), ptr(hv), 0 if hv is None else len(hv), C.byref(a), C.byref(o)),
+                  'cna_assoc_run')
+        T = int(o.T)
+        self._null_T, self._null_obs = T, True
+        status = o.status
+        out = dict(status=status, n_zero=o.n_zero, maxabs=o.max_abs, T=T, G=G, null_fused=o.null_fused,
+                   U=U if o.eig_accepted else None, coef_in_dst=o.coef_in_dst, fdr_in_dst=o.fdr_in_dst, t_ms=o.t_ms)
+        if status in (_ffi.ASSOC_GENERAL, _ffi.ASSOC_STALE):
+            return out
+        # (views of the call's own output block, valid until the next assoc_finish: a caller that keeps them copies them)
+        for f, v in ov.items():
+            out[f] = v[:T]
+        if status == _ffi.ASSOC_DONE:
+            out['minp'], out['r2'], out['kidx'] = minp, r2, kidx
+        out['coef'] = coef_dst if o.coef_in_dst else (self._pinned_view(C.c_void_p(o.coef_ptr)) if o.coef_ptr else None)
+        out['fdr_col'] = fdr_dst if o.fdr_in_dst else (self._pinned_view(C.c_void_p(o.fdr_ptr)) if o.fdr_ptr else None)
+        return out
+
+    @property
+    def last_assoc_t_ms(self):
+        """Stage times of the last cna_assoc_finish (ms from its entry; include/cna_hip.h: cna_assoc_out.t_ms), or None."""
+        return None if self._assoc_out is None else list(self._assoc_out[0].t_ms)
 
     def obs_counts(self, edges, thr):
         edges, thr = _f64(edges), _f64(thr)

@@ -25,6 +25,7 @@ from ._nam import (LazyNamespace, _nam_device, _qc_device, _resid_plan, _resid_r
                    shard_of, global_samples, get_connectivity,
                    _small_svd, _defer_pcs, host_blas_threads, _top_pcs, GramPCs)
 from . import _nam as _nam_mod
+from . import _fast
 from ._out import select_output
 from ._stats import conditional_permutation, grouplevel_permutation, default_ks, minp_stats, native_draw_start
 
@@ -650,6 +651,12 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
     Writes ``data.obs[key_added]`` and ``data.obs[key_added + '_fdr']``."""
     with host_blas_threads(1):
         eng = engine or get_engine()
+        # the fixed-shape call (nsteps given, one batch, a seed, ...) in two library calls (tools/_fast.py); everything
+        # else -- and whatever that path meets and does not handle -- goes on below as if it did not exist
+        out = _fast.association(data, y, sid_name, batches, covs, donorids, ks, key_added, max_frac_pcs, nsteps, show_progress,
+                                allow_low_sample_size, return_full, ridges, eng, kwargs)
+        if out is not _fast.NOT_TAKEN:
+            return out
         # The resident graph is validated by a hash of its full content (engine.ensure_graph).  On one GPU
         # that hash runs on a helper thread while the kernels are already working on the resident copy
         # (optimistic); before anything leaves this call -- the first data.obs write, the return value --

@@ -293,10 +293,11 @@ def _content_hash_threaded(arr):
     """Large id columns (millions of cells): the library's threaded 64-bit content hash
     (csrc/host_graph.c) -- 16 MB in ~0.1 ms on 8 threads, where one thread of xxh3 takes 0.4 ms of a
     call whose whole GPU part is 35 ms; small columns stay on xxh3 (no thread start-up)."""
-    if arr.nbytes < (4 << 20):
-        return _content_hash(memoryview(arr).cast('B'))
+    # (the library's hash at every size -- one thread below 4 MB -- so that the library itself can repeat the check:
+    # cna_assoc_finish's verify list, tools/_fast.py)
     from .._order import usable_cpus
-    return int(_ffi.load().cna_host_hash64(_ffi.ptr(arr), arr.nbytes, min(usable_cpus(8), max(1, arr.nbytes >> 21))))
+    threads = 1 if arr.nbytes < (4 << 20) else min(usable_cpus(8), max(1, arr.nbytes >> 21))
+    return int(_ffi.load().cna_host_hash64(_ffi.ptr(arr), arr.nbytes, threads))
 
 
 def _fingerprint(arr):
@@ -338,6 +339,11 @@ def sample_codes_cached(col, defer=False):
     hit = _codes_cache.get('last')
     where = (arr.__array_interface__['data'][0], arr.shape, arr.strides, arr.dtype.str)
     if defer and hit is not None and hit[0][:4] == where and hit[0][5:] == (extra,) and not isinstance(col.dtype, pd.CategoricalDtype):
+        if defer == 'caller':
+            # the caller has the content hashed itself (take_pending_codes: the library does it inside cna_assoc_finish,
+            # while the device works); confirm_codes() still settles it if the caller never takes it
+            _codes_pending = ('caller', arr, hit[0][4])
+            return hit[1]
         from ..engine import _checker
         _codes_pending = (_checker().submit(_content_hash_threaded, arr), hit[0][4])
         return hit[1]
@@ -356,10 +362,30 @@ def confirm_codes():
     column's content (or nothing was deferred).  False: the ids were edited in place; the memo is dropped."""
     global _codes_pending
     pend, _codes_pending = _codes_pending, None
-    if pend is None or pend[0].result() == pend[1]:
+    if pend is None:
+        return True
+    if pend[0] == 'caller':
+        if _content_hash_threaded(pend[1]) == pend[2]:
+            return True
+    elif pend[0].result() == pend[1]:
         return True
     _codes_cache.pop('last', None)
     return False
+
+
+def take_pending_codes():
+    """The deferred check of sample_codes_cached(defer='caller') as (array, the 64-bit hash its content must have), for a
+    caller that has it verified elsewhere (and drops the memo itself -- drop_codes_memo -- when that fails); else None."""
+    global _codes_pending
+    pend = _codes_pending
+    if pend is None or pend[0] != 'caller':
+        return None
+    _codes_pending = None
+    return pend[1], pend[2]
+
+
+def drop_codes_memo():
+    _codes_cache.pop('last', None)
 
 
 def _column_r2(a, b):
@@ -446,6 +472,31 @@ def diffuse(data, s, nsteps, show_progress=False, self_weight=1, engine=None):
 
 
 # --------------------------------------------------------------------------- NAM on device
+_NO_NAM = object()
+
+
+def _walk_start(engine, codes, labels, counts, token, nsteps, maxnsteps, self_weight, show_progress):
+    """What precedes the first step of a walk on a prepared graph (_nam.py:51-54): the sample codes and sizes on the
+    device -- unless the device still holds the NAM of exactly these inputs.  Returns (signature of the inputs or
+    None, steps of the held NAM or _NO_NAM: the caller walks)."""
+    # (cells per sample, aligned with labels: _qc_device leaves samples without cells -- NaN rows of the NAM -- out of
+    # the batch means, as pandas' mean does in the reference)
+    engine._sample_counts = (np.asarray(counts), len(labels))
+    # NAM cache (SURVEY.md 8f-1): the NAM is a function of the graph, the per-cell sample ids, the
+    # step rule and the self weight only -- not of the phenotype.  When the device still holds the
+    # NAM of exactly these inputs (same resident graph, same id fingerprint, no walk started since),
+    # a further analysis on the same dataset skips the diffusion.  Off while progress is printed
+    # (the per-step diagnostics are part of the output) and when engine.reuse_nam is False.
+    sig = None
+    if token is not None and not show_progress and getattr(engine, 'reuse_nam', False):
+        sig = (token, nsteps, maxnsteps, float(self_weight))
+        held = getattr(engine, '_nam_sig', None)
+        if held is not None and held[0] == sig and held[1] == engine.nam_epoch:
+            return sig, held[2]
+    engine.set_samples(codes, len(labels), counts.astype(np.float64), token=token)
+    return sig, _NO_NAM
+
+
 def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1, show_progress=False,
                 codes_labels=None, defer_last=False):
     """Reference ``_nam`` (_nam.py:44-76) with the state resident on the GPU.  On return the
@@ -471,23 +522,10 @@ def _nam_device(engine, data, sid_name, nsteps=None, maxnsteps=15, self_weight=1
         if codes_labels is None and engine.view_local:
             codes, labels, counts, token = global_samples(engine, codes, labels, counts, None)
     N = len(labels)
-    # (cells per sample, aligned with labels: _qc_device leaves samples without cells -- NaN rows of the NAM -- out of
-    # the batch means, as pandas' mean does in the reference)
-    engine._sample_counts = (np.asarray(counts), len(labels))
-    # NAM cache: the NAM is a function of the graph, the per-cell sample ids, the
-    # step rule and the self weight only -- not of the phenotype.  When the device still holds the
-    # NAM of exactly these inputs (same resident graph, same id fingerprint, no walk started since),
-    # a further analysis on the same dataset skips the diffusion.  Off while progress is printed
-    # (the per-step diagnostics are part of the output) and when engine.reuse_nam is False.
-    sig = None
-    if token is not None and not show_progress and getattr(engine, 'reuse_nam', False):
-        sig = (token, nsteps, maxnsteps, float(self_weight))
-        held = getattr(engine, '_nam_sig', None)
-        if held is not None and held[0] == sig and held[1] == engine.nam_epoch:
-            walk_queued()
-            return labels, held[2]
-    C = counts.astype(np.float64)
-    engine.set_samples(codes, N, C, token=token)
+    sig, held_steps = _walk_start(engine, codes, labels, counts, token, nsteps, maxnsteps, self_weight, show_progress)
+    if held_steps is not _NO_NAM:
+        walk_queued()
+        return labels, held_steps
     n = engine.n
 
     need_kurt = (nsteps is None) or show_progress

@@ -187,14 +187,14 @@ class NativeDraw:
             pass
 
 
-def native_draw_start(B, Y, num, seed, threads=None):
+def native_draw_start(B, Y, num, seed, threads=None, single_level=False):
     """Start conditional_permutation(B, Y, num) of a generator seeded with `seed` (np.random.seed(seed),
     _association.py:15-16) on the library's host thread; None when the shape is not covered (the caller then draws as
     before).  numpy's global generator is not touched before wait(): the worker runs on a copy of the state a PRIVATE
     RandomState has after seed(seed) -- so a draw may be started before the inputs are validated and dropped again
     (NativeDraw.abandon) without a trace."""
     import ctypes as C
-    if seed is None or num < 2 or num % 2 or len(Y) < 1 or len(B) != len(Y):
+    if seed is None or num < 2 or num % 2 or len(Y) < 1 or (not single_level and len(B) != len(Y)):
         return None
     Y = np.asarray(Y)
     if Y.dtype != np.float64:
@@ -209,8 +209,8 @@ def native_draw_start(B, Y, num, seed, threads=None):
         lib.cna_host_draw_start
     except Exception:
         return None
-    levels = np.unique(B)
-    if len(levels) == 1 and bool((np.asarray(B) == levels[0]).all()):
+    levels = None if single_level else np.unique(B)       # (single_level: the caller knows B is one level, e.g. batches=None)
+    if single_level or (len(levels) == 1 and bool((np.asarray(B) == levels[0]).all())):
         members = np.arange(len(Y), dtype=np.int64)
         off = np.array([0, len(Y)], dtype=np.int64)
     else:

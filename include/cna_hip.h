@@ -364,6 +364,95 @@ int  cna_percell_coef_wait(cna_ctx* ctx, double** coef_ptr);
 int  cna_percell_fdr_copy_early(cna_ctx* ctx, double* dst, int64_t n, int nthreads, int* done);
 int  cna_percell_fdr_copied_early(cna_ctx* ctx, int* yes);
 
+/* ---- the fixed-shape analysis in two library calls (round 6) ----------------------------------------------------------
+ * cna.tl.association (_association.py:193-242) is ONE straight-line function; for the call shape that needs no decision
+ * of the host between its stages -- nsteps given, one batch, covariates allowed, a seed, the local test on -- the stages
+ * are queued here without the interpreter in between.  The caller validates the sample-level inputs (check_inputs,
+ * _association.py:131-173), uploads graph and sample codes as usual (cna_graph_upload, cna_colsums, cna_set_samples /
+ * cna_restart_nam), starts the permutation draw (cna_host_draw_start) and then calls
+ *
+ *   cna_assoc_begin   the walk of _nam.py:57-70 with a fixed step count: cna_nam_select_hint(y_hint) when given, then
+ *                     cna_nam_steps(nsteps); nsteps = 0 keeps the NAM the device holds (the caller's NAM cache).
+ *                     Returns once the kernels are queued: the caller builds the projector of _nam.py:128-135 and the
+ *                     storage of the two data.obs columns meanwhile.
+ *   cna_assoc_finish  compute_nam_and_reindex's selection (_association.py:175-191) + _resid_nam (_nam.py:118-177, no
+ *                     batches) as cna_select_standardized_fused; the Gram matrix, its leading eigenpairs and the global
+ *                     F-tests (_nam.py:105, _association.py:35-88) as cna_gram_pcs_tests + cna_global_test_fetch; the
+ *                     conditioned phenotypes (cna_host_draw_then_condition, or cna_condition_phenotypes once the draw is
+ *                     there); the local null (_association.py:91-120) as cna_null_local_launch / _fetch; the FDR table
+ *                     (_stats.py:79-80, _association.py:105-108); and the two per-cell columns (_association.py:230-237),
+ *                     copied into the caller's storage (coef_dst / fdr_dst) as they arrive.  Blocks until all of it is
+ *                     done.  Every stage is the entry point named, in the order the Python host issues them: same bits.
+ *
+ * status (cna_assoc_out): CNA_ASSOC_DONE; CNA_ASSOC_GENERAL -- a selected cell has zero variance, max|ncorrs| is not
+ * finite or the thresholds are out of range: nothing beyond the selection pass was issued, coef_dst / fdr_dst hold
+ * nothing, the caller takes its general path (which reports what the reference reports); CNA_ASSOC_NEED_PCS -- the
+ * library's eigen-solver stepped aside (cna_gram_pcs_tests: *accepted = 0): everything but the global test is done, G is
+ * valid, the caller supplies eigenvectors (LAPACK) through cna_global_test_launch / _fetch; CNA_ASSOC_STALE -- an input
+ * listed in `verify_*` no longer hashes to what the device copy was made from: as CNA_ASSOC_GENERAL, after a fresh upload.
+ * cna_assoc_run = cna_assoc_begin + cna_assoc_finish for callers with nothing to do in between. */
+#define CNA_ASSOC_DONE      0
+#define CNA_ASSOC_GENERAL   1
+#define CNA_ASSOC_NEED_PCS  2
+#define CNA_ASSOC_STALE     3
+#define CNA_ASSOC_MAXT      512
+typedef struct cna_assoc_args {
+  const int32_t* colmap;     /* NAM column of every analysed sample (NAM.reindex(y.index)[filter], _association.py:178-181); NULL: all, in place */
+  int32_t n_sel;             /* analysed samples N */
+  int32_t r;                 /* conditioning columns (covariates): M = I - C.W, _nam.py:128-135; 0: M = I */
+  const double* y;           /* standardised phenotype (numpy ddof=0, _association.py:22), N */
+  const double* M;           /* projector, N x N row-major */
+  const double* resid_C;     /* N x r standardised covariates (NULL when r = 0) */
+  const double* resid_W;     /* r x N: (C^T C)^-1 C^T */
+  const int32_t* ks;         /* PC counts of the global test (_association.py:25-28) */
+  int32_t K;
+  int32_t Nnull;
+  const double* table;       /* N x (Nnull + 1) row-major: [y | permuted phenotypes] (_association.py:80-83) */
+  int32_t draw_pending;      /* 1: cna_host_draw_start is still filling `table` (this call joins it, the caller collects it) */
+  int32_t conditioned;       /* 1: cna_condition_phenotypes(M, table, N, Nnull + 1) has already returned */
+  int32_t use_native_eig;    /* cna_gram_pcs_tests' arguments */
+  int32_t coef_first;        /* (unused since the eigenpairs run on a thread of their own: the coefficient column never waits for them) */
+  double resid_tol, gap_tol;
+  double* coef_dst;          /* storage of data.obs[key] / data.obs[key + '_fdr'] (n_dst doubles each), or NULL: */
+  double* fdr_dst;           /*   pinned pointers are returned in cna_assoc_out instead */
+  int64_t n_dst;
+  int32_t copy_threads;
+  int32_t n_verify;          /* content checks of the inputs the device copy was made from (the reference re-reads the graph and
+                                the ids on every call, _nam.py:25-28,51): cna_host_hash64 of verify_ptr[i] (verify_bytes[i] bytes)
+                                must equal verify_hash[i]; taken on a thread of this call while the device works.  A mismatch:
+                                status CNA_ASSOC_STALE, nothing is written to coef_dst / fdr_dst */
+  const void* verify_ptr[4];
+  int64_t verify_bytes[4];
+  uint64_t verify_hash[4];
+  int32_t verify_threads;
+  int32_t reserved;
+  double* G;                 /* out: N x N Gram matrix */
+  double* U;                 /* out: N x max(ks) leading eigenvectors (valid when eig_accepted) */
+  double* minp;              /* out: Nnull + 1 (column 0: the observed phenotype) */
+  double* r2;
+  int32_t* kidx;
+} cna_assoc_args;
+typedef struct cna_assoc_out {
+  int32_t status, T, eig_accepted, null_fused;
+  int32_t coef_in_dst, fdr_in_dst;
+  int64_t n_zero;
+  double max_abs;
+  double* coef_ptr;          /* pinned, valid until the next per-cell call on the context (when not copied to coef_dst) */
+  double* fdr_ptr;
+  double t_ms[12];           /* when the stages of this call were reached, ms from its entry: [0] phenotypes posted, [1] selection
+                                pass back (the walk is over), [2] local null queued, [3] inputs verified, [4] coefficient column
+                                out, [5] local null over + FDR column out, [6] null results, [7] eigenpairs + F-tests joined,
+                                [8] exit; on the eigenpairs thread: [10] eigenpairs done and F-tests queued, [11] F-tests fetched */
+  double thr[CNA_ASSOC_MAXT], fdr[CNA_ASSOC_MAXT], runmin[CNA_ASSOC_MAXT];
+  int64_t tail_sums[CNA_ASSOC_MAXT], ranks[CNA_ASSOC_MAXT], num_detected[CNA_ASSOC_MAXT];
+} cna_assoc_out;
+int  cna_assoc_begin(cna_ctx* ctx, int nsteps, const double* y_hint, int n_hint);
+int  cna_assoc_finish(cna_ctx* ctx, const cna_assoc_args* args, cna_assoc_out* out);
+int  cna_assoc_run(cna_ctx* ctx, int nsteps, const double* y_hint, int n_hint, const cna_assoc_args* args, cna_assoc_out* out);
+/* blocks until the request of cna_host_draw_start (and its follow-up) is done WITHOUT collecting it: the caller's
+ * cna_host_draw_wait still returns its status (0 / -1 as cna_host_draw_wait; -2: nothing was started) */
+int  cna_host_draw_join(void);
+
 /* ---- device -> host for the lazily materialised result fields (a20) -------------------- */
 int  cna_matrix_shape(cna_ctx* ctx, int which, int64_t* n_rows_local, int* n_cols);
 /* transposed!=0 writes samples x cells (the reference's orientation), else cells x samples */

@@ -4,7 +4,7 @@ against (a) the REFERENCE's own results on the same inputs (tests/golden/d02_con
 import numpy as np
 import pytest
 
-from helpers import load_config2_case, assert_matches_config2, relerr
+from helpers import load_config2_case, assert_matches_config2, relerr, fdr_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +57,7 @@ def test_config2_matches_the_f64_oracle_at_full_size(case, result):
     assert relerr(res.ncorrs.values, ref['ncorrs']) < 1e-10
     assert relerr(res.namresid_svs.values, ref['svs']) < 1e-10
     assert relerr(res.nullminps, ref['nullminps']) < 1e-8
-    T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
+    T = fdr_rows(res.fdrs, ref['fdrs'], ref['ncorrs'])
     assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T])
     np.testing.assert_allclose(res.fdrs.fdr.values[:T], ref['fdrs']['fdr'][:T], rtol=1e-9, atol=1e-13)
     np.testing.assert_allclose(case['data'].obs['coef'].values, ref['obs_coef'], rtol=0, atol=1e-10 * np.abs(ref['obs_coef']).max())

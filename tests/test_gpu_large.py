@@ -24,7 +24,7 @@ import pandas as pd
 import pytest
 import scipy.sparse as sp
 
-from helpers import relerr
+from helpers import relerr, fdr_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -273,7 +273,7 @@ def test_reduced_config5_vs_oracle(eng, orc):
     assert relerr(res.nam.values.T, ref['nam']) < 1e-13
     assert relerr(res.namresid.values.T, ref['namresid']) < 1e-9
     assert relerr(res.ncorrs.values, ref['ncorrs']) < 1e-9
-    T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
+    T = fdr_rows(res.fdrs, ref['fdrs'], ref['ncorrs'])
     assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T])
     np.testing.assert_allclose(res.fdrs.fdr.values[:T], ref['fdrs']['fdr'][:T], rtol=1e-8, atol=1e-13)
     np.testing.assert_allclose(data.obs['coef_fdr'].values, ref['obs_coef_fdr'], rtol=1e-8, atol=1e-13)

@@ -325,6 +325,8 @@ def _shard_worker(rank, world, seg, name, q):
         y2[:] = np.random.RandomState(5).randn(len(y2))
         res2 = cna.tl.association(part, y2, case['sid_name'], batches=case['batches'], covs=case['covs'],
                                   donorids=case['donorids'], return_full=True, engine=eng, **case['call'])
+        from cna_amd.tools import _fast
+        out['two_call_path'] = dict(_fast.stats)     # (the second phenotype of a shaped call goes through cna_assoc_begin / _finish)
         out['p2'], out['ncorrs2'] = res2.p, res2.ncorrs.values
         s0 = np.random.RandomState(1).rand(case['data'].obsp['connectivities'].shape[0], 3)
         r0 = part.uns['cna_shard']['row0']
@@ -430,6 +432,8 @@ def test_sharded_inputs_on_one_gpu(name, world):
     a = parts[0]
     for r, g in enumerate(parts):
         assert g['view'] and g['n_obs'] == max(0, min(rpr, n - r * rpr)) == len(g['kept']) == len(g['coef'])
+        # nsteps given, one batch, a seed: the second call (resident graph) is the two-call path on every rank
+        assert g['two_call_path']['taken'] == (1 if name in ('c01_plain_f32', 'c11_string_ids_null_y') else 0), g['two_call_path']
         assert g['p'] == a['p'] and g['k'] == a['k'] and g['p2'] == a['p2']
         for key in ('fdr', 'num', 'varexp'):
             np.testing.assert_array_equal(g[key], a[key])

@@ -11,7 +11,7 @@ import pandas as pd
 import pytest
 import scipy.sparse as sp
 
-from helpers import messy_names, golden_names, load_case, run_product, assert_matches_golden, relerr
+from helpers import messy_names, golden_names, load_case, run_product, assert_matches_golden, relerr, fdr_rows
 
 pytestmark = pytest.mark.gpu
 
@@ -444,7 +444,7 @@ def test_association_matches_f64_oracle_tightly(eng, orc, name):
     assert relerr(res.ncorrs.values, ref['ncorrs']) < 1e-10
     assert relerr(res.namresid_svs.values, ref['svs']) < 1e-10
     assert relerr(res.nullminps, ref['nullminps']) < 1e-8
-    T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
+    T = fdr_rows(res.fdrs, ref['fdrs'], ref['ncorrs'])
     assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T])
     np.testing.assert_allclose(res.fdrs.fdr.values[:T], ref['fdrs']['fdr'][:T], rtol=1e-9, atol=1e-13)
 
@@ -619,7 +619,7 @@ def test_association_wide_sample_axis_vs_oracle(eng, orc, n, N, extra):
     assert relerr(res.ncorrs.values, ref['ncorrs']) < 1e-9
     assert relerr(res.namresid_svs.values, ref['svs']) < 1e-9
     np.testing.assert_allclose(res.nullminps, ref['nullminps'], rtol=1e-7)
-    T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
+    T = fdr_rows(res.fdrs, ref['fdrs'], ref['ncorrs'])
     assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T])
     np.testing.assert_allclose(res.fdrs.fdr.values[:T], ref['fdrs']['fdr'][:T], rtol=1e-8, atol=1e-13)
     np.testing.assert_allclose(data.obs['coef_fdr'].values, ref['obs_coef_fdr'], rtol=1e-8, atol=1e-13)
@@ -1640,7 +1640,7 @@ def test_random_configurations_vs_oracle(eng, orc, seed):
     assert relerr(res.ncorrs.values, ref['ncorrs']) < 1e-8
     np.testing.assert_allclose(res.nullminps, ref['nullminps'], rtol=1e-6)
     if ref.get('fdrs') is not None:
-        T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
+        T = fdr_rows(res.fdrs, ref['fdrs'], ref['ncorrs'])
         assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T]), (cfg, call)
         np.testing.assert_allclose(res.fdrs.fdr.values[:T], ref['fdrs']['fdr'][:T], rtol=1e-7, atol=1e-13)
 
@@ -1913,7 +1913,7 @@ def test_zero_variance_cells_with_many_samples(eng, orc):
     assert int(res.k) == ref['k'] and res.p == ref['p']
     assert relerr(res.ncorrs.values, ref['ncorrs']) < 1e-10
     assert relerr(res.namresid_svs.values, ref['svs']) < 1e-10
-    T = min(len(res.fdrs), len(ref['fdrs']['fdr']))
+    T = fdr_rows(res.fdrs, ref['fdrs'], ref['ncorrs'])
     assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T])
     # ... and the very next analysis (no zero variance)
     res2 = cna.tl.association(data, meta['y'], 'id', return_full=True, engine=eng, **kw)

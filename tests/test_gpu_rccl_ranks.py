@@ -53,6 +53,8 @@ def _worker(rank, world, port, name, partition, overlap, q):
         y2[:] = np.random.RandomState(5).randn(len(y2))
         res2 = cna.tl.association(part, y2, case['sid_name'], batches=case['batches'], covs=case['covs'],
                                   donorids=case['donorids'], return_full=True, **case['call'])
+        from cna_amd.tools import _fast
+        out['two_call_path'] = dict(_fast.stats)     # (the second phenotype of a shaped call goes through cna_assoc_begin / _finish)
         out['p2'], out['ncorrs2'], out['cells2'] = res2.p, res2.ncorrs.values, list(res2.ncorrs.index)
         s0 = np.random.RandomState(1).rand(case['data'].obsp['connectivities'].shape[0], 3)
         order = part.uns['cna_shard'].get('order')
@@ -156,6 +158,8 @@ def test_rccl_ranks_sharded_inputs(name, world, partition, overlap):
     for r in range(world):
         g = got[r]
         assert g['view'] and tuple(g['comm']) == ('rccl', world)
+        # nsteps given, one batch, a seed: the second call (resident shard) goes through cna_assoc_begin / _finish on every rank
+        assert g['two_call_path']['taken'] == (1 if name in ('c01_plain_f32', 'c11_string_ids_null_y', 'c05_ks_f64') else 0), g['two_call_path']
         assert g['halo_comm'], 'the halo communicator did not pass the start-up self-test'
         assert g['halo'] is not None and g['halo'][0] > 0 and g['halo'][1] > 0
         assert g['p'] == a['p'] and g['k'] == a['k'] and g['p2'] == a['p2']

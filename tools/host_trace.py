@@ -32,8 +32,11 @@ for name in dir(Engine):
     setattr(Engine, name, mk(fn, name))
 from cna_amd.tools import _association as _A
 _A._TRACE = []
+from cna_amd.tools import _fast as _F
+_F._TRACE = _A._TRACE
 t0 = time.perf_counter(); cna.tl.association(data, meta['y'], 'id', **kw); t1 = time.perf_counter()
 marks, _A._TRACE = _A._TRACE, None
+_F._TRACE = None
 ev.sort()
 print('step %.3f ms' % ((t1 - t0) * 1e3))
 last = t0
@@ -41,4 +44,8 @@ for a, b, name, th in ev:
     print('%8.3f  +%6.3f gap  %-22s %6.3f ms  [%s]' % ((a - t0) * 1e3, (a - last) * 1e3, name, (b - a) * 1e3, th))
     if th == 'Main': last = b
 print('%8.3f  +%6.3f gap  end' % ((t1 - t0) * 1e3, (t1 - last) * 1e3))
+tm = getattr(eng, 'last_assoc_t_ms', None)
+if tm:
+    print('cna_assoc_finish stages (ms from its entry): ' + '  '.join('%s=%.3f' % (k, v) for k, v in zip(
+        ('posted', 'select_back', 'null_queued', 'verified', 'coef_out', 'null_over+fdr_out', 'null_results', 'eig_joined', 'exit', '-', 'eig_done', 'ftests_done'), tm)))
 print('marks: ' + '  '.join('%s@%.3f' % (k, (v - t0) * 1e3) for k, v in marks))
