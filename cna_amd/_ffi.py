@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('CNA_HIP_LIB') or os.path.join(_HERE, 'libcna_hip.so')   # override: kernel experiments
+LIB_PATH = os.path.join(_HERE, 'libcna_hip.so')
 
 c_ctx = C.c_void_p
 c_i64p = C.POINTER(C.c_int64)
@@ -94,12 +94,6 @@ SIGNATURES = {
     'cna_host_cluster_order': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     'cna_host_cluster_order_mt': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'cna_host_cluster_graph': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'cna_host_block_sources': (C.c_int64, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
-                                           C.c_void_p, C.c_void_p]),
-    'cna_host_walk_blocks': (C.c_int64, [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    'cna_host_walk_tiles': (C.c_int64, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'cna_host_set_threads': (None, [C.c_int]),
     'cna_host_argsort_gather': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'cna_host_draw_start': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

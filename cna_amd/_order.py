@@ -296,76 +296,6 @@ def cluster_order(A, B):
     return order
 
 
-def block_sources(indptr, indices, n_cols, B, cap):
-    """(src_ptr, src, slot) of cna_host_block_sources for the device-ordered CSR rows (indptr int64,
-    indices int32): per block of B rows the distinct columns, per edge the column's position in it."""
-    from . import _ffi
-    n_local = len(indptr) - 1
-    nblocks = (n_local + B - 1) // B
-    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
-    indices = np.ascontiguousarray(indices, dtype=np.int32)
-    src_ptr = np.zeros(nblocks + 1, dtype=np.int64)
-    src = np.empty(max(len(indices), 1), dtype=np.int32)
-    slot = np.empty(max(len(indices), 1), dtype=np.uint16)
-    tot = _ffi.load().cna_host_block_sources(n_local, int(n_cols), _ffi.ptr(indptr), _ffi.ptr(indices), int(B), int(cap),
-                                             _ffi.ptr(src_ptr), _ffi.ptr(src), _ffi.ptr(slot))
-    if tot < 0:
-        raise MemoryError('cna_host_block_sources')
-    return src_ptr, src[:tot].copy(), slot[:len(indices)]
-
-
-def walk_blocks(indptr, indices, n_cols, bmax=64, cap=960, super_rows=DEFAULT_CLUSTER):
-    """(blk_row, src_ptr, src, slot) of cna_host_walk_blocks for the device-ordered CSR rows: blocks of
-    at most `bmax` consecutive rows with at most `cap` distinct columns, the sorted columns per block and
-    the position of every edge's column in its block's list."""
-    from . import _ffi
-    n_local = len(indptr) - 1
-    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
-    indices = np.ascontiguousarray(indices, dtype=np.int32)
-    blk_row = np.empty(n_local + 1, dtype=np.int64)
-    src_ptr = np.empty(n_local + 1, dtype=np.int64)
-    src = np.empty(max(len(indices), 1), dtype=np.int32)
-    slot = np.empty(max(len(indices), 1), dtype=np.uint16)
-    nb = _ffi.load().cna_host_walk_blocks(n_local, int(n_cols), _ffi.ptr(indptr), _ffi.ptr(indices), int(bmax), int(cap),
-                                          int(super_rows), usable_cpus(16), _ffi.ptr(blk_row), _ffi.ptr(src_ptr),
-                                          _ffi.ptr(src), _ffi.ptr(slot))
-    if nb < 0:
-        raise MemoryError('cna_host_walk_blocks')
-    return blk_row[:nb + 1].copy(), src_ptr[:nb + 1].copy(), src[:int(src_ptr[nb])].copy(), slot[:len(indices)]
-
-
-def walk_tiles(indptr, indices, key, nw=16, rpw=8, S=46):
-    """Tile program of the LDS-tiled walk step (cna_host_walk_tiles) for the device-ordered CSR rows:
-    dict(blk_tile, tile_src0, tile_src, seg, rec_pos, rec_slot, rec_row), or None when the rows do not list
-    their columns in ascending caller's index (key[c] = caller's index of device column c)."""
-    from . import _ffi
-    lib = _ffi.load()
-    n_local = len(indptr) - 1
-    B = nw * rpw
-    nb = (n_local + B - 1) // B
-    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
-    indices = np.ascontiguousarray(indices, dtype=np.int32)
-    key = np.ascontiguousarray(key, dtype=np.int64)
-    blk_tile = np.zeros(nb + 1, dtype=np.int64)
-    args = (n_local, _ffi.ptr(indptr), _ffi.ptr(indices), _ffi.ptr(key), int(nw), int(rpw), int(S), usable_cpus(16))
-    nt = lib.cna_host_walk_tiles(*args, _ffi.ptr(blk_tile), None, None, None, None, None, None)
-    if nt == -2:
-        return None
-    if nt < 0:
-        raise MemoryError('cna_host_walk_tiles')
-    nnz = len(indices)
-    out = dict(blk_tile=blk_tile, tile_src0=np.zeros(nt + 1, dtype=np.int64), tile_src=np.zeros(max(nnz, 1), dtype=np.int32),
-               seg=np.zeros(nt * nw + 1, dtype=np.int64), rec_pos=np.zeros(max(nnz, 1), dtype=np.int64),
-               rec_slot=np.zeros(max(nnz, 1), dtype=np.uint16), rec_row=np.zeros(max(nnz, 1), dtype=np.uint8))
-    got = lib.cna_host_walk_tiles(*args, _ffi.ptr(out['blk_tile']), _ffi.ptr(out['tile_src0']), _ffi.ptr(out['tile_src']),
-                                  _ffi.ptr(out['seg']), _ffi.ptr(out['rec_pos']), _ffi.ptr(out['rec_slot']),
-                                  _ffi.ptr(out['rec_row']))
-    if got != nt:
-        raise RuntimeError('cna_host_walk_tiles: %d' % got)
-    out['tile_src'] = out['tile_src'][:int(out['tile_src0'][nt])].copy()
-    return out
-
-
 def inverse(perm):
     inv = np.empty(len(perm), dtype=np.int64)
     inv[perm] = np.arange(len(perm), dtype=np.int64)

@@ -220,7 +220,6 @@ int cna_ctx_create(int device, cna_ctx** out) {
     cna_set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
     return (int)e;
   }
-  if (const char* sf = getenv("CNA_STATE_F32")) c->state_f32_mode = atoi(sf) != 0;
   *out = c;
   return 0;
 }
@@ -874,8 +873,7 @@ int cna_nam_step(cna_ctx* c, int want_kurt, int may_continue, int may_stop) {
   const bool arm = !first && !may_continue && may_stop && !c->auto_stop && arm_select_byproduct(c) == 1;
   // ... and then the NAM itself is not written: the analysis reads X, and whoever does ask for the NAM (res.nam, a later
   // call with other covariates) gets it from a second run of this step (need_nam), whose input state stays where it is
-  const char* keep = getenv("CNA_WALK_SELECT_KEEP_NAM");
-  const bool skip_nam = arm && !(keep && atoi(keep) != 0);
+  const bool skip_nam = arm;
   c->byp_arm = arm;
   c->byp_skip_nam = skip_nam;
   // A step whose state other ranks need (halo exchange): the rows they asked for first, their exchange on its own

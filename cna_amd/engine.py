@@ -66,12 +66,12 @@ class Engine(_order.CellOrder):
         self.x_rows_total = 0
         self.x_epoch = 0      # bumped whenever the working matrix X is replaced
         self.nam_epoch = 0    # bumped whenever a new NAM is started
-        # keep the NAM across analyses of one dataset (tools._nam._nam_device); CNA_NAM_CACHE=0 or
-        # engine.reuse_nam = False recomputes it every call (what bench.py measures)
-        self.reuse_nam = os.environ.get('CNA_NAM_CACHE', '1') not in ('0', 'off', 'no')
+        # keep the NAM across analyses of one dataset (tools._nam._nam_device); engine.reuse_nam = False recomputes it
+        # every call (what bench.py measures)
+        self.reuse_nam = True
         # ... and, opt-in, the standardised NAM of an analysis without covariates and batches: a further phenotype then
-        # only takes new coefficients (tools._association.compute_nam_and_reindex); CNA_X_CACHE=1 or engine.reuse_x = True
-        self.reuse_x = os.environ.get('CNA_X_CACHE', '0') in ('1', 'on', 'yes')
+        # only takes new coefficients (tools._association.compute_nam_and_reindex)
+        self.reuse_x = False
 
     # ---------------------------------------------------------------- lifetime
     def close(self):

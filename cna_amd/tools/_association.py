@@ -51,9 +51,9 @@ _EARLY_WALK = True       # the walk queued before the (pandas) validation of the
 _EARLY_COEF = True       # (module constants, not environment switches: each was measured against its alternative --
 _EARLY_FDR = True        #  DESIGN.md 6 -- and tests that need the other side patch the attribute)
 _DRAW_THREAD = True
-_PREFETCH_GRAPH = os.environ.get('CNA_PREFETCH_GRAPH', '1') != '0'    # a new graph's upload beside the factorisation of the sample ids
+_PREFETCH_GRAPH = True    # a new graph's upload beside the factorisation of the sample ids
 _PREFETCH_CELLS = 100_000
-_NATIVE_DRAW = os.environ.get('CNA_NATIVE_DRAW', '1') != '0'      # the draw on the library's host thread (0: the interpreter's helper thread, for A/B runs)
+_NATIVE_DRAW = True       # the draw on the library's host thread (False: the interpreter's helper thread; tests patch it)
 _SWITCH_INTERVAL = 5e-5   # GIL hand-over between the helper thread and this one: 2.08 -> 1.86 ms per call at 200k cells (default interval: 5 ms)
 
 
@@ -585,6 +585,18 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
                 'Maximum number of PCs plus number of covariates must be less than n-1. ' +
                 f'Currently it is {max(ks_f)+r_f} while n is {n_f}. Either reduce the number of covariates ' +
                 'or reduce the number of PCs to consider using the optional argument ks=[...].')
+        # ... and after the global F-test of the observed phenotype (_association.py:64), which the reference runs on the
+        # PCs of the empty NAM before it looks at the thresholds: p-values that are all NaN stop it in np.nanargmin
+        # (_association.py:60) -- a projector with NaNs (a constant covariate: 0/0 when it is standardised, _nam.py:125), no
+        # degrees of freedom left for any k (scipy's F survival function of a non-positive dfd), a constant phenotype
+        covs_f = covs[f_] if covs is not None else None
+        with np.errstate(all='ignore'):
+            nan_projector = covs_f is not None and len(covs_f.T) and bool(
+                np.isnan(np.asarray((covs_f - covs_f.mean(axis=0)) / covs_f.std(axis=0), dtype=np.float64)).any())
+        no_dof = all(n_f - (1 + r_f + int(k_)) <= 0 for k_ in ks_f)
+        nan_y = y_std is not None and len(y_std) == n_f and bool(np.isnan(np.asarray(y_std, dtype=np.float64)).any())
+        if nan_projector or no_dof or nan_y:
+            raise ValueError('All-NaN slice encountered')
         if local_test:
             raise ValueError('arange: cannot compute length')
         # (without the local test the reference gets as far as its epilogue, which reads the FDR table that was never made:
@@ -648,7 +660,12 @@ def association(data, y, sid_name, batches=None, covs=None, donorids=None, ks=No
     Returns the global p-value, or with ``return_full=True`` the full result namespace
     (same field names and types as upstream; the three cells x samples sized frames --
     ``nam``, ``namresid``, ``namresid_nbhdXpc`` -- are copied off the GPU when first read).
-    Writes ``data.obs[key_added]`` and ``data.obs[key_added + '_fdr']``."""
+    Writes ``data.obs[key_added]`` and ``data.obs[key_added + '_fdr']``.
+
+    Limits the reference does not have (the library answers CNA_EINVAL beyond them): at most 1024 samples, 256 batches
+    and 512 FDR thresholds (the reference's own call uses 300 or 301), fewer than 2**31 cells.  One result field may
+    differ from the reference's in SHAPE by one row: ``res.fdrs`` ("Result fields whose shape may
+    differ by one row")."""
     with host_blas_threads(1):
         eng = engine or get_engine()
         # the fixed-shape call (nsteps given, one batch, a seed, ...) in two library calls (tools/_fast.py); everything

@@ -91,7 +91,7 @@ def _lapacke_dsyevr():
 # acceptance of the library's own eigen-solver (csrc/host_eig.c): residual and orthogonality at rounding level, and every
 # gap of the leading spectrum wide enough for the individual vectors to be defined to ~1e-10 (two backward-stable solvers
 # agree to ~eps ||G|| / gap); anything else is LAPACK's to decide
-_EIG_NATIVE = os.environ.get('CNA_EIG', 'native') != 'lapack'
+_EIG_NATIVE = True       # (False: always LAPACK's dsyevr; tests patch it)
 _EIG_RESID = 1e-12
 _EIG_GAP = 1e-6
 eig_stats = {'native': 0, 'lapack': 0}
@@ -642,7 +642,9 @@ def nam(data, sid_name, batches=None, nsteps=None, self_weight=1, max_frac_pcs=0
     """Neighborhood abundance matrix and QC mask (reference _nam.py:179-193).
 
     Returns ``(DataFrame samples x kept cells, bool keep[n_cells])``.  ``max_frac_pcs``,
-    ``suffix``, ``ks`` and extra keywords are accepted and ignored exactly as upstream."""
+    ``suffix``, ``ks`` and extra keywords are accepted and ignored exactly as upstream.
+
+    Limits the reference does not have: at most 1024 samples and 256 batches, fewer than 2**31 cells."""
     out = select_output(show_progress)
     engine = engine or get_engine()
     if batches is None:

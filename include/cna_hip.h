@@ -65,8 +65,7 @@ int  cna_ctx_device_bytes(cna_ctx* ctx, int64_t* bytes);
 /* Opt-in storage format of the diffusion state BETWEEN two steps of a walk (reference: the float64 `s` of
    _nam.py:31-34 between iterations of diffuse_stepwise): on != 0 keeps it in 4 bytes per entry from the second step on
    (one rank, more than 64 samples; anything else keeps 8 bytes).  Sums, the NAM and everything after it stay float64;
-   the NAM then agrees with the 8-byte walk to ~1e-7 relative instead of bit for bit.  Default off (env CNA_STATE_F32=1
-   turns it on at context creation). */
+   the NAM then agrees with the 8-byte walk to ~1e-7 relative instead of bit for bit.  Default off. */
 int  cna_set_state_f32(cna_ctx* ctx, int on);
 
 /* ---- multi-GPU (RCCL over xGMI) ------------------------------------------------------ */
@@ -526,36 +525,6 @@ int64_t cna_host_cluster_order_mt(int64_t n, const int64_t* indptr, const int32_
  * fills col / cnt.  Host only; the blocks of a sharded run are packed from it (cna_amd._order.partition_order). */
 int64_t cna_host_cluster_graph(int64_t n, const int64_t* indptr, const int32_t* indices, const int64_t* order, int B,
                                int64_t* ptr, int32_t* col, int64_t* cnt);
-/* Per block of B consecutive rows: the distinct columns referenced (<= cap per block, in order of first
- * appearance) and, per edge, its column's position in the block's list (0xFFFF: not listed).  src_ptr
- * int64[nblocks+1], src int32[>= nnz], slot uint16[nnz].  Returns the total length of the lists or -1. */
-int64_t cna_host_block_sources(int64_t n_local, int64_t n_cols, const int64_t* indptr, const int32_t* indices, int B,
-                               int cap, int64_t* src_ptr, int32_t* src, uint16_t* slot);
-/* Blocks of the LDS-staged walk step (the neighbour rows one workgroup of csrc/walk_lds.hip stages in LDS for
- * the sums of /root/reference/src/cna/tools/_nam.py:33): runs of consecutive device rows with at most `bmax`
- * rows and at most `cap` distinct columns, never across a multiple of `super` rows; per block the distinct
- * columns in ascending order, per edge its column's position in the block's list (0xFFFF: the one row of a
- * block has more than `cap` distinct columns).  blk_row / src_ptr int64[<= n_local + 1] (closed by n_local and
- * the total), src int32[<= nnz], slot uint16[nnz].  Threaded (result independent of the thread count);
- * integer work only, no sum is reordered.  Returns the number of blocks or -1. */
-int64_t cna_host_walk_blocks(int64_t n_local, int64_t n_cols, const int64_t* indptr, const int32_t* indices, int bmax,
-                             int cap, int super, int nthreads, int64_t* blk_row, int64_t* src_ptr, int32_t* src,
-                             uint16_t* slot);
-
-/* Tile program of the LDS-tiled walk step (csrc/walk_lds.hip; the sums of _nam.py:33 with the neighbour rows of
- * a block of nw * rpw destination rows staged tile by tile in LDS): the distinct columns of every block in
- * ascending order of key[column] (the caller's index of a device column), cut into tiles of S, and the CSR
- * entries of the block regrouped by (tile, wave, row) -- inside a row still in CSR order, which is the order of
- * the tiles when the caller's rows list their columns in ascending order (scipy's canonical form).  Returns the
- * number of tiles, -2 when a row is not sorted that way, -1 when out of memory.  With rec_pos == NULL only
- * blk_tile int64[nb + 1] is filled (first tile of every block).  tile_src0 int64[ntiles + 1], tile_src
- * int32[<= nnz], seg int64[ntiles * nw + 1] (first record of (tile, wave)), rec_pos int64[nnz] (record position of
- * every CSR entry), rec_slot uint16[nnz] / rec_row uint8[nnz] (per record: source inside its tile, row inside its
- * wave).  Threaded; integer work only. */
-int64_t cna_host_walk_tiles(int64_t n_local, const int64_t* indptr, const int32_t* indices, const int64_t* key, int nw,
-                            int rpw, int S, int nthreads, int64_t* blk_tile, int64_t* tile_src0, int32_t* tile_src,
-                            int64_t* seg, int64_t* rec_pos, uint16_t* rec_slot, uint8_t* rec_row);
-
 /* Rows [r0, r1) of the graph in the device order: out row i = caller's row perm[r0 + i], columns relabelled
  * through col_map and left in their original order; values (vbytes = 4 | 8) copied bit for bit.  Sizes from
  * cna_host_permuted_nnz.  Threaded; integer work only. */

@@ -65,13 +65,18 @@ def test_cluster_order_handles_isolated_cells_and_asymmetric_graphs():
 
 
 def test_block_sources_lists_every_column_once_per_block():
+    """(a planner of the walk-step probes: tools/micro/host_walk.c since round 6, no longer in the product library)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'micro'))
+    import micro_host
     A = _graph(3000, 10)
     n = A.shape[0]
     B = 32
     order = _order.cluster_order(A, B)
     ip, ix, _ = _order.permuted_rows(A, order, 0, n)
     for cap in (4000, 100):
-        src_ptr, src, slot = _order.block_sources(ip, ix, n, B, cap)
+        src_ptr, src, slot = micro_host.block_sources(ip, ix, n, B, cap)
         assert src_ptr[0] == 0 and src_ptr[-1] == len(src) and len(src_ptr) == (n + B - 1) // B + 1
         for b in range(0, len(src_ptr) - 1, 7):
             lo, hi = ip[b * B], ip[min((b + 1) * B, n)]

@@ -19,9 +19,11 @@ def main():
     lib = C.CDLL(os.path.join(ROOT, 'cna_amd', 'libcna_hip.so'))
     lib.cna_host_cluster_order.restype = C.c_int64
     lib.cna_host_cluster_order.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-    lib.cna_host_block_sources.restype = C.c_int64
-    lib.cna_host_block_sources.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
-                                           C.c_void_p, C.c_void_p]
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import micro_host
+    mlib = micro_host.load()
+    mlib.micro_block_sources.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]
     t = time.time()
     X, _ = synth.mixture_points(n)
     A = synth.fuzzy_knn_graph(X, k=30)
@@ -44,7 +46,7 @@ def main():
             src = np.zeros(len(indices), np.int32)
             slot = np.zeros(len(indices), np.uint16)
             t = time.time()
-            tot = lib.cna_host_block_sources(n, n, indptr.ctypes.data, indices.ctypes.data, B, cap, sp_.ctypes.data,
+            tot = mlib.micro_block_sources(n, n, indptr.ctypes.data, indices.ctypes.data, B, cap, sp_.ctypes.data,
                                              src.ctypes.data, slot.ctypes.data)
             print('B=%d: order %.2fs (%.1f%% in full clusters), sources cap %d: %.2fs, edges/sources %.2f' % (
                 B, t_order, 100.0 * nf / n, cap, time.time() - t, len(indices) / tot), flush=True)

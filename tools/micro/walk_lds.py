@@ -1,5 +1,5 @@
 """Inputs of tools/micro/walk_lds.hip: a synthetic kNN graph in a cluster order of csrc/host_graph.c
-with the blocks of cna_host_walk_blocks (variable-size blocks, sorted source lists).  Run on the GPU box:
+with the blocks of micro_walk_blocks (tools/micro/host_walk.c) (variable-size blocks, sorted source lists).  Run on the GPU box:
     python tools/micro/walk_lds.py /tmp/wl 500000 64 1152 [cluster size] && ./walk_lds /tmp/wl 200"""
 import os
 import sys
@@ -10,6 +10,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from cna_amd import synth, _order  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import micro_host  # noqa: E402
 
 
 def main():
@@ -26,7 +28,7 @@ def main():
     t_order = time.time() - t
     indptr, indices, data = _order.permuted_rows(A, order, 0, n)
     t = time.time()
-    blk_row, src_ptr, src, slot = _order.walk_blocks(indptr, indices, n, bmax, cap, 512)
+    blk_row, src_ptr, src, slot = micro_host.walk_blocks(indptr, indices, n, bmax, cap, 512)
     nb = len(blk_row) - 1
     print('order(%d) %.2fs, blocks %.2fs: %d blocks, %.1f rows and %.0f sources per block, edges/sources %.2f, '
           'overflow edges %d' % (cluster, t_order, time.time() - t, nb, n / nb, len(src) / nb, len(indices) / len(src),

@@ -1,5 +1,5 @@
 """Inputs of tools/micro/walk_tiles.hip: a synthetic kNN graph in the device's cluster order with the tile
-program of cna_host_walk_tiles.  Run on the GPU box:
+program of micro_walk_tiles (tools/micro/host_walk.c).  Run on the GPU box:
     python tools/micro/walk_tiles.py /tmp/wt 500000 16 8 46 [cluster] && ./walk_tiles /tmp/wt 200 16 8 46"""
 import os
 import sys
@@ -10,6 +10,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from cna_amd import synth, _order  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import micro_host  # noqa: E402
 
 
 def main():
@@ -26,7 +28,7 @@ def main():
     t_order = time.time() - t
     indptr, indices, data = _order.permuted_rows(A, order, 0, n)
     t = time.time()
-    tp = _order.walk_tiles(indptr, indices, order, nw, rpw, S)
+    tp = micro_host.walk_tiles(indptr, indices, order, nw, rpw, S)
     t_tiles = time.time() - t
     nt = len(tp['tile_src0']) - 1
     nb = len(tp['blk_tile']) - 1
