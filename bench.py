@@ -77,9 +77,10 @@ DEFAULT_STEPS = {'C4_state_f32': (20, 5), 'C3_state_f32': (20, 5), 'C4_block8': 
 
 
 def usable_cpus():
-    """CPUs this process may use: cgroup v2 quota if set, else the affinity mask."""
+    """CPUs this process may use: cgroup v2 quota if set, else the affinity mask (the whole allowance: the CPU baseline
+    runs on rank 0 alone, whatever LOCAL_WORLD_SIZE says)."""
     from cna_amd._order import usable_cpus as u
-    return u()
+    return u(share=False)
 
 
 def algorithmic_work(kernel, n, nnz, N, P, T, wA):

@@ -25,8 +25,9 @@ import scipy.sparse as sp
 _allowance = None
 
 
-def usable_cpus(limit=None):
-    """CPUs this process may really use: the cgroup v2 quota if there is one, else the affinity mask."""
+def usable_cpus(limit=None, share=True):
+    """CPUs this process may really use: the cgroup v2 quota if there is one, else the affinity mask -- divided by the
+    ranks of the job on this node (share=False: the whole allowance, e.g. for the CPU baseline that rank 0 runs alone)."""
     global _allowance
     if _allowance is None or _allowance[0] != os.getpid():
         n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
@@ -42,22 +43,25 @@ def usable_cpus(limit=None):
     # several ranks on one node (one process per GPU) share that allowance: every rank's helper threads -- the draw,
     # the content hash, the cluster order, the column copies -- take their share, not all of it (eight ranks x four
     # draw threads on a 16-CPU allowance made the draw, identical on every rank, the longest item of a rank's step)
-    n = max(1, n // ranks_on_this_node())
+    if share:
+        n = max(1, n // ranks_on_this_node())
     return n if limit is None else max(1, min(n, int(limit)))
 
 
 def ranks_on_this_node():
-    """Processes of this job on this node: the launcher's LOCAL_WORLD_SIZE, else what cna_amd.dist was told (one node), else 1."""
-    try:
-        k = int(os.environ.get('LOCAL_WORLD_SIZE', '0'))
-        if k >= 1:
-            return k
-    except ValueError:
-        pass
+    """Processes of this job on this node: what cna_amd.dist was told (`local_ranks`: the launcher's LOCAL_WORLD_SIZE, else
+    every rank of a one-node job); without a job description the launcher's LOCAL_WORLD_SIZE, else 1."""
     try:
         from . import dist
-        return max(1, int(dist.current().get('nranks', 1) or 1))
-    except Exception:
+        cfg = dist.current()
+        if cfg.get('nranks'):
+            return max(1, int(cfg.get('local_ranks') or cfg['nranks']))
+    except Exception:                          # noqa: BLE001
+        pass
+    try:
+        k = int(os.environ.get('LOCAL_WORLD_SIZE', '0'))
+        return k if k >= 1 else 1
+    except ValueError:
         return 1
 
 

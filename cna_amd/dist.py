@@ -12,15 +12,23 @@ import os
 _cfg = {}
 
 
-def init(rank, nranks, unique_id=None, device=None, shm=None):
+def init(rank, nranks, unique_id=None, device=None, shm=None, local_ranks=None):
     """Describe this process' place in the job before the first engine is created.  ``shm``:
-    (segment name, slot bytes) selects the host-staged test communicator (ranks may share a GPU)."""
+    (segment name, slot bytes) selects the host-staged test communicator (ranks may share a GPU).
+    ``local_ranks``: processes of this job on THIS node (they share the host's CPUs: _order.usable_cpus); default: the
+    launcher's LOCAL_WORLD_SIZE, else all `nranks` (one node)."""
     global _cfg
     if nranks > 1 and unique_id is None and shm is None:
         raise ValueError('unique_id required when nranks > 1 (create it on rank 0 with new_unique_id())')
+    if local_ranks is None:
+        try:
+            local_ranks = int(os.environ.get('LOCAL_WORLD_SIZE', '0')) or None
+        except ValueError:
+            local_ranks = None
     # with one rank a unique_id is optional: when given, collectives still go through RCCL
     _cfg = dict(rank=int(rank), nranks=int(nranks), unique_id=unique_id, shm=shm,
-                device=int(device) if device is not None else None)
+                device=int(device) if device is not None else None,
+                local_ranks=max(1, min(int(local_ranks), int(nranks))) if local_ranks else int(nranks))
     from . import engine
     engine.set_engine(None)
 

@@ -292,7 +292,12 @@ class Engine(_order.CellOrder):
             # of the renumbered graph, without the second trip over PCIe); column sums and sample codes move with it,
             # everything else per cell follows as after any upload
             perm, full = staged
-            check(self.lib.cna_graph_reorder(self.h, ptr(perm)), 'cna_graph_reorder')
+            try:
+                check(self.lib.cna_graph_reorder(self.h, ptr(perm)), 'cna_graph_reorder')
+            except _ffi.CnaHipError:
+                # the device order is an optimisation (a second copy of the graph plus temporaries: it can run out of
+                # memory); the library leaves the resident copy in the caller's order intact -- that order stays
+                return False
             self.perm = perm
             self._keep_dev = None
             self._kept_order_cache = None

@@ -388,7 +388,10 @@ def _association(engine, res, y, y_, ks=None, Nnull=1000, local_test=True, show_
             except Exception:           # noqa: BLE001
                 pass
         if getattr(engine, 'global_test_discard', None) is not None:
-            engine.global_test_discard()      # (the F-tests may have been queued already, by this thread or the eigenvector thread)
+            try:
+                engine.global_test_discard()  # (the F-tests may have been queued already, by this thread or the eigenvector thread)
+            except Exception:                 # noqa: BLE001 - an engine with other error types: the caller gets the error that brought us here
+                pass
         raise
     if pending:
         tail_sums, ranks, num_detected = engine.null_local_fetch()
@@ -914,11 +917,8 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
         walk_queued.set()
         null_future.cancel() or null_future.exception()     # do not leave the helper thread running
         if native is not None:
-            try:
-                native.wait()                               # ... nor the library's draw uncollected
-            except Exception:                               # noqa: BLE001
-                pass
-        raise
+            native.abandon()                                # ... nor the library's draw uncollected (the reference fails before
+        raise                                               #     it seeds, _association.py:15-16: numpy's generator stays as it was)
     finally:
         engine._on_walk_queued = None
         walk_queued.set()
@@ -935,11 +935,8 @@ def _association_call(data, y, sid_name, batches, covs, donorids, ks, key_added,
     except BaseException:
         null_future.cancel() or null_future.exception()     # do not leave the helper thread running
         if native is not None:
-            try:
-                native.wait()                               # ... nor the library's draw uncollected
-            except Exception:                               # noqa: BLE001
-                pass
-        raise
+            native.abandon()                                # ... nor the library's draw uncollected (the reference fails before
+        raise                                               #     it seeds, _association.py:15-16: numpy's generator stays as it was)
 
     _mark('resid queued')
     print('performing association test', file=out)

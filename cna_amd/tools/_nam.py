@@ -481,7 +481,9 @@ def _walk_start(engine, codes, labels, counts, token, nsteps, maxnsteps, self_we
     None, steps of the held NAM or _NO_NAM: the caller walks)."""
     # (cells per sample, aligned with labels: _qc_device leaves samples without cells -- NaN rows of the NAM -- out of
     # the batch means, as pandas' mean does in the reference)
-    engine._sample_counts = (np.asarray(counts), len(labels))
+    # (keyed on the labels object itself -- the one _nam_device hands back to its caller, who passes it on to
+    # _qc_device: a stash left by another dataset with as many samples can never be mistaken for this one's)
+    engine._sample_counts = (np.asarray(counts), labels)
     # NAM cache (SURVEY.md 8f-1): the NAM is a function of the graph, the per-cell sample ids, the
     # step rule and the self weight only -- not of the phenotype.  When the device still holds the
     # NAM of exactly these inputs (same resident graph, same id fingerprint, no walk started since),
@@ -619,7 +621,7 @@ def _qc_device(engine, labels, batches, show_progress=False):
     # the reference's batch means are DataFrame.mean, which skips NaN (_nam.py:78-82): such a sample belongs to no batch
     # here (fixture c19_unused_category_batches; found by differential fuzzing)
     held = getattr(engine, '_sample_counts', None)
-    if held is not None and held[1] == len(codes) and len(held[0]) == len(codes):
+    if held is not None and held[1] is labels and len(held[0]) == len(codes):
         codes = np.where(held[0] > 0, codes, -1).astype(np.int32)
     engine.batch_kurtosis(_ffi.MAT_NAM, codes, nb)
     if not show_progress and hasattr(engine, 'stat_qc'):

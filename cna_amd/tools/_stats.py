@@ -181,6 +181,7 @@ class NativeDraw:
             pass
 
     def __del__(self):                         # the worker writes into buffers this object keeps alive
+        self._state = None                     # (abandon(): a draw nobody collected must not reseed numpy's generator now)
         try:
             self.wait()
         except Exception:                      # noqa: BLE001

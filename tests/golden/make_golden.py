@@ -144,6 +144,11 @@ def build_cases():
          call=dict(nsteps=3, Nnull=100, seed=18), mutate='unused_category', extras=('nam', 'progress'))
     base('c20_unused_category_autostop', seed=19, N=22, gen=dict(sid_kind='cat'),
          call=dict(Nnull=100, seed=19), mutate='unused_category', extras=('progress',))
+    # a whole batch of categories without cells: its batch mean is the mean of NaN rows only -- NaN, where pandas' mean had
+    # skipped single NaN rows -- so every batch kurtosis is NaN and no neighbourhood passes the QC (_nam.py:78-99); the
+    # reference goes on with an empty NAM and stops where the thresholds are formed (_association.py:99-102)
+    base('c21_unused_batch', seed=20, N=24, gen=dict(sid_kind='cat', n_batches=4),
+         call=dict(nsteps=3, Nnull=100, seed=20), mutate='unused_batch')
     # messy sample-level inputs, drawn at random (seeded): every input in an order of its own, NaNs, samples the data does
     # not have, unused categories, donor groups, custom ks / ridges / max_frac_pcs -- what pandas' label alignment makes
     # of them in the reference is pinned here case by case (tools/fuzz_oracle_vs_reference.py found the first of them)
@@ -285,6 +290,13 @@ def run_case(case):
         col = data.obs[sid_name]
         codes = np.asarray(col.cat.codes).copy()
         codes[codes == 5] = 6                                  # sample 5 keeps its category and its phenotype, not its cells
+        data.obs[sid_name] = pd.Categorical.from_codes(codes, categories=col.cat.categories)
+    elif mut == 'unused_batch':
+        col = data.obs[sid_name]
+        codes = np.asarray(col.cat.codes).copy()
+        gone = np.flatnonzero(np.asarray(batches.reindex(col.cat.categories).values) == np.asarray(batches.values).max())
+        for s_ in gone:                                        # every sample of the last batch keeps category, phenotype and
+            codes[codes == s_] = s_ - 1                        # batch label -- and loses its cells to a sample of another batch
         data.obs[sid_name] = pd.Categorical.from_codes(codes, categories=col.cat.categories)
     elif mut == 'isolated':
         data, lab = add_isolated_blob(data, meta)
