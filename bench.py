@@ -8,7 +8,8 @@ A *step* is one full association() call -- NAM diffusion (3 steps) -> QC/selecti
 residualisation -> Gram/SVD -> global permutation test -> fused local null + FDRs ->
 data.obs write-back -- on one synthetic dataset, with the graph, its device cell order and the
 factorised sample ids resident on the GPU (the steady state of analysing several phenotypes of one
-dataset; `engine.pin_graph`), and the walk recomputed every step (NAM cache off).  The cold first call
+dataset; `engine.pin_graph`), and the walk and the permutation draw recomputed every step (NAM cache and the memo of a
+seed's permutations off: the timed steps repeat one phenotype and must not skip what the reference does per call).  The cold first call
 (graph preparation, upload over PCIe) is timed separately and reported beside it; it is never `value`.
 
 Workload: BASELINE.json configs[3] ("C4": 2M cells x 200 samples, k=30, nsteps=3, Nnull=1000), the
@@ -70,9 +71,21 @@ WORKLOADS = {
     # `value` -- the NAM is then within ~1e-7 of the default walk's instead of bit-identical; what exactness of the walk costs
     'C4_state_f32': (2_000_000, 200, 30, 3, 1000, 0),
     'C3_state_f32': (1_000_000, 100, 30, 3, 1000, 0),
+    # C4 as a drop-in caller gets it: WITHOUT engine.pin_graph (an API the reference does not have) -- the content of the
+    # connectivities matrix and of the id column is hashed in full on every call (inside cna_assoc_finish, while the
+    # device works); same dataset object as the C4 run
+    'C4_unpinned': (2_000_000, 200, 30, 3, 1000, 0),
+    'C2_unpinned': (200_000, 50, 30, 3, 1000, 0),
+    # C2 / a rank's block with the permutation memo ON (the library's default for users: the permutations of a seeded draw
+    # do not depend on the phenotype, so a second phenotype with the same seed replays them) -- never `value`: the timed
+    # steps repeat one phenotype and would skip a draw the reference makes on every call
+    'C2_draw_memo': (200_000, 50, 30, 3, 1000, 0),
+    'C4_block8_draw_memo': (250_000, 200, 30, 3, 1000, 0),
 }
-WORKLOAD_OPTS = {'C4_state_f32': dict(state_f32=True), 'C3_state_f32': dict(state_f32=True)}
-DEFAULT_STEPS = {'C4_state_f32': (20, 5), 'C3_state_f32': (20, 5), 'C4_block8': (50, 10), 'C2': (100, 60), 'C3': (20, 5), 'C4': (20, 5), 'C5': (20, 5), 'C3_default_nsteps': (10, 3),
+WORKLOAD_OPTS = {'C4_state_f32': dict(state_f32=True), 'C3_state_f32': dict(state_f32=True),
+                 'C4_unpinned': dict(pin=False), 'C2_unpinned': dict(pin=False),
+                 'C2_draw_memo': dict(draw_memo=True), 'C4_block8_draw_memo': dict(draw_memo=True)}
+DEFAULT_STEPS = {'C2_draw_memo': (100, 60), 'C4_block8_draw_memo': (50, 10), 'C4_unpinned': (20, 5), 'C2_unpinned': (100, 60), 'C4_state_f32': (20, 5), 'C3_state_f32': (20, 5), 'C4_block8': (50, 10), 'C2': (100, 60), 'C3': (20, 5), 'C4': (20, 5), 'C5': (20, 5), 'C3_default_nsteps': (10, 3),
                  'C3_covs_batches': (10, 3)}
 
 
@@ -189,7 +202,7 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
-def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
+def time_workload(name, args, rank, world, steps, warmup, want_kernels=True, dataset=None):
     """Generate the dataset of `name`, run the cold call, warm up, time `steps` calls.  Returns a dict of
     raw measurements (rank 0 fills the JSON from it)."""
     import warnings
@@ -202,7 +215,10 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
     n_batches = WORKLOADS[name][6] if len(WORKLOADS[name]) > 6 else 0
     n = n_total * world if args.scaling == 'weak' else n_total
     t0 = time.time()
-    (data, meta), shared_file = load_or_make_dataset(synth, n, N, k, rank, world, n_covs=n_covs, n_batches=n_batches)
+    if dataset is not None:                      # (another configuration of the same dataset: C4_unpinned after C4)
+        (data, meta), shared_file = dataset, None
+    else:
+        (data, meta), shared_file = load_or_make_dataset(synth, n, N, k, rank, world, n_covs=n_covs, n_batches=n_batches)
     t_gen = time.time() - t0
     A = get_connectivity(data)
     nnz = int(A.nnz)
@@ -220,8 +236,14 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
     with stdout_to_stderr():
         eng = get_engine()                       # (with a communicator: collective set-up, RCCL's banner)
     eng.reuse_nam = False           # every timed step recomputes the NAM (no result caching across steps)
+    from cna_amd.tools import _stats as _cna_stats
+    _cna_stats.DRAW_MEMO = bool(WORKLOAD_OPTS.get(name, {}).get('draw_memo', False))   # ... and draws its permutations again
     eng.set_state_f32(bool(WORKLOAD_OPTS.get(name, {}).get('state_f32')))      # (back to the default for every other workload)
-    eng.pin_graph(get_connectivity(data))        # the bench never edits the graph in place (see module docstring)
+    pinned = bool(WORKLOAD_OPTS.get(name, {}).get('pin', True))
+    if pinned:
+        eng.pin_graph(get_connectivity(data))    # the bench never edits the graph in place (see module docstring)
+    else:
+        eng.unpin_graph()                        # ... the `*_unpinned` lines: what a caller who does not know pin_graph gets
     kw = dict(nsteps=nsteps, Nnull=Nnull, seed=0)
     if meta.get('covs') is not None:
         kw['covs'] = meta['covs']
@@ -272,9 +294,23 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
     dt = time.perf_counter() - t0
     eng.prof_enable(False)
     prof = eng.prof()
+    dt_local = dt
     if world > 1 or args.force_dist:
         dt = dist.max_over_ranks(dt)               # the slowest rank's clock
     assert p_first == p_last
+    # what a rank's step is made of, from every rank (N > 1: so that a scaling curve explains itself): HIP-event times of
+    # its compute kernels, of the main communicator's collectives, of the halo exchange and of the main stream's wait for
+    # it, its own wall clock -- microseconds per step, gathered through the library's communicator
+    comm_keys = ('rccl', 'halo_exchange', 'halo_wait')
+    side_keys = ('condition', 'global_test')       # second stream, beside the main one
+    mine = dict(wall_ms=dt_local / steps * 1e3,
+                kernel_ms=sum(ms for k_, (ms, _) in prof.items() if k_ not in comm_keys + side_keys) / steps,
+                allreduce_ms=prof.get('rccl', (0.0, 0))[0] / steps,
+                halo_exchange_ms=prof.get('halo_exchange', (0.0, 0))[0] / steps,
+                halo_wait_ms=prof.get('halo_wait', (0.0, 0))[0] / steps)
+    mine['host_ms'] = mine['wall_ms'] - mine['kernel_ms'] - mine['allreduce_ms'] - mine['halo_wait_ms']
+    rank_keys = sorted(mine)
+    per_rank = eng.allgather_fixed([int(round(mine[k_] * 1e3)) for k_ in rank_keys]).astype(np.float64) * 1e-3
 
     if args.profile_host and rank == 0:
         import cProfile
@@ -303,8 +339,52 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True):
     return dict(name=name, n=n, N=N, k=k, nsteps=nsteps, Nnull=Nnull, n_covs=n_covs, n_batches=n_batches, nnz=nnz, wA=wA, dt=dt, t_cold=t_cold, i8=i8,
                 t_gen=t_gen, prof=prof, p=p_last, t_adopt=t_adopt, n_loc=n_loc, nnz_loc=nnz_loc, halo=getattr(eng, 'halo', None),
                 sharded_inputs=sharded_inputs, data=data, meta=meta, kw=kw, steps=steps, warmup=warmup, comm=eng.comm_info(),
+                per_rank={k_: [round(float(v), 3) for v in per_rank[:, i]] for i, k_ in enumerate(rank_keys)}, pinned=pinned,
+                two_call_path=_two_call_stats(),
                 halo_comm=getattr(eng, 'halo_comm', False), dev_bytes=int(eng.device_bytes()),
                 state_f32=bool(WORKLOAD_OPTS.get(name, {}).get('state_f32')))
+
+
+def _two_call_stats():
+    try:
+        from cna_amd.tools import _fast
+        return dict(_fast.stats)
+    except Exception:
+        return None
+
+
+def rccl_transport(rank):
+    """Which transports RCCL set its channels up with, from the NCCL_DEBUG=INFO log this rank wrote (main() points
+    NCCL_DEBUG_FILE at it): counts of 'via P2P/...' (xGMI / PCIe peer access), 'via SHM/...' (host memory) and 'via NET/...'
+    (sockets / NICs) channel lines.  None when there is no log."""
+    path = os.environ.get('CNA_BENCH_NCCL_LOG')
+    if not path or not os.path.exists(path):
+        return None
+    out = {}
+    try:
+        with open(path, errors='replace') as f:
+            for line in f:
+                i = line.find(' via ')
+                if i < 0 or 'Channel' not in line:
+                    continue
+                kind = line[i + 5:].split()[0].split('/')
+                key = '/'.join(kind[:2]) if kind[0] in ('P2P', 'SHM') else kind[0]
+                out[key] = out.get(key, 0) + 1
+    except OSError:
+        return None
+    return out or None
+
+
+def ranks_summary(m, world):
+    """{key: [max over ranks, rank 0]} of the per-rank step decomposition, plus what crossed between the ranks."""
+    pr = m.get('per_rank') or {}
+    out = {k_: [max(v), v[0]] for k_, v in pr.items() if v}
+    halo = m.get('halo')
+    if halo:
+        row_bytes = 8 * m['N']                      # one state row
+        out['halo_rows_out_in_rank0'] = list(halo)
+        out['halo_mb_per_exchange_out_in_rank0'] = [round(h * row_bytes / 1e6, 3) for h in halo]
+    return out
 
 
 def kernel_table(m, world):
@@ -363,7 +443,8 @@ def pmc_traffic(workload, kernel):
 def summary(m, world, steps):
     """The per-workload part of the JSON line."""
     kernels = kernel_table(m, world)
-    dom = max((k_ for k_ in kernels if k_ != 'rccl'), key=lambda k_: kernels[k_]['total_ms'])
+    comm_spans = ('rccl', 'halo_exchange', 'halo_wait')      # communication and waiting: reported under `ranks`, not as kernels
+    dom = max((k_ for k_ in kernels if k_ not in comm_spans), key=lambda k_: kernels[k_]['total_ms'])
     kd = kernels[dom]
     traffic, src = pmc_traffic(m['name'], dom) if world == 1 else (None, None)
     roofline = dict(kernel=dom, bound=kd['bound'], achieved=kd['achieved'], peak=kd['peak'], unit=kd['unit'],
@@ -382,11 +463,14 @@ def summary(m, world, steps):
         roofline['gathered_TBps'] = round(gathered / (kd['avg_us'] * 1e-6) / 1e12, 2)
         if traffic:
             roofline['behind_l2_TBps'] = round(traffic / (kd['avg_us'] * 1e-6) / 1e12, 2)
-    gpu_ms = sum(v['total_ms'] for v in kernels.values()) / steps
+    # (the exchange runs beside the walk on its own stream and `halo_wait` is the main stream standing still: neither is kernel
+    # time; the collectives of the main communicator are, as before)
+    gpu_ms = sum(v['total_ms'] for k_, v in kernels.items() if k_ not in ('halo_exchange', 'halo_wait')) / steps
     ms_per_step = m['dt'] / steps * 1e3
     return dict(value=round(m['n'] * m['Nnull'] * steps / m['dt'], 1), ms_per_step=round(ms_per_step, 3), roofline=roofline,
                 kernels=kernels, gpu_kernel_ms_per_step=round(gpu_ms, 3),
-                host_ms_per_step=round(ms_per_step - gpu_ms, 3),
+                host_ms_per_step=round(ms_per_step - gpu_ms, 3), ranks=ranks_summary(m, world),
+                graph_pinned=m.get('pinned', True), two_call_path=m.get('two_call_path'),
                 cold_first_call=dict(ms=round(m['t_cold'] * 1e3, 1), value=round(m['n'] * m['Nnull'] / m['t_cold'], 1),
                                      call_that_adopts_the_device_order_ms=None if m.get('t_adopt') is None else round(m['t_adopt'] * 1e3, 1),
                                      note='first call: graph H2D over PCIe (in the caller\'s cell order when the graph is large: '
@@ -397,11 +481,12 @@ def summary(m, world, steps):
 
 def workload_text(m, world, args):
     return ('%s: %d cells (%d per GPU) x %d samples, k=%d kNN (%.1f nnz/row, float32 CSR), nsteps=%s, Nnull=%d%s%s, '
-            'local FDR pass on; graph + device cell order + sample codes resident (graph pinned: engine.pin_graph), '
-            'walk recomputed every step (NAM cache off%s)' % (
+            'local FDR pass on; graph + device cell order + sample codes resident (%s), '
+            'walk and permutation draw recomputed every step (NAM cache and draw memo off%s)' % (
                 m['name'], m['n'], -(-m['n'] // world), m['N'], m['k'], m['nnz'] / m['n'],
                 'None (the reference\'s stop rule)' if m['nsteps'] is None else str(m['nsteps']), m['Nnull'],
                 ', %d covariates' % m['n_covs'] if m['n_covs'] else '', ', %d batches' % m['n_batches'] if m.get('n_batches') else '',
+                'graph pinned: engine.pin_graph' if m.get('pinned', True) else 'NOT pinned: graph and ids hashed in full on every call, as a drop-in caller gets it',
                 '; the last walk step leaves the standardised NAM and its coefficients directly -- the raw NAM, which this '
                 'call does not read, is materialised on demand' if (m['nsteps'] is not None and m['nsteps'] >= 2 and m['N'] > 64
                                                                    and not m['n_covs'] and not m.get('n_batches')) else ''))
@@ -460,7 +545,7 @@ def cpu_reference_cost(synth, ns, N, k, nsteps, Nnull, n_covs, extrapolate_to=No
 def workload_short(m, world):
     """<= 200 characters: what the step is, for the contract line (`workload_text` is the long form)."""
     return ('%s: %d cells x %d samples, k=%d kNN (%.1f nnz/row, f32 CSR), nsteps=%s, Nnull=%d%s%s, local FDR on; '
-            'graph resident, walk recomputed every step' % (
+            'graph resident, walk + draw recomputed every step' % (
                 m['name'], m['n'], m['N'], m['k'], m['nnz'] / m['n'], m['nsteps'], m['Nnull'],
                 ', %d covs' % m['n_covs'] if m['n_covs'] else '', ', %d batches' % m['n_batches'] if m.get('n_batches') else ''))[:200]
 
@@ -522,6 +607,9 @@ def assemble_details(m, main_sum, cpu, cpu_c2, extra, world, steps, warmup, args
         'cpu_baseline_C2_full': cpu_c2,
         'gpu_kernel_ms_per_step': main_sum['gpu_kernel_ms_per_step'],
         'host_ms_per_step': main_sum['host_ms_per_step'],
+        'ranks': main_sum.get('ranks') if world > 1 or args.force_dist else None,
+        'rccl_transport': rccl_transport(0) if world > 1 or args.force_dist else None,
+        'two_call_path': main_sum.get('two_call_path'),
         'cold_first_call': main_sum['cold_first_call'],
         'first_call_ms_incl_graph_h2d': main_sum['cold_first_call']['ms'],
         'value_cold': main_sum['cold_first_call']['value'],      # the same metric on the first call (graph preparation + H2D included)
@@ -545,6 +633,7 @@ def contract_line(d, details_file=None):
         others[name] = dict(ms_per_step=o.get('ms_per_step'), value=o.get('value'), steps=o.get('steps'),
                             gpu_kernel_ms=o.get('gpu_kernel_ms_per_step'), host_ms=o.get('host_ms_per_step'),
                             first_call_ms=(o.get('cold_first_call') or {}).get('ms'), p_value=o.get('p_value'),
+                            **({'scaling': o['scaling'], 'cells': o.get('cells'), 'ranks': o.get('ranks')} if o.get('scaling') else {}),
                             roofline=dict(kernel=r.get('kernel'), frac=r.get('frac_step_bytes', r.get('frac')), avg_us=r.get('avg_us')))
     top = sorted((d.get('kernels') or {}).items(), key=lambda kv: -kv[1]['total_ms'])[:6]
     steps = max(int(d['steps']), 1)
@@ -567,6 +656,11 @@ def contract_line(d, details_file=None):
     out['host_ms_per_step'] = d.get('host_ms_per_step')
     out['first_call_ms_incl_graph_h2d'] = d.get('first_call_ms_incl_graph_h2d')
     out['value_cold'] = d.get('value_cold')
+    if d.get('ranks'):
+        # N > 1: what a rank's step is made of -- {key: [max over ranks, rank 0]} in ms per step (HIP events on every rank,
+        # gathered through the communicator) -- and which transports RCCL set up, so that a scaling curve explains itself
+        out['ranks'] = d['ranks']
+        out['rccl_transport'] = d.get('rccl_transport')
     # the kernels that make the step, each with its own fraction of its own roof: {name: [ms per step, launches per step, frac]}
     out['kernels_ms_per_step'] = {k_: [round(v['total_ms'] / steps, 3), round(v['launches'] / steps, 2),
                                        v.get('frac_step_bytes', v.get('frac'))] for k_, v in top}
@@ -591,7 +685,9 @@ def main():
     ap.add_argument('--cpu-sample-cells', type=int, default=150_000)
     ap.add_argument('--no-cpu-c2-full', action='store_true',
                     help='N=1: skip the reference-cost CPU run of the FULL C2 workload (~1-2 min of host time)')
-    ap.add_argument('--cpu-full', default='C2', help='N=1: BASELINE configurations whose FULL workload the reference-cost CPU path runs (C2, C3)')
+    ap.add_argument('--cpu-full', default='auto',
+                    help='N=1: BASELINE configurations whose FULL workload the reference-cost CPU path runs (C2, C3).  auto: C2, '
+                         'and C3 as well (the "HBM roofline run": ~100 s of host time, ~30 GB) when the host allows it (>= 16 usable cores, >= 64 GB free)')
     ap.add_argument('--details', default=DETAILS_FILE, help='where the full per-kernel tables go (JSON)')
     ap.add_argument('--profile-host', default=None, help='write a cProfile of 3 extra steps to this file')
     ap.add_argument('--comm', default='rccl', choices=['rccl', 'shm'],
@@ -621,6 +717,20 @@ def main():
         # max over ranks of the timing go through it as well.
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
+        if args.comm == 'rccl':
+            # RCCL says which transport every channel got (P2P over xGMI / PCIe, host shared memory, sockets) at INFO level:
+            # into a file per rank, parsed for the result line (rccl_transport) -- a scaling curve that came over sockets
+            # should say so itself
+            if os.environ.get('NCCL_DEBUG', 'VERSION').upper() in ('VERSION', 'WARN'):     # (the image exports VERSION)
+                os.environ['NCCL_DEBUG'] = 'INFO'
+            log = '/tmp/cna_bench_nccl_%s_r%d.log' % (os.environ['MASTER_PORT'], rank)
+            try:
+                if os.path.exists(log):
+                    os.remove(log)
+            except OSError:
+                pass
+            os.environ.setdefault('NCCL_DEBUG_FILE', log)
+            os.environ['CNA_BENCH_NCCL_LOG'] = os.environ['NCCL_DEBUG_FILE']
         from cna_amd import dist
         if args.comm == 'shm':
             dist.init_from_env(shm=('cna_bench_%s' % os.environ['MASTER_PORT'],
@@ -643,6 +753,19 @@ def main():
     warmup = args.warmup if args.warmup is not None else DEFAULT_STEPS[args.workload][1]
     m = time_workload(args.workload, args, rank, world, steps, warmup)
     eng = get_engine()
+    weak = None
+    if world > 1 and args.scaling == 'strong' and args.workload == 'C4' and not args.no_extra:
+        # the second triple of an N > 1 line: WEAK scaling -- 250 000 cells x 200 samples per rank (a rank's block of C4
+        # on eight GPUs), so that one run shows both what a fixed problem gains from N GPUs and what a fixed block costs
+        # beside N - 1 others (every rank takes part; rank 0 reports)
+        import copy
+        wargs = copy.copy(args)
+        wargs.scaling = 'weak'
+        st_, wu_ = DEFAULT_STEPS['C4_block8']
+        try:
+            weak = time_workload('C4_block8', wargs, rank, world, st_, wu_)
+        except Exception as e:                      # noqa: BLE001 - the weak triple never takes the headline down
+            weak = dict(error=repr(e))
 
     if world > 1 or args.force_dist:
         # every rank pushes out what its runtime libraries buffered (RCCL's version banner) before
@@ -660,6 +783,25 @@ def main():
         return
 
     main_sum = summary(m, world, steps)
+    extra = {}
+    if weak is not None:
+        if 'error' in weak:
+            extra['C4_block8_weak'] = weak
+        else:
+            s_ = summary(weak, world, weak['steps'])
+            extra['C4_block8_weak'] = dict(workload=workload_text(weak, world, args), steps=weak['steps'], warmup=weak['warmup'],
+                                           scaling='weak', cells=weak['n'], **s_)
+            del weak['data'], weak['meta']
+    if world == 1 and not args.no_extra and args.workload in ('C4', 'C2'):
+        # the same steps as a drop-in caller gets them: no engine.pin_graph (same dataset object, resident graph)
+        uname = args.workload + '_unpinned'
+        st_, wu_ = DEFAULT_STEPS[uname]
+        try:
+            mm = time_workload(uname, args, rank, world, st_, wu_, dataset=(m['data'], m['meta']))
+            extra[uname] = dict(workload=workload_text(mm, world, args), steps=st_, warmup=wu_, **summary(mm, world, st_))
+            del mm
+        except Exception as e:                      # noqa: BLE001
+            extra[uname] = dict(error=repr(e))
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -667,9 +809,9 @@ def main():
                                  extrapolate_to=m['n'])
     del m['data'], m['meta']
 
-    extra = {}
     if world == 1 and not args.no_extra and args.workload == 'C4':
-        for name in ('C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches', 'C4_block8', 'C4_state_f32', 'C3_state_f32'):
+        for name in ('C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches', 'C4_block8', 'C4_state_f32', 'C3_state_f32',
+                     'C2_draw_memo', 'C4_block8_draw_memo'):
             st_, wu_ = DEFAULT_STEPS[name]
             try:
                 mm = time_workload(name, args, rank, world, st_, wu_)
@@ -685,7 +827,16 @@ def main():
         # BASELINE.md 3 asks for the CPU path on a BASELINE configuration in full, in the same run: configs[1] (C2:
         # 200k x 50, nsteps 3, Nnull 1000), no sampling, no extrapolation -- beside this run's GPU time of the same
         # configuration.  (--cpu-full C2,C3 adds configs[2]: minutes of host time and ~30 GB, not in the default run.)
-        for wname in [w for w in args.cpu_full.split(',') if w]:
+        want_full = args.cpu_full
+        if want_full == 'auto':
+            want_full = 'C2'
+            try:
+                free_gb = os.sysconf('SC_AVPHYS_PAGES') * os.sysconf('SC_PAGE_SIZE') / 2 ** 30
+            except (ValueError, OSError):
+                free_gb = 0.0
+            if usable_cpus() >= 16 and free_gb >= 64 and args.workload == 'C4':
+                want_full = 'C2,C3'
+        for wname in [w for w in want_full.split(',') if w]:
             if wname not in ('C2', 'C3') or not (args.workload == 'C4' or args.workload == wname):
                 continue
             n2, N2, k2, ns2, P2, c2 = WORKLOADS[wname][:6]

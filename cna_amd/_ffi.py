@@ -98,9 +98,13 @@ SIGNATURES = {
     'cna_host_argsort_gather': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'cna_host_draw_start': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_int64, C.c_int]),
+    'cna_host_draw_start_idx': (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]),
+    'cna_host_gather_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     'cna_host_draw_wait': (C.c_int, []),
     'cna_host_draw_join': (C.c_int, []),
     'cna_assoc_begin': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int]),
+    'cna_assoc_begin_part': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     'cna_assoc_finish': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),
     'cna_assoc_run': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     'cna_host_draw_then_condition': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
@@ -155,7 +159,7 @@ class AssocOut(C.Structure):
 
 KERNELS = ['colsum', 'nam_first', 'nam_step', 'batch_kurtosis', 'zero_variance', 'select', 'resid_xb',
            'standardize', 'gram', 'gram_reduce', 'ncorrs', 'null_local', 'obs_counts', 'percell_fdr',
-           'project_xb', 'transpose', 'rccl', 'condition', 'global_test', 'nam_step_sparse']
+           'project_xb', 'transpose', 'rccl', 'condition', 'global_test', 'nam_step_sparse', 'halo_exchange', 'halo_wait']
 
 _lib = None
 

@@ -25,6 +25,19 @@ int cna_assoc_begin(cna_ctx* c, int nsteps, const double* y_hint, int n_hint) {
   return cna_nam_steps(c, nsteps);
 }
 
+// Steps first .. first + count - 1 (0-based) of a walk of `total` steps: the caller queues the steps that need nothing but
+// graph and sample codes before it has looked at the phenotype, and the last one -- with the hint -- once it has.
+int cna_assoc_begin_part(cna_ctx* c, int first, int count, int total, const double* y_hint, int n_hint) {
+  if (!c) CNA_FAIL(CNA_EINVAL, "null context");
+  if (first < 0 || count < 0 || total < 1 || first + count > total) CNA_FAIL(CNA_EINVAL, "cna_assoc_begin_part: bad step range");
+  for (int i = first; i < first + count; ++i) {
+    const bool last = i + 1 == total;
+    if (last && y_hint && total >= 2) CNA_TRY(cna_nam_select_hint(c, y_hint, n_hint));
+    CNA_TRY(cna_nam_step(c, 0, last ? 0 : 1, last ? 1 : 0));
+  }
+  return 0;
+}
+
 namespace {
 // every way out of cna_assoc_finish passes here: the draw thread writes the flag on this call's stack and reads the
 // caller's table / M until its follow-up is done

@@ -84,6 +84,7 @@ static void prof_flush(cna_ctx* c) {
   (void)hipStreamSynchronize(c->copy_stream);
   if (c->coef_stream) (void)hipStreamSynchronize(c->coef_stream);
   if (c->gram_stream) (void)hipStreamSynchronize(c->gram_stream);
+  if (c->halo_stream) (void)hipStreamSynchronize(c->halo_stream);
   std::lock_guard<std::mutex> lock(c->prof_mu);
   if (c->prof_pending.empty()) return;
   for (auto& s : c->prof_pending) {
@@ -101,7 +102,7 @@ static void prof_flush(cna_ctx* c) {
 static const char* kKernelNames[CNA_K_COUNT] = {
     "colsum", "nam_first", "nam_step", "batch_kurtosis", "zero_variance", "select", "resid_xb",
     "standardize", "gram", "gram_reduce", "ncorrs", "null_local", "obs_counts", "percell_fdr",
-    "project_xb", "transpose", "rccl", "condition", "global_test", "nam_step_sparse"};
+    "project_xb", "transpose", "rccl", "condition", "global_test", "nam_step_sparse", "halo_exchange", "halo_wait"};
 
 #define CHECK_CTX(c)                                        \
   do {                                                      \
@@ -167,6 +168,8 @@ static int ragged_gather(cna_ctx* c, const double* src_dev, int64_t count_local,
 int halo_settle(cna_ctx* c) {
   if (!c->halo_wait_pending) return 0;
   c->halo_wait_pending = false;
+  // (profiling: how long the main stream stands still here -- the part of the exchange the walk did not hide)
+  ProfScope ps(c, CNA_K_HALO_WAIT);
   HIP_TRY(hipStreamWaitEvent(c->stream, c->halo_e2, 0));
   return 0;
 }
@@ -686,6 +689,7 @@ static int exchange_state(cna_ctx* c, double* T, hipStream_t st = nullptr) {
   if (c->halo_on) {
     const int ld = c->t_ld;
     CNA_TRY(dev_reserve(c, &c->halo_sbuf, &c->halo_sbuf_cap, 8 * std::max<int64_t>(c->halo_ns, 1) * ld));
+    ProfScope ps(c, CNA_K_HALO_EXCHANGE, st);              // pack + send / receive + unpack, on the stream that carries them
     if (c->t_compact) {
       // the rows that arrive ARE the tail of the state, in the order of the receive list: no staging, no scatter
       CNA_TRY(launch_pack_rows(c, T, c->halo_send_idx, c->halo_ns, ld, (double*)c->halo_sbuf, st));

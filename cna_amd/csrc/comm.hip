@@ -399,7 +399,6 @@ int comm_halo_exchange(cna_ctx* c, const double* sendbuf, double* recvbuf, int64
   // the overlap without one
   ncclComm_t comm = (st != c->stream && c->comm_halo) ? (ncclComm_t)c->comm_halo : (ncclComm_t)c->comm;
   if (st != c->stream && !c->comm_halo) CNA_FAIL(CNA_ESTATE, "halo exchange on a second stream without a halo communicator");
-  ProfScope ps(c, CNA_K_ALLGATHER, st);
   NCCL_TRY(g_rccl.GroupStart());
   int64_t so = 0, ro = 0;
   ncclResult_t bad = ncclSuccess;

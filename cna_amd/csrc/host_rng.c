@@ -199,6 +199,7 @@ struct sort_pair { double v; int32_t i; int32_t pad; };
 struct sort_job {
   const double* R; const double* y; double* out; const int64_t* rows;
   int64_t ld_out; int m, num, c0, c1;
+  int32_t* idx_out; int64_t ld_idx;                 /* optional: the row of y every output was taken from (cna_host_draw_start_idx) */
 };
 
 #define SORT_CB 64                                        /* columns handled together: row segments of 512 bytes */
@@ -288,7 +289,8 @@ static void* sort_worker(void* arg) {
   struct sort_pair* a = (struct sort_pair*)malloc(sizeof(struct sort_pair) * (size_t)m * 2);
   double* blk = (double*)malloc(sizeof(double) * ((size_t)m * SORT_CB * 2 + (size_t)n * SORT_CB + m));  /* draws | results | network | one column */
   int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)m);
-  if (!a || !blk || !idx) { free(a); free(blk); free(idx); return (void*)1; }
+  int32_t* resi = j->idx_out ? (int32_t*)malloc(sizeof(int32_t) * (size_t)m * SORT_CB) : NULL;
+  if (!a || !blk || !idx || (j->idx_out && !resi)) { free(a); free(blk); free(idx); free(resi); return (void*)1; }
   struct sort_pair* b = a + m;
   double* res = blk + (size_t)m * SORT_CB;
   double* A = res + (size_t)m * SORT_CB;
@@ -323,6 +325,7 @@ static void* sort_worker(void* arg) {
         const u64a* srow = Au + (size_t)i * SORT_CB;
         double* rrow = res + (size_t)i * SORT_CB;
         for (int cc = 0; cc < w; ++cc) rrow[cc] = j->y[srow[cc] & lowmask];
+        if (resi) for (int cc = 0; cc < w; ++cc) resi[(size_t)i * SORT_CB + cc] = (int32_t)(srow[cc] & lowmask);
       }
     }
     for (int cc = 0; cc < w; ++cc) {
@@ -330,18 +333,30 @@ static void* sort_worker(void* arg) {
       for (int i = 0; i < m; ++i) col[i] = j->R[(size_t)i * j->num + cb + cc];
       sort_column(col, m, a, b, idx);
       for (int i = 0; i < m; ++i) res[(size_t)i * SORT_CB + cc] = j->y[idx[i]];
+      if (resi) for (int i = 0; i < m; ++i) resi[(size_t)i * SORT_CB + cc] = idx[i];
     }
     for (int i = 0; i < m; ++i) {
       const int64_t row = j->rows ? j->rows[i] : i;
       memcpy(j->out + (size_t)row * j->ld_out + cb, res + (size_t)i * SORT_CB, sizeof(double) * (size_t)w);
+      if (resi) {                                          /* (rows of the level -> rows of the whole phenotype) */
+        int32_t* d = j->idx_out + (size_t)row * j->ld_idx + cb;
+        const int32_t* s = resi + (size_t)i * SORT_CB;
+        for (int cc = 0; cc < w; ++cc) d[cc] = j->rows ? (int32_t)j->rows[s[cc]] : s[cc];
+      }
     }
   }
-  free(a); free(blk); free(idx);
+  free(a); free(blk); free(idx); free(resi);
   return NULL;
 }
 
+static int argsort_gather_idx(const double* R, int m, int num, const double* y, double* out, int64_t ld_out,
+                              const int64_t* rows, int32_t* idx_out, int64_t ld_idx);
 int cna_host_argsort_gather(const double* R, int m, int num, const double* y, double* out, int64_t ld_out,
                             const int64_t* rows) {
+  return argsort_gather_idx(R, m, num, y, out, ld_out, rows, NULL, 0);
+}
+static int argsort_gather_idx(const double* R, int m, int num, const double* y, double* out, int64_t ld_out,
+                              const int64_t* rows, int32_t* idx_out, int64_t ld_idx) {
   if (m < 0 || num < 0 || !R || !y || !out) return -1;
   if (m == 0 || num == 0) return 0;
   struct sort_job jobs[64];
@@ -354,7 +369,7 @@ int cna_host_argsort_gather(const double* R, int m, int num, const double* y, do
   if (nt < 1) nt = 1;
   for (int t = 0; t < nt; ++t) {
     jobs[t].R = R; jobs[t].y = y; jobs[t].out = out; jobs[t].rows = rows; jobs[t].ld_out = ld_out;
-    jobs[t].m = m; jobs[t].num = num;
+    jobs[t].m = m; jobs[t].num = num; jobs[t].idx_out = idx_out; jobs[t].ld_idx = ld_idx;
     jobs[t].c0 = (int)((int64_t)num * t / nt); jobs[t].c1 = (int)((int64_t)num * (t + 1) / nt);
     started[t] = 0;
   }
@@ -383,6 +398,7 @@ int cna_host_argsort_gather(const double* R, int m, int num, const double* y, do
 struct draw_req {
   uint32_t* key; int* pos; const double* y; int m, num, nlev; const int64_t* lev_off; const int64_t* members;
   double* out; int64_t ld_out; int threads;
+  int32_t* idx_out;                                  /* m x num, or NULL */
 };
 struct cna_ctx;
 extern int cna_condition_phenotypes(struct cna_ctx* c, const double* M, const double* Y, int N, int P);
@@ -411,7 +427,7 @@ static int draw_run(const struct draw_req* q) {
     double g = 0.0;
     if (cna_host_legacy_randn(q->key, q->pos, &hg, &g, (int64_t)ml * q->num, R) != 0 || hg != 0) { rc = -1; break; }
     for (int i = 0; i < ml; ++i) ysub[i] = q->y[mem[i]];
-    if (cna_host_argsort_gather(R, ml, q->num, ysub, q->out, q->ld_out, mem) != 0) rc = -1;
+    if (argsort_gather_idx(R, ml, q->num, ysub, q->out, q->ld_out, mem, q->idx_out, q->num) != 0) rc = -1;
   }
   t_host_threads = 0;
   free(R); free(ysub);
@@ -460,8 +476,17 @@ static void draw_register_atfork(void) { pthread_atfork(NULL, NULL, draw_atfork_
 /* 0: the request is with the worker (every pointer must stay valid until cna_host_draw_wait returns);
  * -1: bad arguments / an earlier request not collected / no thread: the caller draws the usual way, the generator
  * state has not been touched */
+int cna_host_draw_start_idx(uint32_t* key, int* pos, const double* y, int m, int num, int nlev, const int64_t* lev_off,
+                            const int64_t* members, double* out, int64_t ld_out, int threads, int32_t* idx_out);
 int cna_host_draw_start(uint32_t* key, int* pos, const double* y, int m, int num, int nlev, const int64_t* lev_off,
                         const int64_t* members, double* out, int64_t ld_out, int threads) {
+  return cna_host_draw_start_idx(key, pos, y, m, num, nlev, lev_off, members, out, ld_out, threads, NULL);
+}
+/* the same, also recording WHICH row of y every output is (idx_out: m x num int32, row-major; rows of no level are left
+ * untouched): the permutations of a seeded draw depend on (seed, m, num, levels) only, so a caller that analyses many
+ * phenotypes with one seed replays them with cna_host_gather_rows instead of drawing again */
+int cna_host_draw_start_idx(uint32_t* key, int* pos, const double* y, int m, int num, int nlev, const int64_t* lev_off,
+                            const int64_t* members, double* out, int64_t ld_out, int threads, int32_t* idx_out) {
   if (!key || !pos || !y || !lev_off || !members || !out || m < 1 || num < 2 || (num & 1) || nlev < 1 || ld_out < num) return -1;
   if (*pos < 0 || *pos > MT_N) return -1;
   for (int l = 0; l < nlev; ++l) if (lev_off[l + 1] < lev_off[l] || lev_off[l + 1] > m) return -1;
@@ -474,7 +499,7 @@ int cna_host_draw_start(uint32_t* key, int* pos, const double* y, int m, int num
     pthread_detach(g_draw_th);
     g_draw_alive = 1;
   }
-  g_draw_req = (struct draw_req){key, pos, y, m, num, nlev, lev_off, members, out, ld_out, threads};
+  g_draw_req = (struct draw_req){key, pos, y, m, num, nlev, lev_off, members, out, ld_out, threads, idx_out};
   g_draw_state = 1;
   g_then_state = 0;
   pthread_cond_broadcast(&g_draw_cv);
@@ -519,4 +544,36 @@ int cna_host_draw_join(void) {
   const int rc = g_draw_rc;
   pthread_mutex_unlock(&g_draw_mu);
   return rc;
+}
+
+/* out[r * ld_out + p] = y[idx[r * num + p]] (m x num): the permuted phenotypes of a draw whose source rows were recorded by
+ * cna_host_draw_start_idx -- conditional_permutation's Y[bix] (_stats.py:16-17) without the random numbers and the sorts.
+ * Rows are split over up to nthreads threads (large draws). */
+struct gather_job { const double* y; const int32_t* idx; double* out; int64_t ld_out; int num, r0, r1; };
+static void* gather_worker(void* arg) {
+  const struct gather_job* j = (const struct gather_job*)arg;
+  for (int r = j->r0; r < j->r1; ++r) {
+    const int32_t* s = j->idx + (size_t)r * j->num;
+    double* d = j->out + (size_t)r * j->ld_out;
+    for (int p = 0; p < j->num; ++p) d[p] = j->y[s[p]];
+  }
+  return NULL;
+}
+int cna_host_gather_rows(const double* y, const int32_t* idx, int m, int num, double* out, int64_t ld_out, int nthreads) {
+  if (!y || !idx || !out || m < 1 || num < 1 || ld_out < num) return -1;
+  for (int64_t i = 0; i < (int64_t)m * num; ++i) if (idx[i] < 0 || idx[i] >= m) return -1;
+  if (nthreads > 16) nthreads = 16;
+  if ((int64_t)m * num < 262144 || nthreads < 2) nthreads = 1;
+  if (nthreads > m) nthreads = m;
+  struct gather_job jobs[16];
+  pthread_t th[16];
+  int started[16];
+  for (int t = 0; t < nthreads; ++t) {
+    jobs[t] = (struct gather_job){y, idx, out, ld_out, num, (int)((int64_t)m * t / nthreads), (int)((int64_t)m * (t + 1) / nthreads)};
+    started[t] = 0;
+  }
+  for (int t = 1; t < nthreads; ++t) started[t] = pthread_create(&th[t], NULL, gather_worker, &jobs[t]) == 0;
+  gather_worker(&jobs[0]);
+  for (int t = 1; t < nthreads; ++t) { if (started[t]) pthread_join(th[t], NULL); else gather_worker(&jobs[t]); }
+  return 0;
 }

@@ -848,6 +848,15 @@ class Engine(_order.CellOrder):
         if yv is not None and nsteps >= 2:
             self.x_epoch += 1             # (that step overwrites the working matrix: see nam_select_hint)
 
+    def assoc_begin_part(self, first, count, total, y_hint=None):
+        """Steps first .. first + count - 1 (0-based) of a walk of `total` steps (cna_assoc_begin_part); y_hint goes with
+        the part that holds the last step."""
+        yv = None if y_hint is None else _f64(y_hint)
+        check(self.lib.cna_assoc_begin_part(self.h, int(first), int(count), int(total), ptr(yv), 0 if yv is None else len(yv)),
+              'cna_assoc_begin_part')
+        if yv is not None and total >= 2 and first + count == total:
+            self.x_epoch += 1
+
     def assoc_finish(self, y, M, ks, Nnull, table, colmap=None, Cmat=None, W=None, draw_pending=False, conditioned=False,
                      coef_dst=None, fdr_dst=None, coef_first=False, copy_threads=1, native_eig=True, resid_tol=1e-12,
                      gap_tol=1e-6, run_steps=None, y_hint=None, verify=(), verify_threads=1):

@@ -31,7 +31,7 @@ from ._nam import (LazyNamespace, GramPCs, _NO_NAM, _defer_pcs, _lowrank_ok, _pr
                    _top_pcs, _walk_start, confirm_codes, eig_stats, get_connectivity, global_samples, host_blas_threads,
                    sample_codes_cached, shard_of)
 from . import _nam as _nam_mod
-from ._stats import default_ks, native_draw_start
+from ._stats import default_ks, seeded_draw
 
 ENABLED = os.environ.get('CNA_ONE_CALL', '1') not in ('0', 'off', 'no')     # 0: every call takes the general path (A/B runs, tests)
 NOT_TAKEN = object()
@@ -66,6 +66,17 @@ def _defer_last_cells():
 def _rule_cells(data, engine):
     from ._association import _rule_cells as rule
     return rule(data, engine)
+
+
+def _draw_threads(normals):
+    """(what tools/_stats.py:native_draw_start gives a draw of this size)"""
+    global _cpus
+    if normals < 80_000:
+        return 1
+    if _cpus is None:
+        from .._order import usable_cpus
+        _cpus = usable_cpus(8)
+    return _cpus
 
 
 def _eye(N):
@@ -141,42 +152,97 @@ def association(data, y, sid_name, batches, covs, donorids, ks, key_added, max_f
     if len(y) != N_all or N_all < 2 or not (counts > 0).all() or not labels.equals(y.index):
         stats['not_eligible'] += 1
         return NOT_TAKEN
-    yv = y.values
-    fv = ~np.isnan(yv)
-    cvals = None
-    if covs is not None:
-        cvals = covs.values
-        fv &= ~np.isnan(cvals).any(axis=1)
-    N = int(np.count_nonzero(fv))
-    whole = N == N_all
-    ysel = yv if whole else yv[fv]
-    r = 0 if covs is None else covs.shape[1]
-    ks_ = default_ks(N) if ks is None else ks
-    try:
-        ks_arr = np.asarray(ks_)
-        bad_ks = ks_arr.ndim != 1 or len(ks_arr) < 1 or ks_arr.dtype.kind not in 'iu' or ks_arr.min() < 1 or ks_arr.max() + r >= N
-    except Exception:                          # noqa: BLE001
-        bad_ks = True
-    if (N < 10 and not allow_low_sample_size) or N < 2 or N > 1024 or bad_ks:
-        stats['not_eligible'] += 1
-        return NOT_TAKEN                       # (the general path raises what the reference raises)
-    with np.errstate(all='ignore'):
-        y_std = (ysel - ysel.mean()) / ysel.std()          # numpy ddof=0, _association.py:22
-    if not np.isfinite(y_std).all():
-        stats['not_eligible'] += 1
-        return NOT_TAKEN
-    colmap = None if whole else np.flatnonzero(fv).astype(np.int32)       # NAM.reindex(y.index)[filter]: labels == y.index
-    kmax = int(ks_arr.max())
-
-    _mark('validated')
-    # the draw (_stats.py:4-18; one level: batches = ones, _association.py:146-147) on the library's thread, from now on
-    native = native_draw_start(None, y_std, Nnull, seed, single_level=True)
-    if native is None:
-        stats['not_eligible'] += 1
-        return NOT_TAKEN
-
-    _mark('draw started')
     n = len(data.obs)
+    r = 0 if covs is None else covs.shape[1]
+    verify = []
+    W_ = {}                                     # what queue_walk() leaves for the rest of the call
+
+    def queue_walk():
+        # The walk needs the graph and the sample codes only: every step that does not wait for the phenotype is queued
+        # before the phenotype is even looked at (the last one waits when it may take the selection pass along: it needs y)
+        engine._defer_graph_check = 'caller' if optimistic else False
+        try:
+            pend = _nam_mod.take_pending_codes()
+            if pend is not None:
+                verify.append(pend)
+            _prepare_graph(engine, data, 1)
+            pend = engine.take_pending_graph()
+            if pend is not None:
+                verify.extend(pend)
+            _mark('graph')
+            sig, held = _walk_start(engine, codes, labels, counts, token, nsteps, 15, 1, False)
+            walk = held is _NO_NAM
+            # (the last step leaves the selection pass's results on its way out under the general path's own rule -- wide
+            # sample axis, a block of 150 000 cells or more, _association.py:_DEFER_LAST_CELLS -- so that both paths run the
+            # same kernels)
+            may_hint = walk and covs is None and N_all > 64 and nsteps >= 3 and _rule_cells(data, engine) >= _defer_last_cells()
+            early = (nsteps - 1 if may_hint else nsteps) if walk else 0
+            if early:
+                engine.assoc_begin_part(0, early, nsteps)
+                if early == nsteps:            # the whole walk: whoever analyses this dataset next may keep it (NAM cache)
+                    engine._nam_sig = (sig, engine.nam_epoch, nsteps) if sig is not None else None
+            W_.update(sig=sig, walk=walk, may_hint=may_hint, early=early)
+        finally:
+            engine._defer_graph_check = False
+        _mark('walk queued')
+
+    def validate_and_draw():
+        """-> None (the general path has to take this shape after all: it raises what the reference raises), or
+        (N, whole, fv, y_std, colmap, ks_, ks_arr, kmax, the draw)"""
+        yv = y.values
+        fv = ~np.isnan(yv)
+        if covs is not None:
+            fv &= ~np.isnan(covs.values).any(axis=1)
+        N = int(np.count_nonzero(fv))
+        whole = N == N_all
+        ysel = yv if whole else yv[fv]
+        ks_ = default_ks(N) if ks is None else ks
+        try:
+            ks_arr = np.asarray(ks_)
+            bad_ks = (ks_arr.ndim != 1 or len(ks_arr) < 1 or ks_arr.dtype.kind not in 'iu' or ks_arr.min() < 1
+                      or ks_arr.max() + r >= N)
+        except Exception:                      # noqa: BLE001
+            bad_ks = True
+        if (N < 10 and not allow_low_sample_size) or N < 2 or N > 1024 or bad_ks:
+            return None
+        with np.errstate(all='ignore'):
+            y_std = (ysel - ysel.mean()) / ysel.std()      # numpy ddof=0, _association.py:22
+        if not np.isfinite(y_std).all():
+            return None
+        colmap = None if whole else np.flatnonzero(fv).astype(np.int32)   # NAM.reindex(y.index)[filter]: labels == y.index
+        _mark('validated')
+        # the draw (_stats.py:4-18; one level: batches = ones, _association.py:146-147): replayed from the memo of this seed's
+        # permutations when the process has drawn them before (they do not depend on the phenotype), else on the library's
+        # thread from now on
+        native = seeded_draw(y_std, Nnull, seed)
+        if native is None:
+            return None
+        _mark('draw started')
+        return N, whole, fv, y_std, colmap, ks_, ks_arr, int(ks_arr.max()), native
+
+    # Which goes first: whichever chain is longer -- the draw (~10 ns per normal on the library's threads, plus the sorts)
+    # or the walk (~11 ps per cell, sample and step on one MI355X); the other starts ~0.1 ms later, under it
+    if N_all * Nnull * 1e-2 / _draw_threads(N_all * Nnull) > _rule_cells(data, engine) * N_all * nsteps * 1.1e-5:
+        got = validate_and_draw()
+        if got is None:
+            stats['not_eligible'] += 1
+            return NOT_TAKEN
+        try:
+            queue_walk()
+        except BaseException:
+            got[-1].abandon()
+            raise
+    else:
+        queue_walk()
+        got = validate_and_draw()
+        if got is None:
+            # (the steps queued above are the ones the general path would queue itself: it restarts the walk -- or, with the
+            # NAM cache on, finds this one -- and checks graph and ids on its own)
+            stats['not_eligible'] += 1
+            return NOT_TAKEN
+    N, whole, fv, y_std, colmap, ks_, ks_arr, kmax, native = got
+    sig, walk, may_hint, early = W_['sig'], W_['walk'], W_['may_hint'], W_['early']
+
     fdr_key = f'{key_added}_fdr'
     had_key, had_fdr = key_added in data.obs, fdr_key in data.obs
     previous = data.obs[key_added] if had_key else None
@@ -199,30 +265,12 @@ def association(data, y, sid_name, batches, covs, donorids, ks, key_added, max_f
         if stale:                              # some input is no longer what went to the device: both memos go
             _nam_mod.drop_codes_memo()
             engine.drop_graph()
-        else:
-            confirm_codes()
-            engine.confirm_graph()
         stats[kind] += 1
         return NOT_TAKEN
 
-    _mark('obs looked at')
-    engine._defer_graph_check = 'caller' if optimistic else False
     try:
-        verify = []
-        pend = _nam_mod.take_pending_codes()
-        if pend is not None:
-            verify.append(pend)
-        _prepare_graph(engine, data, 1)
-        pend = engine.take_pending_graph()
-        if pend is not None:
-            verify += pend
-        _mark('graph')
-        sig, held = _walk_start(engine, codes, labels, counts, token, nsteps, 15, 1, False)
-        walk = held is _NO_NAM
-        # (the last step leaves the selection pass's results on its way out under the general path's own rule -- wide sample
-        # axis, a block of 150 000 cells or more, _association.py:_DEFER_LAST_CELLS -- so that both paths run the same kernels)
-        hint = walk and covs is None and whole and N_all > 64 and nsteps >= 3 and _rule_cells(data, engine) >= _defer_last_cells()
-        engine.assoc_begin(nsteps if walk else 0, y_std if hint else None)
+        if walk and early < nsteps:            # the last step, with the phenotype it may need
+            engine.assoc_begin_part(early, nsteps - early, nsteps, y_std if (may_hint and whole) else None)
         if walk:
             engine._nam_sig = (sig, engine.nam_epoch, nsteps) if sig is not None else None
         nam_epoch = engine.nam_epoch
@@ -252,7 +300,7 @@ def association(data, y, sid_name, batches, covs, donorids, ks, key_added, max_f
 
         _mark('storage')
         threads = _copy_threads(n)
-        out = engine.assoc_finish(y_std, Mv, ks_arr, Nnull, native.table, colmap=colmap, Cmat=Cm, W=W, draw_pending=True,
+        out = engine.assoc_finish(y_std, Mv, ks_arr, Nnull, native.table, colmap=colmap, Cmat=Cm, W=W, draw_pending=native.pending,
                                   coef_dst=coef_view if in_place else None, fdr_dst=fdr_view if in_place else None,
                                   copy_threads=threads, native_eig=_nam_mod._EIG_NATIVE, resid_tol=_nam_mod._EIG_RESID,
                                   gap_tol=_nam_mod._EIG_GAP, verify=verify, verify_threads=_verify_threads(verify))

@@ -129,6 +129,10 @@ class NativeDraw:
     the phenotypes are conditioned from -- whose columns 1.. equal the reference's draw bit for bit, numpy's global
     generator left where the reference leaves it."""
 
+    pending = True                               # (the library's thread may still be filling `table`: cna_assoc_finish joins it)
+    _memo_key = None
+    _idx = None
+
     def __init__(self, lib, keep, table):
         self._lib, self._keep, self.table, self._done = lib, keep, table, False
         self._state = None                           # (bit generator, address of its state, the worker's copy)
@@ -157,6 +161,13 @@ class NativeDraw:
         if not self._done:
             rc = self._lib.cna_host_draw_wait()
             self._done = True
+            if rc == 0 and self._memo_key is not None and self._idx is not None and self._keep is not None:
+                # the source rows of this seeded draw and where it leaves the generator: the next phenotype replays them
+                import ctypes as C
+                st = self._keep[4]
+                while len(_draw_memo) >= _DRAW_MEMO_ENTRIES:
+                    _draw_memo.pop(next(iter(_draw_memo)))
+                _draw_memo[self._memo_key] = (self._idx, C.string_at(C.addressof(st), _MT_STATE_BYTES))
             if rc == 0 and self._state is not None:
                 # the worker advanced a COPY of a freshly seeded state; numpy's own generator is seeded and written here,
                 # once, whole, under its lock (np.random.seed(seed) + the draws: where the reference leaves it)
@@ -188,7 +199,74 @@ class NativeDraw:
             pass
 
 
-def native_draw_start(B, Y, num, seed, threads=None, single_level=False):
+_draw_memo = {}          # (seed, samples, permutations) -> (source rows int32[m x num], generator state after the draw)
+DRAW_MEMO = True         # False: every call draws again (bench.py: the timed steps repeat ONE phenotype -- with the memo on they
+                         # would skip the draw the reference makes on every call, as they would skip the walk with the NAM cache)
+_DRAW_MEMO_ENTRIES = 4
+_DRAW_MEMO_BYTES = 64 << 20
+
+
+class ReplayedDraw:
+    """The permuted phenotypes of a seeded one-level draw that this process has made before -- `table[:, 1 + p] =
+    Y[source rows of permutation p]` (conditional_permutation, _stats.py:4-18: the rows depend on seed, sample count and
+    permutation count only) -- with NativeDraw's interface: wait() leaves numpy's generator where the draw leaves it."""
+    flag = None
+    conditioned = False
+    pending = False
+
+    def __init__(self, table, seed, state):
+        self.table, self._seed, self._state = table, seed, state
+
+    def wait(self):
+        if self._state is not None:
+            import ctypes as C
+            st, self._state = self._state, None
+            rs = getattr(np.random.mtrand, '_rand', None)
+            bg = getattr(rs, '_bit_generator', None)
+            np.random.seed(self._seed)
+            with bg.lock:
+                C.memmove(bg.ctypes.state_address, st, _MT_STATE_BYTES)
+        return self.table
+
+    def abandon(self):
+        self._state = None
+
+    def then_condition(self, engine, M):
+        return False
+
+
+def seeded_draw(Y, num, seed, threads=None):
+    """conditional_permutation(ones, Y, num) of a generator seeded with `seed` (one level: batches=None), as an object with
+    .table / .pending / .wait() / .abandon(): replayed from this process's memo of (seed, len(Y), num) when there is one
+    (a gather, ~20 us at 50 x 1000 instead of 0.3-0.7 ms of normals and sorts), else drawn on the library's thread
+    (native_draw_start) with the source rows recorded for the next phenotype.  None: shape not covered."""
+    Y = np.asarray(Y)
+    key = None
+    if (DRAW_MEMO and isinstance(seed, (int, np.integer)) and not isinstance(seed, bool) and Y.dtype == np.float64
+            and len(Y) * num * 4 <= _DRAW_MEMO_BYTES):
+        key = (int(seed), len(Y), int(num))
+        hit = _draw_memo.get(key)
+        if hit is not None:
+            rs = getattr(np.random.mtrand, '_rand', None)
+            bg = getattr(rs, '_bit_generator', None)
+            if bg is not None and type(bg).__name__ == 'MT19937' and _mt_layout_ok(bg, bg.ctypes.state_address):
+                from .. import _ffi
+                Yc = np.ascontiguousarray(Y)
+                table = np.empty((len(Y), num + 1))
+                table[:, 0] = Yc
+                if threads is None:
+                    from .._order import usable_cpus
+                    threads = usable_cpus(8) if len(Y) * num >= _BIG_DRAW else 1
+                if _ffi.load().cna_host_gather_rows(Yc.ctypes.data, hit[0].ctypes.data, len(Y), int(num), table.ctypes.data + 8,
+                                                    num + 1, int(threads)) == 0:
+                    return ReplayedDraw(table, seed, hit[1])
+    d = native_draw_start(None, Y, num, seed, threads=threads, single_level=True, record=key is not None)
+    if d is not None and key is not None:
+        d._memo_key = key
+    return d
+
+
+def native_draw_start(B, Y, num, seed, threads=None, single_level=False, record=False):
     """Start conditional_permutation(B, Y, num) of a generator seeded with `seed` (np.random.seed(seed),
     _association.py:15-16) on the library's host thread; None when the shape is not covered (the caller then draws as
     before).  numpy's global generator is not touched before wait(): the worker runs on a copy of the state a PRIVATE
@@ -231,7 +309,7 @@ def native_draw_start(B, Y, num, seed, threads=None, single_level=False):
         if len(Y) * num >= _BIG_DRAW:
             threads = usable_cpus(16)
         elif len(Y) * num >= _MID_DRAW:        # 200 samples x 1000 permutations: 2.1 ms on one thread, as long as the walk of
-            threads = usable_cpus(4)           # 250 000 cells -- a rank's block of the 2M problem on eight GPUs
+            threads = usable_cpus(8)           # 250 000 cells -- a rank's block of the 2M problem on eight GPUs
         else:
             threads = 1
     addr = bg.ctypes.state_address             # struct mt19937_state { uint32_t key[624]; int pos; }
@@ -250,13 +328,15 @@ def native_draw_start(B, Y, num, seed, threads=None, single_level=False):
     except (TypeError, ValueError):
         return None                            # np.random.seed(seed) in the caller's own draw reports it
     base = C.addressof(st)
-    rc = lib.cna_host_draw_start(base, C.cast(base + 624 * 4, C.POINTER(C.c_int)), Yc.ctypes.data, len(Y), int(num),
-                                 len(off) - 1, off.ctypes.data, members.ctypes.data, table.ctypes.data + 8, num + 1,
-                                 int(threads))
+    idx = np.empty((len(Y), int(num)), dtype=np.int32) if record else None
+    rc = lib.cna_host_draw_start_idx(base, C.cast(base + 624 * 4, C.POINTER(C.c_int)), Yc.ctypes.data, len(Y), int(num),
+                                     len(off) - 1, off.ctypes.data, members.ctypes.data, table.ctypes.data + 8, num + 1,
+                                     int(threads), None if idx is None else idx.ctypes.data)
     if rc != 0:
         return None                            # (nothing drawn, numpy's generator untouched: the caller's own draw seeds it)
-    d = NativeDraw(lib, (Yc, off, members, bg, st), table)
+    d = NativeDraw(lib, (Yc, off, members, bg, st, idx), table)
     d._state = (bg, addr, st, seed)
+    d._idx = idx
     return d
 
 

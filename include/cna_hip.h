@@ -50,6 +50,11 @@ enum {
   CNA_K_NULL_LOCAL, CNA_K_OBS_COUNTS, CNA_K_PERCELL_FDR, CNA_K_PROJECT, CNA_K_TRANSPOSE,
   CNA_K_ALLGATHER, CNA_K_CONDITION, CNA_K_GLOBAL_TEST,
   CNA_K_NAM_STEP_SPARSE,        /* the second walk step on the compressed state (k_nam_step_sparse); CNA_K_NAM_STEP is the dense gather */
+  /* multi-GPU, so that a scaling run explains itself: CNA_K_ALLGATHER ("rccl") times the collectives of the main
+     communicator (all-reduces of column sums / Gram / counts, the all-gather fallback of the state); the two below the
+     exchange of state rows between walk steps (pack + ncclSend/Recv + unpack, on its own stream when it overlaps the step)
+     and how long the main stream then STOOD STILL waiting for it (0 when the step's safe rows hid it) */
+  CNA_K_HALO_EXCHANGE, CNA_K_HALO_WAIT,
   CNA_K_COUNT
 };
 
@@ -446,6 +451,9 @@ typedef struct cna_assoc_out {
   int64_t tail_sums[CNA_ASSOC_MAXT], ranks[CNA_ASSOC_MAXT], num_detected[CNA_ASSOC_MAXT];
 } cna_assoc_out;
 int  cna_assoc_begin(cna_ctx* ctx, int nsteps, const double* y_hint, int n_hint);
+/* the same walk in parts: steps first .. first + count - 1 (0-based) of `total`; y_hint applies to the part that holds the last
+ * step.  A caller queues the steps that need only graph and sample codes before it has validated the phenotype. */
+int  cna_assoc_begin_part(cna_ctx* ctx, int first, int count, int total, const double* y_hint, int n_hint);
 int  cna_assoc_finish(cna_ctx* ctx, const cna_assoc_args* args, cna_assoc_out* out);
 int  cna_assoc_run(cna_ctx* ctx, int nsteps, const double* y_hint, int n_hint, const cna_assoc_args* args, cna_assoc_out* out);
 /* blocks until the request of cna_host_draw_start (and its follow-up) is done WITHOUT collecting it: the caller's
@@ -490,6 +498,14 @@ int  cna_host_argsort_gather(const double* R, int m, int num, const double* y, d
  * touched.  One request at a time per process. */
 int  cna_host_draw_start(uint32_t* key, int* pos, const double* y, int m, int num, int nlev, const int64_t* lev_off,
                          const int64_t* members, double* out, int64_t ld_out, int threads);
+/* cna_host_draw_start that also records WHICH row of y every output was taken from (idx_out: m x num int32 row-major): the
+ * permutations of a seeded draw depend on (seed, m, num, levels) only -- not on y -- so a caller that tests many phenotypes
+ * with one seed (the demo does: demo/demo.ipynb:156,251) replays them with cna_host_gather_rows, out[r][p] = y[idx[r][p]]
+ * (= Y[bix], _stats.py:16-17), instead of drawing and sorting again; numpy's generator is then put where the recorded draw
+ * left it (the caller keeps that state next to idx). */
+int  cna_host_draw_start_idx(uint32_t* key, int* pos, const double* y, int m, int num, int nlev, const int64_t* lev_off,
+                             const int64_t* members, double* out, int64_t ld_out, int threads, int32_t* idx_out);
+int  cna_host_gather_rows(const double* y, const int32_t* idx, int m, int num, double* out, int64_t ld_out, int nthreads);
 /* follow-up of the request under way: the worker conditions the phenotypes itself when the draw is there --
  * cna_condition_phenotypes(ctx, M, table, N, cols) with table = the N x cols matrix [y | permutations] being filled --
  * and stores 1 / -1 (failed) in *flag.  0 accepted, -1 nothing to follow.  cna_host_draw_wait covers it. */

@@ -25,18 +25,25 @@ def stub_measurement(name, steps):
     return dict(name=name, n=n, N=N, k=k, nsteps=nsteps, Nnull=Nnull, n_covs=n_covs, n_batches=n_batches, nnz=int(40.23 * n), wA=4,
                 dt=0.0178123456 * steps, t_cold=0.1084321, i8=(True, 75192, False), t_gen=5.04321, prof=prof, p=0.000999000999000999,
                 t_adopt=0.0828765, n_loc=n, nnz_loc=int(40.23 * n), halo=(123456, 234567), sharded_inputs=True, steps=steps, warmup=5,
-                comm=('rccl', 8), halo_comm=True, kw={}, dev_bytes=20123456789)
+                comm=('rccl', 8), halo_comm=True, kw={}, dev_bytes=20123456789, pinned=not name.endswith('_unpinned'),
+                two_call_path=dict(taken=123456, not_eligible=12345, general=1234, need_pcs=123, stale=12),
+                per_rank={k_: [1234.567 + r for r in range(8)] for k_ in ('allreduce_ms', 'halo_exchange_ms', 'halo_wait_ms', 'host_ms',
+                                                                           'kernel_ms', 'wall_ms')})
 
 
 def build_line(world=1):
-    args = argparse.Namespace(scaling='strong', partition='populations', comm='rccl', details=None)
+    args = argparse.Namespace(scaling='strong', partition='populations', comm='rccl', details=None, force_dist=False)
     m = stub_measurement('C4', 20)
     main_sum = bench.summary(m, world, 20)
     extra = {}
-    for name in ('C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches', 'C4_block8'):
+    for name in ('C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches', 'C4_block8', 'C4_unpinned', 'C4_state_f32', 'C3_state_f32'):
         st = bench.DEFAULT_STEPS[name][0]
         mm = stub_measurement(name, st)
         extra[name] = dict(workload=bench.workload_text(mm, world, args), steps=st, warmup=3, **bench.summary(mm, world, st))
+    if world > 1:                                  # the weak-scaling triple of an N > 1 line, with its own per-rank decomposition
+        mm = stub_measurement('C4_block8', 50)
+        extra['C4_block8_weak'] = dict(workload='w' * 300, steps=50, warmup=10, scaling='weak', cells=250000 * world,
+                                       **bench.summary(mm, world, 50))
     extra['C6_failed'] = dict(error=repr(RuntimeError('x' * 1000)))
     stages = dict(nam=43.71, resid_svd=9.31, global_test=0.64, local_test=16.04, percell_apply=143.21)
     cpu = dict(value=9025360.1, unit='cell*perm/s', cores=16, kind='port', mode='reference-cost', seconds=16.62, host_cpus=256,
@@ -68,7 +75,9 @@ def test_contract_line_is_small_and_loads():
     for key in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert key in d['cpu_baseline'], key
     assert d['cpu_baseline_C2_full']['seconds'] and 'extrapolated' not in d['cpu_baseline_C2_full']
-    assert set(d['other_configs']) == {'C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches', 'C4_block8', 'C6_failed'}
+    assert set(d['other_configs']) == {'C5', 'C3', 'C2', 'C3_default_nsteps', 'C3_covs_batches', 'C4_block8', 'C4_unpinned',
+                                       'C4_state_f32', 'C3_state_f32', 'C6_failed'}
+    assert 'ranks' not in d                        # (one GPU: nothing to decompose across ranks)
     for name, o in d['other_configs'].items():
         if name != 'C6_failed':
             assert o['ms_per_step'] > 0 and o['value'] > 0 and 'frac' in o['roofline']
@@ -93,3 +102,21 @@ def test_line_with_ranks():
     d = json.loads(line)
     assert len(line) < 6144
     assert d['n_gpus'] == 8 and d['config']['comm'] == 'rccl' and d['config']['comm_ranks'] == 8
+    # what a rank's step is made of, [max over ranks, rank 0], so that a scaling curve explains itself
+    for key in ('kernel_ms', 'halo_wait_ms', 'halo_exchange_ms', 'allreduce_ms', 'host_ms', 'wall_ms'):
+        assert len(d['ranks'][key]) == 2 and d['ranks'][key][0] >= d['ranks'][key][1] > 0, key
+    assert d['ranks']['halo_rows_out_in_rank0'] == [123456, 234567] and len(d['ranks']['halo_mb_per_exchange_out_in_rank0']) == 2
+    assert 'rccl_transport' in d
+    w = d['other_configs']['C4_block8_weak']
+    assert w['scaling'] == 'weak' and w['cells'] == 2000000 and w['ranks']['kernel_ms'][0] > 0 and w['ms_per_step'] > 0
+
+
+def test_transport_lines_of_an_rccl_log_are_counted(tmp_path, monkeypatch):
+    log = tmp_path / 'nccl.log'
+    log.write_text('host:1:1 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC\n'
+                   'host:1:1 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC\n'
+                   'host:1:1 [0] NCCL INFO Channel 00/0 : 1[1] -> 0[0] [receive] via NET/Socket/0\n'
+                   'host:1:1 [0] NCCL INFO Channel 00 : 0[0] -> 1[1] via SHM/direct/direct\n'
+                   'host:1:1 [0] NCCL INFO comm 0x1 rank 0 nranks 2 - Init COMPLETE\n')
+    monkeypatch.setenv('CNA_BENCH_NCCL_LOG', str(log))
+    assert bench.rccl_transport(0) == {'P2P/IPC': 2, 'NET': 1, 'SHM/direct': 1}

@@ -253,6 +253,40 @@ def test_an_exception_leaves_no_trace(eng, fast, monkeypatch):
         assert cna.tl.association(data, meta['y'], 'id', **kw) == p
 
 
+def test_errors_inside_and_after_the_library_call(eng, fast, monkeypatch):
+    """The reference's own late errors through the two-call path -- every p-value NaN (no degrees of freedom left:
+    np.nanargmin's ValueError) -- and a failure injected right after cna_assoc_finish: data.obs as it was, nothing pending
+    on the engine, the next call returns what it returned before."""
+    import cna_amd as cna
+    data, meta = _synthetic(12000, 24, seed=15)
+    kw = dict(nsteps=3, Nnull=100, seed=8, engine=eng)
+    fast.ENABLED = True
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        p0 = cna.tl.association(data, meta['y'], 'id', **kw)
+        coef, fdr = data.obs['coef'].values.copy(), data.obs['coef_fdr'].values.copy()
+        before = dict(fast.stats)
+        with pytest.raises(ValueError, match='All-NaN slice'):
+            cna.tl.association(data, meta['y'], 'id', ks=[23], **kw)
+        np.testing.assert_array_equal(data.obs['coef'].values, coef)
+        np.testing.assert_array_equal(data.obs['coef_fdr'].values, fdr)
+        real = eng.assoc_finish
+
+        def boom(*a, **k):
+            real(*a, **k)
+            raise FloatingPointError('injected')
+        monkeypatch.setattr(eng, 'assoc_finish', boom)
+        with pytest.raises(FloatingPointError):
+            cna.tl.association(data, meta['y'], 'id', **kw)
+        monkeypatch.setattr(eng, 'assoc_finish', real)
+        np.testing.assert_array_equal(data.obs['coef'].values, coef)
+        np.testing.assert_array_equal(data.obs['coef_fdr'].values, fdr)
+        assert cna.tl.association(data, meta['y'], 'id', **kw) == p0
+        assert fast.stats['taken'] == before['taken'] + 1
+        fast.ENABLED = False
+        assert cna.tl.association(data, meta['y'], 'id', **kw) == p0
+
+
 def test_nam_cache_skips_the_walk(fast):
     """engine.reuse_nam (the default for users): a second phenotype on the resident dataset queues no walk step."""
     import cna_amd as cna

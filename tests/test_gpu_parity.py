@@ -24,6 +24,18 @@ def eng():
     return get_engine()
 
 
+@pytest.fixture()
+def general_path():
+    """Tests that reach into the general path of tools/_association.py (failures injected into the engine calls it makes,
+    its helper-thread schedules) on REPEATED calls of a shaped analysis: those calls would otherwise go through
+    cna_assoc_begin / cna_assoc_finish (tools/_fast.py; its own error paths: tests/test_gpu_fast.py)."""
+    from cna_amd.tools import _fast
+    keep = _fast.ENABLED
+    _fast.ENABLED = False
+    yield
+    _fast.ENABLED = keep
+
+
 @pytest.fixture(scope='module')
 def orc():
     from oracle import cna_oracle
@@ -846,7 +858,7 @@ def test_ordered_fetch_on_device_equals_host_reorder(monkeypatch):
         np.testing.assert_array_equal(a, b)
 
 
-def test_fdr_column_copied_by_the_helper_thread_equals_the_late_copy(eng, monkeypatch):
+def test_fdr_column_copied_by_the_helper_thread_equals_the_late_copy(eng, monkeypatch, general_path):
     """Large-input schedule: the FDR column follows the local null on the device and the helper thread copies it
     into data.obs[key + '_fdr']'s storage while the main thread is in the SVD (cna_percell_fdr_copy_early).  Same
     column, bit for bit, as with the copy at the end of the call; and the early path is really the one taken."""
@@ -911,7 +923,7 @@ def test_late_exception_leaves_obs_untouched(eng, monkeypatch, big_path):
 
 
 @pytest.mark.parametrize('big_path', [False, True])
-def test_failed_test_leaves_obs_untouched(eng, monkeypatch, big_path):
+def test_failed_test_leaves_obs_untouched(eng, monkeypatch, big_path, general_path):
     """(big_path: the schedule of large inputs -- coefficient column under the Gram kernels, the FDR column's
     storage made early and filled in place at the end -- forced on this small dataset.)
     data.obs[key_added] is written early (between the two halves of the F-test call, under the
@@ -1795,7 +1807,7 @@ def test_small_block_many_samples_takes_the_per_cell_pass_under_lapack(eng, monk
     assert cna.tl.association(data, meta['y'], 'id', engine=eng, **kw) == a[0]
 
 
-def test_error_after_a_fused_null_launch_leaves_the_engine_usable(eng, monkeypatch):
+def test_error_after_a_fused_null_launch_leaves_the_engine_usable(eng, monkeypatch, general_path):
     """The fused selection call may launch the local null itself (the draw thread's flag says the phenotypes are on the
     device).  An analysis that raises AFTER that launch and before its fetch -- `ks` too large for the cohort
     (_association.py:29-33), a draw that fails, a conditioning that refuses -- must not leave the pass pending: the next

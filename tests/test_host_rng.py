@@ -232,3 +232,37 @@ def test_native_draw_in_a_forked_child():
     got = os.read(r, 1)
     os.waitpid(pid, 0)
     assert got == b'1'
+
+
+def test_seeded_draw_memo_replays_the_reference_draw():
+    """tools/_stats.py:seeded_draw: the permutations of a seeded one-level draw depend on (seed, samples, permutations) only.
+    The first draw records which row of y every output is (cna_host_draw_start_idx); later phenotypes with that seed are a
+    gather (cna_host_gather_rows).  Values and numpy's generator state equal conditional_permutation's, bit for bit, for
+    the draw that fills the memo and for every replay; an abandoned draw leaves the generator alone."""
+    from cna_amd.tools import _stats
+    from cna_amd.tools._stats import seeded_draw, conditional_permutation
+    _stats._draw_memo.clear()
+    for m, num, seed in ((50, 1000, 7), (24, 100, 0), (200, 1000, 123), (13, 20, 5)):
+        ys = [np.random.RandomState(s).randn(m) for s in (1, 2, 3)]
+        kinds = []
+        for y in ys:
+            y = (y - y.mean()) / y.std()
+            np.random.seed(seed)
+            want = conditional_permutation(np.ones(m), y, num, clean=True)
+            state = np.random.get_state()
+            np.random.seed(4242)                       # whatever the generator holds before
+            d = seeded_draw(y, num, seed)
+            kinds.append(type(d).__name__)
+            table = d.wait()
+            assert np.array_equal(table[:, 0], y) and np.array_equal(table[:, 1:], want)
+            for a, b in zip(np.random.get_state(), state):
+                assert np.array_equal(np.asarray(a), np.asarray(b))
+        assert kinds == ['NativeDraw', 'ReplayedDraw', 'ReplayedDraw'], kinds
+        np.random.seed(99)
+        before = np.random.get_state()
+        seeded_draw(ys[0], num, seed).abandon()
+        for a, b in zip(np.random.get_state(), before):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+    assert len(_stats._draw_memo) <= _stats._DRAW_MEMO_ENTRIES
+    # not a plain int seed, or an odd permutation count: no memo, the caller's usual draw
+    assert seeded_draw(np.zeros(10), 101, 3) is None

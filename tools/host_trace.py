@@ -12,6 +12,8 @@ n, N = int(sys.argv[1]) if len(sys.argv) > 1 else 200000, int(sys.argv[2]) if le
 ncov = int(os.environ.get('TRACE_COVS', '0'))
 nbat = int(os.environ.get('TRACE_BATCHES', '0'))
 data, meta = synth.make_dataset(n, N, k=30, seed=0, n_covs=ncov, n_batches=nbat)
+from cna_amd.tools import _stats as _S
+_S.DRAW_MEMO = bool(os.environ.get('TRACE_DRAW_MEMO'))
 eng = get_engine(); eng.reuse_nam = False; kw = dict(nsteps=3, Nnull=int(os.environ.get('TRACE_NNULL', '1000')), seed=0)
 if ncov: kw['covs'] = meta['covs']
 if nbat: kw['batches'] = meta['batches']

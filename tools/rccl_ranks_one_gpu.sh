@@ -11,7 +11,7 @@ port=$((29600 + RANDOM % 300))
 pids=()
 for ((r = 0; r < n; r++)); do
   RANK=$r LOCAL_RANK=0 WORLD_SIZE=$n LOCAL_WORLD_SIZE=$n MASTER_ADDR=127.0.0.1 MASTER_PORT=$port \
-  NCCL_HOSTID=cna_one_gpu_host_$r NCCL_SOCKET_IFNAME=lo NCCL_IB_DISABLE=1 NCCL_DEBUG=${NCCL_DEBUG:-WARN} \
+  NCCL_HOSTID=cna_one_gpu_host_$r NCCL_SOCKET_IFNAME=lo NCCL_IB_DISABLE=1 \
   HSA_ENABLE_IPC_MODE_LEGACY=0 CNA_COMM_TIMEOUT=${CNA_COMM_TIMEOUT:-60} \
   timeout ${RANK_TIMEOUT:-300} python bench.py --gpus $n "$@" > gpurun_out/rccl${n}_r$r.log 2>&1 &
   pids+=($!)
