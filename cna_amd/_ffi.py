@@ -62,6 +62,8 @@ SIGNATURES = {
     'cna_resid_apply': (C.c_int, [c_ctx, C.c_void_p, C.c_int]),
     'cna_resid_lowrank': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, c_f64p]),
     'cna_resid_lowrank_bk': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, c_f64p, C.c_void_p, C.c_int, c_f64p]),
+    'cna_select_resid_bk': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, c_f64p, C.c_void_p, C.c_int, c_f64p,
+                                      c_i64p, c_i64p, C.POINTER(C.c_int)]),
     'cna_standardize': (C.c_int, [c_ctx, C.c_int]),
     'cna_gram': (C.c_int, [c_ctx, C.c_void_p]),
     'cna_gram_launch': (C.c_int, [c_ctx]),

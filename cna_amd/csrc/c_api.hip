@@ -1775,6 +1775,108 @@ int cna_resid_lowrank_bk(cna_ctx* c, const double* C, const double* W, int r, co
   return 0;
 }
 
+// Selection + QC + the first ridge in ONE pass over the NAM (round 6).  For the demo's call shape -- covariates AND batches
+// (demo/demo.ipynb:149) with every cell and every sample kept in place and at most seven batches -- the three passes
+// cna_batch_kurtosis(CNA_MAT_NAM) + cna_stat_qc, cna_select_checked and cna_resid_lowrank_bk read the NAM / X three times
+// and write X twice; here the rows go NAM -> registers -> X once (rows16.hip:k_rowpass16<.., QC>), and the answers of all
+// three come back with one wait:
+//   *n_qc_failed   rows whose batch kurtosis is NaN (with <= 7 batches the only way to fail `kurtosis < max(6, 2 median)`,
+//                  _nam.py:94-96: the kurtosis of so few batch means is below 6)
+//   *n_zero        rows that are constant over the samples (_association.py:182)
+//   *median_out    np.median of the batch kurtosis of the residualised rows (_nam.py:150); *max_abs_out as cna_resid_lowrank_bk
+// All of n_qc_failed == 0, n_zero == 0, median <= 6: X is final (what the three calls leave).  Anything else: the caller takes
+// the three calls (the NAM is untouched).  *done = 0: shape not covered, nothing was queued.
+int cna_select_resid_bk(cna_ctx* c, const double* C, const double* W, int r, const double* y, double* max_abs_out,
+                        const int32_t* batch_codes, int n_batches, double* median_out, int64_t* n_qc_failed, int64_t* n_zero,
+                        int* done) {
+  CHECK_CTX(c);
+  AUTO_FINISH(c);
+  if (!done || !median_out || !n_qc_failed || !n_zero || !y || !batch_codes) CNA_FAIL(CNA_EINVAL, "cna_select_resid_bk: null argument");
+  *done = 0;
+  if (!c->nam_valid && !c->nam_lazy) CNA_FAIL(CNA_ESTATE, "NAM not available");
+  const int Nx = c->N;
+  if (r < 1 || r > 16 || !C || !W || n_batches < 2 || n_batches > 7 || Nx < 2 || Nx > 128 || c->n_local < 1) return 0;
+  for (int s = 0; s < Nx; ++s)
+    if (batch_codes[s] < 0 || batch_codes[s] >= n_batches) return 0;      // (a sample of no batch: the general sequence)
+  if (c->n_local > c->n_pad) return 0;
+  CNA_TRY(need_nam(c));
+  CNA_TRY(gram_pre_settle(c));
+  std::vector<int32_t> order(Nx), boff(n_batches + 1, 0);
+  for (int s = 0; s < Nx; ++s) boff[batch_codes[s] + 1]++;
+  for (int b = 0; b < n_batches; ++b) boff[b + 1] += boff[b];
+  std::vector<int32_t> cur(boff.begin(), boff.end() - 1);
+  for (int s = 0; s < Nx; ++s) order[cur[batch_codes[s]]++] = s;
+  c->byp_valid = false; c->gram_pre = false; c->x_ident = false; c->xq_valid = false;
+  c->nx = c->n_local;
+  c->Nx = Nx;
+  c->ldx = x_ld(Nx);
+  c->keep_idx = nullptr;
+  void* xp = c->X;
+  CNA_TRY(dev_reserve(c, &xp, &c->x_cap, (int64_t)sizeof(double) * std::max<int64_t>(c->nx, 1) * c->ldx));
+  c->X = (double*)xp;
+  void* np = c->ncorrs;
+  CNA_TRY(dev_reserve(c, &np, &c->ncorrs_cap, 8 * std::max<int64_t>(c->nx, 1)));
+  c->ncorrs = (double*)np;
+  const int64_t rn = 8 * (int64_t)r * Nx;
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({rn, rn, 8 * (int64_t)Nx, 8 * 2049, 4 * (int64_t)Nx, 4 * (n_batches + 1), 16})));
+  Carver cv(c->scratch);
+  double* Wd = cv.take<double>((int64_t)r * Nx);
+  double* Ctd = cv.take<double>((int64_t)r * Nx);
+  double* yd = cv.take<double>(Nx);
+  unsigned long long* mb = cv.take<unsigned long long>(2049);
+  int32_t* order_dev = cv.take<int32_t>(Nx);
+  int32_t* boff_dev = cv.take<int32_t>(n_batches + 1);
+  unsigned long long* counters = cv.take<unsigned long long>(2);
+  std::vector<double> Ct((size_t)r * Nx, 0.0);
+  for (int i = 0; i < Nx; ++i)
+    for (int k = 0; k < r; ++k) Ct[(size_t)k * Nx + i] = C[(size_t)i * r + k];
+  HIP_TRY(hipMemcpyAsync(Wd, W, 8 * (size_t)r * Nx, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(Ctd, Ct.data(), 8 * (size_t)r * Nx, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(yd, y, 8 * Nx, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(order_dev, order.data(), 4 * (size_t)Nx, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(boff_dev, boff.data(), 4 * (n_batches + 1), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(counters, 0, 16, c->stream));
+  int rc;
+  {
+    ProfScope ps(c, CNA_K_RESID);
+    rc = launch_rowpass16(c, c->nam, c->ld, c->X, c->ldx, c->nx, Nx, Wd, Ctd, r, 1, 1, 1, yd, mb, order_dev, boff_dev, n_batches,
+                          c->stat, counters);
+  }
+  if (rc < 0) return rc;
+  if (rc == 0) {                                   // (CNA_ROWPASS16=0 or a shape the sixteen-row pass does not take)
+    HIP_TRY(hipStreamSynchronize(c->stream));      // (the uploads read locals)
+    c->x_valid = false;
+    return 0;
+  }
+  // every cell is a row of X, also where the NAM has padding columns beyond ldx
+  c->stat_space = CNA_MAT_X;
+  CNA_TRY(comm_allreduce_f64_max(c, (double*)mb, 1));
+  CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)counters, 2));
+  const bool sharded = c->nranks > 1 || comm_active(c);
+  unsigned long long* hist = nullptr;
+  CNA_TRY(ensure_auto_state(c, &hist));
+  const size_t sb = (auto_state_bytes() + 255) & ~(size_t)255;
+  HIP_TRY(hipMemsetAsync(c->auto_state, 0, sb, c->stream));
+  CNA_TRY(launch_auto_median(c, c->stat, c->nx, c->auto_state, hist, -1, 0, sharded));
+  double m = 0.0, med = 0.0;
+  unsigned long long cnt[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(&m, mb, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(&med, (const char*)c->auto_state + auto_state_result_offset(), 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(cnt, counters, 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));        // (Ct, order, boff are locals)
+  if (max_abs_out) *max_abs_out = m;
+  *median_out = med;
+  *n_qc_failed = (int64_t)cnt[0];
+  *n_zero = (int64_t)cnt[1];
+  c->x_valid = true;
+  c->x_from_nam = true;
+  c->ncorrs_valid = true;
+  c->coef_early = false;
+  c->fdr_inline = false;
+  *done = 1;
+  return 0;
+}
+
 int cna_standardize(cna_ctx* c, int center) {
   CHECK_CTX(c);
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");

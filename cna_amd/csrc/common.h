@@ -369,7 +369,8 @@ int launch_fdr_table(cna_ctx* c, const int64_t* sums, const int64_t* ranks, int 
 // rows16.hip: sixteen rows per wave, projector on the matrix cores; 1 = queued, 0 = not eligible
 int launch_rowpass16(cna_ctx* c, const double* src, int lds, double* dst, int ldd, int64_t nrows, int N, const double* W_dev,
                      const double* Ct_dev, int r, int center, int standardize, int write_out, const double* y_dev,
-                     unsigned long long* maxword, const int32_t* bk_order, const int32_t* bk_boff, int nb, double* bk_out);
+                     unsigned long long* maxword, const int32_t* bk_order, const int32_t* bk_boff, int nb, double* bk_out,
+                     unsigned long long* qc_counters = nullptr);   // non-null: src is the NAM; [0] += rows with NaN batch kurtosis, [1] += constant rows
 int launch_percell_bins(cna_ctx* c, hipStream_t st, const double* coef_local, const double* thr_dev, int T, double thr0,
                         double inv_step, unsigned short* bins);
 extern "C" int cna_host_expand_u16(double* dst, const uint16_t* bins, int64_t n, const double* runmin, int T, int nthreads);

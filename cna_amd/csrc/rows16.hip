@@ -35,7 +35,8 @@ __device__ __forceinline__ double r16_sum(double v) {
 // inv_cnt[16] = 1 / samples of batch b | bcode[NP] (int32: batch of a column, -1 none)
 __global__ __launch_bounds__(256) void k_rowpass16_prep(const double* __restrict__ W, const double* __restrict__ Ctg, int r,
                                                         int N, int NP, const int32_t* __restrict__ order,
-                                                        const int32_t* __restrict__ boff, int nb, double* __restrict__ prep) {
+                                                        const int32_t* __restrict__ boff, int nb, double* __restrict__ prep,
+                                                        int qc_cols) {
   double* B1 = prep;
   double* Ct = prep + (size_t)NP * 16;
   double* sw = Ct + (size_t)16 * NP;
@@ -62,14 +63,70 @@ __global__ __launch_bounds__(256) void k_rowpass16_prep(const double* __restrict
   if (order)
     for (int b = 0; b < nb; ++b)
       for (int m = boff[b] + threadIdx.x; m < boff[b + 1]; m += 256) bcode[order[m]] = b;
+  if (qc_cols && order) {
+    // QC mode: columns r .. r + nb - 1 of the first product's B operand are the batch indicators over the batch sizes, so
+    // that P = X.[W^T | E] delivers the batch means of the RAW rows with the projections, in the same matrix instructions
+    __syncthreads();
+    for (int b = 0; b < nb; ++b) {
+      const double w = 1.0 / (double)(boff[b + 1] - boff[b]);
+      for (int m = boff[b] + threadIdx.x; m < boff[b + 1]; m += 256) B1[(size_t)order[m] * 16 + r + b] = w;
+    }
+  }
 }
 
+__device__ __forceinline__ double r16_max(double v) {
+  v = fmax(v, dpp_partner(v, 0));
+  v = fmax(v, dpp_partner(v, 1));
+  v = fmax(v, dpp_partner(v, 2));
+  return fmax(v, dpp_partner(v, 3));
+}
+
+// batch kurtosis of row i of the register tile as it stands (_nam.py:78-82: Fisher kurtosis of the batch means, + 3)
 template <int NT>
+__device__ __forceinline__ double row_batch_kurtosis(const double (&xd)[NT][4], int i, const int (&code)[NT], int nb,
+                                                     const double* __restrict__ pinv) {
+  double bm[16];
+  double bsum = 0.0;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    bm[b] = 0.0;
+    if (b < nb) {
+      double part = 0.0;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) part += code[t] == b ? xd[t][i] : 0.0;
+      bm[b] = r16_sum(part) * pinv[b];
+      bsum += bm[b];
+    }
+  }
+  const double nbd = (double)nb;
+  const double bmean = bsum / nbd;
+  double d2s = 0.0, d4s = 0.0;
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    if (b < nb) {
+      const double d = bm[b] - bmean;
+      const double d2 = d * d;
+      d2s += d2;
+      d4s += d2 * d2;
+    }
+  }
+  const double m2 = d2s / nbd, m4 = d4s / nbd;
+  const double em = 2.220446049250313e-16 * bmean;
+  const double kk = (m2 <= em * em) ? __builtin_nan("") : m4 / (m2 * m2);
+  return (kk - 3.0) + 3.0;
+}
+
+// QC: the pass starts from the NAM itself (src) and also answers what the two passes in front of it would have been asked
+// (round 6: selection + QC + first ridge in ONE pass): counters[0] += rows whose batch kurtosis BEFORE anything
+// is done to them is NaN (the only way a row can fail _qc_nam's `kurtosis < max(6, 2 median)` with at most seven batches,
+// _nam.py:94-96: the kurtosis of so few batch means cannot reach 6), counters[1] += rows that are constant over the samples
+// the way pandas' std sees it (_association.py:182; rows.hip:k_select_zv's test).
+template <int NT, bool QC = false>
 __global__ __launch_bounds__(256) void k_rowpass16(const double* __restrict__ src, int lds_, double* __restrict__ dst, int ldd,
                                                    int64_t nrows, int N, const double* __restrict__ prep, int r, int center,
                                                    int standardize, int write_out, const double* __restrict__ y,
                                                    double* __restrict__ nc, unsigned long long* __restrict__ maxword, int nb,
-                                                   double* __restrict__ bk_out) {
+                                                   double* __restrict__ bk_out, unsigned long long* __restrict__ counters = nullptr) {
   constexpr int NP = 16 * NT;
   extern __shared__ double sm[];
   double* B1 = sm;                               // [NP][16]
@@ -111,6 +168,25 @@ __global__ __launch_bounds__(256) void k_rowpass16(const double* __restrict__ sr
         const int col = 16 * t + n;
         xd[t][i] = (row < nrows && col < N) ? src[row * lds_ + col] : 0.0;
       }
+    bool flat4[4] = {false, false, false, false};
+    if (QC) {                                                // constant rows, tested on the values as they were loaded
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        double hi = -1.7976931348623157e308, lo = 1.7976931348623157e308;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+          if (16 * t + n < N) { hi = fmax(hi, xd[t][i]); lo = fmin(lo, xd[t][i]); }
+        hi = r16_max(hi);
+        lo = -r16_max(-lo);
+        bool flat = hi == lo;
+        if (flat) {                                          // pandas nanvar: zero iff sum / N == x (the sum taken in order)
+          double s = 0.0;
+          for (int cidx = 0; cidx < N; ++cidx) s += hi;
+          flat = s / nn - hi == 0.0;
+        }
+        flat4[i] = flat;
+      }
+    }
     double mean[4] = {0.0, 0.0, 0.0, 0.0};
     if (center) {
 #pragma unroll
@@ -133,6 +209,29 @@ __global__ __launch_bounds__(256) void k_rowpass16(const double* __restrict__ sr
         const int col = 4 * s + g;
         const double a = (arow < nrows && col < N) ? ap[col] : 0.0;
         P = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B1[col * 16 + n], P, 0, 0, 0);
+      }
+      if (QC) {
+        // lanes r <= n < r + nb of a row's sixteen hold its RAW batch means (P = X.[W^T | E], see k_rowpass16_prep): the
+        // row fails the QC iff their kurtosis is NaN -- their variance vanishes against their mean (row_batch_kurtosis'
+        // test) -- and it has zero variance iff it is constant (largest == smallest entry, and pandas' own test)
+        unsigned bad_qc = 0, flat_rows = 0;
+        const bool mine = n >= r && n < r + nb;
+        const double nbd = (double)nb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int64_t row = row0 + g + 4 * i;
+          const double bmean = r16_sum(mine ? P[i] : 0.0) / nbd;
+          const double d = mine ? P[i] - bmean : 0.0;
+          const double m2 = r16_sum(d * d) / nbd;
+          const double em = 2.220446049250313e-16 * bmean;
+          const bool nan_k = m2 <= em * em;
+          if (n == 0 && row < nrows) {
+            bad_qc += nan_k ? 1u : 0u;
+            flat_rows += flat4[i] ? 1u : 0u;
+          }
+        }
+        if (bad_qc) atomicAdd(counters, (unsigned long long)bad_qc);
+        if (flat_rows) atomicAdd(counters + 1, (unsigned long long)flat_rows);
       }
       // lane (g, n) holds p_n of rows g + 4 i: centre, negate, and turn the 16 x 16 block into the A layout through LDS
 #pragma unroll
@@ -157,36 +256,8 @@ __global__ __launch_bounds__(256) void k_rowpass16(const double* __restrict__ sr
     for (int i = 0; i < 4; ++i) {
       const int64_t row = row0 + g + 4 * i;
       if (bk_out) {
-        // batch kurtosis of the row as it stands (_nam.py:78-82: Fisher kurtosis of the batch means, written + 3)
-        double bm[16];
-        double bsum = 0.0;
-#pragma unroll
-        for (int b = 0; b < 16; ++b) {
-          bm[b] = 0.0;
-          if (b < nb) {
-            double part = 0.0;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) part += code[t] == b ? xd[t][i] : 0.0;
-            bm[b] = r16_sum(part) * pinv[b];
-            bsum += bm[b];
-          }
-        }
-        const double nbd = (double)nb;
-        const double bmean = bsum / nbd;
-        double d2s = 0.0, d4s = 0.0;
-#pragma unroll
-        for (int b = 0; b < 16; ++b) {
-          if (b < nb) {
-            const double d = bm[b] - bmean;
-            const double d2 = d * d;
-            d2s += d2;
-            d4s += d2 * d2;
-          }
-        }
-        const double m2 = d2s / nbd, m4 = d4s / nbd;
-        const double em = 2.220446049250313e-16 * bmean;
-        const double kk = (m2 <= em * em) ? __builtin_nan("") : m4 / (m2 * m2);
-        if (n == 0 && row < nrows) bk_out[row] = (kk - 3.0) + 3.0;
+        const double kk3 = row_batch_kurtosis<NT>(xd, i, code, nb, pinv);
+        if (n == 0 && row < nrows) bk_out[row] = kk3;
       }
       if (!write_out && !y) continue;
       double sd = 1.0;
@@ -242,10 +313,14 @@ __global__ __launch_bounds__(256) void k_rowpass16(const double* __restrict__ sr
 // into c->ncorrs and the bits of max |coefficient| into maxword (zeroed here).
 int launch_rowpass16(cna_ctx* c, const double* src, int lds, double* dst, int ldd, int64_t nrows, int N, const double* W_dev,
                      const double* Ct_dev, int r, int center, int standardize, int write_out, const double* y_dev,
-                     unsigned long long* maxword, const int32_t* bk_order, const int32_t* bk_boff, int nb, double* bk_out) {
+                     unsigned long long* maxword, const int32_t* bk_order, const int32_t* bk_boff, int nb, double* bk_out,
+                     unsigned long long* qc_counters) {
   const char* sw = getenv("CNA_ROWPASS16");
   if (sw && atoi(sw) == 0) return 0;
   if (N < 2 || N > 256 || r < 0 || r > 16 || (r > 0 && N > 128) || (bk_out && (nb < 1 || nb > 16))) return 0;
+  // (the QC shortcut holds for at most seven batches -- see k_rowpass16 -- and its batch means ride in the spare columns of
+  // the first product's sixteen)
+  if (qc_counters && (!bk_out || nb > 7 || r < 1 || r + nb > 16)) return 0;
   const int NT0 = (N + 15) / 16;
   const int NT = NT0 <= 8 ? NT0 : (NT0 <= 10 ? 10 : (NT0 <= 13 ? 13 : 16));      // the instantiation that takes it
   const int NP = 16 * NT;
@@ -254,12 +329,17 @@ int launch_rowpass16(cna_ctx* c, const double* src, int lds, double* dst, int ld
   if (y_dev) HIP_TRY(hipMemsetAsync(maxword, 0, sizeof(unsigned long long), c->stream));
   if (nrows == 0) return 1;
   hipLaunchKernelGGL(k_rowpass16_prep, dim3(1), dim3(256), 0, c->stream, W_dev, Ct_dev, r, N, NP, bk_out ? bk_order : nullptr,
-                     bk_boff, bk_out ? nb : 0, (double*)c->rp16_buf);
+                     bk_boff, bk_out ? nb : 0, (double*)c->rp16_buf, qc_counters ? 1 : 0);
   const size_t smem = sizeof(double) * ((size_t)NP * 32 + 4 * 16 * 17);
   const int64_t want = (nrows + 63) / 64;
   const unsigned grid = (unsigned)(want < 2048 ? want : 2048);
-#define RP(T) { static bool once = false; if (smem > 48 * 1024 && !once) { HIP_TRY(hipFuncSetAttribute((const void*)k_rowpass16<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); once = true; } \
-    hipLaunchKernelGGL(k_rowpass16<T>, dim3(grid), dim3(256), smem, c->stream, src, lds, dst, ldd, nrows, N, (const double*)c->rp16_buf, r, center, standardize, write_out, y_dev, c->ncorrs, maxword, nb, bk_out); }
+#define RP(T) { static bool once = false, once_qc = false; \
+    if (qc_counters) { \
+      if (smem > 48 * 1024 && !once_qc) { HIP_TRY(hipFuncSetAttribute((const void*)k_rowpass16<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); once_qc = true; } \
+      hipLaunchKernelGGL((k_rowpass16<T, true>), dim3(grid), dim3(256), smem, c->stream, src, lds, dst, ldd, nrows, N, (const double*)c->rp16_buf, r, center, standardize, write_out, y_dev, c->ncorrs, maxword, nb, bk_out, qc_counters); \
+    } else { \
+      if (smem > 48 * 1024 && !once) { HIP_TRY(hipFuncSetAttribute((const void*)k_rowpass16<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024)); once = true; } \
+      hipLaunchKernelGGL((k_rowpass16<T, false>), dim3(grid), dim3(256), smem, c->stream, src, lds, dst, ldd, nrows, N, (const double*)c->rp16_buf, r, center, standardize, write_out, y_dev, c->ncorrs, maxword, nb, bk_out, (unsigned long long*)nullptr); } }
   switch (NT) {
     case 1: RP(1) break;
     case 2: RP(2) break;

@@ -653,6 +653,25 @@ class Engine(_order.CellOrder):
                                             C.byref(med)), 'cna_resid_lowrank_bk')
         return m.value, med.value
 
+    def select_resid_bk(self, Cmat, W, y, batch_codes, n_batches):
+        """Selection (every cell, samples in place) + QC + the first ridge in ONE pass over the NAM (cna_select_resid_bk).
+        -> None (shape not covered, nothing queued) or (rows failing the QC, rows of zero variance, max |ncorrs|, median
+        batch kurtosis of the residualised rows); X is final when the first two are 0 and the median is <= 6."""
+        Cmat, W, yv = _f64(Cmat), _f64(W), _f64(y)
+        bc = np.ascontiguousarray(batch_codes, dtype=np.int32)
+        if Cmat.ndim != 2 or W.shape != (Cmat.shape[1], Cmat.shape[0]) or len(yv) != Cmat.shape[0] or len(bc) != len(yv):
+            return None
+        m, med = C.c_double(0.0), C.c_double(0.0)
+        nq, nz, done = C.c_int64(0), C.c_int64(0), C.c_int(0)
+        self.null_local_discard()
+        check(self.lib.cna_select_resid_bk(self.h, ptr(Cmat), ptr(W), int(Cmat.shape[1]), ptr(yv), C.byref(m), ptr(bc), int(n_batches),
+                                           C.byref(med), C.byref(nq), C.byref(nz), C.byref(done)), 'cna_select_resid_bk')
+        if not done.value:
+            return None
+        self._selection(None)
+        self.x_epoch += 1
+        return nq.value, nz.value, m.value, med.value
+
     def standardize(self, center=False):
         check(self.lib.cna_standardize(self.h, int(bool(center))), 'cna_standardize')
 

@@ -572,6 +572,31 @@ def compute_nam_and_reindex(engine, data, y, sid_name, batches, covs, donorids, 
             engine.clear_resid_factors()
             hint = y_std
         finish_walk(hint)
+    # Covariates AND batches (the demo's call, demo/demo.ipynb:149) with every sample of the data analysed in place and at
+    # most seven batches: QC, selection and the first ridge -- three passes over the cells -- as ONE
+    # (engine.select_resid_bk).  It answers what the three would have answered; anything but "no cell fails the QC, no
+    # cell of zero variance, the schedule ends at the first ridge" (always so on real data with so few batches) and
+    # the three passes run as before, from the untouched NAM.
+    onepass = None
+    if (plan is not None and plan.kind == 'ridge' and not show_progress and getattr(engine, 'select_resid_bk', None) is not None
+            and y_std is not None and len(y_std) == len(colmap) == len(labels) and not absent_selected
+            and np.array_equal(colmap, np.arange(len(colmap))) and getattr(plan, 'first_ridge', None) is not None
+            and len(plan.ridges) and 2 <= plan.nb <= 7 and _lowrank_ok(engine, plan)
+            and os.environ.get('CNA_RIDGE_ONEPASS', '1') not in ('0', 'off', 'no')):
+        from ._nam import _batch_codes
+        qc_codes, qc_nb = _batch_codes(batches_qc, labels)
+        held = getattr(engine, '_sample_counts', None)
+        if (qc_nb == plan.nb and (qc_codes >= 0).all() and np.array_equal(qc_codes, plan.bcodes)
+                and held is not None and held[1] is labels and (np.asarray(held[0]) > 0).all()):
+            got = engine.select_resid_bk(np.asarray(plan.C.values, dtype=np.float64), np.asarray(plan.first_ridge[0], dtype=np.float64),
+                                         y_std, plan.bcodes, plan.nb)
+            if got is not None and got[0] == 0 and got[1] == 0 and got[3] <= 6:
+                onepass = got
+    if onepass is not None:
+        plan.onepass = onepass                  # (_resid_run: X is final, coefficients and their maximum are there)
+        plan.maxabs = onepass[2]
+        kept = np.repeat(True, engine.n)
+        return (kept, sample_index, colmap, batches, covs, donorids, filter_samples, extra)
     kept = _qc_device(engine, labels, batches_qc, show_progress=show_progress)
     if not kept.any():
         # Every neighbourhood failed the QC (a NaN among the batch labels is enough: it is a level without members, its

@@ -773,7 +773,13 @@ def _resid_run(engine, plan, cell_index, show_progress=False):
         M = None
         y_std = getattr(plan, 'y_std', None)
         done = False
-        if (len(plan.ridges) and y_std is not None and _lowrank_ok(engine, plan) and hasattr(engine, 'resid_lowrank_bk')
+        if getattr(plan, 'onepass', None) is not None:
+            # QC, selection and this first ridge were ONE pass over the NAM (tools/_association.py: engine.select_resid_bk)
+            W, M = plan.first_ridge
+            print('\twith ridge', plan.ridges[0], 'median batch kurtosis = ', plan.onepass[3], file=out)
+            first = False
+            done = True
+        elif (len(plan.ridges) and y_std is not None and _lowrank_ok(engine, plan) and hasattr(engine, 'resid_lowrank_bk')
                 and getattr(plan, 'reselect', None) is not None and os.environ.get('CNA_RIDGE_ONEPASS', '1') not in ('0', 'off', 'no')):
             # The first ridge in ONE pass, optimistically: residualise, batch kurtosis (median taken on the device),
             # and -- assuming the schedule ends here, as it always does with up to seven batches -- the division by the

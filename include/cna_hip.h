@@ -259,6 +259,16 @@ int  cna_resid_lowrank(cna_ctx* ctx, const double* C, const double* W, int r, in
  * final.  Otherwise X has to be restored by the caller (cna_select_checked from the NAM) before the next ridge. */
 int  cna_resid_lowrank_bk(cna_ctx* ctx, const double* C, const double* W, int r, const double* y, double* max_abs_out,
                           const int32_t* batch_codes, int n_batches, double* median_out);
+/* Selection, QC and the first ridge of the demo's call shape (covariates AND batches, demo/demo.ipynb:149) in ONE pass over
+ * the NAM: what cna_batch_kurtosis(CNA_MAT_NAM) + cna_stat_qc (_nam.py:85-99), cna_select_checked with every cell and every
+ * sample in place (_association.py:178-185) and cna_resid_lowrank_bk (_nam.py:136-159, first ridge) compute in three passes.
+ * At most seven batches (the kurtosis of so few batch means cannot reach 6: a row fails the QC only with a NaN kurtosis), no
+ * sample without a batch, at most 128 samples.  Out: *n_qc_failed rows with a NaN batch kurtosis, *n_zero rows constant over
+ * the samples, *median_out / *max_abs_out as cna_resid_lowrank_bk.  When both counts are 0 and the median is <= 6, X is final;
+ * otherwise the caller runs the three calls (the NAM is untouched).  *done = 0: shape not covered, nothing queued. */
+int  cna_select_resid_bk(cna_ctx* ctx, const double* C, const double* W, int r, const double* y, double* max_abs_out,
+                         const int32_t* batch_codes, int n_batches, double* median_out, int64_t* n_qc_failed,
+                         int64_t* n_zero, int* done);
 int  cna_standardize(cna_ctx* ctx, int center);
 /* G = X^T X over all cells of all ranks (NAM.dot(NAM.T), _nam.py:105), n_cols x n_cols row-major */
 int  cna_gram(cna_ctx* ctx, double* G_out);

@@ -1198,6 +1198,54 @@ def test_covariates_and_batches_fast_path(eng, monkeypatch, n, N, nb, nc):
     np.testing.assert_array_equal(f[7], slow.M.values)
 
 
+@pytest.mark.parametrize('n,N,nb,nc,isolated', [(20000, 40, 5, 2, False), (9000, 100, 4, 0, False), (30000, 128, 7, 3, False),
+                                                (12000, 30, 3, 1, True), (15000, 64, 12, 1, False)])
+def test_selection_qc_and_first_ridge_in_one_pass(eng, monkeypatch, n, N, nb, nc, isolated):
+    """Round 6: covariates AND batches with every sample analysed in place and at most seven batches -- QC
+    (cna_batch_kurtosis + cna_stat_qc), selection (cna_select_checked) and the first ridge (cna_resid_lowrank_bk) are ONE
+    pass over the NAM (cna_select_resid_bk; same kernel, same arithmetic: bit-identical results).  `isolated`: a graph with
+    a ring of cells that only one sample reaches (rows of the NAM with a single non-zero entry); twelve batches, or more
+    projector + batch columns than the matrix instruction's sixteen: not covered, nothing is queued."""
+    import cna_amd as cna
+    from cna_amd import synth
+    data, meta = synth.make_dataset(n, N, k=15, seed=23, n_covs=nc, n_batches=nb)
+    y, covs, batches = meta['y'].copy(), meta['covs'], meta['batches']
+    if isolated:
+        sid = data.obs['id'].values.copy()
+        sid[:40] = sid[0]                                     # the first cells and their neighbours: one sample only ...
+        A = data.obsp['connectivities'].tolil()
+        A[:40, :] = 0
+        A[:, :40] = 0
+        for i in range(40):
+            A[i, (i + 1) % 40] = 1.0
+            A[(i + 1) % 40, i] = 1.0
+        data.obsp['connectivities'] = A.tocsr().astype(np.float32)
+        data.obs['id'] = sid
+    kw = dict(covs=covs, batches=batches, Nnull=100, seed=5, nsteps=3, return_full=True, engine=eng)
+    calls = []
+    real = eng.select_resid_bk
+
+    def spy(*a, **k):
+        calls.append(real(*a, **k))
+        return calls[-1]
+    monkeypatch.setattr(eng, 'select_resid_bk', spy)
+    out = {}
+    for one in ('1', '0'):
+        monkeypatch.setenv('CNA_RIDGE_ONEPASS', one)
+        res = cna.tl.association(data, y, 'id', **kw)
+        out[one] = (res.p, int(res.k), res.kept.copy(), res.ncorrs.values.copy(), res.namresid.values.copy(), res.fdrs.values.copy(),
+                    data.obs['coef'].values.copy(), data.obs['coef_fdr'].values.copy(), res.M.values.copy(), res.nullminps.copy())
+    if nb > 7:
+        assert calls == []                                    # (more than seven batches: never asked)
+    elif 2 * nb + nc > 16:
+        assert calls == [None]                                # (asked once, with the switch on: not covered)
+    else:
+        assert len(calls) == 1 and calls[0] is not None and calls[0][0] == 0 and calls[0][1] == 0 and calls[0][3] <= 6, calls
+    assert out['1'][:2] == out['0'][:2]
+    for a, b in zip(out['1'][2:], out['0'][2:]):
+        np.testing.assert_array_equal(a, b)
+
+
 def test_nam_cache_on_device(eng):
     """A second phenotype on the same dataset reuses the resident NAM (no diffusion kernels) and gives
     the results of a from-scratch run."""
