@@ -45,7 +45,7 @@ struct ProfSpan {
 
 // X^T X in parts (mfma.hip: gram_plan / launch_gram_range / launch_gram_finish)
 struct GramPlan {
-  int Nx = 0, nt = 0, ntri = 0, ldp = 0, slab_rows = 32, nblocks = 1;
+  int Nx = 0, nt = 0, ntri = 0, ldp = 0, slab_rows = 32, nblocks = 1, nw = 16;
   bool use_blk = false;
   int64_t nslab = 0;
   int32_t* tiles_dev = nullptr;

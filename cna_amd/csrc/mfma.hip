@@ -268,13 +268,13 @@ __global__ __launch_bounds__(64 * NW) void k_gram(const double* __restrict__ X, 
 // <= 15 (161 ... 240 samples); `blocks` holds per wave {i0, i1, i2, j0, j1, j2} (tile indices, -1: unused) in
 // an order that spreads the work over the four SIMDs; tixmap[i * nt + j] = index of tile (i, j) in the
 // upper-triangular table k_gram_reduce walks.
-template <int NW, int SLAB, bool ACC = false>
+template <int NW, int SLAB, bool ACC = false, int PF = 5>
 __global__ __launch_bounds__(64 * NW) void k_gram_blk(const double* __restrict__ X, int64_t nx, int ldx, int nt,
                                                   int ldp, int ntri, const int32_t* __restrict__ blocks,
                                                   const int32_t* __restrict__ tixmap, double* __restrict__ partial,
                                                   int64_t slab0, int64_t slab1, int accumulate) {
   extern __shared__ double sm[];
-  constexpr int NT = 64 * NW, PF = 5;
+  constexpr int NT = 64 * NW;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1363,12 +1363,21 @@ static int gram_plan(cna_ctx* c, GramPlan& g, bool own_partial) {
   int nblocks = (int)(nslab < 512 ? nslab : 512);
   const int64_t blocks_1g = ((int64_t)1 << 30) / ((int64_t)ntri * 2048);      // per-block partial tiles: keep the slab under 1 GiB
   if (nblocks > blocks_1g) nblocks = (int)(blocks_1g > 1 ? blocks_1g : 1);
-  // 3 x 3 blocks of tiles, one per wave (k_gram_blk), when the triangle has at most 16 of them and enough to
-  // keep 16 waves busy: 11 ... 15 tiles per side (161 ... 240 samples)
+  // 3 x 3 blocks of tiles, one per wave (k_gram_blk), when the triangle has at most 16 of them: 11 ... 15 tiles per side
+  // (161 ... 240 samples) on sixteen waves; round 6: also 6 ... 10 tiles per side (81 ... 160 samples) on as many waves as
+  // there are blocks (4 / 8 / 12: 0.67-1 LDS reads per matrix instruction where the tile-per-wave kernel needs 1.25 --
+  // 453 -> 342 us at 1M x 100, 278 -> 226 at 500k x 128, 423 -> 332 at 500k x 160; at 5 tiles per side the three blocks
+  // leave a SIMD idle and the old kernel stays, 119 vs 136 us at 500k x 80: profiles/r06_kbench_gram.txt), two workgroups
+  // per CU where their slabs fit
   const int ng = (nt + 2) / 3;
-  const bool use_blk = g.use_blk = nt >= 11 && ng * (ng + 1) / 2 <= 16 && slab_rows == 32 &&
+  const int nblk = ng * (ng + 1) / 2;
+  const char* bs = getenv("CNA_GRAM_BLK_SMALL");             // test hook (read per call): 0 = the tile-per-wave kernel
+  const bool blk_small = !(bs && atoi(bs) == 0);
+  const bool use_blk = g.use_blk = (nt >= 11 || (nt >= 6 && blk_small)) && nblk <= 16 && slab_rows == 32 &&
                                    2 * (size_t)32 * ldp * sizeof(double) <= 150 * 1024 && c->ldx <= 320;
-  if (use_blk && nblocks > 256) nblocks = 256;             // one workgroup per CU, every slab after the first prefetched
+  g.nw = !use_blk ? 16 : (nt >= 11 ? 16 : (nblk <= 4 ? 4 : (nblk <= 8 ? 8 : 12)));
+  const int wg_per_cu = use_blk && 2 * (2 * (size_t)32 * ldp * sizeof(double)) <= 150 * 1024 && g.nw <= 8 ? 2 : 1;
+  if (use_blk && nblocks > 256 * wg_per_cu) nblocks = 256 * wg_per_cu;   // a workgroup (or two) per CU, every slab after the first prefetched
   if (nblocks < 1) nblocks = 1;
   g.nblocks = nblocks;
   const int64_t part_bytes = (int64_t)sizeof(double) * nblocks * ntri * 256;
@@ -1381,7 +1390,7 @@ static int gram_plan(cna_ctx* c, GramPlan& g, bool own_partial) {
     CNA_TRY(dev_reserve(c, &c->scratch2, &c->scratch2_cap, part_bytes));
     g.partial = (double*)c->scratch2;
   }
-  if (c->gram_tiles_nt != nt) {                          // the tables depend on nt only: upload once
+  if (c->gram_tiles_nt != 2 * nt + (use_blk ? 1 : 0)) {   // the tables depend on nt (and the kernel family) only: upload once
     std::vector<int32_t> extra(128 + (size_t)nt * nt, -1);   // [16 waves x 8] block table | tixmap
     if (use_blk) {
       struct Blk { int rg, cg, work; };
@@ -1400,6 +1409,7 @@ static int gram_plan(cna_ctx* c, GramPlan& g, bool own_partial) {
       for (size_t p = 0; p < bl.size(); ++p) {               // snake over the four SIMDs (waves w, w+4, w+8, w+12 share one)
         const int round = (int)p / 4, pos = (int)p % 4;
         const int wave = 4 * round + ((round & 1) ? 3 - pos : pos);
+        if (wave >= g.nw) continue;                          // (never: nw is the block count rounded up to whole rounds)
         for (int r = 0; r < 3; ++r) {
           const int i = 3 * bl[p].rg + r, j = 3 * bl[p].cg + r;
           extra[wave * 8 + r] = i < nt ? i : -1;
@@ -1414,7 +1424,7 @@ static int gram_plan(cna_ctx* c, GramPlan& g, bool own_partial) {
     HIP_TRY(hipMemcpyAsync(tp, tiles.data(), sizeof(int32_t) * ntri, hipMemcpyHostToDevice, c->copy_stream));
     HIP_TRY(hipMemcpyAsync((int32_t*)tp + ntri, extra.data(), sizeof(int32_t) * extra.size(), hipMemcpyHostToDevice, c->copy_stream));
     HIP_TRY(hipStreamSynchronize(c->copy_stream));       // the vectors go out of scope (the copy stream: the main one may be busy with a walk)
-    c->gram_tiles_nt = nt;
+    c->gram_tiles_nt = 2 * nt + (use_blk ? 1 : 0);
   }
   g.tiles_dev = (int32_t*)c->gram_tiles_ptr;
   g.smem = sizeof(double) * slab_rows * ldp;
@@ -1426,18 +1436,28 @@ static int launch_gram_range(cna_ctx* c, const GramPlan& g, int64_t slab0, int64
   const int nt = g.nt, ldp = g.ldp, ntri = g.ntri, nblocks = g.nblocks;
   ProfScope ps(c, CNA_K_GRAM, st);
   if (g.use_blk) {
-    static bool attr_blk = false;
-    if (!attr_blk) {
-      HIP_TRY(hipFuncSetAttribute((const void*)k_gram_blk<16, 32, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      HIP_TRY(hipFuncSetAttribute((const void*)k_gram_blk<16, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_blk = true;
+#define GRAM_BLK(NW_, PF_) do { \
+      static bool attr = false; \
+      if (!attr) { \
+        HIP_TRY(hipFuncSetAttribute((const void*)k_gram_blk<NW_, 32, false, PF_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        HIP_TRY(hipFuncSetAttribute((const void*)k_gram_blk<NW_, 32, true, PF_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        attr = true; \
+      } \
+      if (accumulate) \
+        hipLaunchKernelGGL((k_gram_blk<NW_, 32, true, PF_>), dim3(nblocks), dim3(64 * NW_), 2 * g.smem, st, c->X, c->nx, c->ldx, nt, ldp, \
+                           ntri, g.tiles_dev + ntri, g.tiles_dev + ntri + 128, g.partial, slab0, slab1, 1); \
+      else \
+        hipLaunchKernelGGL((k_gram_blk<NW_, 32, false, PF_>), dim3(nblocks), dim3(64 * NW_), 2 * g.smem, st, c->X, c->nx, c->ldx, nt, ldp, \
+                           ntri, g.tiles_dev + ntri, g.tiles_dev + ntri + 128, g.partial, slab0, slab1, 0); \
+    } while (0)
+    // (PF double2 loads per thread must cover a slab: 64 NW x PF x 2 >= 32 ldx -- 4 waves: ldx <= 96, 8: <= 160, 12: <= 240)
+    switch (g.nw) {
+      case 4: GRAM_BLK(4, 6); break;
+      case 8: GRAM_BLK(8, 5); break;
+      case 12: GRAM_BLK(12, 5); break;
+      default: GRAM_BLK(16, 5); break;
     }
-    if (accumulate)
-      hipLaunchKernelGGL((k_gram_blk<16, 32, true>), dim3(nblocks), dim3(1024), 2 * g.smem, st, c->X, c->nx, c->ldx, nt, ldp, ntri,
-                         g.tiles_dev + ntri, g.tiles_dev + ntri + 128, g.partial, slab0, slab1, 1);
-    else
-      hipLaunchKernelGGL((k_gram_blk<16, 32, false>), dim3(nblocks), dim3(1024), 2 * g.smem, st, c->X, c->nx, c->ldx, nt, ldp, ntri,
-                         g.tiles_dev + ntri, g.tiles_dev + ntri + 128, g.partial, slab0, slab1, 0);
+#undef GRAM_BLK
     HIP_TRY(hipGetLastError());
     return 0;
   }

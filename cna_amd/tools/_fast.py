@@ -93,7 +93,10 @@ def _eligible(data, y, batches, covs, donorids, ks, nsteps, show_progress, engin
     """The cheap part of the shape test (no look at the data)."""
     if not ENABLED or show_progress or batches is not None or donorids is not None:
         return False
-    if isinstance(nsteps, bool) or not isinstance(nsteps, (int, np.integer)) or not 1 <= nsteps <= 15:
+    # (nsteps=None: the reference's stop rule, _nam.py:59-68 -- evaluated on the device, cna_nam_auto_launch)
+    if nsteps is not None and (isinstance(nsteps, bool) or not isinstance(nsteps, (int, np.integer)) or not 1 <= nsteps <= 15):
+        return False
+    if nsteps is None and getattr(engine, 'nam_auto_launch', None) is None:
         return False
     if getattr(engine, 'assoc_finish', None) is None or getattr(engine, 'h', None) is None:
         return False
@@ -175,6 +178,15 @@ def association(data, y, sid_name, batches, covs, donorids, ks, key_added, max_f
             # (the last step leaves the selection pass's results on its way out under the general path's own rule -- wide
             # sample axis, a block of 150 000 cells or more, _association.py:_DEFER_LAST_CELLS -- so that both paths run the
             # same kernels)
+            if nsteps is None:
+                # the reference's default: walk until the median kurtosis stops falling (_nam.py:64-68); medians and rule on
+                # the device, the first steps queued ahead of the verdict, which the selection pass collects
+                may_hint, early = False, 0
+                if walk:
+                    engine.nam_auto_launch(15)
+                    engine._nam_sig = (sig, engine.nam_epoch, None) if sig is not None else None
+                W_.update(sig=sig, walk=False, may_hint=False, early=0)
+                return
             may_hint = walk and covs is None and N_all > 64 and nsteps >= 3 and _rule_cells(data, engine) >= _defer_last_cells()
             early = (nsteps - 1 if may_hint else nsteps) if walk else 0
             if early:
@@ -222,7 +234,7 @@ def association(data, y, sid_name, batches, covs, donorids, ks, key_added, max_f
 
     # Which goes first: whichever chain is longer -- the draw (~10 ns per normal on the library's threads, plus the sorts)
     # or the walk (~11 ps per cell, sample and step on one MI355X); the other starts ~0.1 ms later, under it
-    if N_all * Nnull * 1e-2 / _draw_threads(N_all * Nnull) > _rule_cells(data, engine) * N_all * nsteps * 1.1e-5:
+    if N_all * Nnull * 1e-2 / _draw_threads(N_all * Nnull) > _rule_cells(data, engine) * N_all * (nsteps or 3) * 1.1e-5:
         got = validate_and_draw()
         if got is None:
             stats['not_eligible'] += 1

@@ -16,8 +16,11 @@ pytestmark = pytest.mark.gpu
 # take the two-call path depends on the sample-level inputs (y indexed by exactly the data's samples)
 SHAPED = ['c01_plain_f32', 'c05_ks_f64', 'c06_nnull_cap', 'c10_categorical_ids', 'c11_string_ids_null_y', 'c13_zero_variance',
           'c17_low_sample_size', 'c09_y_nan_extra_reordered', 'f08_messy', 'f16_messy', 'f19_messy', 'f23_messy', 'f25_messy',
-          'f26_messy', 'f33_constant_phenotype']
-MUST_TAKE = {'c01_plain_f32', 'c05_ks_f64', 'c06_nnull_cap', 'c10_categorical_ids', 'c11_string_ids_null_y', 'c17_low_sample_size'}
+          'f26_messy', 'f33_constant_phenotype',
+          # nsteps=None: the reference's stop rule (evaluated on the device; the selection pass collects the verdict)
+          'c02_covs_autostop', 'c14_selfweight_autostop_unsorted', 'c20_unused_category_autostop', 'f09_messy', 'f13_messy']
+MUST_TAKE = {'c01_plain_f32', 'c05_ks_f64', 'c06_nnull_cap', 'c10_categorical_ids', 'c11_string_ids_null_y', 'c17_low_sample_size',
+             'c02_covs_autostop', 'c14_selfweight_autostop_unsorted'}
 
 
 @pytest.fixture(scope='module')

@@ -1246,6 +1246,24 @@ def test_selection_qc_and_first_ridge_in_one_pass(eng, monkeypatch, n, N, nb, nc
         np.testing.assert_array_equal(a, b)
 
 
+@pytest.mark.parametrize('n,N', [(5000, 96), (7001, 100), (3000, 112), (4100, 128), (2500, 144), (2049, 160), (3000, 80)])
+def test_gram_in_three_by_three_tile_blocks_at_81_to_160_samples(eng, monkeypatch, n, N):
+    """Round 6: X^T X with a 3 x 3 block of 16 x 16 tiles per wave also for 6 ... 10 tiles per side (k_gram_blk on 4 / 8 / 12
+    waves; it served 161 ... 240 samples before) against the tile-per-wave kernel (CNA_GRAM_BLK_SMALL=0) and numpy."""
+    X = np.random.RandomState(N).randn(n, N)
+    X -= X.mean(axis=1, keepdims=True)
+    out = {}
+    for sw in ('1', '0'):
+        monkeypatch.setenv('CNA_GRAM_BLK_SMALL', sw)
+        eng.upload_x(X)
+        out[sw] = eng.gram()
+    want = X.T @ X
+    for G in out.values():
+        np.testing.assert_array_equal(G, G.T)
+        np.testing.assert_allclose(G, want, rtol=0, atol=1e-12 * np.abs(want).max())
+    np.testing.assert_allclose(out['1'], out['0'], rtol=0, atol=1e-13 * np.abs(want).max())
+
+
 def test_nam_cache_on_device(eng):
     """A second phenotype on the same dataset reuses the resident NAM (no diffusion kernels) and gives
     the results of a from-scratch run."""
