@@ -46,7 +46,7 @@ I8_MFMA_PEAK_TOPS = 5033.0   # dense i8 matrix: 2x the bf16 rate (guide: >= 4404
 # profiles/*_pmc_traffic.json: bytes = 2 * FETCH_SIZE KB + WRITE_SIZE KB; the factor 2 on FETCH_SIZE is the
 # guide's gfx950 correction, re-calibrated on k_ncorrs, which streams the matrix once).  Counted at the L2's
 # fabric side, i.e. Infinity-Cache hits included.  Only valid for the profiled workload on one GPU.
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
 
 METRIC = 'cells*permutations/sec end-to-end cna.tl.association'
 ARITHMETIC_I8 = ('f64 throughout (diffusion, QC, residualisation, Gram, F-tests); the local-null products '

@@ -499,8 +499,8 @@ static size_t i8_lds(int KS, int T) {
 // progression to well within a step and starting more than a step above zero -- zero rows and the
 // padding must stay below the first cut by more than any margin -- and the counters fit in LDS)
 bool null_i8_enabled() {
-  static const int off = getenv("CNA_NULL_F64") ? atoi(getenv("CNA_NULL_F64")) : 0;
-  return off == 0;
+  const char* e = getenv("CNA_NULL_F64");                  // (read per call: tests/test_gpu_parity.py flips it)
+  return !(e && atoi(e) != 0);
 }
 bool null_i8_eligible(const cna_ctx* c, int P, int T, double cut0, double inv_step, double eps) {
   if (!null_i8_enabled()) return false;

@@ -76,7 +76,7 @@ def _draw_threads(normals):
     if _cpus is None:
         from .._order import usable_cpus
         _cpus = usable_cpus(8)
-    return _cpus
+    return min(4, _cpus)
 
 
 def _eye(N):
@@ -393,7 +393,7 @@ def _verify_threads(verify):
     if _cpus is None:
         from .._order import usable_cpus
         _cpus = usable_cpus(8)
-    return _cpus
+    return min(4, _cpus)                       # (beside the draw's threads and the eigenpairs: see tools/_stats.py)
 
 
 def _full_result(engine, data, out, pcs, Uk, best, pv, r2v, k, pfinal, ks, ks_, r, N, n, Mv, M_frame, y_std, sample_index,

@@ -309,7 +309,9 @@ def native_draw_start(B, Y, num, seed, threads=None, single_level=False, record=
         if len(Y) * num >= _BIG_DRAW:
             threads = usable_cpus(16)
         elif len(Y) * num >= _MID_DRAW:        # 200 samples x 1000 permutations: 2.1 ms on one thread, as long as the walk of
-            threads = usable_cpus(8)           # 250 000 cells -- a rank's block of the 2M problem on eight GPUs
+            threads = usable_cpus(4)           # 250 000 cells -- a rank's block of the 2M problem on eight GPUs
+                                               # (eight threads: one step in ten then takes 5 ms -- under a container's CPU quota
+                                               # the draw, the eigenpairs, the content check and the runtime's own threads add up)
         else:
             threads = 1
     addr = bg.ctypes.state_address             # struct mt19937_state { uint32_t key[624]; int pos; }

@@ -1264,6 +1264,26 @@ def test_gram_in_three_by_three_tile_blocks_at_81_to_160_samples(eng, monkeypatc
     np.testing.assert_allclose(out['1'], out['0'], rtol=0, atol=1e-13 * np.abs(want).max())
 
 
+def test_analysis_with_the_f64_local_null_kernel(eng, monkeypatch):
+    """CNA_NULL_F64=1 (README: the documented way to take the integer matrix cores out of the local null): the f64 kernel
+    counts the same integers, so every result field is the same."""
+    import cna_amd as cna
+    from cna_amd import synth
+    data, meta = synth.make_dataset(9000, 48, k=15, seed=31)
+    kw = dict(nsteps=3, Nnull=200, seed=2, return_full=True, engine=eng)
+    out = {}
+    for sw in ('0', '1', '0'):
+        monkeypatch.setenv('CNA_NULL_F64', sw)
+        res = cna.tl.association(data, meta['y'], 'id', **kw)
+        used = eng.null_local_i8_stats()[0]
+        assert used == (sw == '0')
+        out.setdefault(sw, []).append((res.p, res.fdrs.values.copy(), data.obs['coef_fdr'].values.copy(), res.ncorrs.values.copy()))
+    a, b = out['0'][0], out['1'][0]
+    assert a[0] == b[0]
+    for x, y_ in zip(a[1:], b[1:]):
+        np.testing.assert_array_equal(x, y_)
+
+
 def test_nam_cache_on_device(eng):
     """A second phenotype on the same dataset reuses the resident NAM (no diffusion kernels) and gives
     the results of a from-scratch run."""

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Everything profiles/ needs for round 5, on the GPU box:  bash tools/profile_round5.sh
+# Everything profiles/ needs for round 6, on the GPU box:  bash tools/profile_round6.sh
 # (rocprofv3 --kernel-trace --stats of the bench command; PMC passes -- counters only, each in its own
 # run -- for HBM-side traffic (FETCH_SIZE / WRITE_SIZE) and the SQ / TCC view of the dominant kernels)
 set -u
-R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_r05; mkdir -p $OUT
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_r06; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 SHORT="--no-cpu-baseline --no-extra --steps 6 --warmup 2"
 for W in ${WORKLOADS:-C4 C3 C2 C5}; do
@@ -17,5 +17,15 @@ for W in ${WORKLOADS:-C4 C3 C2 C5}; do
     pass tcp1 TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_GATE_EN1_sum
   fi
 done
-python $R/tools/pmc_traffic.py $OUT > $OUT/pmc_traffic.log 2>&1
-ls $OUT | head -80
+PMC_TRAFFIC_NAME=r06_pmc_traffic.json python $R/tools/pmc_traffic.py $OUT > $OUT/pmc_traffic.log 2>&1
+# per-kernel statistics of the timed region only (the last 6 analyses), and the summaries that go to profiles/
+mkdir -p $R/gpurun_out/r06_profiles
+for W in ${WORKLOADS:-C4 C3 C2 C5}; do
+  t=$(ls $OUT/stats_${W}_kernel_trace.csv $OUT/*/stats_${W}_kernel_trace.csv 2>/dev/null | head -1)
+  [ -n "$t" ] && python $R/tools/kernel_stats_timed.py $t $R/gpurun_out/r06_profiles/r06_kernel_stats_$W.csv 6
+  [ -f $OUT/pmc_summary_$W.txt ] && cp $OUT/pmc_summary_$W.txt $R/gpurun_out/r06_profiles/r06_pmc_summary_$W.txt
+  tail -3 $OUT/stats_$W.log > $R/gpurun_out/r06_profiles/r06_stats_bench_line_$W.txt 2>/dev/null
+done
+cp $OUT/r06_pmc_traffic.json $OUT/pmc_traffic.log $R/gpurun_out/r06_profiles/ 2>/dev/null
+rm -rf $OUT          # (the raw traces: hundreds of MB)
+ls -la $R/gpurun_out/r06_profiles
