@@ -262,6 +262,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   if (c->h_bins) (void)hipHostFree(c->h_bins);
   if (c->h_tab) (void)hipHostFree(c->h_tab);
   if (c->h_res) (void)hipHostFree(c->h_res);
+  if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_cell) (void)hipHostFree(c->h_cell);
   delete c;
   return 0;
@@ -1512,11 +1513,19 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
     CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)nz, 1));
     if (y) CNA_TRY(comm_allreduce_f64_max(c, (double*)mb, 1));
   }
-  unsigned long long h = 0;
-  double m = 0.0;
-  HIP_TRY(hipMemcpyAsync(&h, nz, 8, hipMemcpyDeviceToHost, c->stream));
-  if (y) HIP_TRY(hipMemcpyAsync(&m, mb, 8, hipMemcpyDeviceToHost, c->stream));
+  if (!c->h_scal) HIP_TRY(hipHostMalloc(&c->h_scal, 256, hipHostMallocDefault));
+  volatile unsigned long long* hs = (volatile unsigned long long*)c->h_scal;
+  hs[0] = 0;
+  hs[1] = 0;
+  HIP_TRY(hipMemcpyAsync((void*)&hs[0], nz, 8, hipMemcpyDeviceToHost, c->stream));
+  if (y) HIP_TRY(hipMemcpyAsync((void*)&hs[1], mb, 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  const unsigned long long h = hs[0];
+  double m = 0.0;
+  {
+    const unsigned long long bits = hs[1];
+    std::memcpy(&m, &bits, 8);
+  }
   if (n_zero_out) *n_zero_out = (int64_t)h;
   if (max_abs_out) *max_abs_out = m;
   c->x_valid = true;
@@ -2121,7 +2130,7 @@ static int null_local_prepare(cna_ctx* c, int P, const double* edges, int T, int
   exact_cuts(edges, T, c->Nx, cuts, &c->null_cut0, &c->null_inv_step, &c->null_eps);
   const int64_t obs_off = 8 * (int64_t)T + (want_tails ? 8 * (int64_t)P * T : 0);
   const int64_t stage_off = obs_off + 16 * (int64_t)T;      // pinned copies of cuts | edges | thr: uploads need no wait
-  const int64_t hbytes = stage_off + 24 * (int64_t)T;
+  const int64_t hbytes = stage_off + 24 * (int64_t)T + 16;  // (+ the integer pass's status word, see null_local_go)
   HIP_TRY(hipEventSynchronize(c->stage_done));            // uploads of the previous pass out of the staging area (long done)
   if (hbytes > c->h_res_cap) {
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2197,15 +2206,29 @@ static int null_local_go(cna_ctx* c, int col0) {
     CNA_TRY(launch_null_local_i8(c, c->zc + col0, c->zc_ld, P, ed, T, c->null_cut0, c->null_inv_step, c->null_eps,
                                  &i8_sums, &i8_status));
   c->i8_last = i8_status != nullptr;
-  CNA_TRY(launch_null_local(c, c->zc + col0, c->zc_ld, P, ed, T, c->null_cut0, c->null_inv_step, c->null_eps, hist,
-                            i8_status));
-  // suffix sums and the sum over permutations are linear: when only the sums are wanted the ranks
-  // exchange T integers instead of the P x T histogram
-  if (c->null_has_tails) CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)P * T));
-  CNA_TRY(launch_suffix_sum(c, hist, P, T, tails));
-  CNA_TRY(launch_tail_sums(c, tails, P, T, sums));
-  if (i8_status) CNA_TRY(launch_i8_pick(c, i8_status, i8_sums, sums, T, sums));
-  if (!c->null_has_tails) CNA_TRY(comm_allreduce_i64_sum(c, sums, (size_t)T));
+  c->null_col0 = col0;
+  c->null_status_off = -1;
+  if (i8_status) {
+    // Round 6: the f64 kernel is no longer queued behind the integer pass as a stand-by (two guarded launches, the
+    // reductions of an empty histogram and the pick: 45 us of device time and seven launches on the tail of EVERY call,
+    // rocprofv3 timeline profiles/r06_timeline_C2.txt).  The pass's status word travels with its sums; should it be
+    // raised (recheck queue overflow: never seen outside the test that forces it) whoever collects the pass runs the f64
+    // kernel then (null_local_collect).  Several ranks: the word is summed over the ranks, so that all of them decide alike.
+    sums = i8_sums;
+    CNA_TRY(comm_allreduce_i64_sum(c, sums, (size_t)T));
+    int64_t* stw = (int64_t*)i8_status;                    // (the word's upper half is zero: launch_null_local_i8 clears the block)
+    CNA_TRY(comm_allreduce_i64_sum(c, stw, 1));
+    c->null_status_off = 8 * (int64_t)T + 16 * (int64_t)T + 24 * (int64_t)T;      // behind sums | observed counts | staging (no tails here)
+    HIP_TRY(hipMemcpyAsync((char*)c->h_res + c->null_status_off, stw, 8, hipMemcpyDeviceToHost, c->stream));
+  } else {
+    CNA_TRY(launch_null_local(c, c->zc + col0, c->zc_ld, P, ed, T, c->null_cut0, c->null_inv_step, c->null_eps, hist, nullptr));
+    // suffix sums and the sum over permutations are linear: when only the sums are wanted the ranks
+    // exchange T integers instead of the P x T histogram
+    if (c->null_has_tails) CNA_TRY(comm_allreduce_i64_sum(c, (int64_t*)hist, (size_t)P * T));
+    CNA_TRY(launch_suffix_sum(c, hist, P, T, tails));
+    CNA_TRY(launch_tail_sums(c, tails, P, T, sums));
+    if (!c->null_has_tails) CNA_TRY(comm_allreduce_i64_sum(c, sums, (size_t)T));
+  }
   HIP_TRY(hipMemcpyAsync(c->h_res, sums, 8 * (size_t)T, hipMemcpyDeviceToHost, c->stream));
   if (c->coef_early && c->null_has_obs && T <= 512) {
     // the caller already has the coefficient column (cna_percell_coef_launch): the FDR column can
@@ -2265,6 +2288,26 @@ static int null_local_collect(cna_ctx* c, int64_t* tails_out, int64_t* sums_out,
   if (!c->null_pending) CNA_FAIL(CNA_ESTATE, "no local-null pass pending");
   c->null_pending = 0;
   HIP_TRY(hipEventSynchronize(c->null_done));
+  if (c->null_status_off >= 0 && *(volatile int64_t*)((char*)c->h_res + c->null_status_off) != 0) {
+    // the integer pass gave up (on some rank): the same counts from the f64 kernel, now (the thresholds of the prepare
+    // half are still in the scratch carve: nothing that uses it may run between launch and fetch); the FDR table that
+    // followed the pass on the device was made of the wrong sums -- the per-cell column is looked up again
+    c->null_status_off = -1;
+    const int P = c->null_P, T = c->null_T;
+    Carver cv(c->scratch);
+    double* ed = cv.take<double>(T);
+    unsigned long long* hist = cv.take<unsigned long long>((int64_t)P * T);
+    int64_t* tails = cv.take<int64_t>((int64_t)P * T);
+    int64_t* sums = cv.take<int64_t>(T);
+    CNA_TRY(launch_null_local(c, c->zc + c->null_col0, c->zc_ld, P, ed, T, c->null_cut0, c->null_inv_step, c->null_eps, hist, nullptr));
+    CNA_TRY(launch_suffix_sum(c, hist, P, T, tails));
+    CNA_TRY(launch_tail_sums(c, tails, P, T, sums));
+    CNA_TRY(comm_allreduce_i64_sum(c, sums, (size_t)T));
+    HIP_TRY(hipMemcpyAsync(c->h_res, sums, 8 * (size_t)T, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->fdr_inline = false;
+  }
+  c->null_status_off = -1;
   if (ranks_out || numdet_out) {
     if (!c->null_has_obs) CNA_FAIL(CNA_EINVAL, "the pending pass was launched without thresholds");
     const char* o = (const char*)c->h_res + c->null_obs_off;
@@ -2536,6 +2579,8 @@ int cna_percell_fdr_copy_early(cna_ctx* c, double* dst, int64_t n, int nthreads,
   struct Flight { std::atomic<int>& f; Flight(std::atomic<int>& f_) : f(f_) { f.store(1); } ~Flight() { f.store(0); } } flight(c->fdr_early_inflight);
   HIP_TRY(hipEventSynchronize(c->bins_copied));
   HIP_TRY(hipEventSynchronize(c->null_done));
+  if (c->null_status_off >= 0 && *(volatile int64_t*)((char*)c->h_res + c->null_status_off) != 0)
+    return 0;                                   // the integer pass gave up: its table is void (cna_null_local_fetch reruns in f64)
   if (cna_host_expand_u16(dst, c->h_bins, n, c->h_tab, c->null_T, nthreads) != 0)
     CNA_FAIL(CNA_ESTATE, "cna_percell_fdr_copy_early: expansion failed");
   c->fdr_early_dst = dst;

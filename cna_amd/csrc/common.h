@@ -61,9 +61,13 @@ struct cna_ctx {
   hipEvent_t gram_done = nullptr;
   double* gram_buf = nullptr;          // Gram matrix of the last cna_gram_launch
   hipEvent_t null_done = nullptr;      // results of the last local-null launch are in h_res
+  void* h_scal = nullptr;              // pinned: a few words for scalar results a call waits for (a copy into pageable memory -- a stack
+                                       // variable -- is staged by the runtime: 20-25 us each, measured between the selection pass and the Gram kernel)
   void* h_res = nullptr;               // pinned host staging for asynchronously fetched results
   int64_t h_res_cap = 0;
   int null_P = 0, null_T = 0, null_has_tails = 0;
+  int null_col0 = 0;                   // first column of Zc of the pending pass
+  int64_t null_status_off = -1;        // >= 0: h_res + off holds the integer pass's status word of the pending pass (0: its sums stand)
   std::atomic<int> null_pending{0};   // (read by the helper thread's cna_percell_fdr_copy_early, like the four flags below)
   int64_t gram_cap = 0;
   int gram_n = 0;
@@ -400,7 +404,6 @@ bool null_i8_enabled();
 int ensure_xq(cna_ctx* c, int KS);
 int launch_null_local_i8(cna_ctx* c, const double* Yc_dev, int ldy, int P, const double* cuts_dev, int T, double cut0,
                          double inv_step, double eps, int64_t** sums_out, int** status_out);
-int launch_i8_pick(cna_ctx* c, const int* status, const int64_t* a, const int64_t* b, int T, int64_t* out);
 
 // stats.hip
 int launch_condition(cna_ctx* c, hipStream_t st, const double* M_dev, const double* Y_dev, int N, int P,

@@ -462,12 +462,6 @@ __global__ __launch_bounds__(256) void k_i8_reduce(const unsigned int* __restric
   if (lane == 0) hist[t] = s;
 }
 
-__global__ void k_i8_pick(const int* __restrict__ status, const int64_t* __restrict__ a, const int64_t* __restrict__ b,
-                          int T, int64_t* __restrict__ out) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < T) out[t] = *status ? b[t] : a[t];
-}
-
 typedef int (*i8_launch_fn)(cna_ctx*, unsigned, size_t, const unsigned char*, const float2*, int64_t, const v4i*, int, int, int, int, float,
                             unsigned int*, uint2*, unsigned long long*, unsigned long long, int*);
 // strips of 64 permutations per stage: as many as keep a stage near 40-50 KB (two stages + the counters in LDS)
@@ -612,11 +606,5 @@ int launch_null_local_i8(cna_ctx* c, const double* Yc_dev, int ldy, int P, const
   *sums_out = sums_dev;
   *status_out = status;
   c->i8_qcount = qcount;
-  return 0;
-}
-
-int launch_i8_pick(cna_ctx* c, const int* status, const int64_t* a, const int64_t* b, int T, int64_t* out) {
-  hipLaunchKernelGGL(k_i8_pick, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, c->stream, status, a, b, T, out);
-  HIP_TRY(hipGetLastError());
   return 0;
 }

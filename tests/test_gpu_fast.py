@@ -290,6 +290,36 @@ def test_errors_inside_and_after_the_library_call(eng, fast, monkeypatch):
         assert cna.tl.association(data, meta['y'], 'id', **kw) == p0
 
 
+def test_integer_null_that_gives_up_is_redone_in_f64(eng, fast, monkeypatch):
+    """CNA_I8_QCAP=8 makes the integer local null overflow its recheck queue: its status word comes back with the sums, and
+    whoever collects the pass (cna_null_local_fetch; inside cna_assoc_finish on the two-call path) reruns it on the f64
+    kernel and looks the per-cell FDR column up again -- the table that followed the abandoned pass on the device is void.
+    Same results as the undisturbed call, through both paths."""
+    import cna_amd as cna
+    data, meta = _synthetic(20000, 50, seed=17)
+    kw = dict(nsteps=3, Nnull=640, seed=9, engine=eng, return_full=True)
+    out = {}
+    for on in (False, True):
+        fast.ENABLED = on
+        for cap in (None, '8'):
+            if cap:
+                monkeypatch.setenv('CNA_I8_QCAP', cap)
+            else:
+                monkeypatch.delenv('CNA_I8_QCAP', raising=False)
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                res = cna.tl.association(data, meta['y'], 'id', **kw)
+            used, rechecked, fallback = eng.null_local_i8_stats()
+            assert used and fallback == bool(cap)
+            out[(on, cap)] = (res.p, res.fdrs.values.copy(), data.obs['coef'].values.copy(), data.obs['coef_fdr'].values.copy())
+    monkeypatch.delenv('CNA_I8_QCAP', raising=False)
+    base = out[(False, None)]
+    for key, got in out.items():
+        assert got[0] == base[0], key
+        for a, b in zip(got[1:], base[1:]):
+            np.testing.assert_array_equal(a, b, err_msg=str(key))
+
+
 def test_nam_cache_skips_the_walk(fast):
     """engine.reuse_nam (the default for users): a second phenotype on the resident dataset queues no walk step."""
     import cna_amd as cna

@@ -158,8 +158,9 @@ def test_rccl_ranks_sharded_inputs(name, world, partition, overlap):
     for r in range(world):
         g = got[r]
         assert g['view'] and tuple(g['comm']) == ('rccl', world)
-        # nsteps given, one batch, a seed: the second call (resident shard) goes through cna_assoc_begin / _finish on every rank
-        assert g['two_call_path']['taken'] == (1 if name in ('c01_plain_f32', 'c11_string_ids_null_y', 'c05_ks_f64', 'c13_zero_variance') else 0), g['two_call_path']
+        # one batch, a seed (nsteps given or the stop rule): the second call (resident shard) goes through cna_assoc_begin / _finish on every rank
+        assert g['two_call_path']['taken'] == (1 if name in ('c01_plain_f32', 'c11_string_ids_null_y', 'c05_ks_f64', 'c13_zero_variance', 'c02_covs_autostop',
+                                                          'c14_selfweight_autostop_unsorted') else 0), g['two_call_path']
         assert g['halo_comm'], 'the halo communicator did not pass the start-up self-test'
         assert g['halo'] is not None and g['halo'][0] > 0 and g['halo'][1] > 0
         assert g['p'] == a['p'] and g['k'] == a['k'] and g['p2'] == a['p2']

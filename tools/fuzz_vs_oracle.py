@@ -25,7 +25,8 @@ def relerr(a, b):
 
 
 t_end = time.time() + budget
-done = failed = raised_both = ties = 0
+done = failed = raised_both = ties = again = two_call = odd_row_cells = 0
+from cna_amd.tools import _fast
 kinds = {}
 fails = {}
 while time.time() < t_end:
@@ -75,6 +76,9 @@ while time.time() < t_end:
     for t in tag:
         kinds[t] = kinds.get(t, 0) + 1
     ref = res = eref = eres = None
+    if os.environ.get('FUZZ_ONLY') and done + 1 != int(os.environ['FUZZ_ONLY']):       # replay one case of a seed (same draws, nothing run)
+        done += 1
+        continue
     try:
         ref = orc.association(data, y, 'id', covs=covs, batches=batches, donorids=donor, mode='f64', **kw)
     except Exception as e:                       # noqa: BLE001
@@ -104,18 +108,47 @@ while time.time() < t_end:
             assert np.array_equal(res.fdrs.num_detected.values[:T], ref['fdrs']['num_detected'][:T]), 'num_detected'
             got, want = data.obs['coef_fdr'].values, ref['obs_coef_fdr']
             bad = np.flatnonzero(~np.isclose(got, want, rtol=1e-8, atol=1e-13, equal_nan=True))
+            if len(bad) and len(res.fdrs) != len(ref['fdrs']['fdr']):
+                # np.arange's 300 / 301 rows: the odd row's threshold IS max|ncorrs|, so the one cell that
+                # attains the maximum looks the odd row's FDR up on one side and not on the other -- nothing else may differ
+                top = np.abs(data.obs['coef'].values[bad]) >= np.nanmax(np.abs(data.obs['coef'].values)) * (1 - 1e-12)
+                odd_row_cells += int(top.sum())
+                bad = bad[~top]
             if len(bad):
                 # the look-up is a step function of |coefficient|: a cell within rounding of a threshold may take the
                 # neighbouring step (the two sides' coefficients differ in the last bits) -- nothing else may differ
                 thr = res.fdrs.threshold.values
                 c = np.abs(data.obs['coef'].values[bad])
                 near = np.abs(c[:, None] - thr[None, :]).min(axis=1) <= 1e-9 * thr.max()
+                if os.environ.get('FUZZ_ONLY'):
+                    print('coef_fdr detail: cells', bad, 'coef', data.obs['coef'].values[bad], 'oracle coef', ref['obs_coef'][bad] if 'obs_coef' in ref else None,
+                          'nearest thr dist', np.abs(c[:, None] - thr[None, :]).min(axis=1), 'T', len(thr), len(ref['fdrs']['threshold']), 'maxabs', np.nanmax(np.abs(data.obs['coef'].values)),
+                          'thr[-3:]', thr[-3:], 'oracle thr[-3:]', ref['fdrs']['threshold'][-3:], 'fdr[-3:]', res.fdrs.fdr.values[-3:], ref['fdrs']['fdr'][-3:])
                 assert near.all() and len(bad) <= 2, ('coef_fdr', len(bad), got[bad][:3], want[bad][:3])
                 ties += len(bad)
+        # Round 6: the SAME call again -- the graph is resident now, so a call of the fixed shape goes through
+        # cna_assoc_begin / cna_assoc_finish (tools/_fast.py) -- must return the first call's results bit for bit
+        # (below 100 000 cells: from there on the device cell order is adopted by a later call and the Gram sum changes order)
+        if n < 100000:
+            coef1, fdr1 = data.obs['coef'].values.copy(), data.obs['coef_fdr'].values.copy() if 'coef_fdr' in data.obs else None
+            resid1 = res.namresid.values.copy()           # (lives on the device until read: the second call replaces it)
+            before = _fast.stats['taken']
+            res2 = cna.tl.association(data, y, 'id', covs=covs, batches=batches, donorids=donor, return_full=True, engine=eng, **kw)
+            took = _fast.stats['taken'] - before
+            two_call += took
+            again += 1
+            assert res2.p == res.p and res2.k == res.k and np.array_equal(res2.kept, res.kept), ('second call: p / k / kept', took)
+            assert np.array_equal(res2.ncorrs.values, res.ncorrs.values) and np.array_equal(res2.nullminps, res.nullminps), ('second call: ncorrs / nullminps', took)
+            assert np.array_equal(data.obs['coef'].values, coef1, equal_nan=True), ('second call: obs coef', took)
+            if kw.get('local_test', True):
+                assert np.array_equal(res2.fdrs.values, res.fdrs.values) and np.array_equal(data.obs['coef_fdr'].values, fdr1), ('second call: fdrs', took)
+            assert np.array_equal(res2.namresid.values, resid1), ('second call: namresid', took)
     except Exception as exc:                     # noqa: BLE001
         failed += 1
         what = str(exc.args[0] if exc.args else exc)[:160]
         fails.setdefault(what.split(',')[0][:60], []).append((done, n, tag, kw, what))
+print('second calls on the resident graph: %d, of which %d through the two-call path (cna_assoc_finish), all bit-identical to the first unless listed below' % (again, two_call))
+print('cells at max|ncorrs| whose FDR differs because the two sides have 300 / 301 thresholds: %d' % odd_row_cells)
 for key, items in fails.items():
     print('== %d x %s' % (len(items), key))
     for it in items[:4]:
