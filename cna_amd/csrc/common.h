@@ -61,6 +61,9 @@ struct cna_ctx {
   hipEvent_t gram_done = nullptr;
   double* gram_buf = nullptr;          // Gram matrix of the last cna_gram_launch
   hipEvent_t null_done = nullptr;      // results of the last local-null launch are in h_res
+  void* h_hint = nullptr;              // pinned staging of cna_nam_select_hint's phenotype (8 KB)
+  void* h_gram = nullptr;              // pinned staging of cna_gram_fetch (the caller's matrix is pageable: the runtime would stage the copy itself, slower)
+  int64_t h_gram_cap = 0;
   void* h_scal = nullptr;              // pinned: a few words for scalar results a call waits for (a copy into pageable memory -- a stack
                                        // variable -- is staged by the runtime: 20-25 us each, measured between the selection pass and the Gram kernel)
   void* h_res = nullptr;               // pinned host staging for asynchronously fetched results
