@@ -148,6 +148,7 @@ int cna_assoc_finish(cna_ctx* c, const cna_assoc_args* a, cna_assoc_out* o) {
   eig.th = std::thread([&]() {
     eig.rc = cna_gram_pcs_tests(c, kmax, a->ks, a->K, a->r, a->use_native_eig, a->resid_tol, a->gap_tol, a->G, a->U, &eig.acc);
     mark(10);
+    o->t_ms[9] = (c->t_gram_fetched - std::chrono::duration<double>(t_entry.time_since_epoch()).count()) * 1e3;
     if (eig.rc == 0 && eig.acc) eig.rc = cna_global_test_fetch(c, a->minp, a->r2, a->kidx);
     mark(11);
     if (eig.rc != 0) eig.err = cna_last_error();

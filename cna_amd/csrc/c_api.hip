@@ -1,6 +1,7 @@
 // extern "C" entry points of libcna_hip.so (see include/cna_hip.h for the contract).
 #include "common.h"
 #include <sched.h>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -808,6 +809,28 @@ static int ensure_gram_stream(cna_ctx* c) {
   return 1;
 }
 // whoever is about to write c->gram_buf / c->gram_part on another stream, or to start the next ranged product
+// The Gram matrix reaches the host without a copy engine (round 6): its reduction kernel writes it a second time into
+// pinned memory (one rank), or a copy kernel behind the ranks' sum does.  An asynchronous copy from another stream sat
+// in the engine's queue behind the per-cell columns of the same analysis: 2 ms at 2M cells (cna_assoc_out.t_ms[9]).
+static int gram_host_reserve(cna_ctx* c, int Nx) {
+  const int64_t bytes = (int64_t)sizeof(double) * Nx * Nx;
+  if (bytes > c->h_gram_cap) {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->h_gram) HIP_TRY(hipHostFree(c->h_gram));
+    c->h_gram = nullptr;
+    c->h_gram_cap = 0;
+    HIP_TRY(hipHostMalloc(&c->h_gram, (size_t)bytes, hipHostMallocDefault));
+    c->h_gram_cap = bytes;
+  }
+  return 0;
+}
+static bool gram_solo(cna_ctx* c) { return !(c->nranks > 1 || comm_active(c)); }
+static int gram_host_finish(cna_ctx* c, int Nx) {      // behind the reduction (and the ranks' sum): G on the host when gram_done fires
+  if (!c->gram_mirrored) CNA_TRY(launch_copy_f64(c, c->gram_buf, (double*)c->h_gram, (int64_t)Nx * Nx));
+  HIP_TRY(hipEventRecord(c->gram_done, c->stream));
+  c->gram_n = Nx;
+  return 0;
+}
 static int gram_pre_settle(cna_ctx* c) {
   if (c->gram_pre_pending) {
     HIP_TRY(hipStreamWaitEvent(c->stream, c->gram_pre_done, 0));
@@ -1497,8 +1520,13 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
     void* g = c->gram_buf;
     CNA_TRY(dev_reserve(c, &g, &c->gram_cap, (int64_t)sizeof(double) * Nx * Nx));
     c->gram_buf = (double*)g;
-    CNA_TRY(launch_selgram(c, c->gram_buf, nz, yd, mb, with_q ? (unsigned char*)c->xq : nullptr,
-                           with_q ? c->xq_scale : nullptr, 32 * KSq));
+    CNA_TRY(gram_host_reserve(c, Nx));
+    c->gram_mirrored = false;
+    c->gram_mirror = gram_solo(c) ? (double*)c->h_gram : nullptr;
+    const int rc_sg = launch_selgram(c, c->gram_buf, nz, yd, mb, with_q ? (unsigned char*)c->xq : nullptr,
+                                     with_q ? c->xq_scale : nullptr, 32 * KSq);
+    c->gram_mirror = nullptr;
+    CNA_TRY(rc_sg);
   } else {
     CNA_TRY(launch_select_std(c, (colmap && !in_place) ? cm : nullptr, nz, y ? yd : nullptr, y ? mb : nullptr, c->resid_f,
                               c->resid_f ? c->resid_f + (size_t)rk * Nx : nullptr, rk,
@@ -1545,8 +1573,7 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
   c->fdr_inline = false;
   if (fused) {                                   // what cna_gram_launch does after its kernels
     CNA_TRY(comm_allreduce_f64_sum(c, c->gram_buf, (size_t)Nx * Nx));
-    HIP_TRY(hipEventRecord(c->gram_done, c->stream));
-    c->gram_n = Nx;
+    CNA_TRY(gram_host_finish(c, Nx));
     *gram_too = true;
   } else if (byp && gram_pre_was) {
     c->gram_pre = true;                          // X^T X of this X was taken under the walk: cna_gram_launch finds it
@@ -1909,34 +1936,28 @@ int cna_gram_launch(cna_ctx* c) {
   const bool pre = c->gram_pre && c->gram_pre_pending;     // taken under the walk's last step (ranged_last_step), X untouched since
   c->gram_pre = false;
   CNA_TRY(gram_pre_settle(c));
+  CNA_TRY(gram_host_reserve(c, Nx));
+  c->gram_mirrored = false;
   if (!pre) {
     void* g = c->gram_buf;
     CNA_TRY(dev_reserve(c, &g, &c->gram_cap, (int64_t)sizeof(double) * Nx * Nx));
     c->gram_buf = (double*)g;
-    CNA_TRY(launch_gram(c, c->gram_buf));
+    c->gram_mirror = gram_solo(c) ? (double*)c->h_gram : nullptr;
+    const int rc = launch_gram(c, c->gram_buf);
+    c->gram_mirror = nullptr;
+    CNA_TRY(rc);
   }
   CNA_TRY(comm_allreduce_f64_sum(c, c->gram_buf, (size_t)Nx * Nx));
-  HIP_TRY(hipEventRecord(c->gram_done, c->stream));
-  c->gram_n = Nx;
-  return 0;
+  return gram_host_finish(c, Nx);
 }
 
-// Only touches the Gram buffer, the copy stream and the event: safe to call while another host
-// thread is blocked inside a long entry point of the same context (cna_null_local_resident).
+// Only waits for the event and reads the pinned copy: safe to call while another host thread is blocked inside a
+// long entry point of the same context (cna_null_local_resident).
 int cna_gram_fetch(cna_ctx* c, double* G_out) {
   CHECK_CTX(c);
   if (c->gram_n < 1) CNA_FAIL(CNA_ESTATE, "cna_gram_fetch before cna_gram_launch");
-  HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->gram_done, 0));
   const int64_t bytes = (int64_t)sizeof(double) * c->gram_n * c->gram_n;
-  if (bytes > c->h_gram_cap) {
-    if (c->h_gram) HIP_TRY(hipHostFree(c->h_gram));
-    c->h_gram = nullptr;
-    c->h_gram_cap = 0;
-    HIP_TRY(hipHostMalloc(&c->h_gram, (size_t)bytes, hipHostMallocDefault));
-    c->h_gram_cap = bytes;
-  }
-  HIP_TRY(hipMemcpyAsync(c->h_gram, c->gram_buf, (size_t)bytes, hipMemcpyDeviceToHost, c->copy_stream));
-  HIP_TRY(hipStreamSynchronize(c->copy_stream));
+  HIP_TRY(hipEventSynchronize(c->gram_done));
   std::memcpy(G_out, c->h_gram, (size_t)bytes);
   return 0;
 }
@@ -1952,6 +1973,7 @@ int cna_gram_pcs_tests(cna_ctx* c, int kmax, const int32_t* ks, int K, int r, in
   if (!G_out || !U_out || !accepted || !ks) CNA_FAIL(CNA_EINVAL, "cna_gram_pcs_tests: null argument");
   *accepted = 0;
   CNA_TRY(cna_gram_fetch(c, G_out));
+  c->t_gram_fetched = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
   const int n = c->gram_n;
   if (!use_native || n < 8 || kmax < 1 || 4 * kmax > n || kmax + 1 > 256) return 0;
   for (int64_t i = 0; i < (int64_t)n * n; ++i)
@@ -2211,8 +2233,38 @@ static int null_local_go(cna_ctx* c, int col0) {
   // columns beyond col0+P inside the last 64-wide tile are other phenotypes: the kernel only
   // flushes counters of p < P, and reads stay inside the zero-padded leading dimension
   // Only the sums over permutations wanted (the analysis): the integer matrix cores do the products
-  // (null_i8.hip: exact counts, outputs near a cut rechecked in f64); the f64 kernel is launched behind
-  // as a stand-by that returns at once unless the integer pass raised its status word.
+  // (null_i8.hip: exact counts, outputs near a cut rechecked in f64).
+  // The per-cell half of the FDR lookup -- how many thresholds lie at or below |coef_i| -- needs nothing from the null: its
+  // kernel goes IN FRONT of the null on the main stream (beside it, on the coefficient stream, it was starved for the
+  // whole pass: 2.1 ms at 2M cells, profiles/r06_kernel_stats_C4.csv), its 2 bytes per cell cross PCIe under the null
+  // from the coefficient stream, and the host puts table and counts together (cna_percell_fdr_copy_early).
+  const bool inline_fdr = c->coef_early && c->null_has_obs && T <= 512;
+  if (inline_fdr) {
+    Carver cw(c->scratch);
+    cw.take<double>(T);
+    cw.take<unsigned long long>((int64_t)P * T);
+    cw.take<int64_t>((int64_t)P * T);
+    cw.take<int64_t>(T);
+    cw.take<double>(T);                                    // oed
+    double* otd = cw.take<double>(T);
+    const int64_t n_out = c->local_view ? c->n_local : c->n_global;
+    void* bp = c->bins_dev;
+    CNA_TRY(dev_reserve(c, &bp, &c->bins_cap, 2 * std::max<int64_t>(std::max(c->n_pad, n_out), 1)));
+    c->bins_dev = (unsigned short*)bp;
+    if (2 * n_out > c->h_bins_cap) {
+      if (c->h_bins) HIP_TRY(hipHostFree(c->h_bins));
+      c->h_bins = nullptr;
+      HIP_TRY(hipHostMalloc((void**)&c->h_bins, (size_t)std::max<int64_t>(2 * n_out, 64), hipHostMallocDefault));
+      c->h_bins_cap = 2 * n_out;
+    }
+    hipStream_t cs = c->coef_stream;
+    CNA_TRY(launch_percell_bins(c, c->stream, c->coef_dev, otd, T, c->null_thr0, c->null_thr_step, c->bins_dev));
+    HIP_TRY(hipEventRecord(c->stage_done, c->stream));      // (a later point of the stream than the one prepare recorded)
+    HIP_TRY(hipStreamWaitEvent(cs, c->stage_done, 0));
+    if (n_out > 0) HIP_TRY(hipMemcpyAsync(c->h_bins, c->bins_dev, 2 * (size_t)n_out, hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipEventRecord(c->bins_copied, cs));
+    c->bins_pending = true;
+  }
   int* i8_status = nullptr;
   int64_t* i8_sums = nullptr;
   c->i8_last = false;
@@ -2244,41 +2296,19 @@ static int null_local_go(cna_ctx* c, int col0) {
     if (!c->null_has_tails) CNA_TRY(comm_allreduce_i64_sum(c, sums, (size_t)T));
   }
   HIP_TRY(hipMemcpyAsync(c->h_res, sums, 8 * (size_t)T, hipMemcpyDeviceToHost, c->stream));
-  if (c->coef_early && c->null_has_obs && T <= 512) {
-    // the caller already has the coefficient column (cna_percell_coef_launch): the FDR column can
-    // follow the null without the host in between -- FDR table from the tail sums and the observed
-    // counts (still in the scratch carve of the prepare half), per-cell lookup, copy to the pinned block
+  if (inline_fdr) {
+    // the caller already has the coefficient column (cna_percell_coef_launch): the FDR column can follow the null without
+    // the host in between -- behind the null only the FDR table is formed from the tail sums and the observed counts
+    // (still in the scratch carve of the prepare half) and sent (2.4 KB).  (Round 2 stored the finished 8-byte column
+    // from a kernel behind the null: 16 MB over PCIe on the critical path at 2M cells.)
     cv.take<double>(T);                                    // oed
-    double* otd = cv.take<double>(T);
+    cv.take<double>(T);                                    // otd
     cv.take<unsigned long long>(2 * (int64_t)T);           // ohist
     int64_t* otails = cv.take<int64_t>(2 * (int64_t)T);    // [ranks | num_detected]
-    const int64_t n_out = c->local_view ? c->n_local : c->n_global;
-    double* coef_local = c->coef_dev;
     double* tab = c->coef_dev + 4 * c->n_pad;
-    // Behind the null only the FDR table is formed and sent (2.4 KB).  The per-cell half of the lookup -- how many
-    // thresholds lie at or below |coef_i| -- needs nothing from the null: it runs on the coefficient stream now and its
-    // 2 bytes per cell cross PCIe under the null kernel; the host puts table and counts together.  (Round 2 stored
-    // the finished 8-byte column from a kernel behind the null: 16 MB over PCIe on the critical path at 2M cells.)
     CNA_TRY(launch_fdr_table(c, sums, otails, T, P, tab, tab + 512));
     if (!c->h_tab) HIP_TRY(hipHostMalloc((void**)&c->h_tab, 8 * 512, hipHostMallocDefault));
     HIP_TRY(hipMemcpyAsync(c->h_tab, tab + 512, 8 * (size_t)T, hipMemcpyDeviceToHost, c->stream));
-    {
-      void* bp = c->bins_dev;
-      CNA_TRY(dev_reserve(c, &bp, &c->bins_cap, 2 * std::max<int64_t>(std::max(c->n_pad, n_out), 1)));
-      c->bins_dev = (unsigned short*)bp;
-      if (2 * n_out > c->h_bins_cap) {
-        if (c->h_bins) HIP_TRY(hipHostFree(c->h_bins));
-        c->h_bins = nullptr;
-        HIP_TRY(hipHostMalloc((void**)&c->h_bins, (size_t)std::max<int64_t>(2 * n_out, 64), hipHostMallocDefault));
-        c->h_bins_cap = 2 * n_out;
-      }
-      hipStream_t cs = c->coef_stream;
-      HIP_TRY(hipStreamWaitEvent(cs, c->stage_done, 0));        // thresholds uploaded, coefficients formed (c->stream order)
-      CNA_TRY(launch_percell_bins(c, cs, coef_local, otd, T, c->null_thr0, c->null_thr_step, c->bins_dev));
-      if (n_out > 0) HIP_TRY(hipMemcpyAsync(c->h_bins, c->bins_dev, 2 * (size_t)n_out, hipMemcpyDeviceToHost, cs));
-      HIP_TRY(hipEventRecord(c->bins_copied, cs));
-      c->bins_pending = true;
-    }
     c->fdr_inline = true;
   }
   if (c->null_has_tails)

@@ -64,6 +64,9 @@ struct cna_ctx {
   void* h_hint = nullptr;              // pinned staging of cna_nam_select_hint's phenotype (8 KB)
   void* h_gram = nullptr;              // pinned staging of cna_gram_fetch (the caller's matrix is pageable: the runtime would stage the copy itself, slower)
   int64_t h_gram_cap = 0;
+  double* gram_mirror = nullptr;  // set around a Gram launch: the reduction also writes G here (the pinned h_gram)
+  bool gram_mirrored = false;     // ... and says so
+  double t_gram_fetched = 0.0;   // steady-clock seconds at which cna_gram_pcs_tests had the Gram matrix on the host (stage marks of cna_assoc_finish)
   void* h_scal = nullptr;              // pinned: a few words for scalar results a call waits for (a copy into pageable memory -- a stack
                                        // variable -- is staged by the runtime: 20-25 us each, measured between the selection pass and the Gram kernel)
   void* h_res = nullptr;               // pinned host staging for asynchronously fetched results
@@ -389,6 +392,7 @@ int launch_transpose(cna_ctx* c, const double* in, int64_t rows, int cols, int l
 // mfma.hip
 int launch_xb(cna_ctx* c, const double* B_dev, int ldb, int n_out, bool center, double* out, int ld_out);
 int launch_gram(cna_ctx* c, double* G_dev);
+int launch_copy_f64(cna_ctx* c, const double* src, double* dst, int64_t n);   // rows.hip: dst may be mapped host memory
 // the same product range by range (rows [row0, row1), boundaries multiples of *unit_rows) on stream st, partial tiles
 // carried in c->gram_part; bit-identical to launch_gram
 int gram_pre_begin(cna_ctx* c, int64_t* unit_rows);

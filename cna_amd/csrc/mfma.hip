@@ -745,7 +745,7 @@ __global__ __launch_bounds__(64 * NW) void k_gram_db(const double* __restrict__ 
 
 __global__ __launch_bounds__(1024) void k_gram_reduce(const double* __restrict__ partial, int nblocks, int ntri,
                                                       const int32_t* __restrict__ tiles, int Nx,
-                                                      double* __restrict__ G) {
+                                                      double* __restrict__ G, double* __restrict__ G_host) {
   // block = 64 accumulator lanes x 16 strided groups of workgroup partials; fixed summation
   // order (group-strided, then groups 0..15) -> bit-reproducible
   __shared__ double red[16][64];
@@ -765,6 +765,10 @@ __global__ __launch_bounds__(1024) void k_gram_reduce(const double* __restrict__
     if (i < Nx && j < Nx) {
       G[(size_t)i * Nx + j] = t;
       G[(size_t)j * Nx + i] = t;
+      if (G_host) {                                         // pinned copy for the eigen-solver on the host: no copy engine in between
+        G_host[(size_t)i * Nx + j] = t;
+        G_host[(size_t)j * Nx + i] = t;
+      }
     }
   }
 }
@@ -1486,8 +1490,9 @@ static int launch_gram_range(cna_ctx* c, const GramPlan& g, int64_t slab0, int64
 static int launch_gram_finish(cna_ctx* c, const GramPlan& g, double* G_dev, hipStream_t st) {
   ProfScope ps(c, CNA_K_GRAM_REDUCE, st);
   hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)g.ntri * 4), dim3(64, 16), 0, st, g.partial, g.nblocks, g.ntri,
-                     g.tiles_dev, g.Nx, G_dev);
+                     g.tiles_dev, g.Nx, G_dev, c->gram_mirror);
   HIP_TRY(hipGetLastError());
+  if (c->gram_mirror) c->gram_mirrored = true;
   return 0;
 }
 

@@ -1128,6 +1128,10 @@ __global__ void k_fill(double* v, int64_t n, double x) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = x;
 }
+__global__ void k_copy_f64(const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
 __global__ void k_scatter(const double* __restrict__ src, const int64_t* __restrict__ keep, int64_t nx,
                           double* __restrict__ dst) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1520,6 +1524,13 @@ int launch_suffix_sum(cna_ctx* c, const unsigned long long* hist, int P, int T, 
 int launch_tail_sums(cna_ctx* c, const int64_t* tails, int P, int T, int64_t* sums) {
   if (T == 0) return 0;
   hipLaunchKernelGGL(k_tail_sums, dim3((unsigned)((T + 63) / 64)), dim3(64, 16), 0, c->stream, tails, P, T, sums);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+int launch_copy_f64(cna_ctx* c, const double* src, double* dst, int64_t n) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_copy_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, src, dst, n);
   HIP_TRY(hipGetLastError());
   return 0;
 }

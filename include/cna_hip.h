@@ -456,7 +456,7 @@ typedef struct cna_assoc_out {
   double t_ms[12];           /* when the stages of this call were reached, ms from its entry: [0] phenotypes posted, [1] selection
                                 pass back (the walk is over), [2] local null queued, [3] inputs verified, [4] coefficient column
                                 out, [5] local null over + FDR column out, [6] null results, [7] eigenpairs + F-tests joined,
-                                [8] exit; on the eigenpairs thread: [10] eigenpairs done and F-tests queued, [11] F-tests fetched */
+                                [8] exit; on the eigenpairs thread: [9] Gram matrix on the host, [10] eigenpairs done and F-tests queued, [11] F-tests fetched */
   double thr[CNA_ASSOC_MAXT], fdr[CNA_ASSOC_MAXT], runmin[CNA_ASSOC_MAXT];
   int64_t tail_sums[CNA_ASSOC_MAXT], ranks[CNA_ASSOC_MAXT], num_detected[CNA_ASSOC_MAXT];
 } cna_assoc_out;
