@@ -284,8 +284,11 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True, dat
         cna.tl.association(data, y, 'id', **kw)
     assert not getattr(eng, 'reorder_pending', lambda: False)()
 
+    # The timed steps carry HIP events around the walk kernels (the dominant kernel of every configuration: `roofline`) and
+    # the communication spans only; the per-kernel table comes from a second loop of the same steps with every kernel
+    # group timed -- two event records per group are ~0.1 ms of host time per analysis, 8 % of the 200 000-cell one.
     eng.prof_reset()
-    eng.prof_enable(True)
+    eng.prof_enable(True, walk_only=True)
     sync()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -293,7 +296,18 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True, dat
     sync()
     dt = time.perf_counter() - t0
     eng.prof_enable(False)
+    prof_timed = eng.prof()
+    eng.prof_reset()
+    eng.prof_enable(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        cna.tl.association(data, y, 'id', **kw)
+    sync()
+    dt_all_spans = time.perf_counter() - t0
+    eng.prof_enable(False)
     prof = eng.prof()
+    prof.update(prof_timed)                        # (the walk and the communication: as measured in the timed steps)
     dt_local = dt
     if world > 1 or args.force_dist:
         dt = dist.max_over_ranks(dt)               # the slowest rank's clock
@@ -337,7 +351,7 @@ def time_workload(name, args, rank, world, steps, warmup, want_kernels=True, dat
     except Exception:
         i8 = (False, 0, False)
     return dict(name=name, n=n, N=N, k=k, nsteps=nsteps, Nnull=Nnull, n_covs=n_covs, n_batches=n_batches, nnz=nnz, wA=wA, dt=dt, t_cold=t_cold, i8=i8,
-                t_gen=t_gen, prof=prof, p=p_last, t_adopt=t_adopt, n_loc=n_loc, nnz_loc=nnz_loc, halo=getattr(eng, 'halo', None),
+                t_gen=t_gen, prof=prof, dt_all_spans=dt_all_spans, p=p_last, t_adopt=t_adopt, n_loc=n_loc, nnz_loc=nnz_loc, halo=getattr(eng, 'halo', None),
                 sharded_inputs=sharded_inputs, data=data, meta=meta, kw=kw, steps=steps, warmup=warmup, comm=eng.comm_info(),
                 per_rank={k_: [round(float(v), 3) for v in per_rank[:, i]] for i, k_ in enumerate(rank_keys)}, pinned=pinned,
                 two_call_path=_two_call_stats(),
@@ -469,6 +483,7 @@ def summary(m, world, steps):
     ms_per_step = m['dt'] / steps * 1e3
     return dict(value=round(m['n'] * m['Nnull'] * steps / m['dt'], 1), ms_per_step=round(ms_per_step, 3), roofline=roofline,
                 kernels=kernels, gpu_kernel_ms_per_step=round(gpu_ms, 3),
+                ms_per_step_all_spans=None if m.get('dt_all_spans') is None else round(m['dt_all_spans'] / steps * 1e3, 3),
                 host_ms_per_step=round(ms_per_step - gpu_ms, 3), ranks=ranks_summary(m, world),
                 graph_pinned=m.get('pinned', True), two_call_path=m.get('two_call_path'),
                 cold_first_call=dict(ms=round(m['t_cold'] * 1e3, 1), value=round(m['n'] * m['Nnull'] / m['t_cold'], 1),
@@ -607,6 +622,9 @@ def assemble_details(m, main_sum, cpu, cpu_c2, extra, world, steps, warmup, args
         'cpu_baseline_C2_full': cpu_c2,
         'gpu_kernel_ms_per_step': main_sum['gpu_kernel_ms_per_step'],
         'host_ms_per_step': main_sum['host_ms_per_step'],
+        # the same steps again with HIP events around EVERY kernel group (where `kernels` comes from; the timed steps carry
+        # them around the walk kernels and the communication spans only)
+        'ms_per_step_all_spans': main_sum.get('ms_per_step_all_spans'),
         'ranks': main_sum.get('ranks') if world > 1 or args.force_dist else None,
         'rccl_transport': rccl_transport(0) if world > 1 or args.force_dist else None,
         'two_call_path': main_sum.get('two_call_path'),

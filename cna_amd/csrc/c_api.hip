@@ -2844,6 +2844,10 @@ int cna_prof_enable(cna_ctx* c, int on) {
   if (!c) CNA_FAIL(CNA_EINVAL, "null context");
   if (!on) prof_flush(c);
   c->prof = on != 0;
+  static_assert(CNA_K_COUNT <= 64, "prof_mask is one word");
+  c->prof_mask = on == 2 ? (1ull << CNA_K_NAM_FIRST | 1ull << CNA_K_NAM_STEP | 1ull << CNA_K_NAM_STEP_SPARSE | 1ull << CNA_K_ALLGATHER |
+                            1ull << CNA_K_HALO_EXCHANGE | 1ull << CNA_K_HALO_WAIT)
+                         : ~0ull;
   return 0;
 }
 int cna_prof_reset(cna_ctx* c) {

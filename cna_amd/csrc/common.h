@@ -288,6 +288,7 @@ struct cna_ctx {
 
   // ---- profiling
   bool prof = false;
+  uint64_t prof_mask = ~0ull;      // kernel ids that are timed while prof is on (cna_prof_enable level 2: the walk and the communication spans)
   double prof_ms[CNA_K_COUNT] = {0};
   int64_t prof_n[CNA_K_COUNT] = {0};
   std::vector<ProfSpan> prof_pending;
@@ -303,9 +304,9 @@ struct ProfScope {
   int kid;
   hipStream_t st;
   ProfScope(cna_ctx* c_, int k, hipStream_t s = nullptr) : c(c_), kid(k), st(s ? s : c_->stream) {
-    if (c->prof && kid >= 0) prof_begin(c, kid, st);
+    if (c->prof && kid >= 0 && (c->prof_mask >> kid & 1)) prof_begin(c, kid, st);
   }
-  ~ProfScope() { if (c->prof && kid >= 0) prof_end(c, kid, st); }
+  ~ProfScope() { if (c->prof && kid >= 0 && (c->prof_mask >> kid & 1)) prof_end(c, kid, st); }
 };
 
 int dev_alloc(cna_ctx* c, void** p, size_t bytes);

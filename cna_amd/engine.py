@@ -1124,8 +1124,10 @@ class Engine(_order.CellOrder):
         return A
 
     # ---------------------------------------------------------------- measurement
-    def prof_enable(self, on=True):
-        check(self.lib.cna_prof_enable(self.h, int(bool(on))), 'cna_prof_enable')
+    def prof_enable(self, on=True, walk_only=False):
+        """HIP-event timing of the kernel groups (include/cna_hip.h: cna_prof_enable); walk_only: the walk kernels and the
+        communication spans only."""
+        check(self.lib.cna_prof_enable(self.h, (2 if walk_only else 1) if on else 0), 'cna_prof_enable')
 
     def prof_reset(self):
         check(self.lib.cna_prof_reset(self.h), 'cna_prof_reset')

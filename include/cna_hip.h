@@ -568,7 +568,9 @@ int  cna_knn_graph(cna_ctx* ctx, const float* X, int64_t n, int d, int k, int64_
                    int32_t* indices_out, float* data_out, int64_t* nnz_out);
 
 /* ---- measurement ------------------------------------------------------------------------ */
-/* HIP-event timing of every kernel launch on the context's stream (bench.py roofline) */
+/* HIP-event timing of every kernel launch on the context's stream (bench.py roofline).  on = 1: every kernel group;
+ * on = 2: the walk kernels (CNA_K_NAM_FIRST / _STEP / _STEP_SPARSE) and the communication spans only -- two event records
+ * per span cost the host ~0.1 ms of a 1.2 ms analysis when all ~20 groups are timed; 0: off. */
 int  cna_prof_enable(cna_ctx* ctx, int on);
 int  cna_prof_reset(cna_ctx* ctx);
 int  cna_prof_get(cna_ctx* ctx, int kernel_id, double* total_ms, int64_t* launches);
