@@ -341,7 +341,7 @@ int  cna_null_local_discard(cna_ctx* ctx);
 /* Diagnostics of the last local-null pass that wanted only the sums over permutations (the
  * analysis): such a pass forms the products on the integer matrix cores (csrc/null_i8.hip: 24-bit
  * fixed point, exact int32 accumulation, outputs within the error bound of a cut recomputed in f64)
- * with the f64 kernel as stand-by.  used_out: 1 when the integer path ran; rechecked_out: outputs it
+ * ; the f64 kernel runs the pass again when the integer one gives up.  used_out: 1 when the integer path ran; rechecked_out: outputs it
  * sent to the f64 recheck; fallback_out: 1 when it gave up (queue overflow) and the f64 kernel did
  * the work.  Waits for the device.  Environment CNA_NULL_F64=1 disables the integer path. */
 int  cna_null_local_i8_stats(cna_ctx* ctx, int* used_out, int64_t* rechecked_out, int* fallback_out);
