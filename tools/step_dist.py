@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Distribution of step times of repeated association() calls (graph pinned, NAM cache and draw memo off), with the stage marks of the slow ones."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, warnings
 warnings.simplefilter('ignore')
 import cna_amd as cna
