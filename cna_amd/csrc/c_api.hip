@@ -215,6 +215,7 @@ int cna_ctx_create(int device, cna_ctx** out) {
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->gram_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->coef_ready, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->gt_done, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->scal_ready, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->stage_done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->coef_copied, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->null_done, hipEventDisableTiming);
@@ -249,6 +250,7 @@ int cna_ctx_destroy(cna_ctx* c) {
   if (c->gram_done) (void)hipEventDestroy(c->gram_done);
   if (c->coef_ready) (void)hipEventDestroy(c->coef_ready);
   if (c->gt_done) (void)hipEventDestroy(c->gt_done);
+  if (c->scal_ready) (void)hipEventDestroy(c->scal_ready);
   if (c->stage_done) (void)hipEventDestroy(c->stage_done);
   if (c->h_gt) (void)hipHostFree(c->h_gt);
   if (c->coef_copied) (void)hipEventDestroy(c->coef_copied);
@@ -1445,6 +1447,7 @@ int cna_select_checked(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, cons
 
 static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
                                     int64_t* n_zero_out, const double* y, double* max_abs_out, bool* gram_too);
+static int gram_launch_now(cna_ctx* c);
 
 int cna_select_standardized(cna_ctx* c, const int64_t* keep_idx, int64_t n_keep, const int32_t* colmap, int n_sel,
                             int64_t* n_zero_out, const double* y, double* max_abs_out) {
@@ -1483,12 +1486,12 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
   } else {
     c->keep_idx = nullptr;
   }
-  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({4 * (int64_t)Nx, 8, 8 * (int64_t)Nx, 8 * 4098})));
+  CNA_TRY(dev_reserve(c, &c->scratch, &c->scratch_cap, carve_bytes({4 * (int64_t)Nx, 8 * (int64_t)Nx, 8 * 4099})));
   Carver cv(c->scratch);
   int32_t* cm = cv.take<int32_t>(Nx);
-  unsigned long long* nz = cv.take<unsigned long long>(1);
   double* yd = cv.take<double>(Nx);
-  unsigned long long* mb = cv.take<unsigned long long>(4098);
+  unsigned long long* nz = cv.take<unsigned long long>(4099);      // {zero-variance rows, bits of max |coefficient|, per-workgroup maxima}:
+  unsigned long long* mb = nz + 1;                                  // the two results adjacent, one copy to the host
   if (colmap) HIP_TRY(hipMemcpyAsync(cm, colmap, 4 * Nx, hipMemcpyHostToDevice, c->stream));
   if (y) {
     void* np = c->ncorrs;
@@ -1550,9 +1553,20 @@ static int select_standardized_impl(cna_ctx* c, const int64_t* keep_idx, int64_t
   volatile unsigned long long* hs = (volatile unsigned long long*)c->h_scal;
   hs[0] = 0;
   hs[1] = 0;
-  HIP_TRY(hipMemcpyAsync((void*)&hs[0], nz, 8, hipMemcpyDeviceToHost, c->stream));
-  if (y) HIP_TRY(hipMemcpyAsync((void*)&hs[1], mb, 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemcpyAsync((void*)&hs[0], nz, y ? 16 : 8, hipMemcpyDeviceToHost, c->stream));
+  // The caller wants the Gram matrix of this X next: its kernels are queued NOW, behind the two scalars on their way to the
+  // host, and the host waits for the scalars only -- the device goes from the selection pass (or from the walk's last step
+  // that left X as a by-product) straight into the product instead of idling through the host's round trip (30-35 us,
+  // profiles/r06_timeline_C2.txt).  Should the scalars say "rows of zero variance", the matrix is dropped with X.
+  const bool gram_early = gram_too && y && !fused && !(byp && gram_pre_was);
+  if (gram_early) {
+    HIP_TRY(hipEventRecord(c->scal_ready, c->stream));
+    CNA_TRY(gram_launch_now(c));
+    *gram_too = true;
+    HIP_TRY(hipEventSynchronize(c->scal_ready));
+  } else {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   const unsigned long long h = hs[0];
   double m = 0.0;
   {
@@ -1932,6 +1946,9 @@ int cna_standardize(cna_ctx* c, int center) {
 int cna_gram_launch(cna_ctx* c) {
   CHECK_CTX(c);
   if (!c->x_valid) CNA_FAIL(CNA_ESTATE, "X not available");
+  return gram_launch_now(c);
+}
+static int gram_launch_now(cna_ctx* c) {
   const int Nx = c->Nx;
   const bool pre = c->gram_pre && c->gram_pre_pending;     // taken under the walk's last step (ranged_last_step), X untouched since
   c->gram_pre = false;

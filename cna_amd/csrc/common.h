@@ -59,6 +59,7 @@ struct cna_ctx {
   hipStream_t copy_stream = nullptr;   // D2H of small results that must not queue behind long kernels
   hipStream_t coef_stream = nullptr;   // the early coefficient column's copy: the helper thread waits on copy_stream and must not wait for this
   hipEvent_t gram_done = nullptr;
+  hipEvent_t scal_ready = nullptr;     // the selection pass's two scalars are in h_scal (the Gram kernels may already be queued behind them)
   double* gram_buf = nullptr;          // Gram matrix of the last cna_gram_launch
   hipEvent_t null_done = nullptr;      // results of the last local-null launch are in h_res
   void* h_hint = nullptr;              // pinned staging of cna_nam_select_hint's phenotype (8 KB)
