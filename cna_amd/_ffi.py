@@ -105,6 +105,7 @@ SIGNATURES = {
     'cna_host_gather_rows': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int]),
     'cna_host_draw_wait': (C.c_int, []),
     'cna_host_draw_join': (C.c_int, []),
+    'cna_host_draw_times': (None, [C.POINTER(C.c_double)]),
     'cna_assoc_begin': (C.c_int, [c_ctx, C.c_int, C.c_void_p, C.c_int]),
     'cna_assoc_begin_part': (C.c_int, [c_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
     'cna_assoc_finish': (C.c_int, [c_ctx, C.c_void_p, C.c_void_p]),
@@ -155,7 +156,7 @@ class AssocOut(C.Structure):
     """struct cna_assoc_out (include/cna_hip.h)"""
     _fields_ = [('status', C.c_int32), ('T', C.c_int32), ('eig_accepted', C.c_int32), ('null_fused', C.c_int32),
                 ('coef_in_dst', C.c_int32), ('fdr_in_dst', C.c_int32), ('n_zero', C.c_int64), ('max_abs', C.c_double),
-                ('coef_ptr', C.c_void_p), ('fdr_ptr', C.c_void_p), ('t_ms', C.c_double * 12),
+                ('coef_ptr', C.c_void_p), ('fdr_ptr', C.c_void_p), ('t_ms', C.c_double * 16),
                 ('thr', C.c_double * ASSOC_MAXT), ('fdr', C.c_double * ASSOC_MAXT), ('runmin', C.c_double * ASSOC_MAXT),
                 ('tail_sums', C.c_int64 * ASSOC_MAXT), ('ranks', C.c_int64 * ASSOC_MAXT), ('num_detected', C.c_int64 * ASSOC_MAXT)]
 

@@ -12,6 +12,7 @@
 
 extern "C" {
 int cna_host_draw_join(void);
+void cna_host_draw_times(double* out2);
 int cna_host_draw_then_condition(cna_ctx* ctx, const double* M, const double* table, int N, int cols, int* flag);
 int cna_host_copy(void* dst, const void* src, int64_t nbytes, int nthreads);
 uint64_t cna_host_hash64(const void* p, int64_t nbytes, int nthreads);
@@ -228,6 +229,13 @@ int cna_assoc_finish(cna_ctx* c, const cna_assoc_args* a, cna_assoc_out* o) {
   if (!eig.acc) o->status = CNA_ASSOC_NEED_PCS;
   if (draw.join() != 0) CNA_FAIL(CNA_ENOMEM, "cna_assoc_finish: the permutation draw failed");
   mark(8);
+  {
+    double td[2];
+    cna_host_draw_times(td);
+    const double t0 = std::chrono::duration<double>(t_entry.time_since_epoch()).count();
+    o->t_ms[12] = (td[0] - t0) * 1e3;
+    o->t_ms[13] = (td[1] - t0) * 1e3;
+  }
   return 0;
 }
 

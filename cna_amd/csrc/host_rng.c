@@ -84,6 +84,7 @@ CLONES static void candidates(const uint32_t* restrict w, int nc, double* restri
 }
 
 #include <pthread.h>
+#include <sched.h>
 static int g_host_threads = 1;
 /* the library's draw thread runs with the count its request carries: an override of ITS OWN, so that it never races
  * with cna_host_set_threads or with a draw on the caller's thread */
@@ -101,6 +102,145 @@ static void* norm_worker(void* arg) {
   return NULL;
 }
 
+/* ---- the same stream on several threads (round 6) ----------------------------------------------------------------
+ * Every candidate consumes exactly four words, accepted or not, and the generator's blocks follow from the key alone
+ * (a block costs 0.04 us to produce): thread t re-derives the key of its first block and then produces, tests and
+ * compacts the candidates of ITS blocks into a buffer of its own; the accepted counts per block are summed in order,
+ * which tells every thread where its pairs go; each thread then turns its own pairs into normals.  Nothing a thread
+ * computed is read by another one (handing the accepted pairs of ONE producer to helper threads moved 2.4 MB of
+ * dirty cache lines between cores and was slower than no helpers at all: 0.97 against 0.69 ms for 100 000 pairs,
+ * tools/micro/bench_draw.c).  Requires the remaining words of the current block to be a multiple of four (always
+ * true behind np.random.seed), so that no candidate straddles two blocks.  The number of blocks is estimated from the
+ * acceptance rate pi/4 with a wide margin; should it fall short the sequential code below does the draw.
+ * 1: done (key, pos, cached value updated), 0: not applicable / fell short (nothing changed). */
+struct rp_shared {
+  const uint32_t* key0; int pos0, c0, nt;
+  int64_t nblocks, pairs, n_out;
+  double* out;
+  int32_t* cnt; int64_t* offs;
+  int arrived, go;                                   /* atomics */
+};
+struct rp_job { struct rp_shared* sh; int tid; int64_t b0, b1; double* buf; int64_t cap, nacc; int bad; };
+static void rp_block(const struct rp_shared* sh, uint32_t* st, int64_t* reloads, int64_t b, uint32_t* words, int* nc) {
+  if (b == 0) {
+    temper(sh->key0 + sh->pos0, words, 4 * sh->c0);
+    *nc = sh->c0;
+  } else {
+    while (*reloads < b) { mt_reload(st); ++*reloads; }
+    temper(st, words, MT_N);
+    *nc = MT_N / 4;
+  }
+}
+static void* rp_worker(void* arg) {
+  struct rp_job* j = (struct rp_job*)arg;
+  struct rp_shared* sh = j->sh;
+  uint32_t st[MT_N], words[MT_N];
+  double x1[MT_N / 4], x2[MT_N / 4], r2[MT_N / 4];
+  memcpy(st, sh->key0, sizeof(st));
+  int64_t reloads = 0, found = 0;
+  double *ax1 = j->buf, *ax2 = j->buf + j->cap, *ar2 = j->buf + 2 * j->cap;
+  if (j->buf) {
+    for (int64_t b = j->b0; b < j->b1; ++b) {
+      int nc;
+      rp_block(sh, st, &reloads, b, words, &nc);
+      candidates(words, nc, x1, x2, r2);
+      const int64_t before = found;
+      for (int u = 0; u < nc; ++u) {
+        const double r = r2[u];
+        ax1[found] = x1[u];
+        ax2[found] = x2[u];
+        ar2[found] = r;
+        found += (r < 1.0) & (r != 0.0);
+      }
+      sh->cnt[b] = (int32_t)(found - before);
+    }
+  }
+  j->nacc = found;
+  /* all counts in -> thread 0 sums them -> everybody places its pairs */
+  __atomic_fetch_add(&sh->arrived, 1, __ATOMIC_ACQ_REL);
+  if (j->tid == 0) {
+    while (__atomic_load_n(&sh->arrived, __ATOMIC_ACQUIRE) < sh->nt) sched_yield();
+    int64_t tot = 0;
+    for (int64_t b = 0; b < sh->nblocks; ++b) { sh->offs[b] = tot; tot += sh->cnt[b]; }
+    sh->offs[sh->nblocks] = tot;
+    __atomic_store_n(&sh->go, 1, __ATOMIC_RELEASE);
+  } else {
+    while (!__atomic_load_n(&sh->go, __ATOMIC_ACQUIRE)) sched_yield();
+  }
+  if (!j->buf || sh->offs[sh->nblocks] < sh->pairs) return NULL;          /* fell short (or no memory): the caller redoes it */
+  const int64_t g0 = sh->offs[j->b0];
+  int64_t cnt = found;
+  if (g0 + cnt > sh->pairs) cnt = sh->pairs > g0 ? sh->pairs - g0 : 0;
+  struct norm_job nj = {ax1, ax2, ar2, sh->out + 2 * g0, sh->n_out - 2 * g0, 0, cnt};
+  norm_worker(&nj);
+  return NULL;
+}
+static int randn_parallel(uint32_t* key, int* pos, int* has_gauss, double* gauss, int64_t n_out, double* out, int64_t pairs, int nt) {
+  const int c0 = (MT_N - *pos) / 4;
+  if ((MT_N - *pos) % 4 != 0 || nt < 2) return 0;
+  if (nt > 16) nt = 16;
+  const double need = (double)pairs / 0.78539816339744831 + 8.0 * sqrt((double)pairs) + 2.0 * (MT_N / 4);
+  int64_t nblocks = 1 + (int64_t)((need - c0) / (MT_N / 4)) + 1;
+  if (nblocks < 2) nblocks = 2;
+  if (nblocks < nt) nt = (int)nblocks;
+  struct rp_shared sh = {key, *pos, c0, nt, nblocks, pairs, n_out, out, NULL, NULL, 0, 0};
+  sh.cnt = (int32_t*)calloc((size_t)nblocks, sizeof(int32_t));
+  sh.offs = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nblocks + 1));
+  struct rp_job jobs[16];
+  pthread_t th[16];
+  int started[16];
+  int ok = sh.cnt && sh.offs;
+  for (int t = 0; t < nt; ++t) {
+    jobs[t].sh = &sh; jobs[t].tid = t; jobs[t].bad = 0; jobs[t].nacc = 0;
+    jobs[t].b0 = nblocks * t / nt; jobs[t].b1 = nblocks * (t + 1) / nt;
+    jobs[t].cap = (jobs[t].b1 - jobs[t].b0) * (MT_N / 4) + 1;
+    jobs[t].buf = ok ? (double*)malloc(sizeof(double) * 3 * (size_t)jobs[t].cap) : NULL;
+    if (!jobs[t].buf) ok = 0;
+    started[t] = 0;
+  }
+  if (!ok) {
+    for (int t = 0; t < nt; ++t) free(jobs[t].buf);
+    free(sh.cnt); free(sh.offs);
+    return 0;
+  }
+  /* a thread that cannot be started leaves the draw to the sequential code: the others would wait for it */
+  int nstarted = 1;
+  for (int t = 1; t < nt; ++t) { started[t] = pthread_create(&th[t], NULL, rp_worker, &jobs[t]) == 0; nstarted += started[t]; }
+  if (nstarted < nt) {
+    for (int t = 1; t < nt; ++t) if (!started[t]) { jobs[t].nacc = 0; __atomic_fetch_add(&sh.arrived, 1, __ATOMIC_ACQ_REL); }
+  }
+  rp_worker(&jobs[0]);
+  for (int t = 1; t < nt; ++t) if (started[t]) pthread_join(th[t], NULL);
+  int done = nstarted == nt && sh.offs[nblocks] >= pairs;
+  if (done) {
+    /* numpy stops right behind the candidate that completed the last pair: find it, and the key of its block */
+    int64_t bs = 0;
+    while (sh.offs[bs + 1] < pairs) ++bs;
+    uint32_t st[MT_N], words[MT_N];
+    double x1[MT_N / 4], x2[MT_N / 4], r2[MT_N / 4];
+    memcpy(st, key, sizeof(st));
+    int64_t reloads = 0;
+    int nc;
+    rp_block(&sh, st, &reloads, bs, words, &nc);
+    candidates(words, nc, x1, x2, r2);
+    int64_t want = pairs - sh.offs[bs];
+    int u = 0;
+    for (; u < nc; ++u) {
+      if (r2[u] < 1.0 && r2[u] != 0.0 && --want == 0) break;
+    }
+    if (bs > 0) memcpy(key, st, sizeof(st));
+    *pos = (bs == 0 ? *pos : 0) + 4 * (u + 1);
+    if (2 * pairs > n_out) {                           /* odd count: the last second value stays cached */
+      const double f = sqrt(-2.0 * log(r2[u]) / r2[u]);
+      *has_gauss = 1;
+      *gauss = f * x1[u];
+    }
+  }
+  for (int t = 0; t < nt; ++t) free(jobs[t].buf);
+  free(sh.cnt); free(sh.offs);
+  return done;
+}
+
 /* n standard normals of numpy's legacy generator (RandomState.randn / standard_normal) into out.
  * key[624], *pos (0..624), *has_gauss, *gauss: the generator state as np.random.get_state() reports
  * it, updated in place to what numpy's own state would be after the same draws.  Returns 0, or -1
@@ -116,6 +256,9 @@ int cna_host_legacy_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss
   }
   const int64_t pairs = (n - done + 1) / 2;          /* accepted candidate pairs still to find */
   if (pairs == 0) return 0;
+  if (host_threads() > 1 && pairs >= (1 << 13) &&
+      randn_parallel(key, pos, has_gauss, gauss, n - done, out + done, pairs, host_threads()) == 1)
+    return 0;
   double* acc = (double*)malloc(sizeof(double) * 3 * (size_t)pairs);
   if (!acc) return -1;
   double *ax1 = acc, *ax2 = acc + pairs, *ar2 = acc + 2 * pairs;
@@ -130,14 +273,15 @@ int cna_host_legacy_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss
     const int nc = have / 4;
     candidates(words, nc, x1, x2, r2);
     int used = 0;                                    /* candidates consumed */
+    /* accepted candidates are compacted without a branch (one in five is rejected: 0.28 of the 0.44 ms this loop took
+     * for 100 000 pairs went into mispredictions, tools/micro/bench_draw.c): every candidate is stored at the cursor,
+     * which advances only behind an accepted one */
     for (; used < nc && found < pairs; used++) {
       const double r = r2[used];
-      if (r < 1.0 && r != 0.0) {
-        ax1[found] = x1[used];
-        ax2[found] = x2[used];
-        ar2[found] = r;
-        found++;
-      }
+      ax1[found] = x1[used];
+      ax2[found] = x2[used];
+      ar2[found] = r;
+      found += (r < 1.0) & (r != 0.0);
     }
     if (found == pairs) {                            /* numpy stops right after this candidate */
       p += 4 * used;
@@ -164,7 +308,7 @@ int cna_host_legacy_randn(uint32_t* key, int* pos, int* has_gauss, double* gauss
     int started[64];
     int nt = host_threads();
     if (nt > 64) nt = 64;
-    if (nt < 1 || pairs < (1 << 13)) nt = 1;                  /* (25 000 pairs = 50 samples x 1000 permutations split over two to four threads) */
+    if (nt < 1 || pairs < (1 << 18)) nt = 1;         /* (helpers read what ONE producer wrote: slower than none below ~0.25M pairs) */                  /* (25 000 pairs = 50 samples x 1000 permutations split over two to four threads) */
     for (int t = 0; t < nt; ++t) {
       jobs[t].x1 = ax1; jobs[t].x2 = ax2; jobs[t].r2 = ar2; jobs[t].out = out + done; jobs[t].n_out = n - done;
       jobs[t].a = pairs * t / nt; jobs[t].b = pairs * (t + 1) / nt;
@@ -434,6 +578,13 @@ static int draw_run(const struct draw_req* q) {
   return rc;
 }
 
+/* when the last draw and its follow-up finished (CLOCK_MONOTONIC seconds = std::chrono::steady_clock): stage marks of
+ * cna_assoc_finish (cna_assoc_out.t_ms[12], [13]) */
+#include <time.h>
+static double g_draw_times[2];
+static double mono_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+void cna_host_draw_times(double* out2) { out2[0] = g_draw_times[0]; out2[1] = g_draw_times[1]; }
+
 static void* draw_thread(void* arg) {
   (void)arg;
   pthread_mutex_lock(&g_draw_mu);
@@ -444,6 +595,7 @@ static void* draw_thread(void* arg) {
       const struct draw_req q = g_draw_req;
       pthread_mutex_unlock(&g_draw_mu);
       const int rc = draw_run(&q);
+      g_draw_times[0] = mono_now();
       pthread_mutex_lock(&g_draw_mu);
       g_draw_rc = rc;
       g_draw_state = 3;
@@ -453,6 +605,7 @@ static void* draw_thread(void* arg) {
       const int ok = g_draw_rc == 0;
       pthread_mutex_unlock(&g_draw_mu);
       const int rc = ok ? cna_condition_phenotypes(t.ctx, t.M, t.table, t.N, t.cols) : -1;
+      g_draw_times[1] = mono_now();
       __atomic_store_n(t.flag, rc == 0 ? 1 : -1, __ATOMIC_RELEASE);
       pthread_mutex_lock(&g_draw_mu);
       g_then_state = 3;

@@ -453,10 +453,11 @@ typedef struct cna_assoc_out {
   double max_abs;
   double* coef_ptr;          /* pinned, valid until the next per-cell call on the context (when not copied to coef_dst) */
   double* fdr_ptr;
-  double t_ms[12];           /* when the stages of this call were reached, ms from its entry: [0] phenotypes posted, [1] selection
+  double t_ms[16];           /* when the stages of this call were reached, ms from its entry: [0] phenotypes posted, [1] selection
                                 pass back (the walk is over), [2] local null queued, [3] inputs verified, [4] coefficient column
                                 out, [5] local null over + FDR column out, [6] null results, [7] eigenpairs + F-tests joined,
-                                [8] exit; on the eigenpairs thread: [9] Gram matrix on the host, [10] eigenpairs done and F-tests queued, [11] F-tests fetched */
+                                [8] exit; on the eigenpairs thread: [9] Gram matrix on the host, [10] eigenpairs done and F-tests queued, [11] F-tests fetched; on the draw thread (negative: before this call was entered): [12] permutations drawn,
+                                [13] phenotypes conditioned (the flag the fused selection call reads) */
   double thr[CNA_ASSOC_MAXT], fdr[CNA_ASSOC_MAXT], runmin[CNA_ASSOC_MAXT];
   int64_t tail_sums[CNA_ASSOC_MAXT], ranks[CNA_ASSOC_MAXT], num_detected[CNA_ASSOC_MAXT];
 } cna_assoc_out;
@@ -469,6 +470,8 @@ int  cna_assoc_run(cna_ctx* ctx, int nsteps, const double* y_hint, int n_hint, c
 /* blocks until the request of cna_host_draw_start (and its follow-up) is done WITHOUT collecting it: the caller's
  * cna_host_draw_wait still returns its status (0 / -1 as cna_host_draw_wait; -2: nothing was started) */
 int  cna_host_draw_join(void);
+/* out2 = {when the last draw finished, when its follow-up (the conditioning) did}, CLOCK_MONOTONIC seconds: diagnostics */
+void cna_host_draw_times(double* out2);
 
 /* ---- device -> host for the lazily materialised result fields (a20) -------------------- */
 int  cna_matrix_shape(cna_ctx* ctx, int which, int64_t* n_rows_local, int* n_cols);

@@ -31,6 +31,38 @@ def test_legacy_randn_is_numpys_stream(seed):
             assert all(np.array_equal(u, v) for u, v in zip(nxt, ref_next))
 
 
+@pytest.mark.parametrize('threads', [2, 4, 7])
+def test_legacy_randn_on_several_threads_is_numpys_stream(threads):
+    """The block-parallel stream (csrc/host_rng.c:randn_parallel: every thread derives the key of its own blocks) for
+    starting positions that are and are not a multiple of four words from the block end, even and odd counts, a cached
+    value pending: values, generator state and what numpy draws next."""
+    from cna_amd import _ffi
+    lib = _ffi.load()
+    lib.cna_host_set_threads(threads)
+    _stats._threads_set = True
+    try:
+        for m, num in ((50, 1000), (1, 16385), (3, 16667), (200, 1000), (7, 9001)):
+            for pre in (0, 1, 2, 4, 5, 312, 620, 623, 624, 625, 1248):
+                np.random.seed(pre + 17)
+                if pre:
+                    np.random.random_sample(pre)            # two words each
+                if pre == 5:
+                    np.random.randn(1)
+                start = np.random.get_state()
+                ref = np.random.randn(m, num)
+                ref_state = np.random.get_state()
+                ref_next = np.random.randn(3), np.random.randint(0, 1000, 4)
+                np.random.set_state(start)
+                got = _stats.legacy_randn(m, num).copy()
+                assert np.array_equal(got.view(np.uint64), ref.view(np.uint64)), (m, num, pre)
+                assert _same_state(np.random.get_state(), ref_state), (m, num, pre)
+                nxt = np.random.randn(3), np.random.randint(0, 1000, 4)
+                assert all(np.array_equal(u, v) for u, v in zip(nxt, ref_next))
+    finally:
+        lib.cna_host_set_threads(1)
+        _stats._threads_set = False
+
+
 def test_permutation_draws_match_plain_numpy(monkeypatch):
     """conditional_permutation / grouplevel_permutation through the fast stream == through np.random.randn."""
     rs = np.random.RandomState(3)

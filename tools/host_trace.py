@@ -49,5 +49,5 @@ print('%8.3f  +%6.3f gap  end' % ((t1 - t0) * 1e3, (t1 - last) * 1e3))
 tm = getattr(eng, 'last_assoc_t_ms', None)
 if tm:
     print('cna_assoc_finish stages (ms from its entry): ' + '  '.join('%s=%.3f' % (k, v) for k, v in zip(
-        ('posted', 'select_back', 'null_queued', 'verified', 'coef_out', 'null_over+fdr_out', 'null_results', 'eig_joined', 'exit', 'gram_back', 'eig_done', 'ftests_done'), tm)))
+        ('posted', 'select_back', 'null_queued', 'verified', 'coef_out', 'null_over+fdr_out', 'null_results', 'eig_joined', 'exit', 'gram_back', 'eig_done', 'ftests_done', 'drawn', 'conditioned'), tm)))
 print('marks: ' + '  '.join('%s@%.3f' % (k, (v - t0) * 1e3) for k, v in marks))

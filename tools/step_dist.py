@@ -27,6 +27,6 @@ for i in range(reps):
 ts = np.array(ts)
 print('%d x %d: mean %.3f  median %.3f  min %.3f  max %.3f  p90 %.3f' % (n, N, ts.mean(), np.median(ts), ts.min(), ts.max(), np.percentile(ts, 90)))
 print('sorted:', ' '.join('%.2f' % t for t in np.sort(ts)))
-names = ('posted', 'select_back', 'null_queued', 'verified', 'coef_out', 'fdr_out', 'null_results', 'eig_joined', 'exit', 'gram_back', 'eig_done', 'ftests_done')
+names = ('posted', 'select_back', 'null_queued', 'verified', 'coef_out', 'fdr_out', 'null_results', 'eig_joined', 'exit', 'gram_back', 'eig_done', 'ftests_done', 'drawn', 'conditioned')
 for i in np.argsort(ts)[[0, len(ts) // 2, -3, -2, -1]]:
     print('%.3f ms: ' % ts[i] + '  '.join('%s=%.3f' % kv for kv in zip(names, marks[i])))
