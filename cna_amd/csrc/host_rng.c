@@ -85,6 +85,7 @@ CLONES static void candidates(const uint32_t* restrict w, int nc, double* restri
 
 #include <pthread.h>
 #include <sched.h>
+#include <time.h>
 static int g_host_threads = 1;
 /* the library's draw thread runs with the count its request carries: an override of ITS OWN, so that it never races
  * with cna_host_set_threads or with a draw on the caller's thread */
@@ -131,6 +132,13 @@ static void rp_block(const struct rp_shared* sh, uint32_t* st, int64_t* reloads,
     *nc = MT_N / 4;
   }
 }
+/* waiting for the other threads of a draw: they are busy for tens of microseconds -- yield; should one of them have been
+ * descheduled for long (a CPU quota), stop burning the quota it is waiting for */
+static inline void rp_wait_step(int* spins) {
+  if (++*spins < 4096) { sched_yield(); return; }
+  struct timespec ts = {0, 20000};
+  nanosleep(&ts, NULL);
+}
 static void* rp_worker(void* arg) {
   struct rp_job* j = (struct rp_job*)arg;
   struct rp_shared* sh = j->sh;
@@ -159,13 +167,13 @@ static void* rp_worker(void* arg) {
   /* all counts in -> thread 0 sums them -> everybody places its pairs */
   __atomic_fetch_add(&sh->arrived, 1, __ATOMIC_ACQ_REL);
   if (j->tid == 0) {
-    while (__atomic_load_n(&sh->arrived, __ATOMIC_ACQUIRE) < sh->nt) sched_yield();
+    for (int spins = 0; __atomic_load_n(&sh->arrived, __ATOMIC_ACQUIRE) < sh->nt;) rp_wait_step(&spins);
     int64_t tot = 0;
     for (int64_t b = 0; b < sh->nblocks; ++b) { sh->offs[b] = tot; tot += sh->cnt[b]; }
     sh->offs[sh->nblocks] = tot;
     __atomic_store_n(&sh->go, 1, __ATOMIC_RELEASE);
   } else {
-    while (!__atomic_load_n(&sh->go, __ATOMIC_ACQUIRE)) sched_yield();
+    for (int spins = 0; !__atomic_load_n(&sh->go, __ATOMIC_ACQUIRE);) rp_wait_step(&spins);
   }
   if (!j->buf || sh->offs[sh->nblocks] < sh->pairs) return NULL;          /* fell short (or no memory): the caller redoes it */
   const int64_t g0 = sh->offs[j->b0];
